@@ -1,0 +1,94 @@
+"""ctypes binding of libbayesic_hip.so (C ABI: include/bayesic_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails this
+module raises.  Device memory and streams come from torch (plumbing only); the
+library itself has no torch dependency -- every entry point takes raw device
+pointers.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t,
+                    c_uint32, c_uint64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libbayesic_hip.so")
+
+
+class BayesicHipError(RuntimeError):
+    """A libbayesic_hip.so call returned a non-zero status."""
+
+
+# name -> (restype, argtypes); every symbol declared in include/bayesic_hip.h.
+SIGNATURES = {
+    "bsc_ctx_create": (c_int, [c_int, c_void_p, POINTER(c_void_p)]),
+    "bsc_ctx_destroy": (c_int, [c_void_p]),
+    "bsc_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
+    "bsc_ctx_reserve": (c_int, [c_void_p, c_size_t]),
+    "bsc_ctx_sync": (c_int, [c_void_p]),
+    "bsc_ctx_profile": (c_int, [c_void_p, c_int]),
+    "bsc_ctx_profile_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
+    "bsc_device_info": (c_int, [c_void_p, POINTER(c_int64)]),
+    "bsc_last_error": (c_char_p, []),
+    "bsc_version": (c_int, []),
+    "bsc_malloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+    "bsc_free": (c_int, [c_void_p, c_void_p]),
+    "bsc_h2d": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "bsc_d2h": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "bsc_memset": (c_int, [c_void_p, c_void_p, c_int, c_size_t]),
+    "bsc_event_create": (c_int, [POINTER(c_void_p)]),
+    "bsc_event_destroy": (c_int, [c_void_p]),
+    "bsc_event_record": (c_int, [c_void_p, c_void_p]),
+    "bsc_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    "bsc_philox_normal": (c_int, [c_void_p, c_uint64, c_uint32, c_uint32, c_int32, c_int32,
+                                  c_void_p]),
+    "bsc_blr_sample": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_uint64, c_uint32,
+                               c_void_p, c_void_p, c_void_p]),
+    "bsc_blr_data_pass": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32,
+                                  c_void_p, c_int32, c_void_p, c_void_p]),
+    "bsc_blr_elbo_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_int32, c_int32, c_double, c_double, c_double,
+                                  c_double, c_void_p, c_void_p]),
+    "bsc_adam_ascent": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                c_int64, c_double, c_double, c_double, c_double]),
+    "bsc_natgrad_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
+                                   c_double]),
+    "bsc_suffstats_normal": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load (once) and type the shared library.  Raises if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise BayesicHipError(
+            "libbayesic_hip.so not found at %s -- run `python -m bayesic_amd.build` "
+            "(there is no CPU fallback)" % path)
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load_library().bsc_last_error()
+        raise BayesicHipError("%s failed with status %d: %s" %
+                              (what or "libbayesic_hip call", status,
+                               msg.decode("utf-8", "replace") if msg else ""))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None / int passthrough)."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()

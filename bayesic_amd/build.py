@@ -1,0 +1,73 @@
+"""Builds bayesic_amd/_lib/libbayesic_hip.so from bayesic_amd/csrc/*.hip with
+hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m bayesic_amd.build [--force] [--verbose]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ_DIR = os.path.join(CSRC, "_obj")
+LIB_DIR = os.path.join(HERE, "_lib")
+LIB_PATH = os.path.join(LIB_DIR, "libbayesic_hip.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+CXXFLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall",
+            "-Wno-unused-function", "-I", INCLUDE]
+
+
+def _sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(INCLUDE, "bayesic_hip.h"))
+    return hs
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), proc.stdout))
+    if verbose and proc.stdout.strip():
+        print(proc.stdout)
+
+
+def build(force=False, verbose=False):
+    """Compile and link; returns the path of the shared library."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    headers = _headers()
+    jobs, objs = [], []
+    for src in _sources():
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            jobs.append([HIPCC] + CXXFLAGS + ["-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
+            list(pool.map(lambda c: _run(c, verbose), jobs))
+    if force or jobs or _stale(LIB_PATH, objs):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs,
+             verbose)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
+    print(path)

@@ -1,0 +1,200 @@
+// Context, memory and event entry points of the C ABI (include/bayesic_hip.h).
+#include "bsc_common.h"
+
+#include <cstring>
+#include <new>
+
+namespace {
+thread_local char g_last_error[512] = "";
+}
+
+int bsc_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int bsc_workspace(bsc_ctx* ctx, size_t bytes, void** out) {
+    if (bytes > ctx->workspace_bytes) {
+        // Growing is synchronous: earlier launches may still read the old slab.
+        BSC_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->workspace) BSC_HIP(hipFree(ctx->workspace));
+        ctx->workspace = nullptr;
+        ctx->workspace_bytes = 0;
+        size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        hipError_t err = hipMalloc(&ctx->workspace, want);
+        if (err != hipSuccess)
+            return bsc_fail(BSC_ERR_NOMEM, "workspace hipMalloc(%zu) failed: %s", want,
+                            hipGetErrorString(err));
+        ctx->workspace_bytes = want;
+    }
+    *out = ctx->workspace;
+    return BSC_OK;
+}
+
+extern "C" {
+
+const char* bsc_last_error(void) { return g_last_error; }
+
+int bsc_version(void) { return BSC_VERSION; }
+
+int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
+    BSC_REQUIRE(out != nullptr, "bsc_ctx_create: out is null");
+    int count = 0;
+    BSC_HIP(hipGetDeviceCount(&count));
+    BSC_REQUIRE(device >= 0 && device < count, "bsc_ctx_create: device %d of %d", device,
+                count);
+    BSC_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    BSC_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return bsc_fail(BSC_ERR_UNSUPPORTED,
+                        "libbayesic_hip is built for gfx950 only; device %d is %s", device,
+                        prop.gcnArchName);
+    bsc_ctx* ctx = new (std::nothrow) bsc_ctx();
+    if (!ctx) return bsc_fail(BSC_ERR_NOMEM, "bsc_ctx_create: out of host memory");
+    ctx->device = device;
+    ctx->stream = (hipStream_t)stream;
+    ctx->cu_count = prop.multiProcessorCount;
+    *out = ctx;
+    return BSC_OK;
+}
+
+int bsc_ctx_destroy(bsc_ctx* ctx) {
+    if (!ctx) return BSC_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->workspace) (void)hipFree(ctx->workspace);
+    for (auto* v : {&ctx->prof_events, &ctx->prof_pool})
+        for (auto& ev : *v) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+    delete ctx;
+    return BSC_OK;
+}
+
+int bsc_ctx_set_stream(bsc_ctx* ctx, void* stream) {
+    BSC_CHECK_CTX(ctx);
+    ctx->stream = (hipStream_t)stream;
+    return BSC_OK;
+}
+
+int bsc_ctx_reserve(bsc_ctx* ctx, size_t bytes) {
+    BSC_CHECK_CTX(ctx);
+    void* p;
+    return bsc_workspace(ctx, bytes, &p);
+}
+
+int bsc_ctx_profile(bsc_ctx* ctx, int enable) {
+    BSC_CHECK_CTX(ctx);
+    ctx->profile = enable != 0;
+    return BSC_OK;
+}
+
+int bsc_ctx_profile_read(bsc_ctx* ctx, double* host_total_ms, int64_t* host_launches) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(host_total_ms && host_launches, "bsc_ctx_profile_read: null output");
+    BSC_HIP(hipStreamSynchronize(ctx->stream));
+    double total = 0.0;
+    for (auto& ev : ctx->prof_events) {
+        float ms = 0.f;
+        BSC_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+        total += ms;
+        ctx->prof_pool.push_back(ev);
+    }
+    *host_total_ms = total;
+    *host_launches = (int64_t)ctx->prof_events.size();
+    ctx->prof_events.clear();
+    return BSC_OK;
+}
+
+int bsc_ctx_sync(bsc_ctx* ctx) {
+    BSC_CHECK_CTX(ctx);
+    BSC_HIP(hipStreamSynchronize(ctx->stream));
+    return BSC_OK;
+}
+
+int bsc_device_info(bsc_ctx* ctx, int64_t info[8]) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(info != nullptr, "bsc_device_info: info is null");
+    hipDeviceProp_t prop;
+    BSC_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    info[0] = prop.multiProcessorCount;
+    info[1] = prop.warpSize;
+    info[2] = (int64_t)prop.sharedMemPerBlock;
+    info[3] = prop.clockRate;
+    info[4] = prop.l2CacheSize;
+    int arch = 0;
+    sscanf(prop.gcnArchName, "gfx%d", &arch);
+    info[5] = arch;
+    info[6] = (int64_t)(prop.totalGlobalMem >> 20);
+    info[7] = 0;
+    return BSC_OK;
+}
+
+int bsc_malloc(bsc_ctx* ctx, size_t bytes, void** out) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(out != nullptr, "bsc_malloc: out is null");
+    hipError_t err = hipMalloc(out, bytes ? bytes : 1);
+    if (err != hipSuccess)
+        return bsc_fail(BSC_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes,
+                        hipGetErrorString(err));
+    return BSC_OK;
+}
+
+int bsc_free(bsc_ctx* ctx, void* ptr) {
+    BSC_CHECK_CTX(ctx);
+    if (ptr) BSC_HIP(hipFree(ptr));
+    return BSC_OK;
+}
+
+int bsc_h2d(bsc_ctx* ctx, void* dst, const void* host_src, size_t bytes) {
+    BSC_CHECK_CTX(ctx);
+    BSC_HIP(hipMemcpyAsync(dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    BSC_HIP(hipStreamSynchronize(ctx->stream));  // host_src may be pageable
+    return BSC_OK;
+}
+
+int bsc_d2h(bsc_ctx* ctx, void* host_dst, const void* src, size_t bytes) {
+    BSC_CHECK_CTX(ctx);
+    BSC_HIP(hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BSC_HIP(hipStreamSynchronize(ctx->stream));
+    return BSC_OK;
+}
+
+int bsc_memset(bsc_ctx* ctx, void* dst, int value, size_t bytes) {
+    BSC_CHECK_CTX(ctx);
+    BSC_HIP(hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return BSC_OK;
+}
+
+int bsc_event_create(void** event) {
+    BSC_REQUIRE(event != nullptr, "bsc_event_create: event is null");
+    hipEvent_t ev;
+    BSC_HIP(hipEventCreate(&ev));
+    *event = (void*)ev;
+    return BSC_OK;
+}
+
+int bsc_event_destroy(void* event) {
+    if (event) BSC_HIP(hipEventDestroy((hipEvent_t)event));
+    return BSC_OK;
+}
+
+int bsc_event_record(bsc_ctx* ctx, void* event) {
+    BSC_CHECK_CTX(ctx);
+    BSC_HIP(hipEventRecord((hipEvent_t)event, ctx->stream));
+    return BSC_OK;
+}
+
+int bsc_event_elapsed_ms(void* start, void* stop, float* host_ms) {
+    BSC_REQUIRE(host_ms != nullptr, "bsc_event_elapsed_ms: host_ms is null");
+    BSC_HIP(hipEventSynchronize((hipEvent_t)stop));
+    BSC_HIP(hipEventElapsedTime(host_ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return BSC_OK;
+}
+
+}  // extern "C"

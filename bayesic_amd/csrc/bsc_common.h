@@ -1,0 +1,124 @@
+// Internal helpers shared by the kernels of libbayesic_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <utility>
+#include <vector>
+
+#include "../../include/bayesic_hip.h"
+
+struct bsc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    void* workspace = nullptr;   // partial-sum slabs; grown on demand
+    size_t workspace_bytes = 0;
+    int cu_count = 256;
+    // optional per-kernel timing of the dominant kernel (bsc_ctx_profile)
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;  // recorded pairs
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;    // reusable pairs
+};
+
+// Records an event pair around one launch when ctx->profile is on.
+struct bsc_prof_scope {
+    bsc_ctx* ctx;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    explicit bsc_prof_scope(bsc_ctx* c) : ctx(c) {
+        if (!ctx->profile) return;
+        if (!ctx->prof_pool.empty()) {
+            ev = ctx->prof_pool.back();
+            ctx->prof_pool.pop_back();
+        } else {
+            (void)hipEventCreate(&ev.first);
+            (void)hipEventCreate(&ev.second);
+        }
+        (void)hipEventRecord(ev.first, ctx->stream);
+    }
+    ~bsc_prof_scope() {
+        if (!ev.first) return;
+        (void)hipEventRecord(ev.second, ctx->stream);
+        ctx->prof_events.push_back(ev);
+    }
+};
+
+// thread-local error message; returns `code` so callers can `return bsc_fail(...)`
+int bsc_fail(int code, const char* fmt, ...);
+
+// Make sure ctx->workspace holds at least `bytes`; may hipMalloc (synchronous).
+int bsc_workspace(bsc_ctx* ctx, size_t bytes, void** out);
+
+#define BSC_HIP(call)                                                            \
+    do {                                                                         \
+        hipError_t err__ = (call);                                               \
+        if (err__ != hipSuccess)                                                 \
+            return bsc_fail(BSC_ERR_HIP, "%s failed: %s (%s:%d)", #call,         \
+                            hipGetErrorString(err__), __FILE__, __LINE__);       \
+    } while (0)
+
+#define BSC_REQUIRE(cond, ...)                                                   \
+    do {                                                                         \
+        if (!(cond)) return bsc_fail(BSC_ERR_INVALID, __VA_ARGS__);              \
+    } while (0)
+
+#define BSC_CHECK_CTX(ctx)                                                       \
+    do {                                                                         \
+        if ((ctx) == nullptr) return bsc_fail(BSC_ERR_INVALID, "null bsc_ctx");  \
+        BSC_HIP(hipSetDevice((ctx)->device));                                    \
+    } while (0)
+
+#define BSC_LAUNCH_CHECK()                                                       \
+    do {                                                                         \
+        hipError_t err__ = hipGetLastError();                                    \
+        if (err__ != hipSuccess)                                                 \
+            return bsc_fail(BSC_ERR_HIP, "kernel launch failed: %s (%s:%d)",     \
+                            hipGetErrorString(err__), __FILE__, __LINE__);       \
+    } while (0)
+
+constexpr int BSC_WAVE = 64;
+
+// ---- wave-level helpers ---------------------------------------------------
+
+// DPP controls (cdna4 ISA): quad_perm encodes the source lane of each quad lane.
+constexpr int DPP_QUAD_XOR1 = 0xB1;  // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;  // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_ROR4 = 0x124;
+constexpr int DPP_ROW_ROR8 = 0x128;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// Sum over the 16 lanes of a DPP row, result in every lane of the row.
+// Rotation direction does not matter: each stage is applied to a value that is
+// already periodic with the stage's period.
+__device__ __forceinline__ float row16_allsum(float v) {
+    v += dpp_f32<DPP_QUAD_XOR1>(v);
+    v += dpp_f32<DPP_QUAD_XOR2>(v);
+    v += dpp_f32<DPP_ROW_ROR4>(v);
+    v += dpp_f32<DPP_ROW_ROR8>(v);
+    return v;
+}
+
+// Full 64-lane sum, result in every lane.
+__device__ __forceinline__ float wave_allsum(float v) {
+    v = row16_allsum(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+__device__ __forceinline__ double wave_allsum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ float readlane_f32(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}

@@ -1,0 +1,139 @@
+// Summed sufficient statistics of iid draws and the parameter-update kernels.
+//
+// Reference contract: ExpFamIndependentObservations.sufficient_statistics sums
+// the per-datum statistics over the iid-draw axes
+// (bayesic/distribution/base.py:328-332); Normal t(x) = (x, x^2)
+// (bayesic/distribution/core.py:16-17).  The natural-gradient step is the
+// README.md:36 "unit-step natural gradient" VMP update generalised to a step
+// rho (Hoffman et al., ref [4], README.md:75-77).
+#include "bsc_common.h"
+
+namespace {
+
+constexpr int STAT_BLOCK = 256;
+constexpr int STAT_WAVES = STAT_BLOCK / BSC_WAVE;
+
+// Stage 1: grid-stride, 16 B/lane loads, float64 accumulation per lane, wave
+// and block reduction in fixed order -> partial[block][2].
+__global__ __launch_bounds__(STAT_BLOCK) void normal_stats_partial_kernel(
+    const float* __restrict__ x, int64_t n, double* __restrict__ partial) {
+    __shared__ double red[STAT_WAVES][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s1 = 0.0, s2 = 0.0;
+    // x may be only 4-byte aligned: peel to a 16-byte boundary
+    const int64_t head = (int64_t)((16 - ((uintptr_t)x & 15)) & 15) / 4;
+    const int64_t h = head < n ? head : n;
+    const int64_t nvec = (n - h) / 4;
+    const float4* xv = reinterpret_cast<const float4*>(x + h);
+    const int64_t gstride = (int64_t)gridDim.x * STAT_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * STAT_BLOCK + tid; i < nvec; i += gstride) {
+        float4 v = xv[i];
+        double a = v.x, b = v.y, c = v.z, d = v.w;
+        s1 += (a + b) + (c + d);
+        s2 += (a * a + b * b) + (c * c + d * d);
+    }
+    if (blockIdx.x == 0) {
+        // scalar head and tail elements
+        const int64_t tail0 = h + nvec * 4;
+        for (int64_t i = tid; i < h; i += STAT_BLOCK) { double a = x[i]; s1 += a; s2 += a * a; }
+        for (int64_t i = tail0 + tid; i < n; i += STAT_BLOCK) { double a = x[i]; s1 += a; s2 += a * a; }
+    }
+    s1 = wave_allsum_f64(s1);
+    s2 = wave_allsum_f64(s2);
+    if (lane == 0) { red[wave][0] = s1; red[wave][1] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int k = 0; k < STAT_WAVES; ++k) { t1 += red[k][0]; t2 += red[k][1]; }
+        partial[2 * blockIdx.x] = t1;
+        partial[2 * blockIdx.x + 1] = t2;
+    }
+}
+
+__global__ __launch_bounds__(BSC_WAVE) void normal_stats_final_kernel(
+    const double* __restrict__ partial, int n_blocks, int64_t n, double* __restrict__ stats) {
+    const int lane = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = lane; b < n_blocks; b += BSC_WAVE) {
+        s1 += partial[2 * b];
+        s2 += partial[2 * b + 1];
+    }
+    s1 = wave_allsum_f64(s1);
+    s2 = wave_allsum_f64(s2);
+    if (lane == 0) {
+        stats[0] = (double)n;
+        stats[1] = s1;
+        stats[2] = s2;
+    }
+}
+
+#pragma clang fp contract(off)
+__global__ void adam_ascent_kernel(double* __restrict__ lam, const double* __restrict__ grad,
+                                   double* __restrict__ m1, double* __restrict__ m2, int64_t n,
+                                   double lr, double beta1, double beta2, double eps,
+                                   double corr1, double corr2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double g = grad[i];
+    const double a = beta1 * m1[i] + (1.0 - beta1) * g;
+    const double b = beta2 * m2[i] + (1.0 - beta2) * g * g;
+    m1[i] = a;
+    m2[i] = b;
+    const double mhat = a / corr1;
+    const double vhat = b / corr2;
+    lam[i] = lam[i] + lr * mhat / (sqrt(vhat) + eps);
+}
+
+__global__ void natgrad_update_kernel(double* __restrict__ eta, const double* __restrict__ eta0,
+                                      const double* __restrict__ message, int64_t n,
+                                      double scale, double rho) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    eta[i] = (1.0 - rho) * eta[i] + rho * (eta0[i] + scale * message[i]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int bsc_suffstats_normal(bsc_ctx* ctx, const float* x, int64_t n, double* stats) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(stats && (x || n == 0) && n >= 0, "bsc_suffstats_normal: bad arguments");
+    BSC_REQUIRE(((uintptr_t)x & 3) == 0, "bsc_suffstats_normal: x must be 4-byte aligned");
+    int64_t want = (n / 4 + STAT_BLOCK - 1) / STAT_BLOCK;
+    int n_blocks = (int)(want < 1 ? 1 : (want > 8 * ctx->cu_count ? 8 * ctx->cu_count : want));
+    void* ws = nullptr;
+    int rc = bsc_workspace(ctx, (size_t)n_blocks * 2 * sizeof(double), &ws);
+    if (rc != BSC_OK) return rc;
+    hipLaunchKernelGGL(normal_stats_partial_kernel, dim3(n_blocks), dim3(STAT_BLOCK), 0,
+                       ctx->stream, x, n, (double*)ws);
+    BSC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(normal_stats_final_kernel, dim3(1), dim3(BSC_WAVE), 0, ctx->stream,
+                       (const double*)ws, n_blocks, n, stats);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_adam_ascent(bsc_ctx* ctx, double* lam, const double* grad, double* m1, double* m2,
+                    int64_t n, int64_t t, double lr, double beta1, double beta2, double eps) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(lam && grad && m1 && m2 && n > 0 && t >= 1, "bsc_adam_ascent: bad arguments");
+    const double corr1 = 1.0 - pow(beta1, (double)t);
+    const double corr2 = 1.0 - pow(beta2, (double)t);
+    hipLaunchKernelGGL(adam_ascent_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, lam, grad, m1, m2, n, lr, beta1, beta2, eps, corr1, corr2);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_natgrad_update(bsc_ctx* ctx, double* eta, const double* eta0, const double* message,
+                       int64_t n, double scale, double rho) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(eta && eta0 && message && n > 0, "bsc_natgrad_update: bad arguments");
+    hipLaunchKernelGGL(natgrad_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, eta, eta0, message, n, scale, rho);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+}  // extern "C"

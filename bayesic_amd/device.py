@@ -1,0 +1,131 @@
+"""Device context: one per process / GPU, wrapping a ``bsc_ctx``.
+
+torch supplies device memory (``torch.empty(..., device='cuda')``) and the HIP
+stream; every compute call goes through the C ABI.  Creating a ``Context``
+without a visible gfx950 GPU raises -- there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _ffi
+
+
+class Context:
+    def __init__(self, device=None, stream=None):
+        if not torch.cuda.is_available():
+            raise _ffi.BayesicHipError(
+                "bayesic_amd needs a gfx950 (MI355X) GPU: torch.cuda.is_available() is False "
+                "and there is no CPU fallback")
+        self.lib = _ffi.load_library()
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self._stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        handle = ctypes.c_void_p()
+        _ffi.check(self.lib.bsc_ctx_create(self.device_index, self._stream.cuda_stream,
+                                           ctypes.byref(handle)), "bsc_ctx_create")
+        self.handle = handle
+
+    # -- plumbing ----------------------------------------------------------
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.bsc_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return self._stream
+
+    def set_stream(self, stream):
+        self._stream = stream
+        _ffi.check(self.lib.bsc_ctx_set_stream(self.handle, stream.cuda_stream),
+                   "bsc_ctx_set_stream")
+
+    def sync(self):
+        _ffi.check(self.lib.bsc_ctx_sync(self.handle), "bsc_ctx_sync")
+
+    def reserve(self, nbytes):
+        _ffi.check(self.lib.bsc_ctx_reserve(self.handle, nbytes), "bsc_ctx_reserve")
+
+    def profile(self, enable=True):
+        """Time the dominant kernel of each entry point with hipEvents on the ctx stream."""
+        _ffi.check(self.lib.bsc_ctx_profile(self.handle, int(bool(enable))), "bsc_ctx_profile")
+
+    def profile_read(self):
+        """(total_ms, launches) of the dominant kernel since the last read; syncs."""
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        _ffi.check(self.lib.bsc_ctx_profile_read(self.handle, ctypes.byref(ms), ctypes.byref(n)),
+                   "bsc_ctx_profile_read")
+        return float(ms.value), int(n.value)
+
+    def info(self):
+        buf = (ctypes.c_int64 * 8)()
+        _ffi.check(self.lib.bsc_device_info(self.handle, buf), "bsc_device_info")
+        keys = ["cu_count", "wave_size", "lds_bytes", "clock_khz", "l2_bytes", "gfx", "hbm_mib"]
+        return dict(zip(keys, list(buf)))
+
+    def empty(self, shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype=torch.float32):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def to_device(self, array, dtype=None):
+        t = torch.as_tensor(array)
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.contiguous().to(self.device)
+
+    # -- timing on the ctx stream -----------------------------------------
+    def event(self):
+        return Event(self)
+
+    def call(self, name, *args):
+        _ffi.check(getattr(self.lib, name)(self.handle, *args), name)
+
+
+class Event:
+    """hipEvent recorded on the context stream through the C ABI."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        _ffi.check(ctx.lib.bsc_event_create(ctypes.byref(h)), "bsc_event_create")
+        self.handle = h
+
+    def record(self):
+        _ffi.check(self.ctx.lib.bsc_event_record(self.ctx.handle, self.handle),
+                   "bsc_event_record")
+        return self
+
+    def elapsed_ms(self, stop):
+        ms = ctypes.c_float()
+        _ffi.check(self.ctx.lib.bsc_event_elapsed_ms(self.handle, stop.handle, ctypes.byref(ms)),
+                   "bsc_event_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.ctx.lib.bsc_event_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+_default = None
+
+
+def default_context():
+    global _default
+    if _default is None:
+        _default = Context()
+    return _default

@@ -1,0 +1,137 @@
+/* bayesic_hip.h -- C ABI of libbayesic_hip.so, the MI355X (gfx950) backend for
+ * Bayesic's ELBO-gradient / mean-field update path.
+ *
+ * The reference (mjwillson/Bayesic) has no FFI: its numeric boundary is the
+ * Python hook set that emits Theano ops.  Every entry
+ * point below names the reference interface it stands behind.  All functions:
+ *
+ *   - are extern "C", take plain pointers and sizes, and return 0 on success or
+ *     a negative bsc_status; bsc_last_error() gives the thread-local message;
+ *   - take DEVICE pointers unless the parameter is named host_*;
+ *   - are asynchronous on the context's HIP stream (no host sync, no
+ *     allocation) unless documented otherwise, so a caller may capture a
+ *     sequence of them into a hipGraph;
+ *   - never fall back to a CPU implementation.
+ *
+ * Arithmetic: data operands float32 (the reference default dtype,
+ * bayesic/algebra.py:109); statistics, gradients and variational parameters
+ * float64 unless stated.
+ */
+#ifndef BAYESIC_HIP_H
+#define BAYESIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSC_VERSION 100 /* 0.1.0 */
+#define BSC_MAX_RANK 6  /* strided-tensor entry points accept up to 6 axes */
+
+typedef enum bsc_status {
+    BSC_OK = 0,
+    BSC_ERR_INVALID = -1,     /* bad argument (shape, alignment, null pointer) */
+    BSC_ERR_HIP = -2,         /* a HIP runtime call failed */
+    BSC_ERR_UNSUPPORTED = -3, /* valid request outside what the kernels cover */
+    BSC_ERR_NOMEM = -4
+} bsc_status;
+
+typedef struct bsc_ctx bsc_ctx;
+
+/* ---- context, memory, timing (build decision; reference has none) ------- */
+
+/* Binds to `device`; `stream` is a hipStream_t (or NULL for the null stream)
+ * owned by the caller -- e.g. torch.cuda.current_stream().cuda_stream. */
+int bsc_ctx_create(int device, void* stream, bsc_ctx** out);
+int bsc_ctx_destroy(bsc_ctx* ctx);
+int bsc_ctx_set_stream(bsc_ctx* ctx, void* stream);
+/* Pre-size the context workspace (partial-sum slabs).  Synchronous.  Entry
+ * points grow it on demand; call this first when capturing into a graph. */
+int bsc_ctx_reserve(bsc_ctx* ctx, size_t bytes);
+int bsc_ctx_sync(bsc_ctx* ctx);
+/* info[0]=CU count, [1]=wavefront size, [2]=max LDS bytes per workgroup,
+ * [3]=clock kHz, [4]=L2 bytes, [5]=gcn arch number (950 for gfx950). */
+int bsc_device_info(bsc_ctx* ctx, int64_t info[8]);
+const char* bsc_last_error(void);
+int bsc_version(void);
+
+int bsc_malloc(bsc_ctx* ctx, size_t bytes, void** out); /* synchronous */
+int bsc_free(bsc_ctx* ctx, void* ptr);                  /* synchronous */
+int bsc_h2d(bsc_ctx* ctx, void* dst, const void* host_src, size_t bytes);
+int bsc_d2h(bsc_ctx* ctx, void* host_dst, const void* src, size_t bytes); /* syncs */
+int bsc_memset(bsc_ctx* ctx, void* dst, int value, size_t bytes);
+
+/* Per-kernel timing of the dominant kernel of each entry point, with hipEvents
+ * recorded on the ctx stream immediately around that one launch.  Off by
+ * default.  bsc_ctx_profile_read synchronises, returns the summed duration and
+ * the launch count since the last read, and resets both. */
+int bsc_ctx_profile(bsc_ctx* ctx, int enable);
+int bsc_ctx_profile_read(bsc_ctx* ctx, double* host_total_ms, int64_t* host_launches);
+
+/* hipEvent wrappers so a ctypes caller can time the ctx stream. */
+int bsc_event_create(void** event);
+int bsc_event_destroy(void* event);
+int bsc_event_record(bsc_ctx* ctx, void* event);
+int bsc_event_elapsed_ms(void* start, void* stop, float* host_ms); /* syncs on stop */
+
+/* ---- reparameterisation sampler (ABSENT in reference; README.md:51) ----- */
+
+/* Philox4x32-10 keyed standard normals, float64:
+ *   eps[s*n_params + d], counter=(d/4, s, stream, step), key=(seed lo, hi). */
+int bsc_philox_normal(bsc_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t step,
+                      int32_t n_samples, int32_t n_params, double* eps);
+
+/* Bayesian linear regression q(w)=N(m,diag e^{2rho}), q(xi)=N(a,e^{2b});
+ * lam=[m(D),rho(D),a,b] float64.  Writes eps[S,(D+1)] f64, W[S,D] f32
+ * (w_s = m + e^rho * eps_s, rounded), xi[S] f64. */
+int bsc_blr_sample(bsc_ctx* ctx, const double* lam, int32_t D, int32_t S,
+                   uint64_t seed, uint32_t step, double* eps, float* W, double* xi);
+
+/* ---- the mini-batch data pass (ABSENT in reference; README.md:51,69-79;
+ *      likelihood decomposition bayesic/distribution/base.py:47-69) --------
+ *
+ * One streaming pass over X[B,D] (row-major, leading dimension ldx floats)
+ * and y[B]:
+ *      r[n,s] = y[n] - sum_d X[n,d] W[s,d]
+ *      Q[s]   = sum_n r[n,s]^2            (float64 out)
+ *      G[s,d] = sum_n r[n,s] X[n,d]       (float64 out, [S,D])
+ * Requires D % 4 == 0, D <= 256, 1 <= S <= 64, X 16-byte aligned, ldx % 4 == 0.
+ * Deterministic: fixed partition, fixed-order float64 finish. */
+int bsc_blr_data_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y,
+                      int64_t B, int32_t D, const float* W, int32_t S,
+                      double* Q, double* G);
+
+/* Monte-Carlo ELBO and pathwise gradient from the (all-reduced) pass outputs.
+ * batch_rows = global mini-batch rows, scale = N_total / batch_rows.
+ * Writes elbo[1], grad[2D+2] (float64). */
+int bsc_blr_elbo_grad(bsc_ctx* ctx, const double* lam, const double* eps,
+                      const float* W, const double* xi, const double* Q,
+                      const double* G, int32_t D, int32_t S, double batch_rows,
+                      double scale, double alpha0, double beta0, double* elbo,
+                      double* grad);
+
+/* ---- parameter updates --------------------------------------------------- */
+
+/* Adam ascent on a flat float64 vector; t is the 1-based step count. */
+int bsc_adam_ascent(bsc_ctx* ctx, double* lam, const double* grad, double* m1,
+                    double* m2, int64_t n, int64_t t, double lr, double beta1,
+                    double beta2, double eps);
+
+/* SVI natural-gradient / VMP step (README.md:36,75-77; Hoffman et al. [4]):
+ *   eta <- (1-rho) eta + rho (eta0 + scale * message),  all float64[n]. */
+int bsc_natgrad_update(bsc_ctx* ctx, double* eta, const double* eta0,
+                       const double* message, int64_t n, double scale, double rho);
+
+/* ---- summed sufficient statistics of iid draws ---------------------------
+ * ExpFamIndependentObservations.sufficient_statistics,
+ * bayesic/distribution/base.py:328-332; Normal t(x)=(x,x^2),
+ * bayesic/distribution/core.py:16-17.
+ * stats[0]=n, stats[1]=sum x, stats[2]=sum x^2 (float64). */
+int bsc_suffstats_normal(bsc_ctx* ctx, const float* x, int64_t n, double* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BAYESIC_HIP_H */

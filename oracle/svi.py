@@ -1,0 +1,254 @@
+"""float64 numpy restatement of the SVI inner loop (oracle; test infrastructure).
+
+PARITY UNPINNED: the reference contains no ELBO, sampler, gradient or update
+code -- only the prose plan ``README.md:24-80`` and the exponential-family
+decomposition contract ``bayesic/distribution/base.py:47-69`` (log-lik =
+data term + interaction term - log-normaliser).  Each function cites the line
+of that plan / the paper it restates, and is validated by tests against exact
+conjugate posteriors, scipy.stats and finite differences.
+
+Conventions shared with the HIP path (bayesic_amd/csrc):
+
+* data arrays are float32 (``bayesic/algebra.py:109`` default dtype); every sum
+  over rows is accumulated in float64 here;
+* variational parameters are float64; Monte-Carlo weight samples are rounded to
+  float32 before the data pass (the device streams float32 operands);
+* ``scale = N_total / B`` multiplies every mini-batch sum (``README.md:69-79``,
+  SVI ref [4]).
+"""
+import math
+
+import numpy as np
+
+from . import philox
+
+LOG_2PI = math.log(2.0 * math.pi)
+
+
+# --------------------------------------------------------------------------
+# Config 1: Gaussian with unknown mean and precision, Normal-Gamma node.
+# Sufficient statistics of Normal (bayesic/distribution/core.py:16-17) summed
+# over iid draws (bayesic/distribution/base.py:329-332).
+# --------------------------------------------------------------------------
+
+def normal_suffstats(x):
+    """(count, sum x, sum x^2) in float64 from float32 data."""
+    x64 = np.asarray(x, dtype=np.float32).astype(np.float64)
+    return np.array([x64.size, x64.sum(), (x64 * x64).sum()], dtype=np.float64)
+
+
+def normal_gamma_to_natural(mu0, kappa0, alpha0, beta0):
+    """Natural parameters of NormalGamma(mu, tau) w.r.t. statistics
+    (tau*mu, -tau*mu^2/2 (paired with kappa), log tau, -tau):
+
+        eta = (kappa*mu, kappa, 2*alpha - 1, 2*beta + kappa*mu^2)
+
+    chosen so that the conjugate update is a plain addition of
+    (sum x, n, n, sum x^2) -- i.e. the VMP message from N iid Normal children
+    (README.md:36, VIBES ref [1]).
+    """
+    return np.array([kappa0 * mu0, kappa0, 2.0 * alpha0 - 1.0,
+                     2.0 * beta0 + kappa0 * mu0 * mu0], dtype=np.float64)
+
+
+def normal_gamma_from_natural(eta):
+    e1, e2, e3, e4 = (float(v) for v in eta)
+    kappa = e2
+    mu = e1 / kappa
+    alpha = 0.5 * (e3 + 1.0)
+    beta = 0.5 * (e4 - kappa * mu * mu)
+    return mu, kappa, alpha, beta
+
+
+def normal_gamma_message(stats):
+    """Map summed Normal statistics (n, sx, sxx) to the natural-parameter
+    increment of the Normal-Gamma parent."""
+    n, sx, sxx = (float(v) for v in stats)
+    return np.array([sx, n, n, sxx], dtype=np.float64)
+
+
+def natgrad_update(eta, eta0, message, scale, rho):
+    """SVI natural-gradient step (Hoffman et al. ref [4], README.md:36,75-77):
+
+        eta <- (1 - rho) * eta + rho * (eta0 + scale * message)
+
+    With rho = 1 and the full data set this is the exact VMP / conjugate update.
+    """
+    eta = np.asarray(eta, dtype=np.float64)
+    return (1.0 - rho) * eta + rho * (np.asarray(eta0, np.float64) +
+                                      scale * np.asarray(message, np.float64))
+
+
+def normal_gamma_posterior_closed_form(x, mu0, kappa0, alpha0, beta0):
+    """Textbook posterior (SURVEY.md 8(d) cfg 1) -- independent check."""
+    x = np.asarray(x, dtype=np.float32).astype(np.float64)
+    n = x.size
+    xbar = x.mean()
+    kappa = kappa0 + n
+    mu = (kappa0 * mu0 + n * xbar) / kappa
+    alpha = alpha0 + 0.5 * n
+    beta = beta0 + 0.5 * ((x - xbar) ** 2).sum() + \
+        kappa0 * n * (xbar - mu0) ** 2 / (2.0 * kappa)
+    return mu, kappa, alpha, beta
+
+
+# --------------------------------------------------------------------------
+# Config 2: Bayesian linear regression, mean-field Gaussian q, reparam ELBO.
+#
+#   y_n ~ N(x_n . w, sigma^2),  w | sigma^2 ~ N(0, sigma^2 I),
+#   sigma^2 ~ InvGamma(alpha0, beta0);   xi = log sigma^2
+#   q(w) = N(m, diag exp(2 rho)),  q(xi) = N(a, exp(2 b))
+#
+# lam = [m (D), rho (D), a, b]  float64.
+# --------------------------------------------------------------------------
+
+def blr_sample(lam, D, S, seed, step=0):
+    """Reparameterised draws (README.md:51 -> refs [10][11][12]).
+
+    Returns eps [S, D+1] f64, W [S, D] float32 (rounded), xi [S] f64.
+    eps[:, :D] from Philox stream 0, eps[:, D] from stream 1.
+    """
+    lam = np.asarray(lam, dtype=np.float64)
+    m, rho, a, b = lam[:D], lam[D:2 * D], lam[2 * D], lam[2 * D + 1]
+    eps_w = philox.normal_draws(seed, S, D, stream=0, step=step)
+    eps_x = philox.normal_draws(seed, S, 1, stream=1, step=step)
+    eps = np.concatenate([eps_w, eps_x], axis=1)
+    W = (m[None, :] + np.exp(rho)[None, :] * eps_w).astype(np.float32)
+    xi = a + math.exp(b) * eps_x[:, 0]
+    return eps, W, xi
+
+
+def blr_data_pass(X, y, W):
+    """The one pass over the mini-batch.
+
+    r[n, s] = y[n] - x[n] . W[s];  Q[s] = sum_n r^2;  G[s, :] = sum_n r[n, s] x[n].
+    float32 operands, float64 arithmetic.  Returns (Q [S], G [S, D]).
+    """
+    X64 = np.asarray(X, dtype=np.float32).astype(np.float64)
+    y64 = np.asarray(y, dtype=np.float32).astype(np.float64)
+    W64 = np.asarray(W, dtype=np.float32).astype(np.float64)
+    R = y64[:, None] - X64 @ W64.T
+    return (R * R).sum(axis=0), R.T @ X64
+
+
+def blr_data_pass_chunked(X, y, W, chunk=65536):
+    """Same as ``blr_data_pass`` but bounded memory for 1M-row inputs."""
+    S, D = W.shape
+    Q = np.zeros(S)
+    G = np.zeros((S, D))
+    W64 = np.asarray(W, dtype=np.float32).astype(np.float64)
+    for i in range(0, X.shape[0], chunk):
+        Xc = np.asarray(X[i:i + chunk], dtype=np.float32).astype(np.float64)
+        yc = np.asarray(y[i:i + chunk], dtype=np.float32).astype(np.float64)
+        R = yc[:, None] - Xc @ W64.T
+        Q += (R * R).sum(axis=0)
+        G += R.T @ Xc
+    return Q, G
+
+
+def blr_log_joint(w, xi, Q, B, scale, alpha0=1.0, beta0=1.0):
+    """f(w, xi) = scale * log p(y_B | w, xi) + log p(w | xi) + log p(xi)
+    with Q = sum_n (y_n - x_n.w)^2.  Three-term decomposition per
+    bayesic/distribution/base.py:47-69; Normal normaliser corrected."""
+    D = w.shape[-1]
+    e = np.exp(-xi)
+    loglik = scale * (-0.5 * B * (LOG_2PI + xi) - 0.5 * e * Q)
+    logpw = -0.5 * D * (LOG_2PI + xi) - 0.5 * e * (w * w).sum(axis=-1)
+    logpxi = alpha0 * math.log(beta0) - math.lgamma(alpha0) - alpha0 * xi - beta0 * e
+    return loglik + logpw + logpxi
+
+
+def blr_elbo_and_grad(lam, eps, W, xi, Q, G, B, scale, alpha0=1.0, beta0=1.0):
+    """Monte-Carlo ELBO estimate and its pathwise gradient w.r.t. lam.
+
+    ELBO = mean_s f(w_s, xi_s) + H[q];  H = sum_d rho_d + b + (D+1)/2 log(2 pi e).
+    d f/d w  = exp(-xi) (scale*G - w)
+    d f/d xi = -(scale*B + D)/2 - alpha0 + exp(-xi) (scale*Q/2 + |w|^2/2 + beta0)
+    (Kucukelbir et al. ref [11], eq. for mean-field Gaussian ADVI.)
+    """
+    lam = np.asarray(lam, dtype=np.float64)
+    S, D = W.shape
+    rho, b = lam[D:2 * D], lam[2 * D + 1]
+    W64 = W.astype(np.float64)
+    e = np.exp(-xi)
+    f = blr_log_joint(W64, xi, Q, B, scale, alpha0, beta0)
+    entropy = rho.sum() + b + 0.5 * (D + 1) * (1.0 + LOG_2PI)
+    elbo = f.mean() + entropy
+    dw = e[:, None] * (scale * G - W64)                       # [S, D]
+    dxi = -0.5 * (scale * B + D) - alpha0 + \
+        e * (0.5 * scale * Q + 0.5 * (W64 * W64).sum(axis=1) + beta0)
+    grad = np.empty_like(lam)
+    grad[:D] = dw.mean(axis=0)
+    grad[D:2 * D] = (dw * eps[:, :D]).mean(axis=0) * np.exp(rho) + 1.0
+    grad[2 * D] = dxi.mean()
+    grad[2 * D + 1] = (dxi * eps[:, D]).mean() * math.exp(b) + 1.0
+    return elbo, grad
+
+
+def adam_ascent(lam, grad, m1, m2, t, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """One Adam *ascent* step; t is the 1-based step count.  Returns new
+    (lam, m1, m2)."""
+    m1 = beta1 * m1 + (1.0 - beta1) * grad
+    m2 = beta2 * m2 + (1.0 - beta2) * grad * grad
+    mhat = m1 / (1.0 - beta1 ** t)
+    vhat = m2 / (1.0 - beta2 ** t)
+    return lam + lr * mhat / (np.sqrt(vhat) + eps), m1, m2
+
+
+def blr_step(lam, m1, m2, t, X, y, S, seed, n_total, lr, alpha0=1.0, beta0=1.0,
+             chunked=False):
+    """One full ELBO-gradient update on one mini-batch (sample -> pass ->
+    gradient -> Adam).  ``t`` is the 1-based step index and also the Philox
+    step counter (t - 1).  Returns (lam, m1, m2, elbo, grad)."""
+    B, D = X.shape
+    eps, W, xi = blr_sample(lam, D, S, seed, step=t - 1)
+    Q, G = (blr_data_pass_chunked if chunked else blr_data_pass)(X, y, W)
+    elbo, grad = blr_elbo_and_grad(lam, eps, W, xi, Q, G, B, n_total / B, alpha0, beta0)
+    lam, m1, m2 = adam_ascent(lam, grad, m1, m2, t, lr)
+    return lam, m1, m2, elbo, grad
+
+
+def blr_exact_posterior(X, y, alpha0=1.0, beta0=1.0):
+    """Exact Normal-Inverse-Gamma posterior for the prior w|s2 ~ N(0, s2 I),
+    s2 ~ IG(alpha0, beta0): returns (mean_w, Lambda_n, a_n, b_n).  Uses the
+    conjugate statistics XtX, Xty, yty (SURVEY 8(d) cfg 2')."""
+    X64 = np.asarray(X, np.float32).astype(np.float64)
+    y64 = np.asarray(y, np.float32).astype(np.float64)
+    D = X64.shape[1]
+    Lam = X64.T @ X64 + np.eye(D)
+    mu = np.linalg.solve(Lam, X64.T @ y64)
+    a_n = alpha0 + 0.5 * X64.shape[0]
+    b_n = beta0 + 0.5 * (y64 @ y64 - mu @ Lam @ mu)
+    return mu, Lam, a_n, b_n
+
+
+def blr_conjugate_stats(X, y):
+    """(XtX [D,D], Xty [D], yty) in float64 -- the lowered forms
+    _tensordot(_dimshuffle(X,1,0), X,[1],[0]) etc.."""
+    X64 = np.asarray(X, np.float32).astype(np.float64)
+    y64 = np.asarray(y, np.float32).astype(np.float64)
+    return X64.T @ X64, X64.T @ y64, float(y64 @ y64)
+
+
+# --------------------------------------------------------------------------
+# Synthetic inputs fixed by SURVEY.md 8(d).
+# --------------------------------------------------------------------------
+
+def make_cfg1(n=10000):
+    return (2.0 + 1.5 * np.random.RandomState(1234).standard_normal(n)).astype(np.float32)
+
+
+def make_cfg2(n=1000000, d=256):
+    X = np.random.RandomState(1234).standard_normal((n, d)).astype(np.float32)
+    w_true = (np.random.RandomState(1).standard_normal(d) / 16.0)
+    y = (X.astype(np.float64) @ w_true +
+         0.5 * np.random.RandomState(2).standard_normal(n)).astype(np.float32)
+    return X, y, w_true
+
+
+def blr_init_lam(D):
+    """m = 0, rho = log 0.1, a = 0, b = log 0.1."""
+    lam = np.zeros(2 * D + 2)
+    lam[D:2 * D] = math.log(0.1)
+    lam[2 * D + 1] = math.log(0.1)
+    return lam

@@ -1,0 +1,259 @@
+"""GPU parity: HIP BLR reparam path (through the C ABI) vs the float64 oracle.
+
+Tolerances (stated, float path): the device streams float32 operands, forms
+products and per-lane partial sums in float32, and finishes in float64.
+ * data pass Q, G: |dev - oracle| <= 2e-5 * scale_of_sum, where scale_of_sum is
+   the Cauchy-Schwarz bound of the summed terms (rtol 1e-5 is the reference's
+   own tolerance for contractions, bayesic/tests/test_algebra.py:82);
+ * sampler eps / xi (float64 both sides): rtol 1e-12; W equal after float32
+   rounding up to 1 ulp;
+ * ELBO / gradient finish (float64 both sides, same inputs): rtol 1e-10.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox, svi
+
+pytestmark = pytest.mark.gpu
+
+
+def _pass(ctx, X, y, W):
+    from bayesic_amd._ffi import ptr
+    Xd, yd, Wd = ctx.to_device(X), ctx.to_device(y), ctx.to_device(W)
+    S, D = W.shape
+    Q = ctx.zeros(S, torch.float64)
+    G = ctx.zeros((S, D), torch.float64)
+    ctx.call("bsc_blr_data_pass", ptr(Xd), Xd.stride(0) if X.shape[0] else D, ptr(yd),
+             X.shape[0], D, ptr(Wd), S, ptr(Q), ptr(G))
+    ctx.sync()
+    return Q.cpu().numpy(), G.cpu().numpy()
+
+
+def _check_pass(ctx, X, y, W, tol=2e-5):
+    Q, G = _pass(ctx, X, y, W)
+    Qr, Gr = svi.blr_data_pass_chunked(X, y, W) if X.shape[0] else \
+        (np.zeros(W.shape[0]), np.zeros(W.shape))
+    X64 = X.astype(np.float64)
+    # scale of the summed terms: sum_n r^2 and sqrt(sum r^2 * sum x_d^2)
+    np.testing.assert_allclose(Q, Qr, rtol=tol, atol=tol)
+    colnorm = np.sqrt((X64 * X64).sum(axis=0))[None, :]
+    bound = np.sqrt(Qr)[:, None] * colnorm
+    err = np.abs(G - Gr)
+    assert (err <= tol * bound + 1e-12).all(), "max err/bound %g" % (err / (bound + 1e-300)).max()
+    return Q, G
+
+
+@pytest.mark.parametrize("B,D,S", [
+    (8, 256, 8),          # exactly one tile
+    (64, 256, 8),
+    (1000, 256, 8),       # ragged: 1000 = 125 tiles, needs multiple waves
+    (1003, 256, 8),       # partial last tile
+    (7, 256, 8),          # fewer rows than a tile
+    (1, 256, 1),
+    (4099, 256, 3),       # S < 8 zero-padded
+    (513, 64, 8),         # D < 256: masked lanes
+    (2050, 4, 2),         # minimum D
+    (777, 252, 5),
+    (300, 128, 16),       # S > 8: two sample groups
+    (100, 32, 64),        # S = 64 (config-5 sample count)
+])
+def test_data_pass_matches_oracle(ctx, B, D, S):
+    rs = np.random.RandomState(B * 7 + D + S)
+    X = rs.standard_normal((B, D)).astype(np.float32)
+    y = rs.standard_normal(B).astype(np.float32)
+    W = (rs.standard_normal((S, D)) / math.sqrt(D)).astype(np.float32)
+    _check_pass(ctx, X, y, W)
+
+
+def test_data_pass_empty_batch(ctx):
+    Q, G = _pass(ctx, np.zeros((0, 256), np.float32), np.zeros(0, np.float32),
+                 np.ones((8, 256), np.float32))
+    assert (Q == 0).all() and (G == 0).all()
+
+
+def test_data_pass_butterfly_maps_every_row_and_sample(ctx):
+    """Exact-integer data: any lane/row/sample mix-up in the transposing
+    reduction or the readlane broadcast changes an integer result."""
+    B, D, S = 64, 256, 8
+    n = np.arange(B)[:, None]
+    d = np.arange(D)[None, :]
+    X = ((n * 3 + d * 5) % 7 - 3).astype(np.float32)
+    W = ((np.arange(S)[:, None] * 11 + d * 2) % 5 - 2).astype(np.float32)
+    y = ((np.arange(B) * 13) % 17 - 8).astype(np.float32)
+    Q, G = _pass(ctx, X, y, W)
+    Qr, Gr = svi.blr_data_pass(X, y, W)
+    np.testing.assert_array_equal(Q, Qr)      # all sums are exact small integers
+    np.testing.assert_array_equal(G, Gr)
+
+
+def test_data_pass_is_linear_in_y_and_deterministic(ctx):
+    rs = np.random.RandomState(5)
+    B, D, S = 5000, 256, 8
+    X = rs.standard_normal((B, D)).astype(np.float32)
+    W = (rs.standard_normal((S, D)) / 16).astype(np.float32)
+    y1 = rs.standard_normal(B).astype(np.float32)
+    _, G0 = _pass(ctx, X, np.zeros(B, np.float32), W)
+    _, G1 = _pass(ctx, X, y1, W)
+    _, G1b = _pass(ctx, X, y1, W)
+    np.testing.assert_array_equal(G1, G1b)            # bitwise reproducible
+    # G(y) - G(0) = X^T y for every sample
+    Xty = X.astype(np.float64).T @ y1.astype(np.float64)
+    scale = np.sqrt((X.astype(np.float64) ** 2).sum(0) * (y1.astype(np.float64) ** 2).sum())
+    assert (np.abs((G1 - G0) - Xty[None, :]) <= 4e-5 * scale[None, :]).all()
+
+
+def test_data_pass_respects_leading_dimension(ctx):
+    from bayesic_amd._ffi import ptr
+    rs = np.random.RandomState(9)
+    B, D, ld, S = 333, 64, 96, 8
+    buf = rs.standard_normal((B, ld)).astype(np.float32)
+    y = rs.standard_normal(B).astype(np.float32)
+    W = rs.standard_normal((S, D)).astype(np.float32) / 8
+    bd, yd, Wd = ctx.to_device(buf), ctx.to_device(y), ctx.to_device(W)
+    Q, G = ctx.zeros(S, torch.float64), ctx.zeros((S, D), torch.float64)
+    ctx.call("bsc_blr_data_pass", ptr(bd), ld, ptr(yd), B, D, ptr(Wd), S, ptr(Q), ptr(G))
+    ctx.sync()
+    Qr, Gr = svi.blr_data_pass(buf[:, :D], y, W)
+    np.testing.assert_allclose(Q.cpu().numpy(), Qr, rtol=2e-5)
+    np.testing.assert_allclose(G.cpu().numpy(), Gr, rtol=1e-4, atol=1e-4 * np.abs(Gr).max())
+
+
+def test_data_pass_rejects_bad_shapes(ctx):
+    from bayesic_amd._ffi import BayesicHipError, ptr
+    X = ctx.zeros((8, 260))
+    y, W = ctx.zeros(8), ctx.zeros((8, 260))
+    Q, G = ctx.zeros(8, torch.float64), ctx.zeros((8, 260), torch.float64)
+    with pytest.raises(BayesicHipError, match="multiple of 4"):
+        ctx.call("bsc_blr_data_pass", ptr(X), 260, ptr(y), 8, 260, ptr(W), 8, ptr(Q), ptr(G))
+    with pytest.raises(BayesicHipError, match="S="):
+        ctx.call("bsc_blr_data_pass", ptr(X), 256, ptr(y), 8, 256, ptr(W), 65, ptr(Q), ptr(G))
+
+
+def test_philox_normal_matches_oracle(ctx):
+    from bayesic_amd._ffi import ptr
+    for (S, P, stream, step) in [(8, 257, 0, 0), (64, 1001, 1, 3), (1, 1, 0, 7)]:
+        eps = ctx.zeros(S * P, torch.float64)
+        ctx.call("bsc_philox_normal", 1234, stream, step, S, P, ptr(eps))
+        ctx.sync()
+        want = philox.normal_draws(1234, S, P, stream=stream, step=step)
+        np.testing.assert_allclose(eps.cpu().numpy().reshape(S, P), want, rtol=1e-12, atol=1e-14)
+
+
+def test_sampler_matches_oracle(ctx):
+    from bayesic_amd._ffi import ptr
+    D, S = 256, 8
+    lam = svi.blr_init_lam(D) + 0.001 * np.arange(2 * D + 2)
+    lamd = ctx.to_device(lam, torch.float64)
+    eps, W, xi = ctx.zeros(S * (D + 1), torch.float64), ctx.zeros(S * D), ctx.zeros(S, torch.float64)
+    ctx.call("bsc_blr_sample", ptr(lamd), D, S, (5 << 32) + 99, 4, ptr(eps), ptr(W), ptr(xi))
+    ctx.sync()
+    e, w, x = svi.blr_sample(lam, D, S, (5 << 32) + 99, step=4)
+    np.testing.assert_allclose(eps.cpu().numpy().reshape(S, D + 1), e, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(xi.cpu().numpy(), x, rtol=1e-13)
+    wd = W.cpu().numpy().reshape(S, D)
+    assert (np.abs(wd - w) <= np.spacing(np.abs(w))).all()
+    assert (wd == w).mean() > 0.999
+
+
+def test_elbo_grad_and_adam_match_oracle(ctx):
+    from bayesic_amd._ffi import ptr
+    rs = np.random.RandomState(11)
+    D, S, B, scale = 256, 8, 1000.0, 4.0
+    lam = svi.blr_init_lam(D) + 0.01 * rs.standard_normal(2 * D + 2)
+    eps = rs.standard_normal((S, D + 1))
+    W = (lam[:D][None] + np.exp(lam[D:2 * D])[None] * eps[:, :D]).astype(np.float32)
+    xi = lam[2 * D] + math.exp(lam[2 * D + 1]) * eps[:, D]
+    Q = rs.uniform(200, 400, S)
+    G = rs.standard_normal((S, D)) * 30
+    f64 = torch.float64
+    d = {k: ctx.to_device(v, f64) for k, v in dict(lam=lam, eps=eps, xi=xi, Q=Q, G=G).items()}
+    Wd = ctx.to_device(W)
+    elbo, grad = ctx.zeros(1, f64), ctx.zeros(2 * D + 2, f64)
+    ctx.call("bsc_blr_elbo_grad", ptr(d["lam"]), ptr(d["eps"]), ptr(Wd), ptr(d["xi"]), ptr(d["Q"]),
+             ptr(d["G"]), D, S, B, scale, 1.5, 0.7, ptr(elbo), ptr(grad))
+    ctx.sync()
+    e_ref, g_ref = svi.blr_elbo_and_grad(lam, eps, W, xi, Q, G, B, scale, 1.5, 0.7)
+    np.testing.assert_allclose(elbo.cpu().numpy()[0], e_ref, rtol=1e-10)
+    np.testing.assert_allclose(grad.cpu().numpy(), g_ref, rtol=1e-10, atol=1e-10 * np.abs(g_ref).max())
+    # Adam ascent, three steps
+    m1, m2 = np.zeros_like(lam), np.zeros_like(lam)
+    m1d, m2d = ctx.zeros(lam.size, f64), ctx.zeros(lam.size, f64)
+    lr = 0.01
+    lam_ref = lam.copy()
+    for t in (1, 2, 3):
+        ctx.call("bsc_adam_ascent", ptr(d["lam"]), ptr(grad), ptr(m1d), ptr(m2d), lam.size, t, lr,
+                 0.9, 0.999, 1e-8)
+        lam_ref, m1, m2 = svi.adam_ascent(lam_ref, g_ref, m1, m2, t, lr)
+    ctx.sync()
+    np.testing.assert_allclose(d["lam"].cpu().numpy(), lam_ref, rtol=1e-12, atol=1e-14)
+
+
+def test_full_update_steps_track_the_oracle(ctx):
+    """sample -> pass -> gradient -> Adam for several steps, on cfg-2-shaped data
+    (small B); compares the variational parameters after each step."""
+    from bayesic_amd.svi.blr import BLRReparamSVI
+    X, y, _ = svi.make_cfg2(6000, 256)
+    model = BLRReparamSVI(X, y, n_total=60000, n_samples=8, seed=1234, lr=0.01, ctx=ctx)
+    lam = svi.blr_init_lam(256)
+    m1, m2 = np.zeros_like(lam), np.zeros_like(lam)
+    for t in range(1, 6):
+        model.step()
+        lam, m1, m2, elbo, grad = svi.blr_step(lam, m1, m2, t, X, y, 8, 1234, 60000, 0.01)
+        ctx.sync()
+        g_dev = model.grad.cpu().numpy()
+        np.testing.assert_allclose(model.elbo.item(), elbo, rtol=1e-6)
+        assert np.abs(g_dev - grad).max() <= 1e-4 * np.abs(grad).max()
+        np.testing.assert_allclose(model.lam.cpu().numpy(), lam, atol=2e-4)
+
+
+def test_suffstats_normal_and_conjugate_update_cfg1(ctx):
+    """BASELINE config 1: Gaussian-Gamma, 10k rows, one latent node.  A full-batch
+    rho=1 natural-gradient step must land on the exact posterior."""
+    from bayesic_amd._ffi import ptr
+    x = svi.make_cfg1()
+    f64 = torch.float64
+    for arr in (x, x[1:], x[:5], x[3:4], x[:0]):
+        xd = ctx.to_device(arr) if arr.size else ctx.zeros(1)
+        if arr is x[1:]:
+            xd = ctx.to_device(x)[1:]            # 4-byte aligned, not 16
+        stats = ctx.zeros(3, f64)
+        ctx.call("bsc_suffstats_normal", ptr(xd), arr.size, ptr(stats))
+        ctx.sync()
+        np.testing.assert_allclose(stats.cpu().numpy(), svi.normal_suffstats(arr), rtol=1e-13)
+    xd = ctx.to_device(x)
+    stats = ctx.zeros(3, f64)
+    ctx.call("bsc_suffstats_normal", ptr(xd), x.size, ptr(stats))
+    n, sx, sxx = stats.cpu().numpy()
+    eta0 = svi.normal_gamma_to_natural(0.0, 1.0, 1.0, 1.0)
+    eta = ctx.to_device(eta0, f64).clone()
+    msg = ctx.to_device(np.array([sx, n, n, sxx]), f64)
+    ctx.call("bsc_natgrad_update", ptr(eta), ptr(ctx.to_device(eta0, f64)), ptr(msg), 4, 1.0, 1.0)
+    ctx.sync()
+    got = svi.normal_gamma_from_natural(eta.cpu().numpy())
+    want = svi.normal_gamma_posterior_closed_form(x, 0.0, 1.0, 1.0, 1.0)
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+
+
+def test_cfg2_full_size_properties(ctx):
+    """BASELINE config 2 size (1M x 256): size-independent properties.
+    Q(y=Xw) = 0-ish and G(W=0) = X^T y computed by torch on the device."""
+    from bayesic_amd._ffi import ptr
+    g = torch.Generator(device=ctx.device).manual_seed(1)
+    B, D, S = 1_000_000, 256, 8
+    X = torch.randn((B, D), generator=g, device=ctx.device, dtype=torch.float32)
+    y = torch.randn(B, generator=g, device=ctx.device, dtype=torch.float32)
+    W = torch.zeros((S, D), device=ctx.device)
+    Q, G = ctx.zeros(S, torch.float64), ctx.zeros((S, D), torch.float64)
+    ctx.call("bsc_blr_data_pass", ptr(X), D, ptr(y), B, D, ptr(W), S, ptr(Q), ptr(G))
+    ctx.sync()
+    yty = (y.double() ** 2).sum().item()
+    np.testing.assert_allclose(Q.cpu().numpy(), yty, rtol=1e-6)
+    Xty = (X.double().T @ y.double()).cpu().numpy()
+    colnorm = torch.sqrt((X.double() ** 2).sum(0)).cpu().numpy()
+    bound = math.sqrt(yty) * colnorm                      # Cauchy-Schwarz scale of the sum
+    assert (np.abs(G.cpu().numpy() - Xty[None, :]) <= 2e-5 * bound[None, :]).all()
+    # all eight samples saw the same W=0, so the rows of G must be identical
+    assert (G.cpu().numpy() == G.cpu().numpy()[0:1]).all()
