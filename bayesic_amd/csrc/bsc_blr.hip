@@ -434,8 +434,8 @@ int bsc_blr_sample(bsc_ctx* ctx, const double* lam, int32_t D, int32_t S, uint64
 int bsc_blr_data_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B,
                       int32_t D, const float* W, int32_t S, double* Q, double* G) {
     BSC_CHECK_CTX(ctx);
-    BSC_REQUIRE(X && y && W && Q && G, "bsc_blr_data_pass: null pointer");
     BSC_REQUIRE(B >= 0, "bsc_blr_data_pass: B=%lld", (long long)B);
+    BSC_REQUIRE(((X && y) || B == 0) && W && Q && G, "bsc_blr_data_pass: null pointer");
     BSC_REQUIRE(D > 0 && D <= GCOLS && D % 4 == 0,
                 "bsc_blr_data_pass: D=%d must be a multiple of 4 in [4,%d]", D, GCOLS);
     BSC_REQUIRE(S >= 1 && S <= FIN_MAX_S, "bsc_blr_data_pass: S=%d must be in [1,%d]", S,
