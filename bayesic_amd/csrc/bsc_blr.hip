@@ -10,13 +10,15 @@
 //     G[s,:] = sum_n (y_n - x_n.w_s) x_n
 // Layout: a wave owns 8-row tiles; lane l holds columns 4l..4l+3 of every row
 // (one 16-byte load per row per lane = 1 KiB coalesced per wave instruction at
-// D=256).  Forward dot products are reduced across the 64 lanes with a
-// transposing butterfly (v_permlane32_swap / v_permlane16_swap / DPP), so that
-// lane l ends up holding the residual of (row l>>3, sample l&7).  The backward
-// rank-1 updates broadcast each residual through an SGPR (v_readlane) into
-// per-lane accumulators acc[s][4] that live in registers for the whole kernel.
-// Block partials go to a slab; a second kernel sums slabs in float64 in a fixed
-// order (bitwise reproducible, no float atomics).
+// D=256).  The 64 per-lane partial dot products (8 rows x 8 samples) are
+// transposed and summed through a wave-private LDS region (no workgroup
+// barrier), the residuals are broadcast back through LDS, and the backward
+// rank-1 updates accumulate into per-lane registers acc[s][4] that live for the
+// whole kernel.  Measured VALU issue costs on gfx950 (profiles/
+// r01_ubench_valu_issue_rates.txt: v_permlane*_swap 2.9x, DPP 1.5x, SGPR-operand
+// FMA 1.55x a plain FMA) are why the cross-lane work rides the LDS pipe and
+// every FMA is all-VGPR.  Block partials go to a slab; they are summed in
+// float64 in a fixed order (bitwise reproducible, no float atomics).
 #include "bsc_common.h"
 
 namespace {
@@ -25,13 +27,21 @@ constexpr int TILE_ROWS = 8;
 constexpr int SG = 8;  // samples per pass
 constexpr int PASS_BLOCK = 256;
 constexpr int PASS_WAVES = PASS_BLOCK / BSC_WAVE;
-constexpr int GCOLS = 256;                       // column capacity of the lane layout
-constexpr int SLAB_STRIDE = SG * GCOLS + SG;     // floats per block partial
+constexpr int GCOLS = 256;                    // column capacity of the lane layout
+constexpr int SLAB_G = SG * GCOLS;            // slab[b][d*8 + s], then Q at [SLAB_G + s]
+constexpr int SLAB_STRIDE = SLAB_G + SG;      // floats per block partial
+constexpr int PSTR = 68;                      // floats per lane row of the transpose buffer
+constexpr int WAVE_LDS = 64 * PSTR + 64;      // + residual broadcast buffer
 
 struct Tile {
     float4 x[TILE_ROWS];
     float yv;
 };
+
+// After the transposing reduction lane k holds value v(k) = row*8 + sample:
+__device__ __forceinline__ int lane_value(int lane) {
+    return 4 * (lane & 15) + 2 * ((lane >> 5) & 1) + ((lane >> 4) & 1);
+}
 
 template <bool CHECK>
 __device__ __forceinline__ void load_tile(Tile& t, const float* __restrict__ X, int64_t ldx,
@@ -46,98 +56,91 @@ __device__ __forceinline__ void load_tile(Tile& t, const float* __restrict__ X, 
         if (ok) v = *reinterpret_cast<const float4*>(base + (int64_t)r * ldx);
         t.x[r] = v;
     }
-    int64_t yr = row0 + (lane >> 3);
+    int64_t yr = row0 + ((lane & 15) >> 1);  // row of lane_value(lane)
     float yv = 0.f;
     if (!CHECK || yr < B) yv = y[yr];
     t.yv = yv;
 }
 
-__device__ __forceinline__ void swap_add32(float a, float b, float& out) {
+__device__ __forceinline__ float swap_add32(float a, float b) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false,
                                               false);
-    out = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-__device__ __forceinline__ void swap_add16(float a, float b, float& out) {
+__device__ __forceinline__ float swap_add16(float a, float b) {
     auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false,
                                               false);
-    out = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-struct LaneSel {
-    bool q1, q2, q3;  // ((lane>>2)&3) == 1,2,3
-    bool l1, l2, l3;  // (lane&3) == 1,2,3
-};
-
-__device__ __forceinline__ float sel4(float v0, float v1, float v2, float v3, bool is1,
-                                      bool is2, bool is3) {
-    float r = is1 ? v1 : v0;
-    r = is2 ? v2 : r;
-    r = is3 ? v3 : r;
-    return r;
+// Orders this wave's LDS writes before its later LDS reads of other lanes'
+// data.  LDS operations of one wave execute in order; this only stops the
+// compiler from moving them.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Forward + backward for one tile.  After the butterfly, lane l holds
-// dot(x[l>>3], w[l&7]).
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+    float v = a.x * b.x;
+    v = fmaf(a.y, b.y, v);
+    v = fmaf(a.z, b.z, v);
+    return fmaf(a.w, b.w, v);
+}
+
+__device__ __forceinline__ void axpy4(float4& acc, float c, const float4& x) {
+    acc.x = fmaf(c, x.x, acc.x);
+    acc.y = fmaf(c, x.y, acc.y);
+    acc.z = fmaf(c, x.z, acc.z);
+    acc.w = fmaf(c, x.w, acc.w);
+}
+
+// Forward + backward for one tile; `wl` is this wave's LDS region.
 __device__ __forceinline__ void compute_tile(const Tile& t, const float4 (&w)[SG],
-                                             float4 (&acc)[SG], float& qacc,
-                                             const LaneSel& ls) {
-    float p[TILE_ROWS * SG];
+                                             float4 (&acc)[SG], float& qacc, float* wl,
+                                             int lane) {
+    // 1. per-lane partial dots, row by row, into this lane's row of the buffer
+    float* mine = wl + lane * PSTR;
 #pragma unroll
     for (int r = 0; r < TILE_ROWS; ++r) {
-#pragma unroll
-        for (int s = 0; s < SG; ++s) {
-            float v = t.x[r].x * w[s].x;
-            v = fmaf(t.x[r].y, w[s].y, v);
-            v = fmaf(t.x[r].z, w[s].z, v);
-            v = fmaf(t.x[r].w, w[s].w, v);
-            p[r * SG + s] = v;
-        }
+        float4 lo, hi;
+        lo.x = dot4(t.x[r], w[0]); lo.y = dot4(t.x[r], w[1]);
+        lo.z = dot4(t.x[r], w[2]); lo.w = dot4(t.x[r], w[3]);
+        hi.x = dot4(t.x[r], w[4]); hi.y = dot4(t.x[r], w[5]);
+        hi.z = dot4(t.x[r], w[6]); hi.w = dot4(t.x[r], w[7]);
+        *reinterpret_cast<float4*>(mine + r * SG) = lo;
+        *reinterpret_cast<float4*>(mine + r * SG + 4) = hi;
     }
-    // 64 values/lane -> 32: lanes 0-31 keep value i, lanes 32-63 value i+32.
-    float a[32];
+    wave_lds_sync();
+    // 2. lane k sums values 4g..4g+3 (g = k&15) over the 16 lane-rows l = 4i + q
+    const int g = lane & 15, q = lane >> 4;
+    const float* col = wl + q * PSTR + 4 * g;
+    float4 s4 = *reinterpret_cast<const float4*>(col);
 #pragma unroll
-    for (int i = 0; i < 32; ++i) swap_add32(p[i], p[i + 32], a[i]);
-    // 32 -> 16: rows with lane bit 4 clear keep i, set keep i+16.
-    float b[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) swap_add16(a[i], a[i + 16], b[i]);
-    // 16 -> 4: sum over the 4 lanes of the row sharing lane&3 (rotation
-    // direction is irrelevant: ror8 then ror4 of a period-8 value), then keep
-    // the value selected by lane bits 2-3.
-    float c[4];
-    {
-        float u[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float h = b[i] + dpp_f32<DPP_ROW_ROR8>(b[i]);
-            u[i] = h + dpp_f32<DPP_ROW_ROR4>(h);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            c[i] = sel4(u[i], u[i + 4], u[i + 8], u[i + 12], ls.q1, ls.q2, ls.q3);
+    for (int i = 1; i < 16; ++i) {
+        float4 v = *reinterpret_cast<const float4*>(col + 4 * i * PSTR);
+        s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
     }
-    // 4 -> 1 inside the quad.
-    float v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float h = c[i] + dpp_f32<DPP_QUAD_XOR1>(c[i]);
-        v[i] = h + dpp_f32<DPP_QUAD_XOR2>(h);
-    }
-    float dot = sel4(v[0], v[1], v[2], v[3], ls.l1, ls.l2, ls.l3);
+    // 3. fold the four q groups: lane k ends with value lane_value(k)
+    float t0 = swap_add32(s4.x, s4.z);
+    float t1 = swap_add32(s4.y, s4.w);
+    float dot = swap_add16(t0, t1);
     float resid = t.yv - dot;
     qacc = fmaf(resid, resid, qacc);
-    // backward: acc[s] += resid(r,s) * x[r]
+    float* rb = wl + 64 * PSTR;
+    rb[lane_value(lane)] = resid;
+    wave_lds_sync();
+    // 4. backward: acc[s] += resid(r,s) * x[r]; residuals arrive by LDS broadcast
 #pragma unroll
     for (int r = 0; r < TILE_ROWS; ++r) {
-#pragma unroll
-        for (int s = 0; s < SG; ++s) {
-            float cst = readlane_f32(resid, r * SG + s);
-            acc[s].x = fmaf(cst, t.x[r].x, acc[s].x);
-            acc[s].y = fmaf(cst, t.x[r].y, acc[s].y);
-            acc[s].z = fmaf(cst, t.x[r].z, acc[s].z);
-            acc[s].w = fmaf(cst, t.x[r].w, acc[s].w);
-        }
+        float4 c0 = *reinterpret_cast<const float4*>(rb + r * SG);
+        float4 c1 = *reinterpret_cast<const float4*>(rb + r * SG + 4);
+        axpy4(acc[0], c0.x, t.x[r]); axpy4(acc[1], c0.y, t.x[r]);
+        axpy4(acc[2], c0.z, t.x[r]); axpy4(acc[3], c0.w, t.x[r]);
+        axpy4(acc[4], c1.x, t.x[r]); axpy4(acc[5], c1.y, t.x[r]);
+        axpy4(acc[6], c1.z, t.x[r]); axpy4(acc[7], c1.w, t.x[r]);
     }
 }
 
@@ -145,19 +148,14 @@ template <bool FULL>  // FULL: D == 256, every lane owns four live columns
 __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ y, int64_t B, int D,
     const float* __restrict__ W, int S, float* __restrict__ slab) {
-    __shared__ float lds[PASS_WAVES][SLAB_STRIDE];
+    // one array: wave-private regions during the loop, [wave][SLAB_STRIDE] in the epilogue
+    __shared__ __attribute__((aligned(16))) float lds[PASS_WAVES * WAVE_LDS];
+    static_assert(PASS_WAVES * WAVE_LDS >= PASS_WAVES * SLAB_STRIDE, "epilogue alias");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const bool lane_active = FULL ? true : (4 * lane < D);
-
-    LaneSel ls;
-    ls.q1 = ((lane >> 2) & 3) == 1;
-    ls.q2 = ((lane >> 2) & 3) == 2;
-    ls.q3 = ((lane >> 2) & 3) == 3;
-    ls.l1 = (lane & 3) == 1;
-    ls.l2 = (lane & 3) == 2;
-    ls.l3 = (lane & 3) == 3;
+    float* wl = lds + wave * WAVE_LDS;
 
     float4 w[SG], acc[SG];
 #pragma unroll
@@ -185,7 +183,7 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_kernel(
             if (nxt < n_full) load_tile<false>(tb, X, ldx, y, nxt * TILE_ROWS, B, lane, lane_active);
             else load_tile<true>(tb, X, ldx, y, nxt * TILE_ROWS, B, lane, lane_active);
         }
-        compute_tile(ta, w, acc, qacc, ls);
+        compute_tile(ta, w, acc, qacc, wl, lane);
         tile = nxt;
         if (tile >= n_tiles) break;
         nxt = tile + stride;
@@ -193,25 +191,30 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_kernel(
             if (nxt < n_full) load_tile<false>(ta, X, ldx, y, nxt * TILE_ROWS, B, lane, lane_active);
             else load_tile<true>(ta, X, ldx, y, nxt * TILE_ROWS, B, lane, lane_active);
         }
-        compute_tile(tb, w, acc, qacc, ls);
+        compute_tile(tb, w, acc, qacc, wl, lane);
         tile = nxt;
     }
 
     // block reduction through LDS, fixed order over waves
+    __syncthreads();  // every wave is done with its private region
+    float* ep = lds + wave * SLAB_STRIDE;
 #pragma unroll
     for (int s = 0; s < SG; ++s)
-        *reinterpret_cast<float4*>(&lds[wave][s * GCOLS + 4 * lane]) = acc[s];
-    float q = qacc;  // lane l: sample l&7, rows l>>3
-    q += __shfl_xor(q, 8);
-    q += __shfl_xor(q, 16);
-    q += __shfl_xor(q, 32);
-    if (lane < SG) lds[wave][SG * GCOLS + lane] = q;
+        *reinterpret_cast<float4*>(ep + s * GCOLS + 4 * lane) = acc[s];
+    // qacc of lane k belongs to sample lane_value(k)&7; fold the 8 rows (lane bits 1-3)
+    float qv = qacc;
+    qv += __shfl_xor(qv, 2);
+    qv += __shfl_xor(qv, 4);
+    qv += __shfl_xor(qv, 8);
+    if ((lane & 14) == 0) ep[SLAB_G + (lane_value(lane) & 7)] = qv;
     __syncthreads();
     float* out = slab + (int64_t)blockIdx.x * SLAB_STRIDE;
     for (int i = tid; i < SLAB_STRIDE; i += PASS_BLOCK) {
-        float v = lds[0][i];
+        // slab order is [d][s] so that a finisher reads 8 columns x 8 samples as one 256-B run
+        const int src = i < SLAB_G ? (i & 7) * GCOLS + (i >> 3) : i;
+        float v = lds[src];
 #pragma unroll
-        for (int k = 1; k < PASS_WAVES; ++k) v += lds[k][i];
+        for (int k = 1; k < PASS_WAVES; ++k) v += lds[k * SLAB_STRIDE + src];
         out[i] = v;
     }
 }
@@ -239,11 +242,11 @@ __global__ __launch_bounds__(RED_BLOCK) void blr_slab_reduce_kernel(
         double tot = part[0][lane];
 #pragma unroll
         for (int k = 1; k < RED_WAVES; ++k) tot += part[k][lane];
-        if (i < SG * GCOLS) {
-            int s = i / GCOLS, d = i % GCOLS;
+        if (i < SLAB_G) {
+            int s = i & 7, d = i >> 3;
             if (s_base + s < S && d < D) G[(int64_t)(s_base + s) * D + d] = tot;
         } else {
-            int s = i - SG * GCOLS;
+            int s = i - SLAB_G;
             if (s_base + s < S) Q[s_base + s] = tot;
         }
     }
@@ -304,49 +307,62 @@ __global__ void philox_normal_kernel(uint64_t seed, uint32_t stream, uint32_t st
         if (4 * b + j < n_params) eps[(int64_t)s * n_params + 4 * b + j] = z[j];
 }
 
+// Draws for Philox block `pb` (columns 4pb..4pb+3) of sample s, given m, rho
+// indexed by absolute column.
+__device__ __forceinline__ void blr_draw_block(const double* m, const double* rho, int D, int s,
+                                               int pb, uint64_t seed, uint32_t step,
+                                               double* __restrict__ eps, float* __restrict__ W) {
+    double z[4];
+    philox_normal4(seed, (uint32_t)pb, (uint32_t)s, 0u, step, z);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int d = 4 * pb + j;
+        if (d < D) {
+            eps[(int64_t)s * (D + 1) + d] = z[j];
+            double sd = exp(rho[d]);
+            double wv = m[d] + sd * z[j];
+            W[(int64_t)s * D + d] = (float)wv;
+        }
+    }
+}
+
+__device__ __forceinline__ void blr_draw_scale(double a, double b, int D, int s, uint64_t seed,
+                                               uint32_t step, double* __restrict__ eps,
+                                               double* __restrict__ xi) {
+    double z[4];
+    philox_normal4(seed, 0u, (uint32_t)s, 1u, step, z);
+    eps[(int64_t)s * (D + 1) + D] = z[0];
+    double sd = exp(b);
+    xi[s] = a + sd * z[0];
+}
+
 __global__ void blr_sample_kernel(const double* __restrict__ lam, int D, int S, uint64_t seed,
                                   uint32_t step, double* __restrict__ eps,
                                   float* __restrict__ W, double* __restrict__ xi) {
     const int n_blocks = (D + 3) / 4;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < S * n_blocks) {
-        const int s = idx / n_blocks, b = idx % n_blocks;
-        double z[4];
-        philox_normal4(seed, (uint32_t)b, (uint32_t)s, 0u, step, z);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int d = 4 * b + j;
-            if (d < D) {
-                eps[(int64_t)s * (D + 1) + d] = z[j];
-                double sd = exp(lam[D + d]);
-                double wv = lam[d] + sd * z[j];
-                W[(int64_t)s * D + d] = (float)wv;
-            }
-        }
+        blr_draw_block(lam, lam + D, D, idx / n_blocks, idx % n_blocks, seed, step, eps, W);
     } else if (idx < S * n_blocks + S) {
-        const int s = idx - S * n_blocks;
-        double z[4];
-        philox_normal4(seed, 0u, (uint32_t)s, 1u, step, z);
-        eps[(int64_t)s * (D + 1) + D] = z[0];
-        double sd = exp(lam[2 * D + 1]);
-        xi[s] = lam[2 * D] + sd * z[0];
+        blr_draw_scale(lam[2 * D], lam[2 * D + 1], D, idx - S * n_blocks, seed, step, eps, xi);
     }
 }
 
 // One workgroup.  Thread d owns column d (strided when D > blockDim).
 constexpr int FIN_BLOCK = 256;
+constexpr int FIN_WAVES = FIN_BLOCK / BSC_WAVE;
 constexpr int FIN_MAX_S = 64;
+constexpr double LOG_2PI = 1.8378770664093454835606594728112;
 
 __global__ __launch_bounds__(FIN_BLOCK) void blr_elbo_grad_kernel(
     const double* __restrict__ lam, const double* __restrict__ eps,
     const float* __restrict__ W, const double* __restrict__ xi, const double* __restrict__ Q,
     const double* __restrict__ G, int D, int S, double batch_rows, double scale, double alpha0,
     double beta0, double* __restrict__ elbo, double* __restrict__ grad) {
-    __shared__ double red[FIN_BLOCK / BSC_WAVE][FIN_MAX_S + 1];
+    __shared__ double red[FIN_WAVES][FIN_MAX_S + 1];
     __shared__ double wsq[FIN_MAX_S];
     __shared__ double e_inv[FIN_MAX_S];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double LOG_2PI = 1.8378770664093454835606594728112;
 
     // |w_s|^2 for every sample and sum(rho), fixed-order block reduction
     for (int s = 0; s <= S; ++s) {
@@ -365,7 +381,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void blr_elbo_grad_kernel(
     __syncthreads();
     if (tid < S) {
         double t = 0.0;
-        for (int k = 0; k < FIN_BLOCK / BSC_WAVE; ++k) t += red[k][tid];
+        for (int k = 0; k < FIN_WAVES; ++k) t += red[k][tid];
         wsq[tid] = t;
         e_inv[tid] = exp(-xi[tid]);
     }
@@ -385,7 +401,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void blr_elbo_grad_kernel(
     }
     if (tid == 0) {
         double sum_rho = 0.0;
-        for (int k = 0; k < FIN_BLOCK / BSC_WAVE; ++k) sum_rho += red[k][S];
+        for (int k = 0; k < FIN_WAVES; ++k) sum_rho += red[k][S];
         const double b = lam[2 * D + 1];
         double fa = 0.0, fb = 0.0, fsum = 0.0;
         for (int s = 0; s < S; ++s) {
@@ -403,6 +419,233 @@ __global__ __launch_bounds__(FIN_BLOCK) void blr_elbo_grad_kernel(
         grad[2 * D + 1] = fb * inv_S * exp(b) + 1.0;
         elbo[0] = fsum * inv_S + sum_rho + b + 0.5 * (double)(D + 1) * (1.0 + LOG_2PI);
     }
+}
+
+// ---- fused finish: slab reduce + ELBO/gradient + Adam + next draw ----------
+//
+// Grid = ceil(D/8) column workgroups + 1 scalar workgroup.  A column workgroup
+// owns 8 columns x S<=8 samples (one 256-B run per slab row); the scalar
+// workgroup owns Q, |w_s|^2, the entropy term, (a, b) and the ELBO.  State is
+// double-buffered by the caller (lam_in/lam_out, cur/next draws) so no
+// workgroup reads what another one writes.
+struct FusedArgs {
+    const float* slab;     // block partials of the pass kernel, or nullptr
+    int n_slab;            // slab rows
+    const double* stats;   // [Q (S) | G (S*D)] when slab == nullptr
+    const double* lam_in;
+    double* lam_out;
+    double* m1;
+    double* m2;
+    const double* eps;
+    const float* W;
+    const double* xi;
+    double* eps_next;      // nullptr: no next draw
+    float* W_next;
+    double* xi_next;
+    double* elbo;
+    double* grad;
+    int D, S;
+    double batch_rows, scale, alpha0, beta0;
+    double lr, beta1, beta2, adam_eps, corr1, corr2;
+    uint64_t seed;
+    uint32_t next_step;
+};
+
+__device__ __forceinline__ double adam_ascent_one(double lam, double g, double& m1, double& m2,
+                                                  const FusedArgs& a) {
+    const double na = a.beta1 * m1 + (1.0 - a.beta1) * g;
+    const double nb = a.beta2 * m2 + (1.0 - a.beta2) * g * g;
+    m1 = na;
+    m2 = nb;
+    const double mhat = na / a.corr1;
+    const double vhat = nb / a.corr2;
+    return lam + a.lr * mhat / (sqrt(vhat) + a.adam_eps);
+}
+
+__global__ __launch_bounds__(FIN_BLOCK) void blr_fused_update_kernel(FusedArgs a) {
+    __shared__ double red[FIN_WAVES][BSC_WAVE];
+    __shared__ double sh[2 * FIN_MAX_S + 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = a.D, S = a.S;
+    const int n_chunks = (D + 7) / 8;
+    const double inv_S = 1.0 / (double)S;
+
+    if ((int)blockIdx.x < n_chunks) {
+        // ---------------- column workgroup: columns d0 .. d0+7 ----------------
+        const int d0 = 8 * blockIdx.x;
+        const int dl = lane >> 3, sl = lane & 7;  // slab order within the run is [d][s]
+        const int d = d0 + dl;
+        double gm = 0.0, gr = 0.0;
+        for (int s0 = 0; s0 < S; s0 += 8) {
+            const int s = s0 + sl;
+            double g = 0.0;
+            if (a.slab) {  // S <= 8 here: a single trip through this loop
+                double part = 0.0;
+                const float* p = a.slab + 64 * blockIdx.x + lane;
+                for (int b = wave; b < a.n_slab; b += FIN_WAVES)
+                    part += (double)p[(int64_t)b * SLAB_STRIDE];
+                red[wave][lane] = part;
+                __syncthreads();
+                g = red[0][lane];
+#pragma unroll
+                for (int k = 1; k < FIN_WAVES; ++k) g += red[k][lane];
+            } else if (s < S && d < D) {
+                g = a.stats[S + (int64_t)s * D + d];
+            }
+            if (s < S && d < D) {
+                const double wv = (double)a.W[(int64_t)s * D + d];
+                const double dw = exp(-a.xi[s]) * (a.scale * g - wv);
+                gm += dw;
+                gr += dw * a.eps[(int64_t)s * (D + 1) + d];
+            }
+        }
+        if (wave != 0) return;
+        // fold the 8 sample lanes (lane bits 0-2)
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            gm += __shfl_xor(gm, off);
+            gr += __shfl_xor(gr, off);
+        }
+        double* new_m = sh;        // [8]
+        double* new_rho = sh + 8;  // [8]
+        if (sl == 0 && d < D) {
+            const double rho = a.lam_in[D + d];
+            const double g_m = gm * inv_S;
+            const double g_r = gr * inv_S * exp(rho) + 1.0;
+            a.grad[d] = g_m;
+            a.grad[D + d] = g_r;
+            double m1 = a.m1[d], m2 = a.m2[d];
+            const double nm = adam_ascent_one(a.lam_in[d], g_m, m1, m2, a);
+            a.m1[d] = m1; a.m2[d] = m2;
+            double r1 = a.m1[D + d], r2 = a.m2[D + d];
+            const double nr = adam_ascent_one(rho, g_r, r1, r2, a);
+            a.m1[D + d] = r1; a.m2[D + d] = r2;
+            a.lam_out[d] = nm;
+            a.lam_out[D + d] = nr;
+            new_m[dl] = nm;
+            new_rho[dl] = nr;
+        }
+        wave_lds_sync();
+        if (a.eps_next) {
+            // two Philox blocks per sample cover the 8 columns
+            for (int i = lane; i < 2 * S; i += BSC_WAVE) {
+                const int s = i >> 1, pb = 2 * blockIdx.x + (i & 1);
+                if (4 * pb < D)
+                    blr_draw_block(new_m - d0, new_rho - d0, D, s, pb, a.seed, a.next_step,
+                                   a.eps_next, a.W_next);
+            }
+        }
+        return;
+    }
+
+    // ---------------------------- scalar workgroup ----------------------------
+    double* Qs = sh;                    // [S]
+    double* wsq = sh + FIN_MAX_S;       // [S]
+    double* misc = sh + 2 * FIN_MAX_S;  // [1]=new a [2]=new b
+    if (a.slab) {  // S <= 8: thread -> (sample tid&7, slab-row group tid>>3)
+        double part = 0.0;
+        for (int b = tid >> 3; b < a.n_slab; b += FIN_BLOCK / 8)
+            part += (double)a.slab[(int64_t)b * SLAB_STRIDE + SLAB_G + (tid & 7)];
+        double* stage = &red[0][0];  // [32][8]
+        stage[tid] = part;
+        __syncthreads();
+        if (tid < 8) {
+            double t = 0.0;
+            for (int k = 0; k < FIN_BLOCK / 8; ++k) t += stage[8 * k + tid];
+            Qs[tid] = t;
+        }
+        __syncthreads();
+    } else {
+        for (int s = tid; s < S; s += FIN_BLOCK) Qs[s] = a.stats[s];
+    }
+    // |w_s|^2: wave-per-sample, fixed order
+    for (int s = wave; s < S; s += FIN_WAVES) {
+        double part = 0.0;
+        for (int d = lane; d < D; d += BSC_WAVE) {
+            const double wv = (double)a.W[(int64_t)s * D + d];
+            part += wv * wv;
+        }
+        part = wave_allsum_f64(part);
+        if (lane == 0) wsq[s] = part;
+    }
+    {
+        double part = 0.0;
+        for (int d = tid; d < D; d += FIN_BLOCK) part += a.lam_in[D + d];
+        part = wave_allsum_f64(part);
+        __syncthreads();  // `red` was the Q staging area
+        if (lane == 0) red[wave][0] = part;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double sum_rho = 0.0;
+        for (int k = 0; k < FIN_WAVES; ++k) sum_rho += red[k][0];
+        const double av = a.lam_in[2 * D], bv = a.lam_in[2 * D + 1];
+        double fa = 0.0, fb = 0.0, fsum = 0.0;
+        for (int s = 0; s < S; ++s) {
+            const double x = a.xi[s], e = exp(-x);
+            const double dxi = -0.5 * (a.scale * a.batch_rows + (double)D) - a.alpha0 +
+                               e * (0.5 * a.scale * Qs[s] + 0.5 * wsq[s] + a.beta0);
+            fa += dxi;
+            fb += dxi * a.eps[(int64_t)s * (D + 1) + D];
+            const double loglik =
+                a.scale * (-0.5 * a.batch_rows * (LOG_2PI + x) - 0.5 * e * Qs[s]);
+            const double logpw = -0.5 * (double)D * (LOG_2PI + x) - 0.5 * e * wsq[s];
+            const double logpxi =
+                a.alpha0 * log(a.beta0) - lgamma(a.alpha0) - a.alpha0 * x - a.beta0 * e;
+            fsum += loglik + logpw + logpxi;
+        }
+        const double g_a = fa * inv_S;
+        const double g_b = fb * inv_S * exp(bv) + 1.0;
+        a.grad[2 * D] = g_a;
+        a.grad[2 * D + 1] = g_b;
+        a.elbo[0] = fsum * inv_S + sum_rho + bv + 0.5 * (double)(D + 1) * (1.0 + LOG_2PI);
+        double m1 = a.m1[2 * D], m2 = a.m2[2 * D];
+        const double na = adam_ascent_one(av, g_a, m1, m2, a);
+        a.m1[2 * D] = m1; a.m2[2 * D] = m2;
+        double b1 = a.m1[2 * D + 1], b2 = a.m2[2 * D + 1];
+        const double nb = adam_ascent_one(bv, g_b, b1, b2, a);
+        a.m1[2 * D + 1] = b1; a.m2[2 * D + 1] = b2;
+        a.lam_out[2 * D] = na;
+        a.lam_out[2 * D + 1] = nb;
+        misc[1] = na;
+        misc[2] = nb;
+    }
+    __syncthreads();
+    if (a.eps_next)
+        for (int s = tid; s < S; s += FIN_BLOCK)
+            blr_draw_scale(misc[1], misc[2], D, s, a.seed, a.next_step, a.eps_next, a.xi_next);
+}
+
+int pass_grid(bsc_ctx* ctx, int64_t B) {
+    const int64_t n_tiles = (B + TILE_ROWS - 1) / TILE_ROWS;
+    int64_t want = (n_tiles + PASS_WAVES - 1) / PASS_WAVES;
+    const int64_t cap = 2 * (int64_t)ctx->cu_count;
+    return (int)(want < 1 ? 1 : (want > cap ? cap : want));
+}
+
+int check_pass_args(const float* X, int64_t ldx, const float* y, int64_t B, int32_t D,
+                    const float* W, int32_t S, int max_s) {
+    BSC_REQUIRE(B >= 0, "bsc_blr_data_pass: B=%lld", (long long)B);
+    BSC_REQUIRE(((X && y) || B == 0) && W, "bsc_blr_data_pass: null pointer");
+    BSC_REQUIRE(D > 0 && D <= GCOLS && D % 4 == 0,
+                "bsc_blr_data_pass: D=%d must be a multiple of 4 in [4,%d]", D, GCOLS);
+    BSC_REQUIRE(S >= 1 && S <= max_s, "bsc_blr_data_pass: S=%d must be in [1,%d]", S, max_s);
+    BSC_REQUIRE(ldx >= D && ldx % 4 == 0,
+                "bsc_blr_data_pass: ldx=%lld must be >= D and %% 4 == 0", (long long)ldx);
+    BSC_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0,
+                "bsc_blr_data_pass: X and W must be 16-byte aligned");
+    return BSC_OK;
+}
+
+void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B, int D,
+                 const float* W, int sg, int n_blocks, float* slab) {
+    bsc_prof_scope prof(ctx);  // times the pass kernel alone
+    if (D == GCOLS)
+        hipLaunchKernelGGL(blr_pass_kernel<true>, dim3(n_blocks), dim3(PASS_BLOCK), 0,
+                           ctx->stream, X, ldx, y, B, D, W, sg, slab);
+    else
+        hipLaunchKernelGGL(blr_pass_kernel<false>, dim3(n_blocks), dim3(PASS_BLOCK), 0,
+                           ctx->stream, X, ldx, y, B, D, W, sg, slab);
 }
 
 }  // namespace
@@ -434,40 +677,39 @@ int bsc_blr_sample(bsc_ctx* ctx, const double* lam, int32_t D, int32_t S, uint64
 int bsc_blr_data_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B,
                       int32_t D, const float* W, int32_t S, double* Q, double* G) {
     BSC_CHECK_CTX(ctx);
-    BSC_REQUIRE(B >= 0, "bsc_blr_data_pass: B=%lld", (long long)B);
-    BSC_REQUIRE(((X && y) || B == 0) && W && Q && G, "bsc_blr_data_pass: null pointer");
-    BSC_REQUIRE(D > 0 && D <= GCOLS && D % 4 == 0,
-                "bsc_blr_data_pass: D=%d must be a multiple of 4 in [4,%d]", D, GCOLS);
-    BSC_REQUIRE(S >= 1 && S <= FIN_MAX_S, "bsc_blr_data_pass: S=%d must be in [1,%d]", S,
-                FIN_MAX_S);
-    BSC_REQUIRE(ldx >= D && ldx % 4 == 0, "bsc_blr_data_pass: ldx=%lld must be >= D and %% 4 == 0",
-                (long long)ldx);
-    BSC_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0,
-                "bsc_blr_data_pass: X and W must be 16-byte aligned");
-    const int64_t n_tiles = (B + TILE_ROWS - 1) / TILE_ROWS;
-    int64_t want = (n_tiles + PASS_WAVES - 1) / PASS_WAVES;
-    int n_blocks = (int)(want < 1 ? 1 : (want > 2 * ctx->cu_count ? 2 * ctx->cu_count : want));
+    int rc = check_pass_args(X, ldx, y, B, D, W, S, FIN_MAX_S);
+    if (rc != BSC_OK) return rc;
+    BSC_REQUIRE(Q && G, "bsc_blr_data_pass: null output");
+    const int n_blocks = pass_grid(ctx, B);
     void* ws = nullptr;
-    int rc = bsc_workspace(ctx, (size_t)n_blocks * SLAB_STRIDE * sizeof(float), &ws);
+    rc = bsc_workspace(ctx, (size_t)n_blocks * SLAB_STRIDE * sizeof(float), &ws);
     if (rc != BSC_OK) return rc;
     float* slab = (float*)ws;
+    ctx->slab_rows = 0;  // the slab is consumed here
     for (int s0 = 0; s0 < S; s0 += SG) {
         const int sg = (S - s0 < SG) ? (S - s0) : SG;
-        {
-        bsc_prof_scope prof(ctx);  // times the pass kernel alone
-        if (D == GCOLS)
-            hipLaunchKernelGGL(blr_pass_kernel<true>, dim3(n_blocks), dim3(PASS_BLOCK), 0,
-                               ctx->stream, X, ldx, y, B, (int)D, W + (int64_t)s0 * D, sg, slab);
-        else
-            hipLaunchKernelGGL(blr_pass_kernel<false>, dim3(n_blocks), dim3(PASS_BLOCK), 0,
-                               ctx->stream, X, ldx, y, B, (int)D, W + (int64_t)s0 * D, sg, slab);
-        }
+        launch_pass(ctx, X, ldx, y, B, (int)D, W + (int64_t)s0 * D, sg, n_blocks, slab);
         BSC_LAUNCH_CHECK();
         hipLaunchKernelGGL(blr_slab_reduce_kernel, dim3((SLAB_STRIDE + BSC_WAVE - 1) / BSC_WAVE),
                            dim3(RED_BLOCK), 0, ctx->stream, slab, n_blocks, (int)D, (int)S, s0, Q,
                            G);
         BSC_LAUNCH_CHECK();
     }
+    return BSC_OK;
+}
+
+int bsc_blr_data_pass_partial(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y,
+                              int64_t B, int32_t D, const float* W, int32_t S) {
+    BSC_CHECK_CTX(ctx);
+    int rc = check_pass_args(X, ldx, y, B, D, W, S, SG);
+    if (rc != BSC_OK) return rc;
+    const int n_blocks = pass_grid(ctx, B);
+    void* ws = nullptr;
+    rc = bsc_workspace(ctx, (size_t)n_blocks * SLAB_STRIDE * sizeof(float), &ws);
+    if (rc != BSC_OK) return rc;
+    launch_pass(ctx, X, ldx, y, B, (int)D, W, (int)S, n_blocks, (float*)ws);
+    BSC_LAUNCH_CHECK();
+    ctx->slab_rows = n_blocks;
     return BSC_OK;
 }
 
@@ -482,6 +724,53 @@ int bsc_blr_elbo_grad(bsc_ctx* ctx, const double* lam, const double* eps, const 
     BSC_REQUIRE(alpha0 > 0 && beta0 > 0, "bsc_blr_elbo_grad: alpha0, beta0 must be positive");
     hipLaunchKernelGGL(blr_elbo_grad_kernel, dim3(1), dim3(FIN_BLOCK), 0, ctx->stream, lam, eps, W,
                        xi, Q, G, (int)D, (int)S, batch_rows, scale, alpha0, beta0, elbo, grad);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_blr_fused_update(bsc_ctx* ctx, const double* stats, const double* lam_in, double* lam_out,
+                         double* m1, double* m2, const double* eps, const float* W,
+                         const double* xi, int32_t D, int32_t S, double batch_rows, double scale,
+                         double alpha0, double beta0, int64_t t, double lr, double beta1,
+                         double beta2, double adam_eps, uint64_t seed, uint32_t next_step,
+                         double* eps_next, float* W_next, double* xi_next, double* elbo,
+                         double* grad) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(lam_in && lam_out && m1 && m2 && eps && W && xi && elbo && grad,
+                "bsc_blr_fused_update: null pointer");
+    BSC_REQUIRE(lam_in != lam_out, "bsc_blr_fused_update: lam_in and lam_out must differ");
+    BSC_REQUIRE(D > 0 && S >= 1 && S <= FIN_MAX_S, "bsc_blr_fused_update: D=%d S=%d (S<=%d)", D,
+                S, FIN_MAX_S);
+    BSC_REQUIRE(alpha0 > 0 && beta0 > 0 && t >= 1, "bsc_blr_fused_update: bad hyper-parameters");
+    BSC_REQUIRE((eps_next && W_next && xi_next) || (!eps_next && !W_next && !xi_next),
+                "bsc_blr_fused_update: next-draw buffers must be all set or all null");
+    BSC_REQUIRE(!eps_next || (eps_next != eps && W_next != W && xi_next != xi),
+                "bsc_blr_fused_update: next-draw buffers must not alias the current draws");
+    FusedArgs a;
+    a.stats = stats;
+    a.slab = nullptr;
+    a.n_slab = 0;
+    if (!stats) {
+        BSC_REQUIRE(ctx->slab_rows > 0 && ctx->workspace,
+                    "bsc_blr_fused_update: stats is null and no bsc_blr_data_pass_partial slab "
+                    "is pending");
+        BSC_REQUIRE(S <= SG && D <= GCOLS, "bsc_blr_fused_update: slab input needs S<=8, D<=256");
+        a.slab = (const float*)ctx->workspace;
+        a.n_slab = ctx->slab_rows;
+    }
+    a.lam_in = lam_in; a.lam_out = lam_out; a.m1 = m1; a.m2 = m2;
+    a.eps = eps; a.W = W; a.xi = xi;
+    a.eps_next = eps_next; a.W_next = W_next; a.xi_next = xi_next;
+    a.elbo = elbo; a.grad = grad;
+    a.D = D; a.S = S;
+    a.batch_rows = batch_rows; a.scale = scale; a.alpha0 = alpha0; a.beta0 = beta0;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.adam_eps = adam_eps;
+    a.corr1 = 1.0 - pow(beta1, (double)t);
+    a.corr2 = 1.0 - pow(beta2, (double)t);
+    a.seed = seed;
+    a.next_step = next_step;
+    hipLaunchKernelGGL(blr_fused_update_kernel, dim3((D + 7) / 8 + 1), dim3(FIN_BLOCK), 0,
+                       ctx->stream, a);
     BSC_LAUNCH_CHECK();
     return BSC_OK;
 }

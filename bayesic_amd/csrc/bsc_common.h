@@ -17,6 +17,7 @@ struct bsc_ctx {
     void* workspace = nullptr;   // partial-sum slabs; grown on demand
     size_t workspace_bytes = 0;
     int cu_count = 256;
+    int slab_rows = 0;  // block partials left in `workspace` by bsc_blr_data_pass_partial
     // optional per-kernel timing of the dominant kernel (bsc_ctx_profile)
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;  // recorded pairs

@@ -9,10 +9,15 @@ bayesic/distribution/base.py:47-69.
 Model:  y_n ~ N(x_n.w, s2),  w | s2 ~ N(0, s2 I),  s2 ~ InvGamma(alpha0, beta0)
 q:      w ~ N(m, diag e^{2 rho}),  log s2 ~ N(a, e^{2b});  lam = [m, rho, a, b].
 
+One update is two launches on one GPU -- the streaming data pass and a fused
+finish (float64 reduction of the pass partials, ELBO + pathwise gradient, Adam
+step, next step's Philox draws) -- with lam and the draws double-buffered.
+
 Data parallelism: each rank holds a contiguous block of mini-batch rows.  The
 only exchange per update is ONE all-reduce(sum) of the float64 vector
-[Q (S), G (S*D)] (16 KB at S=8, D=256); noise is keyed by (seed, step, sample,
-parameter) and never by rank, so all ranks apply the identical update.
+[Q (S), G (S*D)] (16 KB at S=8, D=256) between the pass and the finish; noise is
+keyed by (seed, step, sample, parameter) and never by rank, so all ranks apply
+the identical update.
 """
 import math
 
@@ -24,7 +29,7 @@ from .._ffi import ptr
 
 class BLRReparamSVI:
     def __init__(self, X, y, n_total=None, n_samples=8, seed=1234, lr=1e-2, alpha0=1.0,
-                 beta0=1.0, ctx=None, group=None, lam0=None):
+                 beta0=1.0, ctx=None, group=None, lam0=None, fused=True):
         self.ctx = ctx or default_context()
         dev = self.ctx.device
         self.X = X if isinstance(X, torch.Tensor) else self.ctx.to_device(X, torch.float32)
@@ -51,32 +56,58 @@ class BLRReparamSVI:
             torch.distributed.all_reduce(rows, group=self.group)
         self.batch_rows = float(rows.item())
         self.n_total = float(n_total) if n_total is not None else self.batch_rows
+        self.fused = bool(fused)
         D, S = self.D, self.S
         f64 = torch.float64
-        self.lam = torch.zeros(2 * D + 2, dtype=f64, device=dev)
+        # double-buffered state: index t & 1 is current at the start of step t+1
+        self._lam = torch.zeros((2, 2 * D + 2), dtype=f64, device=dev)
         if lam0 is None:
-            self.lam[D:2 * D] = math.log(0.1)
-            self.lam[2 * D + 1] = math.log(0.1)
+            self._lam[0, D:2 * D] = math.log(0.1)
+            self._lam[0, 2 * D + 1] = math.log(0.1)
         else:
-            self.lam.copy_(torch.as_tensor(lam0, dtype=f64))
-        self.m1 = torch.zeros_like(self.lam)
-        self.m2 = torch.zeros_like(self.lam)
-        self.grad = torch.zeros_like(self.lam)
+            self._lam[0].copy_(torch.as_tensor(lam0, dtype=f64))
+        self._eps = torch.zeros((2, S * (D + 1)), dtype=f64, device=dev)
+        self._W = torch.zeros((2, S * D), dtype=torch.float32, device=dev)
+        self._xi = torch.zeros((2, S), dtype=f64, device=dev)
+        self.m1 = torch.zeros(2 * D + 2, dtype=f64, device=dev)
+        self.m2 = torch.zeros(2 * D + 2, dtype=f64, device=dev)
+        self.grad = torch.zeros(2 * D + 2, dtype=f64, device=dev)
         self.elbo = torch.zeros(1, dtype=f64, device=dev)
-        self.eps = torch.zeros(S * (D + 1), dtype=f64, device=dev)
-        self.W = torch.zeros(S * D, dtype=torch.float32, device=dev)
-        self.xi = torch.zeros(S, dtype=f64, device=dev)
         self.stats = torch.zeros(S * (D + 1), dtype=f64, device=dev)  # [Q | G]
         self.Q = self.stats[:S]
         self.G = self.stats[S:]
         self.t = 0
+        self._drawn = False
         # size the slab once so step() never allocates
         self.ctx.reserve(2 * self.ctx.info()["cu_count"] * (8 * 256 + 8) * 4)
 
-    # -- the four phases of one update --------------------------------------
+    # -- current views ---------------------------------------------------------
+    @property
+    def cur(self):
+        return self.t & 1
+
+    @property
+    def lam(self):
+        return self._lam[self.cur]
+
+    @property
+    def W(self):
+        return self._W[self.cur]
+
+    @property
+    def eps(self):
+        return self._eps[self.cur]
+
+    @property
+    def xi(self):
+        return self._xi[self.cur]
+
+    # -- unfused phases (also the multi-sample-group path) ---------------------
     def sample(self, step):
-        self.ctx.call("bsc_blr_sample", ptr(self.lam), self.D, self.S, self.seed, step,
-                      ptr(self.eps), ptr(self.W), ptr(self.xi))
+        c = self.cur
+        self.ctx.call("bsc_blr_sample", ptr(self._lam[c]), self.D, self.S, self.seed, step,
+                      ptr(self._eps[c]), ptr(self._W[c]), ptr(self._xi[c]))
+        self._drawn = True
 
     def data_pass(self):
         self.ctx.call("bsc_blr_data_pass", ptr(self.X), self.X.stride(0), ptr(self.y), self.B,
@@ -86,24 +117,31 @@ class BLRReparamSVI:
         if self.world > 1:
             torch.distributed.all_reduce(self.stats, group=self.group)
 
-    def elbo_grad(self):
-        self.ctx.call("bsc_blr_elbo_grad", ptr(self.lam), ptr(self.eps), ptr(self.W),
-                      ptr(self.xi), ptr(self.Q), ptr(self.G), self.D, self.S, self.batch_rows,
-                      self.n_total / self.batch_rows, self.alpha0, self.beta0, ptr(self.elbo),
+    def _finish(self, stats):
+        """Fused gradient + Adam + next draw; flips the double buffer."""
+        c, n = self.cur, 1 - self.cur
+        t = self.t + 1
+        self.ctx.call("bsc_blr_fused_update", ptr(stats) if stats is not None else None,
+                      ptr(self._lam[c]), ptr(self._lam[n]), ptr(self.m1), ptr(self.m2),
+                      ptr(self._eps[c]), ptr(self._W[c]), ptr(self._xi[c]), self.D, self.S,
+                      self.batch_rows, self.n_total / self.batch_rows, self.alpha0, self.beta0,
+                      t, self.lr, 0.9, 0.999, 1e-8, self.seed, t,
+                      ptr(self._eps[n]), ptr(self._W[n]), ptr(self._xi[n]), ptr(self.elbo),
                       ptr(self.grad))
-
-    def adam(self):
-        self.ctx.call("bsc_adam_ascent", ptr(self.lam), ptr(self.grad), ptr(self.m1),
-                      ptr(self.m2), self.lam.numel(), self.t, self.lr, 0.9, 0.999, 1e-8)
+        self.t = t
 
     def step(self):
         """One ELBO-gradient update; asynchronous on the context stream."""
-        self.t += 1
-        self.sample(self.t - 1)
-        self.data_pass()
-        self.all_reduce()
-        self.elbo_grad()
-        self.adam()
+        if not self._drawn:
+            self.sample(self.t)  # Philox step index == number of completed updates
+        if self.fused and self.world == 1 and self.S <= 8:
+            self.ctx.call("bsc_blr_data_pass_partial", ptr(self.X), self.X.stride(0),
+                          ptr(self.y), self.B, self.D, ptr(self.W), self.S)
+            self._finish(None)
+        else:
+            self.data_pass()
+            self.all_reduce()
+            self._finish(self.stats)
 
     # -- host views -----------------------------------------------------------
     def params(self):

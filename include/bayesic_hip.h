@@ -103,6 +103,13 @@ int bsc_blr_data_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y,
                       int64_t B, int32_t D, const float* W, int32_t S,
                       double* Q, double* G);
 
+/* Same pass, but leaves the per-workgroup float32 partials in the context
+ * workspace for bsc_blr_fused_update(stats = NULL) to finish -- saves the
+ * separate reduction launch on the single-GPU path.  Requires S <= 8.  The
+ * partials stay valid until the next call that uses the workspace. */
+int bsc_blr_data_pass_partial(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y,
+                              int64_t B, int32_t D, const float* W, int32_t S);
+
 /* Monte-Carlo ELBO and pathwise gradient from the (all-reduced) pass outputs.
  * batch_rows = global mini-batch rows, scale = N_total / batch_rows.
  * Writes elbo[1], grad[2D+2] (float64). */
@@ -111,6 +118,21 @@ int bsc_blr_elbo_grad(bsc_ctx* ctx, const double* lam, const double* eps,
                       const double* G, int32_t D, int32_t S, double batch_rows,
                       double scale, double alpha0, double beta0, double* elbo,
                       double* grad);
+
+/* Fused finish of one update, one launch: (float64 reduction of the pending
+ * partials when stats == NULL, else stats = [Q (S) | G (S*D)] as all-reduced)
+ * -> ELBO + pathwise gradient (as bsc_blr_elbo_grad) -> Adam ascent step t
+ * (as bsc_adam_ascent) written to lam_out (lam_in is not modified; m1, m2
+ * updated in place) -> when the *_next buffers are non-NULL, the reparameterised
+ * draws of Philox step `next_step` from lam_out (as bsc_blr_sample).  The caller
+ * double-buffers lam and the draws: *_next must not alias eps/W/xi. */
+int bsc_blr_fused_update(bsc_ctx* ctx, const double* stats, const double* lam_in,
+                         double* lam_out, double* m1, double* m2, const double* eps,
+                         const float* W, const double* xi, int32_t D, int32_t S,
+                         double batch_rows, double scale, double alpha0, double beta0,
+                         int64_t t, double lr, double beta1, double beta2, double adam_eps,
+                         uint64_t seed, uint32_t next_step, double* eps_next, float* W_next,
+                         double* xi_next, double* elbo, double* grad);
 
 /* ---- parameter updates --------------------------------------------------- */
 

@@ -257,3 +257,77 @@ def test_cfg2_full_size_properties(ctx):
     assert (np.abs(G.cpu().numpy() - Xty[None, :]) <= 2e-5 * bound[None, :]).all()
     # all eight samples saw the same W=0, so the rows of G must be identical
     assert (G.cpu().numpy() == G.cpu().numpy()[0:1]).all()
+
+
+@pytest.mark.parametrize("D,S", [(256, 8), (100, 16), (8, 1), (36, 64), (252, 3)])
+def test_fused_update_from_stats_matches_oracle(ctx, D, S):
+    """The multi-GPU finish: all-reduced [Q|G] in, gradient + Adam + next draws out."""
+    from bayesic_amd._ffi import ptr
+    rs = np.random.RandomState(D + S)
+    B, scale, lr, t = 5000.0, 3.0, 0.02, 4
+    lam = svi.blr_init_lam(D) + 0.01 * rs.standard_normal(2 * D + 2)
+    eps = rs.standard_normal((S, D + 1))
+    W = (lam[:D][None] + np.exp(lam[D:2 * D])[None] * eps[:, :D]).astype(np.float32)
+    xi = lam[2 * D] + math.exp(lam[2 * D + 1]) * eps[:, D]
+    Q = rs.uniform(200, 400, S)
+    G = rs.standard_normal((S, D)) * 30
+    m1, m2 = rs.standard_normal(2 * D + 2), rs.uniform(0.5, 2.0, 2 * D + 2)
+    f64 = torch.float64
+    dev = lambda v: ctx.to_device(v, f64)
+    lam_in, lam_out = dev(lam), ctx.zeros(2 * D + 2, f64)
+    m1d, m2d, epsd, xid = dev(m1), dev(m2), dev(eps), dev(xi)
+    stats = dev(np.concatenate([Q, G.ravel()]))
+    Wd = ctx.to_device(W)
+    eps_n, W_n, xi_n = ctx.zeros(S * (D + 1), f64), ctx.zeros(S * D), ctx.zeros(S, f64)
+    elbo, grad = ctx.zeros(1, f64), ctx.zeros(2 * D + 2, f64)
+    ctx.call("bsc_blr_fused_update", ptr(stats), ptr(lam_in), ptr(lam_out), ptr(m1d), ptr(m2d),
+             ptr(epsd), ptr(Wd), ptr(xid), D, S, B, scale, 1.5, 0.7, t, lr, 0.9, 0.999, 1e-8,
+             77, t, ptr(eps_n), ptr(W_n), ptr(xi_n), ptr(elbo), ptr(grad))
+    ctx.sync()
+    e_ref, g_ref = svi.blr_elbo_and_grad(lam, eps, W, xi, Q, G, B, scale, 1.5, 0.7)
+    lam_ref, m1r, m2r = svi.adam_ascent(lam, g_ref, m1, m2, t, lr)
+    np.testing.assert_allclose(elbo.item(), e_ref, rtol=1e-10)
+    np.testing.assert_allclose(grad.cpu().numpy(), g_ref, rtol=1e-10, atol=1e-10 * np.abs(g_ref).max())
+    np.testing.assert_allclose(lam_out.cpu().numpy(), lam_ref, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(m1d.cpu().numpy(), m1r, rtol=1e-12)
+    np.testing.assert_allclose(m2d.cpu().numpy(), m2r, rtol=1e-12)
+    np.testing.assert_array_equal(lam_in.cpu().numpy(), lam)          # input untouched
+    e_n, w_n, x_n = svi.blr_sample(lam_ref, D, S, 77, step=t)
+    np.testing.assert_allclose(eps_n.cpu().numpy().reshape(S, D + 1), e_n, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(xi_n.cpu().numpy(), x_n, rtol=1e-12)
+    wd = W_n.cpu().numpy().reshape(S, D)
+    assert (np.abs(wd - w_n) <= np.spacing(np.abs(w_n))).all()
+
+
+def test_fused_and_unfused_update_paths_agree(ctx):
+    from bayesic_amd.svi.blr import BLRReparamSVI
+    X, y, _ = svi.make_cfg2(3001, 256)
+    a = BLRReparamSVI(X, y, n_total=30010, n_samples=8, seed=5, lr=0.01, ctx=ctx, fused=True)
+    b = BLRReparamSVI(X, y, n_total=30010, n_samples=8, seed=5, lr=0.01, ctx=ctx, fused=False)
+    for _ in range(4):
+        a.step()
+        b.step()
+    ctx.sync()
+    np.testing.assert_allclose(a.lam.cpu().numpy(), b.lam.cpu().numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(a.elbo.item(), b.elbo.item(), rtol=1e-12)
+
+
+def test_fused_update_requires_pending_partials(ctx):
+    from bayesic_amd._ffi import BayesicHipError, ptr
+    f64 = torch.float64
+    D, S = 8, 2
+    z = lambda n: ctx.zeros(n, f64)
+    lam_in, lam_out, m1, m2 = z(2 * D + 2), z(2 * D + 2), z(2 * D + 2), z(2 * D + 2)
+    eps, W, xi, elbo, grad = z(S * (D + 1)), ctx.zeros(S * D), z(S), z(1), z(2 * D + 2)
+    # a full data pass consumes the slab, so nothing is pending afterwards
+    X, y = ctx.zeros((16, D)), ctx.zeros(16)
+    Q, G = z(S), z(S * D)
+    ctx.call("bsc_blr_data_pass", ptr(X), D, ptr(y), 16, D, ptr(W), S, ptr(Q), ptr(G))
+    with pytest.raises(BayesicHipError, match="pending"):
+        ctx.call("bsc_blr_fused_update", None, ptr(lam_in), ptr(lam_out), ptr(m1), ptr(m2),
+                 ptr(eps), ptr(W), ptr(xi), D, S, 16.0, 1.0, 1.0, 1.0, 1, 0.01, 0.9, 0.999, 1e-8,
+                 1, 1, None, None, None, ptr(elbo), ptr(grad))
+    with pytest.raises(BayesicHipError, match="differ"):
+        ctx.call("bsc_blr_fused_update", ptr(Q), ptr(lam_in), ptr(lam_in), ptr(m1), ptr(m2),
+                 ptr(eps), ptr(W), ptr(xi), D, S, 16.0, 1.0, 1.0, 1.0, 1, 0.01, 0.9, 0.999, 1e-8,
+                 1, 1, None, None, None, ptr(elbo), ptr(grad))
