@@ -17,7 +17,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-CXXFLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall",
+CXXFLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-fno-slp-vectorize",
             "-Wno-unused-function", "-I", INCLUDE]
 
 

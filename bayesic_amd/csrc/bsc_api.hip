@@ -1,6 +1,7 @@
 // Context, memory and event entry points of the C ABI (include/bayesic_hip.h).
 #include "bsc_common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -58,6 +59,8 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
     ctx->device = device;
     ctx->stream = (hipStream_t)stream;
     ctx->cu_count = prop.multiProcessorCount;
+    // tuning knob for A/B runs in one process; not part of the ABI contract
+    if (const char* e = getenv("BSC_BLR_TILE_ROWS")) ctx->blr_tile_rows = atoi(e) == 4 ? 4 : 8;
     *out = ctx;
     return BSC_OK;
 }

@@ -23,43 +23,73 @@
 
 namespace {
 
-constexpr int TILE_ROWS = 8;
 constexpr int SG = 8;  // samples per pass
 constexpr int PASS_BLOCK = 256;
 constexpr int PASS_WAVES = PASS_BLOCK / BSC_WAVE;
 constexpr int GCOLS = 256;                    // column capacity of the lane layout
 constexpr int SLAB_G = SG * GCOLS;            // slab[b][d*8 + s], then Q at [SLAB_G + s]
 constexpr int SLAB_STRIDE = SLAB_G + SG;      // floats per block partial
-constexpr int PSTR = 68;                      // floats per lane row of the transpose buffer
-constexpr int WAVE_LDS = 64 * PSTR + 64;      // + residual broadcast buffer
 
+// Geometry of one wave's tile, for ROWS = 8 (2 waves/SIMD) or 4 (3 waves/SIMD).
+// A lane writes its ROWS*8 partial dots as one LDS row of PSTR floats; PSTR = 4 mod 32
+// keeps the 16-byte writes conflict-free, and the row blocks read by the four (eight)
+// lane groups start a multiple of 32 (64) floats apart, so the 16-byte column reads are
+// conflict-free as well.
+template <int ROWS>
+struct Geo {
+    static constexpr int NVAL = ROWS * SG;        // values per lane: 64 or 32
+    static constexpr int PSTR = NVAL + 4;         // 68 or 36 floats
+    static constexpr int NGRP = NVAL / 4;         // lanes per value group set: 16 or 8
+    static constexpr int NQ = BSC_WAVE / NGRP;    // row subsets: 4 or 8
+    static constexpr int RPQ = BSC_WAVE / NQ;     // lane-rows per subset: 16 or 8
+    static constexpr int WAVE_LDS = BSC_WAVE * PSTR + NVAL;  // + residual broadcast buffer
+    static constexpr int OCC = ROWS == 8 ? 2 : 3;  // waves per SIMD (VGPR budget 256 / 168)
+};
+
+template <int ROWS>
 struct Tile {
-    float4 x[TILE_ROWS];
+    float4 x[ROWS];
     float yv;
 };
 
-// After the transposing reduction lane k holds value v(k) = row*8 + sample:
+// After the transposing reduction lane k holds value v(k) = row*8 + sample.
+template <int ROWS>
 __device__ __forceinline__ int lane_value(int lane) {
-    return 4 * (lane & 15) + 2 * ((lane >> 5) & 1) + ((lane >> 4) & 1);
+    return 4 * (lane & (Geo<ROWS>::NGRP - 1)) + 2 * ((lane >> 5) & 1) + ((lane >> 4) & 1);
 }
 
-template <bool CHECK>
-__device__ __forceinline__ void load_tile(Tile& t, const float* __restrict__ X, int64_t ldx,
-                                          const float* __restrict__ y, int64_t row0,
-                                          int64_t B, int lane, bool lane_active) {
-    const float* base = X + row0 * ldx + 4 * lane;
-#pragma unroll
-    for (int r = 0; r < TILE_ROWS; ++r) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool ok = lane_active;
-        if (CHECK) ok = ok && (row0 + r < B);
-        if (ok) v = *reinterpret_cast<const float4*>(base + (int64_t)r * ldx);
-        t.x[r] = v;
+// One tile = ROWS rows starting at row0, through buffer loads: the descriptor
+// (SGPRs) covers exactly the rows [row0, B), so rows past the end -- and whole
+// tiles past the end -- read as zeros without touching memory.  No ragged-tail
+// code path and a trip count that is the same for every wave.  Everything but
+// the 16*lane byte offset is wave-uniform.
+template <int ROWS, bool FULL>
+__device__ __forceinline__ void load_tile(Tile<ROWS>& t, const float* __restrict__ X,
+                                          int64_t ldx, const float* __restrict__ y,
+                                          int64_t row0, int64_t B, int D, int lane) {
+    const int64_t rem = B - row0;  // rows left; <= 0 for a tile past the end
+    uint64_t xbytes = 0, ybytes = 0;
+    if (rem > 0) {
+        xbytes = ((uint64_t)(rem - 1) * (uint64_t)ldx + (uint64_t)D) * 4u;
+        ybytes = (uint64_t)rem * 4u;
     }
-    int64_t yr = row0 + ((lane & 15) >> 1);  // row of lane_value(lane)
-    float yv = 0.f;
-    if (!CHECK || yr < B) yv = y[yr];
-    t.yv = yv;
+    const unsigned xrec = xbytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)xbytes;
+    const unsigned yrec = ybytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)ybytes;
+    const int64_t safe0 = rem > 0 ? row0 : 0;  // keep the base pointer inside the allocation
+    auto xs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + safe0 * ldx), 0, xrec, 0x00020000);
+    auto ys = __builtin_amdgcn_make_buffer_rsrc((void*)(y + safe0), 0, yrec, 0x00020000);
+    const int lane_off = 16 * lane;
+    const int row_bytes = (int)(ldx * 4);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(xs, lane_off, r * row_bytes, 0);
+        float4 f = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]),
+                               __uint_as_float(v[2]), __uint_as_float(v[3]));
+        if (!FULL && 4 * lane >= D) f = make_float4(0.f, 0.f, 0.f, 0.f);  // next row's bytes
+        t.x[r] = f;
+    }
+    t.yv = __uint_as_float(
+        __builtin_amdgcn_raw_buffer_load_b32(ys, 4 * (lane_value<ROWS>(lane) >> 3), 0, 0));
 }
 
 __device__ __forceinline__ float swap_add32(float a, float b) {
@@ -98,13 +128,15 @@ __device__ __forceinline__ void axpy4(float4& acc, float c, const float4& x) {
 }
 
 // Forward + backward for one tile; `wl` is this wave's LDS region.
-__device__ __forceinline__ void compute_tile(const Tile& t, const float4 (&w)[SG],
+template <int ROWS>
+__device__ __forceinline__ void compute_tile(const Tile<ROWS>& t, const float4 (&w)[SG],
                                              float4 (&acc)[SG], float& qacc, float* wl,
                                              int lane) {
+    using G = Geo<ROWS>;
     // 1. per-lane partial dots, row by row, into this lane's row of the buffer
-    float* mine = wl + lane * PSTR;
+    float* mine = wl + lane * G::PSTR;
 #pragma unroll
-    for (int r = 0; r < TILE_ROWS; ++r) {
+    for (int r = 0; r < ROWS; ++r) {
         float4 lo, hi;
         lo.x = dot4(t.x[r], w[0]); lo.y = dot4(t.x[r], w[1]);
         lo.z = dot4(t.x[r], w[2]); lo.w = dot4(t.x[r], w[3]);
@@ -114,27 +146,43 @@ __device__ __forceinline__ void compute_tile(const Tile& t, const float4 (&w)[SG
         *reinterpret_cast<float4*>(mine + r * SG + 4) = hi;
     }
     wave_lds_sync();
-    // 2. lane k sums values 4g..4g+3 (g = k&15) over the 16 lane-rows l = 4i + q
-    const int g = lane & 15, q = lane >> 4;
-    const float* col = wl + q * PSTR + 4 * g;
-    float4 s4 = *reinterpret_cast<const float4*>(col);
+    // 2. lane k sums values 4g..4g+3 (g = k % NGRP) over the lane-rows q*RPQ .. q*RPQ+RPQ-1
+    const int g = lane & (G::NGRP - 1), q = lane / G::NGRP;
+    const float* col = wl + q * G::RPQ * G::PSTR + 4 * g;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int RB = ROWS == 8 ? 8 : 4;  // reads in flight before the first add
 #pragma unroll
-    for (int i = 1; i < 16; ++i) {
-        float4 v = *reinterpret_cast<const float4*>(col + 4 * i * PSTR);
-        s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+    for (int part = 0; part < G::RPQ / RB; ++part) {
+        float4 v[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            v[i] = *reinterpret_cast<const float4*>(col + (RB * part + i) * G::PSTR);
+#pragma unroll
+        for (int h = RB / 2; h >= 1; h >>= 1) {
+#pragma unroll
+            for (int i = 0; i < h; ++i) {
+                v[i].x += v[i + h].x; v[i].y += v[i + h].y;
+                v[i].z += v[i + h].z; v[i].w += v[i + h].w;
+            }
+        }
+        s4.x += v[0].x; s4.y += v[0].y; s4.z += v[0].z; s4.w += v[0].w;
     }
-    // 3. fold the four q groups: lane k ends with value lane_value(k)
+    // 3. fold the row subsets (lane bits 4,5; and bit 3 when ROWS == 4): lane k ends
+    //    with value lane_value(k)
     float t0 = swap_add32(s4.x, s4.z);
     float t1 = swap_add32(s4.y, s4.w);
     float dot = swap_add16(t0, t1);
+    if (ROWS == 4) dot += dpp_f32<DPP_ROW_ROR8>(dot);  // lanes k and k^8 hold the same value
     float resid = t.yv - dot;
     qacc = fmaf(resid, resid, qacc);
-    float* rb = wl + 64 * PSTR;
-    rb[lane_value(lane)] = resid;
+    float* rb = wl + BSC_WAVE * G::PSTR;
+    rb[lane_value<ROWS>(lane)] = resid;
     wave_lds_sync();
     // 4. backward: acc[s] += resid(r,s) * x[r]; residuals arrive by LDS broadcast
 #pragma unroll
-    for (int r = 0; r < TILE_ROWS; ++r) {
+    for (int r = 0; r < ROWS; ++r) {
+        // keep at most four rows of broadcast reads in flight (register budget)
+        if (r == 4) asm volatile("" ::: "memory");
         float4 c0 = *reinterpret_cast<const float4*>(rb + r * SG);
         float4 c1 = *reinterpret_cast<const float4*>(rb + r * SG + 4);
         axpy4(acc[0], c0.x, t.x[r]); axpy4(acc[1], c0.y, t.x[r]);
@@ -144,56 +192,48 @@ __device__ __forceinline__ void compute_tile(const Tile& t, const float4 (&w)[SG
     }
 }
 
-template <bool FULL>  // FULL: D == 256, every lane owns four live columns
-__global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_kernel(
+// FULL: D == 256, every lane owns four live columns.  ROWS: tile height.
+// n_iter: tiles per wave (same for every wave; tiles past the end read zeros).
+template <bool FULL, int ROWS>
+__global__ __launch_bounds__(PASS_BLOCK, Geo<ROWS>::OCC) void blr_pass_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ y, int64_t B, int D,
-    const float* __restrict__ W, int S, float* __restrict__ slab) {
+    const float* __restrict__ W, int S, float* __restrict__ slab, int n_iter) {
+    using G = Geo<ROWS>;
     // one array: wave-private regions during the loop, [wave][SLAB_STRIDE] in the epilogue
-    __shared__ __attribute__((aligned(16))) float lds[PASS_WAVES * WAVE_LDS];
-    static_assert(PASS_WAVES * WAVE_LDS >= PASS_WAVES * SLAB_STRIDE, "epilogue alias");
+    constexpr int LDS_FLOATS = PASS_WAVES * (G::WAVE_LDS > SLAB_STRIDE ? G::WAVE_LDS : SLAB_STRIDE);
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const bool lane_active = FULL ? true : (4 * lane < D);
-    float* wl = lds + wave * WAVE_LDS;
+    // wave-uniform by construction; telling the compiler keeps tile indices and
+    // buffer descriptors in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* wl = lds + wave * G::WAVE_LDS;
 
     float4 w[SG], acc[SG];
 #pragma unroll
     for (int s = 0; s < SG; ++s) {
         w[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane_active && s < S)
+        if (4 * lane < D && s < S)
             w[s] = *reinterpret_cast<const float4*>(W + (int64_t)s * D + 4 * lane);
         acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float qacc = 0.f;
 
-    const int64_t n_tiles = (B + TILE_ROWS - 1) / TILE_ROWS;
-    const int64_t n_full = B / TILE_ROWS;  // tiles [0, n_full) need no row check
+    // This wave owns tiles first, first+stride, ... (n_iter of them).  Every
+    // prefetch is unconditional -- a conditional one makes the compiler wait with
+    // vmcnt(0), i.e. no prefetch at all -- and out-of-range tiles cost no traffic.
     const int64_t stride = (int64_t)gridDim.x * PASS_WAVES;
     int64_t tile = (int64_t)blockIdx.x * PASS_WAVES + wave;
-
-    Tile ta, tb;
-    if (tile < n_tiles) {
-        if (tile < n_full) load_tile<false>(ta, X, ldx, y, tile * TILE_ROWS, B, lane, lane_active);
-        else load_tile<true>(ta, X, ldx, y, tile * TILE_ROWS, B, lane, lane_active);
+    Tile<ROWS> ta, tb;
+    load_tile<ROWS, FULL>(ta, X, ldx, y, tile * ROWS, B, D, lane);
+    for (int k = 0; k + 1 < n_iter; k += 2) {
+        load_tile<ROWS, FULL>(tb, X, ldx, y, (tile + stride) * ROWS, B, D, lane);
+        compute_tile<ROWS>(ta, w, acc, qacc, wl, lane);
+        load_tile<ROWS, FULL>(ta, X, ldx, y, (tile + 2 * stride) * ROWS, B, D, lane);
+        compute_tile<ROWS>(tb, w, acc, qacc, wl, lane);
+        tile += 2 * stride;
     }
-    while (tile < n_tiles) {
-        int64_t nxt = tile + stride;
-        if (nxt < n_tiles) {
-            if (nxt < n_full) load_tile<false>(tb, X, ldx, y, nxt * TILE_ROWS, B, lane, lane_active);
-            else load_tile<true>(tb, X, ldx, y, nxt * TILE_ROWS, B, lane, lane_active);
-        }
-        compute_tile(ta, w, acc, qacc, wl, lane);
-        tile = nxt;
-        if (tile >= n_tiles) break;
-        nxt = tile + stride;
-        if (nxt < n_tiles) {
-            if (nxt < n_full) load_tile<false>(ta, X, ldx, y, nxt * TILE_ROWS, B, lane, lane_active);
-            else load_tile<true>(ta, X, ldx, y, nxt * TILE_ROWS, B, lane, lane_active);
-        }
-        compute_tile(tb, w, acc, qacc, wl, lane);
-        tile = nxt;
-    }
+    if (n_iter & 1) compute_tile<ROWS>(ta, w, acc, qacc, wl, lane);
 
     // block reduction through LDS, fixed order over waves
     __syncthreads();  // every wave is done with its private region
@@ -201,12 +241,14 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_kernel(
 #pragma unroll
     for (int s = 0; s < SG; ++s)
         *reinterpret_cast<float4*>(ep + s * GCOLS + 4 * lane) = acc[s];
-    // qacc of lane k belongs to sample lane_value(k)&7; fold the 8 rows (lane bits 1-3)
+    // qacc of lane k belongs to sample lane_value(k)&7; fold the tile rows (lane bits 1..)
+    // -- with ROWS == 4 lanes k and k^8 carry the same residuals, hence the 0.5
     float qv = qacc;
     qv += __shfl_xor(qv, 2);
     qv += __shfl_xor(qv, 4);
     qv += __shfl_xor(qv, 8);
-    if ((lane & 14) == 0) ep[SLAB_G + (lane_value(lane) & 7)] = qv;
+    if (ROWS == 4) qv *= 0.5f;
+    if ((lane & 14) == 0) ep[SLAB_G + (lane_value<ROWS>(lane) & 7)] = qv;
     __syncthreads();
     float* out = slab + (int64_t)blockIdx.x * SLAB_STRIDE;
     for (int i = tid; i < SLAB_STRIDE; i += PASS_BLOCK) {
@@ -217,6 +259,27 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_kernel(
         for (int k = 1; k < PASS_WAVES; ++k) v += lds[k * SLAB_STRIDE + src];
         out[i] = v;
     }
+}
+
+// float64 sum of p[b * SLAB_STRIDE] over slab rows b = first, first+step, ...
+// Loads are issued in batches of 16 before any add: the partials were written by
+// another kernel, so every load is a MALL/HBM round trip (~0.4 us) and a
+// load-add-load-add chain would serialise them.
+__device__ __forceinline__ double slab_column_sum(const float* __restrict__ p, int first,
+                                                  int step, int n_rows) {
+    constexpr int BATCH = 16;
+    double sum = 0.0;
+    for (int b0 = first; b0 < n_rows; b0 += step * BATCH) {
+        float v[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const int b = b0 + j * step;
+            v[j] = b < n_rows ? p[(int64_t)b * SLAB_STRIDE] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) sum += (double)v[j];
+    }
+    return sum;
 }
 
 // Sum block partials in float64, fixed order.  One output per lane; the 16
@@ -232,10 +295,7 @@ __global__ __launch_bounds__(RED_BLOCK) void blr_slab_reduce_kernel(
     const int wave = threadIdx.x >> 6;
     const int i = blockIdx.x * BSC_WAVE + lane;
     double sum = 0.0;
-    if (i < SLAB_STRIDE) {
-        for (int b = wave; b < n_blocks; b += RED_WAVES)
-            sum += (double)slab[(int64_t)b * SLAB_STRIDE + i];
-    }
+    if (i < SLAB_STRIDE) sum = slab_column_sum(slab + i, wave, RED_WAVES, n_blocks);
     part[wave][lane] = sum;
     __syncthreads();
     if (wave == 0 && i < SLAB_STRIDE) {
@@ -351,6 +411,8 @@ __global__ void blr_sample_kernel(const double* __restrict__ lam, int D, int S, 
 // One workgroup.  Thread d owns column d (strided when D > blockDim).
 constexpr int FIN_BLOCK = 256;
 constexpr int FIN_WAVES = FIN_BLOCK / BSC_WAVE;
+constexpr int FUSED_BLOCK = 1024;  // 16 waves: 32 slab rows per wave at 512 partials
+constexpr int FUSED_WAVES = FUSED_BLOCK / BSC_WAVE;
 constexpr int FIN_MAX_S = 64;
 constexpr double LOG_2PI = 1.8378770664093454835606594728112;
 
@@ -447,6 +509,7 @@ struct FusedArgs {
     int D, S;
     double batch_rows, scale, alpha0, beta0;
     double lr, beta1, beta2, adam_eps, corr1, corr2;
+    double log_prior_const;  // alpha0 * log(beta0) - lgamma(alpha0), computed on the host
     uint64_t seed;
     uint32_t next_step;
 };
@@ -462,8 +525,8 @@ __device__ __forceinline__ double adam_ascent_one(double lam, double g, double& 
     return lam + a.lr * mhat / (sqrt(vhat) + a.adam_eps);
 }
 
-__global__ __launch_bounds__(FIN_BLOCK) void blr_fused_update_kernel(FusedArgs a) {
-    __shared__ double red[FIN_WAVES][BSC_WAVE];
+__global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs a) {
+    __shared__ double red[FUSED_WAVES][BSC_WAVE];
     __shared__ double sh[2 * FIN_MAX_S + 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = a.D, S = a.S;
@@ -476,30 +539,32 @@ __global__ __launch_bounds__(FIN_BLOCK) void blr_fused_update_kernel(FusedArgs a
         const int dl = lane >> 3, sl = lane & 7;  // slab order within the run is [d][s]
         const int d = d0 + dl;
         double gm = 0.0, gr = 0.0;
-        for (int s0 = 0; s0 < S; s0 += 8) {
-            const int s = s0 + sl;
-            double g = 0.0;
-            if (a.slab) {  // S <= 8 here: a single trip through this loop
-                double part = 0.0;
-                const float* p = a.slab + 64 * blockIdx.x + lane;
-                for (int b = wave; b < a.n_slab; b += FIN_WAVES)
-                    part += (double)p[(int64_t)b * SLAB_STRIDE];
-                red[wave][lane] = part;
-                __syncthreads();
-                g = red[0][lane];
+        if (a.slab) {  // S <= 8: lane <-> (column dl, sample sl) of one 256-B slab run
+            red[wave][lane] =
+                slab_column_sum(a.slab + 64 * blockIdx.x + lane, wave, FUSED_WAVES, a.n_slab);
+            __syncthreads();
+            if (wave != 0) return;
+            double g = red[0][lane];
 #pragma unroll
-                for (int k = 1; k < FIN_WAVES; ++k) g += red[k][lane];
-            } else if (s < S && d < D) {
-                g = a.stats[S + (int64_t)s * D + d];
+            for (int k = 1; k < FUSED_WAVES; ++k) g += red[k][lane];
+            if (sl < S && d < D) {
+                const double wv = (double)a.W[(int64_t)sl * D + d];
+                const double dw = exp(-a.xi[sl]) * (a.scale * g - wv);
+                gm = dw;
+                gr = dw * a.eps[(int64_t)sl * (D + 1) + d];
             }
-            if (s < S && d < D) {
-                const double wv = (double)a.W[(int64_t)s * D + d];
-                const double dw = exp(-a.xi[s]) * (a.scale * g - wv);
-                gm += dw;
-                gr += dw * a.eps[(int64_t)s * (D + 1) + d];
+        } else {
+            if (wave != 0) return;
+            for (int s = sl; s < S; s += 8) {
+                if (d < D) {
+                    const double g = a.stats[S + (int64_t)s * D + d];
+                    const double wv = (double)a.W[(int64_t)s * D + d];
+                    const double dw = exp(-a.xi[s]) * (a.scale * g - wv);
+                    gm += dw;
+                    gr += dw * a.eps[(int64_t)s * (D + 1) + d];
+                }
             }
         }
-        if (wave != 0) return;
         // fold the 8 sample lanes (lane bits 0-2)
 #pragma unroll
         for (int off = 1; off < 8; off <<= 1) {
@@ -543,23 +608,24 @@ __global__ __launch_bounds__(FIN_BLOCK) void blr_fused_update_kernel(FusedArgs a
     double* wsq = sh + FIN_MAX_S;       // [S]
     double* misc = sh + 2 * FIN_MAX_S;  // [1]=new a [2]=new b
     if (a.slab) {  // S <= 8: thread -> (sample tid&7, slab-row group tid>>3)
-        double part = 0.0;
-        for (int b = tid >> 3; b < a.n_slab; b += FIN_BLOCK / 8)
-            part += (double)a.slab[(int64_t)b * SLAB_STRIDE + SLAB_G + (tid & 7)];
-        double* stage = &red[0][0];  // [32][8]
-        stage[tid] = part;
+        double part = slab_column_sum(a.slab + SLAB_G + (tid & 7), tid >> 3, FUSED_BLOCK / 8,
+                                      a.n_slab);
+        // fold the 8 row groups of this wave (lane bits 3-5), then the 16 waves
+        part += __shfl_xor(part, 8);
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (lane < 8) red[wave][lane] = part;
         __syncthreads();
         if (tid < 8) {
             double t = 0.0;
-            for (int k = 0; k < FIN_BLOCK / 8; ++k) t += stage[8 * k + tid];
+            for (int k = 0; k < FUSED_WAVES; ++k) t += red[k][tid];
             Qs[tid] = t;
         }
-        __syncthreads();
     } else {
-        for (int s = tid; s < S; s += FIN_BLOCK) Qs[s] = a.stats[s];
+        for (int s = tid; s < S; s += FUSED_BLOCK) Qs[s] = a.stats[s];
     }
     // |w_s|^2: wave-per-sample, fixed order
-    for (int s = wave; s < S; s += FIN_WAVES) {
+    for (int s = wave; s < S; s += FUSED_WAVES) {
         double part = 0.0;
         for (int d = lane; d < D; d += BSC_WAVE) {
             const double wv = (double)a.W[(int64_t)s * D + d];
@@ -570,29 +636,38 @@ __global__ __launch_bounds__(FIN_BLOCK) void blr_fused_update_kernel(FusedArgs a
     }
     {
         double part = 0.0;
-        for (int d = tid; d < D; d += FIN_BLOCK) part += a.lam_in[D + d];
+        for (int d = tid; d < D; d += FUSED_BLOCK) part += a.lam_in[D + d];
         part = wave_allsum_f64(part);
-        __syncthreads();  // `red` was the Q staging area
-        if (lane == 0) red[wave][0] = part;
+        if (lane == 0) red[wave][32] = part;  // column 32: clear of the Q staging columns
+    }
+    __syncthreads();
+    // per-sample terms in parallel (one thread per sample), then a fixed-order sum
+    __shared__ double terms[3 * FIN_MAX_S];
+    double* t_dxi = terms;              // [S]
+    double* t_dxe = t_dxi + FIN_MAX_S;  // [S]
+    double* t_f = t_dxe + FIN_MAX_S;    // [S]
+    if (tid < S) {
+        const int s = tid;
+        const double x = a.xi[s], e = exp(-x);
+        const double dxi = -0.5 * (a.scale * a.batch_rows + (double)D) - a.alpha0 +
+                           e * (0.5 * a.scale * Qs[s] + 0.5 * wsq[s] + a.beta0);
+        const double loglik = a.scale * (-0.5 * a.batch_rows * (LOG_2PI + x) - 0.5 * e * Qs[s]);
+        const double logpw = -0.5 * (double)D * (LOG_2PI + x) - 0.5 * e * wsq[s];
+        const double logpxi = a.log_prior_const - a.alpha0 * x - a.beta0 * e;
+        t_dxi[s] = dxi;
+        t_dxe[s] = dxi * a.eps[(int64_t)s * (D + 1) + D];
+        t_f[s] = loglik + logpw + logpxi;
     }
     __syncthreads();
     if (tid == 0) {
         double sum_rho = 0.0;
-        for (int k = 0; k < FIN_WAVES; ++k) sum_rho += red[k][0];
+        for (int k = 0; k < FUSED_WAVES; ++k) sum_rho += red[k][32];
         const double av = a.lam_in[2 * D], bv = a.lam_in[2 * D + 1];
         double fa = 0.0, fb = 0.0, fsum = 0.0;
         for (int s = 0; s < S; ++s) {
-            const double x = a.xi[s], e = exp(-x);
-            const double dxi = -0.5 * (a.scale * a.batch_rows + (double)D) - a.alpha0 +
-                               e * (0.5 * a.scale * Qs[s] + 0.5 * wsq[s] + a.beta0);
-            fa += dxi;
-            fb += dxi * a.eps[(int64_t)s * (D + 1) + D];
-            const double loglik =
-                a.scale * (-0.5 * a.batch_rows * (LOG_2PI + x) - 0.5 * e * Qs[s]);
-            const double logpw = -0.5 * (double)D * (LOG_2PI + x) - 0.5 * e * wsq[s];
-            const double logpxi =
-                a.alpha0 * log(a.beta0) - lgamma(a.alpha0) - a.alpha0 * x - a.beta0 * e;
-            fsum += loglik + logpw + logpxi;
+            fa += t_dxi[s];
+            fb += t_dxe[s];
+            fsum += t_f[s];
         }
         const double g_a = fa * inv_S;
         const double g_b = fb * inv_S * exp(bv) + 1.0;
@@ -612,16 +687,35 @@ __global__ __launch_bounds__(FIN_BLOCK) void blr_fused_update_kernel(FusedArgs a
     }
     __syncthreads();
     if (a.eps_next)
-        for (int s = tid; s < S; s += FIN_BLOCK)
+        for (int s = tid; s < S; s += FUSED_BLOCK)
             blr_draw_scale(misc[1], misc[2], D, s, a.seed, a.next_step, a.eps_next, a.xi_next);
 }
 
-int pass_grid(bsc_ctx* ctx, int64_t B) {
-    const int64_t n_tiles = (B + TILE_ROWS - 1) / TILE_ROWS;
-    int64_t want = (n_tiles + PASS_WAVES - 1) / PASS_WAVES;
-    const int64_t cap = 2 * (int64_t)ctx->cu_count;
-    return (int)(want < 1 ? 1 : (want > cap ? cap : want));
+// Grid and per-wave trip count: fill the resident wave slots, then balance so
+// that every wave runs the same number of (almost all real) tiles.
+struct PassGrid {
+    int n_blocks;
+    int n_iter;
+};
+
+PassGrid pass_grid(bsc_ctx* ctx, int64_t B) {
+    const int rows = ctx->blr_tile_rows;
+    const int64_t n_tiles = (B + rows - 1) / rows;
+    const int64_t max_waves = (int64_t)(rows == 8 ? Geo<8>::OCC : Geo<4>::OCC) * 4 * ctx->cu_count;
+    PassGrid g;
+    if (n_tiles <= 0) {
+        g.n_blocks = 1;
+        g.n_iter = 0;
+        return g;
+    }
+    const int64_t n_iter = (n_tiles + max_waves - 1) / max_waves;
+    const int64_t waves = (n_tiles + n_iter - 1) / n_iter;
+    g.n_blocks = (int)((waves + PASS_WAVES - 1) / PASS_WAVES);
+    g.n_iter = (int)n_iter;
+    return g;
 }
+
+constexpr int MAX_SLAB_ROWS = 4 * 256 + 64;  // workspace sizing hint for callers
 
 int check_pass_args(const float* X, int64_t ldx, const float* y, int64_t B, int32_t D,
                     const float* W, int32_t S, int max_s) {
@@ -630,22 +724,31 @@ int check_pass_args(const float* X, int64_t ldx, const float* y, int64_t B, int3
     BSC_REQUIRE(D > 0 && D <= GCOLS && D % 4 == 0,
                 "bsc_blr_data_pass: D=%d must be a multiple of 4 in [4,%d]", D, GCOLS);
     BSC_REQUIRE(S >= 1 && S <= max_s, "bsc_blr_data_pass: S=%d must be in [1,%d]", S, max_s);
-    BSC_REQUIRE(ldx >= D && ldx % 4 == 0,
-                "bsc_blr_data_pass: ldx=%lld must be >= D and %% 4 == 0", (long long)ldx);
+    BSC_REQUIRE(ldx >= D && ldx % 4 == 0 && ldx < ((int64_t)1 << 26),
+                "bsc_blr_data_pass: ldx=%lld must be >= D, %% 4 == 0 and < 2^26", (long long)ldx);
     BSC_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0,
                 "bsc_blr_data_pass: X and W must be 16-byte aligned");
     return BSC_OK;
 }
 
-void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B, int D,
-                 const float* W, int sg, int n_blocks, float* slab) {
-    bsc_prof_scope prof(ctx);  // times the pass kernel alone
+template <int ROWS>
+void launch_pass_rows(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B,
+                      int D, const float* W, int sg, PassGrid g, float* slab) {
     if (D == GCOLS)
-        hipLaunchKernelGGL(blr_pass_kernel<true>, dim3(n_blocks), dim3(PASS_BLOCK), 0,
-                           ctx->stream, X, ldx, y, B, D, W, sg, slab);
+        hipLaunchKernelGGL((blr_pass_kernel<true, ROWS>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0,
+                           ctx->stream, X, ldx, y, B, D, W, sg, slab, g.n_iter);
     else
-        hipLaunchKernelGGL(blr_pass_kernel<false>, dim3(n_blocks), dim3(PASS_BLOCK), 0,
-                           ctx->stream, X, ldx, y, B, D, W, sg, slab);
+        hipLaunchKernelGGL((blr_pass_kernel<false, ROWS>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0,
+                           ctx->stream, X, ldx, y, B, D, W, sg, slab, g.n_iter);
+}
+
+void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B, int D,
+                 const float* W, int sg, PassGrid g, float* slab) {
+    bsc_prof_scope prof(ctx);  // times the pass kernel alone
+    if (ctx->blr_tile_rows == 8)
+        launch_pass_rows<8>(ctx, X, ldx, y, B, D, W, sg, g, slab);
+    else
+        launch_pass_rows<4>(ctx, X, ldx, y, B, D, W, sg, g, slab);
 }
 
 }  // namespace
@@ -680,19 +783,19 @@ int bsc_blr_data_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y,
     int rc = check_pass_args(X, ldx, y, B, D, W, S, FIN_MAX_S);
     if (rc != BSC_OK) return rc;
     BSC_REQUIRE(Q && G, "bsc_blr_data_pass: null output");
-    const int n_blocks = pass_grid(ctx, B);
+    const PassGrid g = pass_grid(ctx, B);
     void* ws = nullptr;
-    rc = bsc_workspace(ctx, (size_t)n_blocks * SLAB_STRIDE * sizeof(float), &ws);
+    rc = bsc_workspace(ctx, (size_t)g.n_blocks * SLAB_STRIDE * sizeof(float), &ws);
     if (rc != BSC_OK) return rc;
     float* slab = (float*)ws;
     ctx->slab_rows = 0;  // the slab is consumed here
     for (int s0 = 0; s0 < S; s0 += SG) {
         const int sg = (S - s0 < SG) ? (S - s0) : SG;
-        launch_pass(ctx, X, ldx, y, B, (int)D, W + (int64_t)s0 * D, sg, n_blocks, slab);
+        launch_pass(ctx, X, ldx, y, B, (int)D, W + (int64_t)s0 * D, sg, g, slab);
         BSC_LAUNCH_CHECK();
         hipLaunchKernelGGL(blr_slab_reduce_kernel, dim3((SLAB_STRIDE + BSC_WAVE - 1) / BSC_WAVE),
-                           dim3(RED_BLOCK), 0, ctx->stream, slab, n_blocks, (int)D, (int)S, s0, Q,
-                           G);
+                           dim3(RED_BLOCK), 0, ctx->stream, slab, g.n_blocks, (int)D, (int)S, s0,
+                           Q, G);
         BSC_LAUNCH_CHECK();
     }
     return BSC_OK;
@@ -703,13 +806,13 @@ int bsc_blr_data_pass_partial(bsc_ctx* ctx, const float* X, int64_t ldx, const f
     BSC_CHECK_CTX(ctx);
     int rc = check_pass_args(X, ldx, y, B, D, W, S, SG);
     if (rc != BSC_OK) return rc;
-    const int n_blocks = pass_grid(ctx, B);
+    const PassGrid g = pass_grid(ctx, B);
     void* ws = nullptr;
-    rc = bsc_workspace(ctx, (size_t)n_blocks * SLAB_STRIDE * sizeof(float), &ws);
+    rc = bsc_workspace(ctx, (size_t)g.n_blocks * SLAB_STRIDE * sizeof(float), &ws);
     if (rc != BSC_OK) return rc;
-    launch_pass(ctx, X, ldx, y, B, (int)D, W, (int)S, n_blocks, (float*)ws);
+    launch_pass(ctx, X, ldx, y, B, (int)D, W, (int)S, g, (float*)ws);
     BSC_LAUNCH_CHECK();
-    ctx->slab_rows = n_blocks;
+    ctx->slab_rows = g.n_blocks;
     return BSC_OK;
 }
 
@@ -767,9 +870,10 @@ int bsc_blr_fused_update(bsc_ctx* ctx, const double* stats, const double* lam_in
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.adam_eps = adam_eps;
     a.corr1 = 1.0 - pow(beta1, (double)t);
     a.corr2 = 1.0 - pow(beta2, (double)t);
+    a.log_prior_const = alpha0 * log(beta0) - lgamma(alpha0);
     a.seed = seed;
     a.next_step = next_step;
-    hipLaunchKernelGGL(blr_fused_update_kernel, dim3((D + 7) / 8 + 1), dim3(FIN_BLOCK), 0,
+    hipLaunchKernelGGL(blr_fused_update_kernel, dim3((D + 7) / 8 + 1), dim3(FUSED_BLOCK), 0,
                        ctx->stream, a);
     BSC_LAUNCH_CHECK();
     return BSC_OK;

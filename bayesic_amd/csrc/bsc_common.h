@@ -17,6 +17,7 @@ struct bsc_ctx {
     void* workspace = nullptr;   // partial-sum slabs; grown on demand
     size_t workspace_bytes = 0;
     int cu_count = 256;
+    int blr_tile_rows = 8;  // pass-kernel tile height: 8 (2 waves/SIMD, default) or 4 (3 waves/SIMD)
     int slab_rows = 0;  // block partials left in `workspace` by bsc_blr_data_pass_partial
     // optional per-kernel timing of the dominant kernel (bsc_ctx_profile)
     bool profile = false;

@@ -79,7 +79,7 @@ class BLRReparamSVI:
         self.t = 0
         self._drawn = False
         # size the slab once so step() never allocates
-        self.ctx.reserve(2 * self.ctx.info()["cu_count"] * (8 * 256 + 8) * 4)
+        self.ctx.reserve((4 * self.ctx.info()["cu_count"] + 8) * (8 * 256 + 8) * 4)
 
     # -- current views ---------------------------------------------------------
     @property

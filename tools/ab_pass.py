@@ -1,0 +1,54 @@
+"""Interleaved A/B timing of blr_pass_kernel variants in ONE process
+(tile rows 4 vs 8), hipEvents around the kernel alone.
+
+    python tools/ab_pass.py [rounds] [launches_per_round]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from bayesic_amd._ffi import ptr
+from bayesic_amd.device import Context
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    per = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    B, D, S = 1_000_000, 256, 8
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    X = torch.randn((B, D), generator=g, device=dev)
+    y = torch.randn(B, generator=g, device=dev)
+    W = torch.randn((S, D), generator=g, device=dev) / 16
+    ctxs = {}
+    for rows in (4, 8):
+        os.environ["BSC_BLR_TILE_ROWS"] = str(rows)
+        ctxs[rows] = Context(0)
+        ctxs[rows].reserve(8 << 20)
+    res = {4: [], 8: []}
+    for rows, c in ctxs.items():     # warm-up
+        for _ in range(5):
+            c.call("bsc_blr_data_pass_partial", ptr(X), D, ptr(y), B, D, ptr(W), S)
+        c.sync()
+    for r in range(rounds):
+        for rows, c in ctxs.items():
+            c.profile(True)
+            for _ in range(per):
+                c.call("bsc_blr_data_pass_partial", ptr(X), D, ptr(y), B, D, ptr(W), S)
+            ms, n = c.profile_read()
+            c.profile(False)
+            res[rows].append(ms / n * 1e3)
+    bytes_ = 4.0 * B * D + 4.0 * B
+    for rows in (4, 8):
+        a = np.array(res[rows])
+        print("rows=%d  per-launch us: median %.1f  min %.1f  max %.1f  -> %.0f GB/s (median)"
+              % (rows, np.median(a), a.min(), a.max(), bytes_ / np.median(a) / 1e3))
+
+
+if __name__ == "__main__":
+    main()
