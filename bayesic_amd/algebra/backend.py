@@ -1,0 +1,113 @@
+"""Numeric backends for expression evaluation.
+
+The reference evaluates an expression by asking every node for a Theano
+variable (``Expression.apply`` / ``_apply_to_parents``, bayesic/algebra.py:34-61)
+and compiling the graph with ``theano.function`` (:50-58).  Here a backend is an
+object with one method per hook the reference's nodes call into Theano for
+(SURVEY.md 8(b)): constant, shape, eye, elemwise, sum, mul, dimshuffle,
+tensordot, diagonal -- plus ``from_host`` / ``to_host``.  ``evaluate`` walks the
+(lowered, cached) tree once in post-order; there is no tracing compiler, so
+``compile`` just binds the cached plan to a callable.
+
+The only backend shipped with the package is the MI355X one
+(bayesic_amd/algebra/device_backend.py).  There is NO CPU fallback: without a GPU
+``resolve_backend(None)`` raises.  (The float64 numpy executor used by the CPU
+tests lives in oracle/einsum_eval.py and is test infrastructure.)
+"""
+
+
+class Backend(object):
+    name = "abstract"
+
+    # -- hooks (one per Theano call site of the reference) --------------------
+    def from_host(self, array, dtype, ndim):
+        raise NotImplementedError
+
+    def to_host(self, value):
+        raise NotImplementedError
+
+    def constant(self, value):
+        raise NotImplementedError
+
+    def shape(self, x, axis):
+        raise NotImplementedError
+
+    def eye(self, n):
+        raise NotImplementedError
+
+    def elemwise(self, op_name, *args):
+        raise NotImplementedError
+
+    def sum(self, x, axes):
+        raise NotImplementedError
+
+    def mul(self, *factors):
+        raise NotImplementedError
+
+    def dimshuffle(self, x, axes):
+        raise NotImplementedError
+
+    def tensordot(self, x, y, x_dot, y_dot, x_batch, y_batch):
+        raise NotImplementedError
+
+    def diagonal(self, x, axis1, axis2):
+        raise NotImplementedError
+
+    # -- tree walk -------------------------------------------------------------
+    def evaluate(self, expr, inputs):
+        from .einsum_form import Einsum
+        from .expr import var
+        done = {}
+
+        def visit(node):
+            key = id(node)
+            if key in done:
+                return done[key]
+            if isinstance(node, var):
+                value = inputs[node.name]
+            elif isinstance(node, Einsum):
+                value = visit(node.lowered())
+            else:
+                value = node._emit(self, *[visit(p) for p in node.parents])
+            done[key] = value
+            return value
+
+        return visit(expr)
+
+    def compile(self, expr):
+        types = expr.input_types
+        backend = self
+
+        def device_fn(**device_inputs):
+            return backend.evaluate(expr, device_inputs)
+
+        def f(**inputs):
+            missing = [n for n in types if n not in inputs]
+            if missing:
+                raise TypeError("missing inputs: %s" % ", ".join(sorted(missing)))
+            bound = {n: backend.from_host(inputs[n], *types[n]) for n in types}
+            return backend.to_host(device_fn(**bound))
+
+        f.device_fn = device_fn
+        f.backend = backend
+        return f
+
+
+_default = None
+
+
+def set_default_backend(backend):
+    global _default
+    _default = backend
+
+
+def resolve_backend(backend):
+    """``backend`` itself, else the process default, else a new MI355X backend
+    (raises when no GPU / library is available)."""
+    global _default
+    if backend is not None:
+        return backend
+    if _default is None:
+        from .device_backend import DeviceBackend
+        _default = DeviceBackend()
+    return _default
