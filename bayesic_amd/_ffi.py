@@ -60,6 +60,17 @@ SIGNATURES = {
     "bsc_natgrad_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
                                    c_double]),
     "bsc_suffstats_normal": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "bsc_elemwise": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int64), c_void_p,
+                             POINTER(c_int64), c_int, POINTER(c_void_p), POINTER(c_int64)]),
+    "bsc_convert": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int64), c_void_p,
+                            POINTER(c_int64), c_void_p, POINTER(c_int64)]),
+    "bsc_sum": (c_int, [c_void_p, c_int, c_int, POINTER(c_int64), POINTER(c_int64), c_int,
+                        POINTER(c_int64), POINTER(c_int64), c_void_p, c_void_p]),
+    "bsc_gemm_strided_batched": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64,
+                                         c_void_p, c_int64, c_int64, c_int64,
+                                         c_void_p, c_int64, c_int64, c_int64,
+                                         c_void_p, c_int64, c_int64, c_int64]),
+    "bsc_eye": (c_int, [c_void_p, c_int, c_void_p, c_int64]),
 }
 
 _lib = None

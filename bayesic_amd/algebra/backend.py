@@ -86,7 +86,11 @@ class Backend(object):
             if missing:
                 raise TypeError("missing inputs: %s" % ", ".join(sorted(missing)))
             bound = {n: backend.from_host(inputs[n], *types[n]) for n in types}
-            return backend.to_host(device_fn(**bound))
+            out = backend.to_host(device_fn(**bound))
+            if getattr(out, "ndim", 0) == 0 and expr.ndim > 0:
+                # a broadcast scalar (e.g. einsum([], 2)): all axes are broadcastable
+                out = out.reshape((1,) * expr.ndim)
+            return out
 
         f.device_fn = device_fn
         f.backend = backend

@@ -1,0 +1,253 @@
+// _tensordot on the device: C[b,m,n] = sum_k A[b,m,k] B[b,k,n] with free strides.
+//
+// Reference: _tensordot._apply_to_parents, bayesic/algebra.py:1347-1383
+// (T.tensordot / T.batched_dot).  The batched branches there are broken; batched
+// contraction follows the einsum semantics (:334-338).
+//
+// float32: v_mfma_f32_32x32x2_f32 (exact f32, bit-for-bit a k-ordered fmaf chain).
+// Block tile 128x128, four waves as 2x2, each wave 64x64 = 2x2 MFMA tiles (64
+// accumulator registers), K step 16 through LDS.  LDS tiles are k-major
+// (As[k][m], Bs[k][n]) so an MFMA operand read is 32 consecutive floats per lane
+// half -- conflict-free for ds_read_b32 -- and the global->LDS mapping is chosen
+// per operand by which stride is 1, so global loads are coalesced for both
+// "m contiguous" (X^T) and "k contiguous" (X) operands.
+//
+// Split-K: tall-skinny products (X^T X: M=N=256, K=1e6) have 4 output tiles for
+// 256 CUs, so K is cut into `splits` ranges, partial tiles go to the workspace
+// and a second kernel adds them in split order (deterministic; float atomics
+// would be order-dependent and cap at ~1.3 TB/s).
+#include "bsc_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDA = BM + 4;  // +4 floats: staggers rows for the k-contiguous fill
+constexpr int GEMM_BLOCK = 256;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;          // or the partial slab when splits > 1
+    int64_t M, N, K;
+    int64_t sa_b, sa_m, sa_k, sb_b, sb_k, sb_n, sc_b, sc_m, sc_n;
+    int tiles_m, tiles_n, splits;
+    int64_t k_chunk;   // multiple of BK
+};
+
+// Fill one [BK][BM] LDS tile from a (rows = m, k) operand with strides (s_m, s_k).
+// M_CONTIG: consecutive threads walk m (stride s_m == 1); else they walk k.
+template <bool M_CONTIG>
+__device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ src, int64_t s_m,
+                                           int64_t s_k, int64_t m0, int64_t M, int64_t k0,
+                                           int64_t k_end, int tid) {
+    if (M_CONTIG) {
+        const int m = tid & (BM - 1);
+#pragma unroll
+        for (int kk = tid >> 7; kk < BK; kk += GEMM_BLOCK / BM) {
+            const int64_t gm = m0 + m, gk = k0 + kk;
+            float v = 0.f;
+            if (gm < M && gk < k_end) v = src[gm * s_m + gk * s_k];
+            lds[kk * LDA + m] = v;
+        }
+    } else {
+        const int kk = tid & (BK - 1);
+#pragma unroll
+        for (int m = tid >> 4; m < BM; m += GEMM_BLOCK / BK) {
+            const int64_t gm = m0 + m, gk = k0 + kk;
+            float v = 0.f;
+            if (gm < M && gk < k_end) v = src[gm * s_m + gk * s_k];
+            lds[kk * LDA + m] = v;
+        }
+    }
+}
+
+template <bool A_M_CONTIG, bool B_N_CONTIG>
+__global__ __launch_bounds__(GEMM_BLOCK) void gemm_f32_mfma_kernel(GemmArgs g) {
+    __shared__ float As[BK * LDA];
+    __shared__ float Bs[BK * LDA];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves
+    const int tile = blockIdx.x;
+    const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+    const int split = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int64_t k_begin = (int64_t)split * g.k_chunk;
+    const int64_t k_end = (k_begin + g.k_chunk < g.K) ? k_begin + g.k_chunk : g.K;
+    const float* A = g.A + b * g.sa_b;
+    const float* B = g.B + b * g.sb_b;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fr = lane & 31, fk = lane >> 5;  // operand fragment: row/col fr, k offset fk
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
+        stage_tile<A_M_CONTIG>(As, A, g.sa_m, g.sa_k, m0, g.M, k0, k_end, tid);
+        stage_tile<B_N_CONTIG>(Bs, B, g.sb_n, g.sb_k, n0, g.N, k0, k_end, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[2], bq[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[(kk + fk) * LDA + wm * 64 + i * 32 + fr];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bq[j] = Bs[(kk + fk) * LDA + wn * 64 + j * 32 + fr];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    float* C;
+    int64_t sm, sn;
+    if (g.splits > 1) {  // partial slab [batch][split][M][N], dense
+        C = g.C + ((b * g.splits + split) * g.M) * g.N;
+        sm = g.N;
+        sn = 1;
+    } else {
+        C = g.C + b * g.sc_b;
+        sm = g.sc_m;
+        sn = g.sc_n;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < g.M && col < g.N) C[row * sm + col * sn] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t M,
+                                     int64_t N, float* __restrict__ C, int64_t sc_b, int64_t sc_m,
+                                     int64_t sc_n) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t b = blockIdx.y;
+    if (idx >= M * N) return;
+    const float* p = slab + (b * splits) * M * N + idx;
+    float v = p[0];
+    for (int s = 1; s < splits; ++s) v += p[(int64_t)s * M * N];
+    C[b * sc_b + (idx / N) * sc_m + (idx % N) * sc_n] = v;
+}
+
+// float64 (and the degenerate shapes): one thread per output, k-ordered fma chain.
+template <typename T>
+__global__ void gemm_naive_kernel(int64_t M, int64_t N, int64_t K, const T* A, int64_t sa_b,
+                                  int64_t sa_m, int64_t sa_k, const T* B, int64_t sb_b,
+                                  int64_t sb_k, int64_t sb_n, T* C, int64_t sc_b, int64_t sc_m,
+                                  int64_t sc_n) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t b = blockIdx.y;
+    if (idx >= M * N) return;
+    const int64_t m = idx / N, n = idx % N;
+    const T* a = A + b * sa_b + m * sa_m;
+    const T* bb = B + b * sb_b + n * sb_n;
+    T acc = 0;
+    for (int64_t k = 0; k < K; ++k) acc = fma(a[k * sa_k], bb[k * sb_k], acc);
+    C[b * sc_b + m * sc_m + n * sc_n] = acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t N,
+                             int64_t K, const void* A, int64_t sa_b, int64_t sa_m, int64_t sa_k,
+                             const void* B, int64_t sb_b, int64_t sb_k, int64_t sb_n, void* C,
+                             int64_t sc_b, int64_t sc_m, int64_t sc_n) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(dtype == BSC_F32 || dtype == BSC_F64, "bsc_gemm_strided_batched: unknown dtype %d",
+                dtype);
+    BSC_REQUIRE(batch >= 0 && M >= 0 && N >= 0 && K >= 0, "bsc_gemm_strided_batched: negative extent");
+    if (batch == 0 || M == 0 || N == 0) return BSC_OK;
+    BSC_REQUIRE(C && ((A && B) || K == 0), "bsc_gemm_strided_batched: null pointer");
+    BSC_REQUIRE(batch <= 65535, "bsc_gemm_strided_batched: batch %lld exceeds 65535",
+                (long long)batch);
+    if (dtype == BSC_F64 || K == 0) {
+        const dim3 grid((unsigned)((M * N + 255) / 256), (unsigned)batch);
+        if (dtype == BSC_F64)
+            hipLaunchKernelGGL(gemm_naive_kernel<double>, grid, dim3(256), 0, ctx->stream, M, N, K,
+                               (const double*)A, sa_b, sa_m, sa_k, (const double*)B, sb_b, sb_k,
+                               sb_n, (double*)C, sc_b, sc_m, sc_n);
+        else
+            hipLaunchKernelGGL(gemm_naive_kernel<float>, grid, dim3(256), 0, ctx->stream, M, N, K,
+                               (const float*)A, sa_b, sa_m, sa_k, (const float*)B, sb_b, sb_k, sb_n,
+                               (float*)C, sc_b, sc_m, sc_n);
+        BSC_LAUNCH_CHECK();
+        return BSC_OK;
+    }
+    GemmArgs g;
+    g.A = (const float*)A; g.B = (const float*)B;
+    g.M = M; g.N = N; g.K = K;
+    g.sa_b = sa_b; g.sa_m = sa_m; g.sa_k = sa_k;
+    g.sb_b = sb_b; g.sb_k = sb_k; g.sb_n = sb_n;
+    g.sc_b = sc_b; g.sc_m = sc_m; g.sc_n = sc_n;
+    g.tiles_m = (int)((M + BM - 1) / BM);
+    g.tiles_n = (int)((N + BN - 1) / BN);
+    const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * batch;
+    // split K until the grid has about two workgroups per CU, keeping >= 512 of K per split
+    int64_t splits = 1;
+    const int64_t want = 2 * (int64_t)ctx->cu_count;
+    if (tiles < want) {
+        splits = want / tiles;
+        const int64_t max_splits = K / 512;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        if (splits > 1024) splits = 1024;
+    }
+    int64_t chunk = (K + splits - 1) / splits;
+    chunk = (chunk + BK - 1) / BK * BK;
+    splits = (K + chunk - 1) / chunk;
+    g.splits = (int)splits;
+    g.k_chunk = chunk;
+    g.C = (float*)C;
+    float* slab = nullptr;
+    if (splits > 1) {
+        void* ws = nullptr;
+        int rc = bsc_workspace(ctx, (size_t)batch * splits * M * N * sizeof(float), &ws);
+        if (rc != BSC_OK) return rc;
+        slab = (float*)ws;
+        g.C = slab;
+        ctx->slab_rows = 0;
+    }
+    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)splits, (unsigned)batch);
+    const bool a_m = (sa_m == 1) || (sa_k != 1 && M >= K);   // which axis consecutive threads walk
+    const bool b_n = (sb_n == 1) || (sb_k != 1 && N >= K);
+    {
+        bsc_prof_scope prof(ctx);
+        if (a_m && b_n)
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, true>), grid, dim3(GEMM_BLOCK), 0, ctx->stream, g);
+        else if (a_m)
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, false>), grid, dim3(GEMM_BLOCK), 0, ctx->stream, g);
+        else if (b_n)
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, true>), grid, dim3(GEMM_BLOCK), 0, ctx->stream, g);
+        else
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, false>), grid, dim3(GEMM_BLOCK), 0, ctx->stream, g);
+    }
+    BSC_LAUNCH_CHECK();
+    if (splits > 1) {
+        const dim3 rgrid((unsigned)((M * N + 255) / 256), (unsigned)batch);
+        hipLaunchKernelGGL(splitk_reduce_kernel, rgrid, dim3(256), 0, ctx->stream, slab, g.splits, M,
+                           N, (float*)C, sc_b, sc_m, sc_n);
+        BSC_LAUNCH_CHECK();
+    }
+    return BSC_OK;
+}
+
+}  // extern "C"

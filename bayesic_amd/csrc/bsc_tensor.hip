@@ -1,0 +1,456 @@
+// Strided N-d kernels behind the algebra front end's executable IR:
+// element-wise / n-ary add and mul (elemwise, add, _mul: bayesic/algebra.py:195-233,
+// 1297-1309, 1435-1448), axis sums (_sum :1284-1294), conversion/materialisation
+// of views (_dimshuffle :1312-1326 and _diagonal :1398-1414 are stride views and
+// need no kernel of their own) and eye (:236-258).  All memory-bound.
+#include "bsc_common.h"
+
+namespace {
+
+constexpr int MAXR = BSC_MAX_RANK;
+constexpr int MAXIN = 8;
+
+struct Dims {
+    int rank;
+    int64_t shape[MAXR];
+};
+
+struct ElemArgs {
+    Dims d;
+    int64_t total;
+    int n_in;
+    int64_t out_strides[MAXR];
+    int64_t in_strides[MAXIN][MAXR];
+    const void* in[MAXIN];
+    void* out;
+};
+
+__device__ __forceinline__ void unravel(int64_t flat, const Dims& d, int64_t (&idx)[MAXR]) {
+#pragma unroll
+    for (int a = MAXR - 1; a >= 0; --a) {
+        if (a < d.rank) {
+            const int64_t s = d.shape[a];
+            const int64_t q = flat / s;
+            idx[a] = flat - q * s;
+            flat = q;
+        } else {
+            idx[a] = 0;
+        }
+    }
+}
+
+__device__ __forceinline__ int64_t dot_strides(const int64_t (&idx)[MAXR], const int64_t* strides,
+                                               int rank) {
+    int64_t off = 0;
+#pragma unroll
+    for (int a = 0; a < MAXR; ++a)
+        if (a < rank) off += idx[a] * strides[a];
+    return off;
+}
+
+template <typename T>
+__device__ __forceinline__ T op_unary(int op, T x) {
+    switch (op) {
+        case BSC_OP_LOG: return log(x);
+        case BSC_OP_EXP: return exp(x);
+        case BSC_OP_ABS: return fabs(x);
+        default: return x;
+    }
+}
+
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void elemwise_kernel(ElemArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t flat = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; flat < a.total;
+         flat += stride) {
+        int64_t idx[MAXR];
+        unravel(flat, a.d, idx);
+        T v = static_cast<const T*>(a.in[0])[dot_strides(idx, a.in_strides[0], a.d.rank)];
+        if (OP == BSC_OP_ADD || OP == BSC_OP_MUL) {
+            for (int k = 1; k < a.n_in; ++k) {
+                const T u = static_cast<const T*>(a.in[k])[dot_strides(idx, a.in_strides[k], a.d.rank)];
+                v = (OP == BSC_OP_ADD) ? v + u : v * u;
+            }
+        } else if (OP == BSC_OP_POW) {
+            const T u = static_cast<const T*>(a.in[1])[dot_strides(idx, a.in_strides[1], a.d.rank)];
+            v = pow(v, u);
+        } else {
+            v = op_unary<T>(OP, v);
+        }
+        static_cast<T*>(a.out)[dot_strides(idx, a.out_strides, a.d.rank)] = v;
+    }
+}
+
+// Contiguous fast path for the common case: every operand dense in the same
+// order (or a broadcast scalar), 16 bytes per lane.
+template <int OP>
+__global__ __launch_bounds__(256) void elemwise_dense_f32_kernel(int64_t n4, int n_in,
+                                                                 const float* in0, const float* in1,
+                                                                 const float* in2, const float* in3,
+                                                                 int scalar_mask, float* out) {
+    const float* ins[4] = {in0, in1, in2, in3};
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v;
+        if (scalar_mask & 1) { const float s = ins[0][0]; v = make_float4(s, s, s, s); }
+        else v = reinterpret_cast<const float4*>(ins[0])[i];
+        if (OP == BSC_OP_ADD || OP == BSC_OP_MUL) {
+            for (int k = 1; k < n_in; ++k) {
+                float4 u;
+                if (scalar_mask & (1 << k)) { const float s = ins[k][0]; u = make_float4(s, s, s, s); }
+                else u = reinterpret_cast<const float4*>(ins[k])[i];
+                if (OP == BSC_OP_ADD) { v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+                else { v.x *= u.x; v.y *= u.y; v.z *= u.z; v.w *= u.w; }
+            }
+        } else if (OP == BSC_OP_POW) {
+            float4 u;
+            if (scalar_mask & 2) { const float s = ins[1][0]; u = make_float4(s, s, s, s); }
+            else u = reinterpret_cast<const float4*>(ins[1])[i];
+            v.x = powf(v.x, u.x); v.y = powf(v.y, u.y); v.z = powf(v.z, u.z); v.w = powf(v.w, u.w);
+        } else {
+            v.x = op_unary<float>(OP, v.x); v.y = op_unary<float>(OP, v.y);
+            v.z = op_unary<float>(OP, v.z); v.w = op_unary<float>(OP, v.w);
+        }
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+
+template <typename S, typename T>
+__global__ __launch_bounds__(256) void convert_kernel(Dims d, int64_t total, const S* src,
+                                                      ElemArgs strides, T* dst) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t flat = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; flat < total;
+         flat += stride) {
+        int64_t idx[MAXR];
+        unravel(flat, d, idx);
+        dst[dot_strides(idx, strides.out_strides, d.rank)] =
+            (T)src[dot_strides(idx, strides.in_strides[0], d.rank)];
+    }
+}
+
+// ---- sums --------------------------------------------------------------------
+
+struct SumArgs {
+    Dims keep, red;
+    int64_t n_out, n_red;
+    int64_t keep_strides[MAXR];
+    int64_t red_strides[MAXR];
+    const void* in;
+    void* out;
+    double* partial;  // [splits][n_out] when splits > 1
+    int splits;
+};
+
+// Variant A: the fastest-varying input axis is a REDUCED one.  One wave per
+// (output, split); lanes stride over the flattened reduce index.
+template <typename T>
+__global__ __launch_bounds__(256) void sum_wave_kernel(SumArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t job = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (job >= a.n_out * a.splits) return;
+    const int64_t o = job % a.n_out;
+    const int split = (int)(job / a.n_out);
+    int64_t kidx[MAXR];
+    unravel(o, a.keep, kidx);
+    const T* base = static_cast<const T*>(a.in) + dot_strides(kidx, a.keep_strides, a.keep.rank);
+    const int64_t chunk = (a.n_red + a.splits - 1) / a.splits;
+    const int64_t r0 = split * chunk;
+    const int64_t r1 = (r0 + chunk < a.n_red) ? r0 + chunk : a.n_red;
+    double acc = 0.0;
+    for (int64_t r = r0 + lane; r < r1; r += 64) {
+        int64_t ridx[MAXR];
+        unravel(r, a.red, ridx);
+        acc += (double)base[dot_strides(ridx, a.red_strides, a.red.rank)];
+    }
+    acc = wave_allsum_f64(acc);
+    if (lane == 0) {
+        if (a.splits > 1) a.partial[(int64_t)split * a.n_out + o] = acc;
+        else static_cast<T*>(a.out)[o] = (T)acc;
+    }
+}
+
+// Variant B: the fastest-varying input axis is a KEPT one.  Lane <-> output, so a
+// wave reads 64 consecutive elements per reduce step; the four waves of a block
+// and `splits` blocks divide the reduce range.
+template <typename T>
+__global__ __launch_bounds__(256) void sum_lane_kernel(SumArgs a) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_groups = (a.n_out + 63) / 64;
+    const int64_t group = blockIdx.x % n_groups;
+    const int split = (int)(blockIdx.x / n_groups);
+    const int64_t o = group * 64 + lane;
+    const int64_t chunk = (a.n_red + a.splits - 1) / a.splits;
+    const int64_t r0 = split * chunk;
+    const int64_t r1 = (r0 + chunk < a.n_red) ? r0 + chunk : a.n_red;
+    double acc = 0.0;
+    if (o < a.n_out) {
+        int64_t kidx[MAXR];
+        unravel(o, a.keep, kidx);
+        const T* base = static_cast<const T*>(a.in) + dot_strides(kidx, a.keep_strides, a.keep.rank);
+        for (int64_t r = r0 + wave; r < r1; r += 4) {
+            int64_t ridx[MAXR];
+            unravel(r, a.red, ridx);
+            acc += (double)base[dot_strides(ridx, a.red_strides, a.red.rank)];
+        }
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && o < a.n_out) {
+        const double tot = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+        if (a.splits > 1) a.partial[(int64_t)split * a.n_out + o] = tot;
+        else static_cast<T*>(a.out)[o] = (T)tot;
+    }
+}
+
+template <typename T>
+__global__ void sum_finish_kernel(const double* partial, int splits, int64_t n_out, T* out) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_out) return;
+    double tot = 0.0;
+    for (int s = 0; s < splits; ++s) tot += partial[(int64_t)s * n_out + o];
+    out[o] = (T)tot;
+}
+
+template <typename T>
+__global__ void eye_kernel(T* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * n) out[i] = (i / n == i % n) ? (T)1 : (T)0;
+}
+
+int fill_dims(Dims& d, int rank, const int64_t* shape, int64_t* total, const char* who) {
+    BSC_REQUIRE(rank >= 0 && rank <= MAXR, "%s: rank %d exceeds %d", who, rank, MAXR);
+    d.rank = rank;
+    int64_t t = 1;
+    for (int a = 0; a < MAXR; ++a) {
+        d.shape[a] = a < rank ? shape[a] : 1;
+        BSC_REQUIRE(d.shape[a] >= 0, "%s: negative extent", who);
+        t *= d.shape[a];
+    }
+    *total = t;
+    return BSC_OK;
+}
+
+int grid_for(int64_t work_items, int cu_count) {
+    int64_t blocks = (work_items + 255) / 256;
+    const int64_t cap = (int64_t)cu_count * 8;
+    if (blocks > cap) blocks = cap;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+template <typename T>
+void launch_elemwise(bsc_ctx* ctx, int op, const ElemArgs& a, int grid) {
+#define BSC_CASE(OPV)                                                                      \
+    case OPV:                                                                              \
+        hipLaunchKernelGGL((elemwise_kernel<T, OPV>), dim3(grid), dim3(256), 0, ctx->stream, a); \
+        break;
+    switch (op) {
+        BSC_CASE(BSC_OP_ADD)
+        BSC_CASE(BSC_OP_MUL)
+        BSC_CASE(BSC_OP_LOG)
+        BSC_CASE(BSC_OP_EXP)
+        BSC_CASE(BSC_OP_POW)
+        BSC_CASE(BSC_OP_ABS)
+        BSC_CASE(BSC_OP_COPY)
+    }
+#undef BSC_CASE
+}
+
+}  // namespace
+
+extern "C" {
+
+int bsc_elemwise(bsc_ctx* ctx, int op, int dtype, int rank, const int64_t* host_shape, void* out,
+                 const int64_t* host_out_strides, int n_in, const void* const* host_in,
+                 const int64_t* host_in_strides) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(op >= BSC_OP_ADD && op <= BSC_OP_COPY, "bsc_elemwise: unknown op %d", op);
+    BSC_REQUIRE(dtype == BSC_F32 || dtype == BSC_F64, "bsc_elemwise: unknown dtype %d", dtype);
+    BSC_REQUIRE(out && host_in && n_in >= 1 && n_in <= MAXIN, "bsc_elemwise: bad operands");
+    const int arity = (op == BSC_OP_ADD || op == BSC_OP_MUL) ? n_in : (op == BSC_OP_POW ? 2 : 1);
+    BSC_REQUIRE(arity == n_in, "bsc_elemwise: op %d takes %d inputs, got %d", op, arity, n_in);
+    ElemArgs a{};
+    int rc = fill_dims(a.d, rank, host_shape, &a.total, "bsc_elemwise");
+    if (rc != BSC_OK) return rc;
+    if (a.total == 0) return BSC_OK;
+    a.n_in = n_in;
+    a.out = out;
+    bool dense = dtype == BSC_F32 && n_in <= 4 && (a.total % 4) == 0 && (((uintptr_t)out) & 15) == 0;
+    int scalar_mask = 0;
+    int64_t expect = 1;
+    for (int ax = MAXR - 1; ax >= 0; --ax) {
+        a.out_strides[ax] = ax < rank ? host_out_strides[ax] : 0;
+        if (ax < rank && a.d.shape[ax] != 1) {
+            if (a.out_strides[ax] != expect) dense = false;
+            expect *= a.d.shape[ax];
+        }
+    }
+    for (int k = 0; k < n_in; ++k) {
+        BSC_REQUIRE(host_in[k] != nullptr, "bsc_elemwise: input %d is null", k);
+        a.in[k] = host_in[k];
+        bool all_zero = true, same = true;
+        for (int ax = 0; ax < MAXR; ++ax) {
+            a.in_strides[k][ax] = ax < rank ? host_in_strides[k * rank + ax] : 0;
+            if (ax < rank && a.d.shape[ax] != 1) {
+                if (a.in_strides[k][ax] != 0) all_zero = false;
+                if (a.in_strides[k][ax] != a.out_strides[ax]) same = false;
+            }
+        }
+        if (all_zero) scalar_mask |= 1 << k;
+        else if (!same || (((uintptr_t)host_in[k]) & 15) != 0) dense = false;
+    }
+    if (dense && scalar_mask == (1 << n_in) - 1) dense = false;
+    if (dense) {
+        const int64_t n4 = a.total / 4;
+        const int grid = grid_for(n4, ctx->cu_count);
+        const float* p[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int k = 0; k < n_in; ++k) p[k] = (const float*)host_in[k];
+#define BSC_DENSE(OPV)                                                                        \
+    case OPV:                                                                                 \
+        hipLaunchKernelGGL((elemwise_dense_f32_kernel<OPV>), dim3(grid), dim3(256), 0,        \
+                           ctx->stream, n4, n_in, p[0], p[1], p[2], p[3], scalar_mask, (float*)out); \
+        break;
+        switch (op) {
+            BSC_DENSE(BSC_OP_ADD)
+            BSC_DENSE(BSC_OP_MUL)
+            BSC_DENSE(BSC_OP_LOG)
+            BSC_DENSE(BSC_OP_EXP)
+            BSC_DENSE(BSC_OP_POW)
+            BSC_DENSE(BSC_OP_ABS)
+            BSC_DENSE(BSC_OP_COPY)
+        }
+#undef BSC_DENSE
+    } else {
+        const int grid = grid_for(a.total, ctx->cu_count);
+        if (dtype == BSC_F32) launch_elemwise<float>(ctx, op, a, grid);
+        else launch_elemwise<double>(ctx, op, a, grid);
+    }
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_convert(bsc_ctx* ctx, int src_dtype, int dst_dtype, int rank, const int64_t* host_shape,
+                const void* src, const int64_t* host_src_strides, void* dst,
+                const int64_t* host_dst_strides) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE((src_dtype == BSC_F32 || src_dtype == BSC_F64) &&
+                    (dst_dtype == BSC_F32 || dst_dtype == BSC_F64),
+                "bsc_convert: unknown dtype");
+    BSC_REQUIRE(src && dst, "bsc_convert: null pointer");
+    ElemArgs a{};
+    int64_t total;
+    int rc = fill_dims(a.d, rank, host_shape, &total, "bsc_convert");
+    if (rc != BSC_OK) return rc;
+    if (total == 0) return BSC_OK;
+    for (int ax = 0; ax < MAXR; ++ax) {
+        a.in_strides[0][ax] = ax < rank ? host_src_strides[ax] : 0;
+        a.out_strides[ax] = ax < rank ? host_dst_strides[ax] : 0;
+    }
+    const int grid = grid_for(total, ctx->cu_count);
+    if (src_dtype == BSC_F32 && dst_dtype == BSC_F32)
+        hipLaunchKernelGGL((convert_kernel<float, float>), dim3(grid), dim3(256), 0, ctx->stream,
+                           a.d, total, (const float*)src, a, (float*)dst);
+    else if (src_dtype == BSC_F32)
+        hipLaunchKernelGGL((convert_kernel<float, double>), dim3(grid), dim3(256), 0, ctx->stream,
+                           a.d, total, (const float*)src, a, (double*)dst);
+    else if (dst_dtype == BSC_F32)
+        hipLaunchKernelGGL((convert_kernel<double, float>), dim3(grid), dim3(256), 0, ctx->stream,
+                           a.d, total, (const double*)src, a, (float*)dst);
+    else
+        hipLaunchKernelGGL((convert_kernel<double, double>), dim3(grid), dim3(256), 0, ctx->stream,
+                           a.d, total, (const double*)src, a, (double*)dst);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_sum(bsc_ctx* ctx, int dtype, int rank_keep, const int64_t* host_keep_shape,
+            const int64_t* host_in_keep_strides, int rank_red, const int64_t* host_red_shape,
+            const int64_t* host_in_red_strides, const void* in, void* out) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(dtype == BSC_F32 || dtype == BSC_F64, "bsc_sum: unknown dtype %d", dtype);
+    BSC_REQUIRE(out != nullptr, "bsc_sum: out is null");
+    SumArgs a{};
+    int rc = fill_dims(a.keep, rank_keep, host_keep_shape, &a.n_out, "bsc_sum(keep)");
+    if (rc != BSC_OK) return rc;
+    rc = fill_dims(a.red, rank_red, host_red_shape, &a.n_red, "bsc_sum(reduce)");
+    if (rc != BSC_OK) return rc;
+    if (a.n_out == 0) return BSC_OK;
+    BSC_REQUIRE(in != nullptr || a.n_red == 0, "bsc_sum: in is null");
+    int64_t min_keep = INT64_MAX, min_red = INT64_MAX;
+    for (int ax = 0; ax < MAXR; ++ax) {
+        a.keep_strides[ax] = ax < rank_keep ? host_in_keep_strides[ax] : 0;
+        a.red_strides[ax] = ax < rank_red ? host_in_red_strides[ax] : 0;
+        if (ax < rank_keep && a.keep.shape[ax] > 1) {
+            int64_t s = a.keep_strides[ax] < 0 ? -a.keep_strides[ax] : a.keep_strides[ax];
+            if (s != 0 && s < min_keep) min_keep = s;
+        }
+        if (ax < rank_red && a.red.shape[ax] > 1) {
+            int64_t s = a.red_strides[ax] < 0 ? -a.red_strides[ax] : a.red_strides[ax];
+            if (s != 0 && s < min_red) min_red = s;
+        }
+    }
+    a.in = in;
+    a.out = out;
+    const bool lanes_over_outputs = min_keep < min_red && a.n_out >= 16;
+    // split the reduce range when there are too few outputs to fill the chip
+    const int64_t jobs = lanes_over_outputs ? (a.n_out + 63) / 64 : (a.n_out + 3) / 4;
+    int64_t splits = 1;
+    const int64_t want_blocks = (int64_t)ctx->cu_count * 4;
+    if (jobs < want_blocks) {
+        splits = want_blocks / jobs;
+        const int64_t max_splits = a.n_red / (lanes_over_outputs ? 64 : 1024);
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        if (splits > 4096) splits = 4096;
+    }
+    a.splits = (int)splits;
+    a.partial = nullptr;
+    if (splits > 1) {
+        void* ws = nullptr;
+        rc = bsc_workspace(ctx, (size_t)splits * a.n_out * sizeof(double), &ws);
+        if (rc != BSC_OK) return rc;
+        a.partial = (double*)ws;
+        ctx->slab_rows = 0;
+    }
+    if (lanes_over_outputs) {
+        const int64_t blocks = ((a.n_out + 63) / 64) * splits;
+        if (dtype == BSC_F32)
+            hipLaunchKernelGGL(sum_lane_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(sum_lane_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+    } else {
+        const int64_t blocks = (a.n_out * splits + 3) / 4;
+        if (dtype == BSC_F32)
+            hipLaunchKernelGGL(sum_wave_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(sum_wave_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+    }
+    BSC_LAUNCH_CHECK();
+    if (splits > 1) {
+        const unsigned blocks = (unsigned)((a.n_out + 255) / 256);
+        if (dtype == BSC_F32)
+            hipLaunchKernelGGL(sum_finish_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               a.partial, a.splits, a.n_out, (float*)out);
+        else
+            hipLaunchKernelGGL(sum_finish_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               a.partial, a.splits, a.n_out, (double*)out);
+        BSC_LAUNCH_CHECK();
+    }
+    return BSC_OK;
+}
+
+int bsc_eye(bsc_ctx* ctx, int dtype, void* out, int64_t n) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(out && n >= 0, "bsc_eye: bad arguments");
+    BSC_REQUIRE(dtype == BSC_F32 || dtype == BSC_F64, "bsc_eye: unknown dtype %d", dtype);
+    if (n == 0) return BSC_OK;
+    const unsigned blocks = (unsigned)((n * n + 255) / 256);
+    if (dtype == BSC_F32)
+        hipLaunchKernelGGL(eye_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, (float*)out, n);
+    else
+        hipLaunchKernelGGL(eye_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, (double*)out, n);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+}  // extern "C"

@@ -153,6 +153,56 @@ int bsc_natgrad_update(bsc_ctx* ctx, double* eta, const double* eta0,
  * stats[0]=n, stats[1]=sum x, stats[2]=sum x^2 (float64). */
 int bsc_suffstats_normal(bsc_ctx* ctx, const float* x, int64_t n, double* stats);
 
+/* ---- executable primitives of the algebra front end -----------------------
+ * The five-op IR that Einsum lowering emits plus element-wise nodes:
+ * _sum bayesic/algebra.py:1284-1294, _mul :1297-1309, _dimshuffle :1312-1326 and
+ * _diagonal :1398-1414 (both are stride views -- no kernel), _tensordot
+ * :1329-1383, elemwise/add :195-233, log/exp/pow/abs_ :1435-1448, eye :236-258.
+ * Tensors are (pointer, shape, strides-in-elements); a stride of 0 broadcasts a
+ * size-1 axis (the 'x' axes of dimshuffle).  rank <= BSC_MAX_RANK. */
+
+typedef enum bsc_dtype { BSC_F32 = 0, BSC_F64 = 1 } bsc_dtype;
+
+typedef enum bsc_op {
+    BSC_OP_ADD = 0, /* n-ary, 1..8 inputs */
+    BSC_OP_MUL = 1, /* n-ary, 1..8 inputs */
+    BSC_OP_LOG = 2,
+    BSC_OP_EXP = 3,
+    BSC_OP_POW = 4, /* in0 ** in1 */
+    BSC_OP_ABS = 5,
+    BSC_OP_COPY = 6 /* materialise a strided view */
+} bsc_op;
+
+/* out[i] = op(in_0[i], ..., in_{n-1}[i]) over the index space `shape`;
+ * in_strides is [n_in][rank] row-major; `in` is a HOST array of n_in device
+ * pointers. */
+int bsc_elemwise(bsc_ctx* ctx, int op, int dtype, int rank, const int64_t* host_shape, void* out,
+                 const int64_t* host_out_strides, int n_in, const void* const* host_in,
+                 const int64_t* host_in_strides);
+
+/* dst = (dst_dtype) src, both strided (dtype conversion + layout change). */
+int bsc_convert(bsc_ctx* ctx, int src_dtype, int dst_dtype, int rank, const int64_t* host_shape,
+                const void* src, const int64_t* host_src_strides, void* dst,
+                const int64_t* host_dst_strides);
+
+/* out[keep...] = sum over red... of in[keep..., red...]; float64 accumulation,
+ * fixed summation order (deterministic).  out is contiguous over keep_shape. */
+int bsc_sum(bsc_ctx* ctx, int dtype, int rank_keep, const int64_t* host_keep_shape,
+            const int64_t* host_in_keep_strides, int rank_red, const int64_t* host_red_shape,
+            const int64_t* host_in_red_strides, const void* in, void* out);
+
+/* C[b,m,n] = sum_k A[b,m,k] * B[b,k,n], every stride free (so transposed and
+ * broadcast operands cost nothing).  float32 runs on v_mfma_f32_32x32x2_f32 with
+ * a deterministic split-K when M*N is small against K (XtX: M=N=256, K=1e6);
+ * float64 is a plain VALU kernel. */
+int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t N,
+                             int64_t K, const void* A, int64_t sa_b, int64_t sa_m, int64_t sa_k,
+                             const void* B, int64_t sb_b, int64_t sb_k, int64_t sb_n, void* C,
+                             int64_t sc_b, int64_t sc_m, int64_t sc_n);
+
+/* out[n,n] = identity, contiguous. */
+int bsc_eye(bsc_ctx* ctx, int dtype, void* out, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

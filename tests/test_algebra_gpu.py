@@ -1,0 +1,159 @@
+"""GPU parity of the algebra front end's device executor (HIP kernels through the
+C ABI) against numpy -- the reference's own numeric oracle
+(bayesic/tests/test_algebra.py:44-191) -- and against the einsum definition.
+
+Tolerances are the reference's: rtol 1e-5 wherever a sum/contraction is involved
+(test_algebra.py:82), tight for pure element-wise results (device libm vs numpy:
+rtol 1e-6 for log/exp/pow, exact for + - * abs).
+"""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+import test_algebra as T                     # the CPU suite's inputs and CHECKS
+from bayesic_amd.algebra import *            # noqa: F401,F403
+from oracle.einsum_eval import einsum_semantics
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(ctx):
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    return DeviceBackend(ctx)
+
+
+def run(dev, expr, **inputs):
+    return expr.compile(dev)(**inputs)
+
+
+def test_reference_numeric_tests_on_device(dev):
+    X, Y, x, y, S, a = T.X, T.Y, T.x, T.y, T.S, T.a
+    X_, Y_, x_, y_, S_ = T.X_, T.Y_, T.x_, T.y_, T.S_
+    npt.assert_array_equal(run(dev, X + Y, X=X_, Y=Y_), X_ + Y_)
+    npt.assert_array_equal(run(dev, X - Y, X=X_, Y=Y_), X_ - Y_)
+    npt.assert_array_equal(run(dev, abs(X), X=X_), abs(X_))
+    npt.assert_array_equal(run(dev, X + 1, X=X_), X_ + 1)
+    npt.assert_array_equal(run(dev, 1 - X, X=X_), 1 - X_)
+    npt.assert_array_equal(run(dev, 2 * X, X=X_), 2 * X_)
+    assert run(dev, add(1, 1)) == 2
+    npt.assert_array_equal(run(dev, X * Y_, X=X_), X_ * Y_)
+    npt.assert_allclose(run(dev, dot(X, Y), X=X_, Y=Y_), np.dot(X_, Y_), rtol=1e-5)
+    npt.assert_allclose(run(dev, X.dot(y), X=X_, y=y_), np.dot(X_, y_), rtol=1e-5)
+    npt.assert_allclose(run(dev, dot(x, y), x=x_, y=y_), np.dot(x_, y_), rtol=1e-5)
+    npt.assert_array_equal(run(dev, X * Y, X=X_, Y=Y_), X_ * Y_)
+    npt.assert_allclose(run(dev, X / Y, X=X_, Y=Y_), X_ / Y_, rtol=1e-5)
+    with np.errstate(all="ignore"):
+        npt.assert_allclose(run(dev, X ** Y, X=X_, Y=Y_), X_ ** Y_, rtol=1e-6)   # NaN == NaN
+        npt.assert_allclose(run(dev, 2 ** X, X=X_), 2 ** X_, rtol=1e-6)
+        npt.assert_allclose(run(dev, X ** 2, X=X_), X_ ** 2, rtol=1e-6)
+        npt.assert_allclose(run(dev, log(X), X=X_), np.log(X_), rtol=1e-6)
+    npt.assert_allclose(run(dev, exp(X), X=X_), np.exp(X_), rtol=1e-6)
+    npt.assert_array_equal(run(dev, X.T, X=X_), X_.T)
+    npt.assert_array_equal(run(dev, dimshuffle(S, 2, 0, 1), S=S_), np.transpose(S_, (2, 0, 1)))
+    npt.assert_array_equal(run(dev, X + x.dimshuffle(0, "x"), X=X_, x=x_), X_ + x_[:, None])
+    npt.assert_array_equal(run(dev, X * dimshuffle(x, "x", 0), X=X_, x=x_), X_ * x_[None, :])
+    npt.assert_allclose(run(dev, trace(X), X=X_), np.trace(X_), rtol=1e-5)
+    npt.assert_array_equal(run(dev, diagonal(X), X=X_), np.diagonal(X_))
+    npt.assert_array_equal(run(dev, outer(x, y), x=x_, y=y_), np.outer(x_, y_))
+    npt.assert_allclose(run(dev, sum(S), S=S_), S_.sum(), rtol=1e-5)
+    npt.assert_allclose(run(dev, sum(S, axis=0), S=S_), S_.sum(axis=0), rtol=1e-5)
+    npt.assert_allclose(run(dev, S.sum(axis=(0, 2)), S=S_), S_.sum(axis=(0, 2)), rtol=1e-5)
+    data = np.array([[1, 2], [3, 4], [5, 6]], dtype="float32")
+    assert run(dev, X.shape[0], X=data) == 3 and run(dev, X.size, X=data) == 6
+    npt.assert_equal(run(dev, eye(a), a=2), np.eye(2))
+    npt.assert_equal(run(dev, eye(a), a=5), np.eye(5))
+    expr = dot(diagonal(dot(X, outer(x, y))), Y)
+    npt.assert_allclose(run(dev, expr, x=x_, y=y_, X=X_, Y=Y_),
+                        np.dot(np.diagonal(np.dot(X_, np.outer(x_, y_))), Y_), rtol=1e-5)
+
+
+@pytest.mark.parametrize("case", range(len(T.CHECKS)))
+def test_corpus_on_device_equals_einsum_definition(dev, case):
+    build, expected = T.CHECKS[case]
+    e = build()
+    got = run(dev, e, **{k: T.VALUES[k] for k in e.input_types})
+    want = expected()
+    if want is not None:
+        npt.assert_allclose(got, want, rtol=2e-5, atol=1e-6)
+    if isinstance(e, Einsum):
+        ref64 = einsum_semantics(e, {k: T.VALUES[k].astype(np.float64) for k in e.input_types})
+        assert got.shape == ref64.shape
+        npt.assert_allclose(got, ref64, rtol=2e-5, atol=1e-5)
+
+
+def test_batched_tensordot_on_device(dev):
+    X, Y, S = T.X, T.Y, T.S
+    e = (X * Y.T).sum(axis=1)
+    npt.assert_allclose(run(dev, e, X=T.X_, Y=T.Y_), (T.X_ * T.Y_.T).sum(axis=1), rtol=1e-5)
+    e2 = tensordot(S, S, [1], [1], [0], [0])
+    npt.assert_allclose(run(dev, e2, S=T.S_), np.einsum("uiv,uiw->uvw", T.S_, T.S_), rtol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (33, 17, 5), (128, 128, 16), (130, 257, 1000),
+                                   (256, 256, 40000), (64, 16, 100003), (5, 300, 2), (300, 5, 777)])
+def test_gemm_shapes_incl_split_k(dev, M, N, K):
+    """dot(A.T, B) with K long: exercises m-contiguous operands, ragged tiles and the
+    deterministic split-K (the X^T X / R^T X shapes of configs 2 and 3)."""
+    rs = np.random.RandomState(M + N + K)
+    A_ = rs.standard_normal((K, M)).astype(np.float32)
+    B_ = rs.standard_normal((K, N)).astype(np.float32)
+    A, Bv = var("A", 2), var("Bv", 2)
+    got = run(dev, dot(A.T, Bv), A=A_, Bv=B_)
+    want = A_.astype(np.float64).T @ B_.astype(np.float64)
+    bound = np.sqrt((A_.astype(np.float64) ** 2).sum(0))[:, None] * \
+        np.sqrt((B_.astype(np.float64) ** 2).sum(0))[None, :]
+    assert (np.abs(got - want) <= 1e-5 * bound + 1e-12).all()
+    assert (got == run(dev, dot(A.T, Bv), A=A_, Bv=B_)).all()       # deterministic
+    # k-contiguous operands of the same product
+    got2 = run(dev, dot(A, Bv.T), A=np.ascontiguousarray(A_.T), Bv=np.ascontiguousarray(B_.T))
+    assert (np.abs(got2 - want) <= 1e-5 * bound + 1e-12).all()
+
+
+def test_sum_access_patterns_and_determinism(dev):
+    rs = np.random.RandomState(3)
+    Xb = rs.standard_normal((20000, 96)).astype(np.float32)
+    X = T.X
+    for expr, want in [(sum(X, 0), Xb.astype(np.float64).sum(0)), (sum(X, 1), Xb.astype(np.float64).sum(1)),
+                       (sum(X), Xb.astype(np.float64).sum()), (sum(X.T, 0), Xb.astype(np.float64).sum(1))]:
+        got = run(dev, expr, X=Xb)
+        npt.assert_allclose(got, want, rtol=1e-5, atol=1e-3)
+        npt.assert_array_equal(got, run(dev, expr, X=Xb))
+    S5 = rs.standard_normal((7, 5, 3, 4, 6)).astype(np.float32)
+    V = var("V", 5)
+    npt.assert_allclose(run(dev, sum(V, axis=(1, 3)), V=S5), S5.sum(axis=(1, 3)), rtol=1e-5, atol=1e-5)
+
+
+def test_float64_inputs_stay_float64(dev):
+    A, b = var("A", 2, "float64"), var("b", 1, "float64")
+    rs = np.random.RandomState(0)
+    A_, b_ = rs.standard_normal((40, 30)), rs.standard_normal(30)
+    got = run(dev, dot(A, b) + exp(sum(A, 1)), A=A_, b=b_)
+    assert got.dtype == np.float64
+    npt.assert_allclose(got, A_ @ b_ + np.exp(A_.sum(1)), rtol=1e-12)
+
+
+def test_config_shaped_expressions_on_device(dev):
+    """The lowered forms of SURVEY 8(a) A7 at small sizes: conjugate BLR statistics,
+    MoG responsibilities-weighted moments, LDA sufficient statistics."""
+    rs = np.random.RandomState(7)
+    n, d, k = 3000, 32, 8
+    Xv = rs.standard_normal((n, d)).astype(np.float32)
+    yv = rs.standard_normal(n).astype(np.float32)
+    Rv = rs.dirichlet(np.ones(k), n).astype(np.float32)
+    X, y, R = var("X", 2), var("y", 1), var("R", 2)
+    X64, y64, R64 = Xv.astype(np.float64), yv.astype(np.float64), Rv.astype(np.float64)
+    npt.assert_allclose(run(dev, dot(X.T, X), X=Xv), X64.T @ X64, rtol=1e-4, atol=1e-2)
+    npt.assert_allclose(run(dev, dot(X.T, y), X=Xv, y=yv), X64.T @ y64, rtol=1e-4, atol=1e-2)
+    npt.assert_allclose(run(dev, sum(y * y), y=yv), y64 @ y64, rtol=1e-5)
+    npt.assert_allclose(run(dev, sum(R, 0), R=Rv), R64.sum(0), rtol=1e-5)
+    npt.assert_allclose(run(dev, dot(R.T, X), R=Rv, X=Xv), R64.T @ X64, rtol=1e-4, atol=1e-3)
+    npt.assert_allclose(run(dev, dot(R.T, X * X), R=Rv, X=Xv), R64.T @ (X64 * X64), rtol=1e-4, atol=1e-3)
+    Th, C, Bm = var("Th", 2), var("C", 2), var("Bm", 2)
+    docs, V, K = 60, 500, 16
+    Thv = rs.gamma(1.0, 1.0, (docs, K)).astype(np.float32)
+    Cv = rs.poisson(0.3, (docs, V)).astype(np.float32)
+    Bv = rs.gamma(1.0, 1.0, (K, V)).astype(np.float32)
+    npt.assert_allclose(run(dev, Bm * dot(Th.T, C), Bm=Bv, Th=Thv, C=Cv),
+                        Bv.astype(np.float64) * (Thv.astype(np.float64).T @ Cv.astype(np.float64)),
+                        rtol=1e-4, atol=1e-4)
