@@ -60,6 +60,11 @@ SIGNATURES = {
     "bsc_natgrad_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
                                    c_double]),
     "bsc_suffstats_normal": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "bsc_mog_estep": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p,
+                              c_void_p, c_void_p, c_void_p]),
+    "bsc_mog_expected_params": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "bsc_mog_natgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,
+                                c_double]),
     "bsc_elemwise": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int64), c_void_p,
                              POINTER(c_int64), c_int, POINTER(c_void_p), POINTER(c_int64)]),
     "bsc_convert": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int64), c_void_p,
@@ -71,6 +76,8 @@ SIGNATURES = {
                                          c_void_p, c_int64, c_int64, c_int64,
                                          c_void_p, c_int64, c_int64, c_int64]),
     "bsc_eye": (c_int, [c_void_p, c_int, c_void_p, c_int64]),
+    "bsc_logdet_spd": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                               c_int64, c_void_p]),
 }
 
 _lib = None

@@ -53,6 +53,10 @@ class Backend(object):
     def diagonal(self, x, axis1, axis2):
         raise NotImplementedError
 
+    def logdet(self, x):
+        """log det over the trailing two axes (bayesic/distribution/core.py:50)."""
+        raise NotImplementedError
+
     # -- tree walk -------------------------------------------------------------
     def evaluate(self, expr, inputs):
         from .einsum_form import Einsum

@@ -66,7 +66,9 @@ class DeviceBackend(Backend):
             a = a.astype(dtype, copy=False)
             if a.dtype not in (np.float32, np.float64):
                 a = a.astype(np.float32)
-        return torch.from_numpy(np.ascontiguousarray(a)).to(self.ctx.device)
+        # (np.ascontiguousarray would turn a 0-d array into shape (1,))
+        a = np.array(a, order="C", copy=True)
+        return torch.from_numpy(a).to(self.ctx.device)
 
     def to_host(self, value):
         if isinstance(value, HostScalar):
@@ -197,6 +199,19 @@ class DeviceBackend(Backend):
 
     def diagonal(self, x, axis1, axis2):
         return torch.diagonal(x, 0, axis1, axis2)     # view; the diagonal axis goes last
+
+    def logdet(self, x):
+        lead = list(x.shape[:-2])
+        n = x.shape[-1]
+        if x.shape[-2] != n:
+            raise ValueError("logdet needs square matrices")
+        xb = x.reshape([-1, n, n]) if x.dim() != 3 else x     # view when possible
+        if not (x.dim() == 3 or xb.data_ptr() == x.data_ptr()):
+            xb = self._contiguous(x).reshape([-1, n, n])
+        out = torch.empty(lead, dtype=x.dtype, device=self.ctx.device)
+        self.ctx.call("bsc_logdet_spd", _DT[x.dtype], xb.shape[0], n, _ffi.ptr(xb), xb.stride(0),
+                      xb.stride(1), xb.stride(2), _ffi.ptr(out))
+        return out
 
     @staticmethod
     def _merge(t, axes):

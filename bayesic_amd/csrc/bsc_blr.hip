@@ -104,15 +104,6 @@ __device__ __forceinline__ float swap_add16(float a, float b) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// Orders this wave's LDS writes before its later LDS reads of other lanes'
-// data.  LDS operations of one wave execute in order; this only stops the
-// compiler from moving them.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
     float v = a.x * b.x;
     v = fmaf(a.y, b.y, v);

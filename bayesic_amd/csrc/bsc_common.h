@@ -121,6 +121,15 @@ __device__ __forceinline__ double wave_allsum_f64(double v) {
     return v;
 }
 
+// Orders this wave's LDS writes before its later LDS reads of other lanes' data
+// (wave-private LDS regions, no workgroup barrier).  LDS operations of one wave
+// execute in order; this only stops the compiler from moving them.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float readlane_f32(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }

@@ -1,0 +1,378 @@
+// Mixture of Gaussians (BASELINE config 3): per-row marginalisation of the
+// discrete latent by summation, fused with the responsibility-weighted
+// sufficient statistics.
+//
+// ABSENT in the reference: spec is README.md:43,72 ("marginalise them by
+// summation", also after mini-batching) with the exponential-family statistics of
+// bayesic/distribution/base.py:329-332; in bayesic.algebra terms the two
+// contractions are dot(F, W.T) and dot(R.T, F) (cfg 3).
+//
+// Per row n, with features f_n = [x_n (16) | x_n^2 (16)] and K <= 64 components:
+//     logit_nk = c_k + sum_f W_kf f_nf                  (forward,  rows x 32 x 64)
+//     r_nk     = softmax_k(logit_nk)
+//     S_kf    += r_nk f_nf,  R_k += r_nk,  L += logsumexp_k(logit_nk)
+//                                                       (backward, 64 x rows x 32)
+// Both contractions are dense with no padding waste at K=64, D=16, so both run on
+// v_mfma_f32_32x32x2_f32 (exact f32).  A wave owns 32-row tiles:
+//   forward  D[row][comp]  = A(features: lane = row, k = feature pair) * B(W, in registers)
+//   softmax  across the 32 lanes of each half-wave (DPP + one permlane16 swap per row)
+//   backward D[comp][feat] = A(r) * B(features from LDS)
+// and the responsibility tile is ALREADY laid out as the next MFMA's A operand:
+// accumulator register q of lane l holds row (q&3)+8(q>>2)+4(l>>5) for component
+// l&31, i.e. exactly A[i = comp][k = l>>5] of the row pair (rho, rho+4) -- no lane
+// movement, no LDS round trip for r.
+#include "bsc_common.h"
+
+namespace {
+
+constexpr int MK = 64;        // components (padded)
+constexpr int MD = 16;        // data columns (padded)
+constexpr int MF = 2 * MD;    // features
+constexpr int MT = 32;        // rows per tile
+constexpr int MOG_BLOCK = 256;
+constexpr int MOG_WAVES = MOG_BLOCK / BSC_WAVE;
+constexpr int XT_STRIDE = MD + 4;                    // LDS row stride of the x tile
+constexpr int MOG_SLAB = MK * (1 + MF) + 1;          // [comp][R | S(32)] + L
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int drow(int q, int lane) {  // C/D row of accumulator register q
+    return (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) { return fmaxf(v, dpp_f32<CTRL>(v)); }
+
+// all-reduce over the 32 lanes of each half-wave
+__device__ __forceinline__ float half_allmax(float v) {
+    v = dpp_max<DPP_QUAD_XOR1>(v);
+    v = dpp_max<DPP_QUAD_XOR2>(v);
+    v = dpp_max<DPP_ROW_ROR4>(v);
+    v = dpp_max<DPP_ROW_ROR8>(v);
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+__device__ __forceinline__ float half_allsum(float v) {
+    v = row16_allsum(v);
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+struct XRow {
+    float x[MD];
+};
+
+// lane l loads row (row0 + (l&31)): 16 floats; rows past the end and columns >= D read 0
+__device__ __forceinline__ void load_rows(XRow& t, const float* __restrict__ X, int64_t ldx,
+                                          int64_t row0, int64_t N, int D, int lane) {
+    const int64_t rem = N - row0;
+    uint64_t bytes = 0;
+    if (rem > 0) bytes = ((uint64_t)(rem - 1) * (uint64_t)ldx + (uint64_t)D) * 4u;
+    const unsigned rec = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes;
+    const int64_t safe0 = rem > 0 ? row0 : 0;
+    auto xs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + safe0 * ldx), 0, rec, 0x00020000);
+    const int off = (lane & 31) * (int)(ldx * 4);
+#pragma unroll
+    for (int c4 = 0; c4 < MD / 4; ++c4) {
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(xs, off + 16 * c4, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float f = __uint_as_float(v[j]);
+            if (4 * c4 + j >= D) f = 0.f;   // D < 16: those bytes belong to the next row
+            t.x[4 * c4 + j] = f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
+    const float* __restrict__ X, int64_t ldx, int64_t N, int D, const float* __restrict__ Wmat,
+    const float* __restrict__ cvec, int K, float* __restrict__ slab, int n_iter) {
+    __shared__ __attribute__((aligned(16))) float lds[MOG_WAVES * (MT * XT_STRIDE) > MOG_WAVES * MOG_SLAB
+                                                          ? MOG_WAVES * (MT * XT_STRIDE)
+                                                          : MOG_WAVES * MOG_SLAB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    float* xt = lds + wave * (MT * XT_STRIDE);
+
+    // B operand of the forward product: W[comp = 32cb + l31][feature 2s + half]
+    float wreg[2][MF / 2];
+    float bias[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int comp = 32 * cb + l31;
+        bias[cb] = comp < K ? cvec[comp] : -1.0e30f;
+#pragma unroll
+        for (int s = 0; s < MF / 2; ++s) {
+            const int f = 2 * s + half;            // f < 16: x_f ; else x^2_{f-16}
+            const int d = f & (MD - 1);
+            float v = 0.f;
+            if (comp < K && d < D) v = Wmat[(int64_t)comp * 2 * D + (f < MD ? d : D + d)];
+            wreg[cb][s] = v;
+        }
+    }
+
+    f32x16 S[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) S[cb][q] = 0.f;
+    float rsum[2] = {0.f, 0.f};
+    float lse_acc = 0.f;
+
+    const int64_t stride = (int64_t)gridDim.x * MOG_WAVES;
+    int64_t tile = (int64_t)blockIdx.x * MOG_WAVES + wave;
+    XRow cur, nxt;
+    load_rows(cur, X, ldx, tile * MT, N, D, lane);
+    for (int it = 0; it < n_iter; ++it) {
+        load_rows(nxt, X, ldx, (tile + stride) * MT, N, D, lane);   // unconditional prefetch
+        const int64_t row0 = tile * MT;
+
+        // stage the tile for the backward B operand (lanes 0-31 own one row each)
+        if (half == 0) {
+#pragma unroll
+            for (int c4 = 0; c4 < MD / 4; ++c4)
+                *reinterpret_cast<float4*>(xt + l31 * XT_STRIDE + 4 * c4) =
+                    make_float4(cur.x[4 * c4], cur.x[4 * c4 + 1], cur.x[4 * c4 + 2], cur.x[4 * c4 + 3]);
+        }
+        // forward: logits[row][comp]
+        f32x16 logit[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) logit[cb][q] = bias[cb];
+#pragma unroll
+        for (int s = 0; s < MF / 2; ++s) {
+            const int t = s & 7;
+            float a = half ? cur.x[2 * t + 1] : cur.x[2 * t];
+            if (s >= 8) a = a * a;
+            logit[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[0][s], logit[0], 0, 0, 0);
+            logit[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[1][s], logit[1], 0, 0, 0);
+        }
+        // softmax over the 64 components of every row; rows past N get r = 0
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const bool valid = row0 + drow(q, lane) < N;
+            const float m = half_allmax(fmaxf(logit[0][q], logit[1][q]));
+            const float e0 = __expf(logit[0][q] - m), e1 = __expf(logit[1][q] - m);
+            const float s = half_allsum(e0 + e1);
+            const float inv = valid ? 1.0f / s : 0.f;
+            logit[0][q] = e0 * inv;
+            logit[1][q] = e1 * inv;
+            rsum[0] += logit[0][q];
+            rsum[1] += logit[1][q];
+            if (valid && l31 == 0) lse_acc += m + __logf(s);
+        }
+        wave_lds_sync();
+        // backward: S[comp][feat] += r[row][comp] * f[row][feat]
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float b = xt[drow(q, lane) * XT_STRIDE + (lane & (MD - 1))];
+            if (lane & MD) b = b * b;               // features 16..31 are the squares
+            S[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(logit[0][q], b, S[0], 0, 0, 0);
+            S[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(logit[1][q], b, S[1], 0, 0, 0);
+        }
+        wave_lds_sync();   // the next tile overwrites xt
+        cur = nxt;
+        tile += stride;
+    }
+
+    // block reduction: per wave [comp][R | S] + L, then fixed-order sum over waves
+    __syncthreads();
+    float* ep = lds + wave * MOG_SLAB;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int comp = 32 * cb + drow(q, lane);
+            ep[comp * (1 + MF) + 1 + l31] = S[cb][q];
+        }
+        float r = rsum[cb];
+        r += __shfl_xor(r, 32);                   // the two row halves of the same component
+        if (half == 0) ep[(32 * cb + l31) * (1 + MF)] = r;
+    }
+    float l = lse_acc;
+    l += __shfl_xor(l, 32);
+    if (lane == 0) ep[MK * (1 + MF)] = l;
+    __syncthreads();
+    float* out = slab + (int64_t)blockIdx.x * MOG_SLAB;
+    for (int i = tid; i < MOG_SLAB; i += MOG_BLOCK) {
+        float v = lds[i];
+#pragma unroll
+        for (int k = 1; k < MOG_WAVES; ++k) v += lds[k * MOG_SLAB + i];
+        out[i] = v;
+    }
+}
+
+// float64, fixed-order sum of the block partials; compacts [64][1+32] to [K][1+2D]
+__global__ __launch_bounds__(1024) void mog_reduce_kernel(const float* __restrict__ slab, int n_rows,
+                                                          int K, int D, double* __restrict__ stats,
+                                                          double* __restrict__ lse) {
+    __shared__ double part[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    double sum = 0.0;
+    if (i < MOG_SLAB) {
+        constexpr int BATCH = 16;
+        for (int b0 = wave; b0 < n_rows; b0 += 16 * BATCH) {
+            float v[BATCH];
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                const int b = b0 + 16 * j;
+                v[j] = b < n_rows ? slab[(int64_t)b * MOG_SLAB + i] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) sum += (double)v[j];
+        }
+    }
+    part[wave][lane] = sum;
+    __syncthreads();
+    if (wave == 0 && i < MOG_SLAB) {
+        double tot = part[0][lane];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) tot += part[k][lane];
+        if (i == MK * (1 + MF)) {
+            lse[0] = tot;
+        } else {
+            const int comp = i / (1 + MF), col = i % (1 + MF);
+            if (comp < K) {
+                if (col == 0) stats[(int64_t)comp * (1 + 2 * D)] = tot;
+                else {
+                    const int f = col - 1, d = f & (MD - 1);
+                    if (d < D) stats[(int64_t)comp * (1 + 2 * D) + 1 + (f < MD ? d : D + d)] = tot;
+                }
+            }
+        }
+    }
+}
+
+// digamma in float64: recurrence up to x >= 8, then the asymptotic series
+#pragma clang fp contract(off)
+__device__ double digamma_f64(double x) {
+    double acc = 0.0;
+    while (x < 8.0) {
+        acc -= 1.0 / x;
+        x += 1.0;
+    }
+    const double inv = 1.0 / x, inv2 = inv * inv;
+    // ln x - 1/2x - 1/12x^2 + 1/120x^4 - 1/252x^6 + 1/240x^8 - 5/660x^10 + 691/32760x^12
+    const double series = inv2 * (1.0 / 12.0 - inv2 * (1.0 / 120.0 - inv2 * (1.0 / 252.0 - inv2 *
+                          (1.0 / 240.0 - inv2 * (5.0 / 660.0 - inv2 * (691.0 / 32760.0))))));
+    return acc + log(x) - 0.5 * inv - series;
+}
+
+// eta layout: [alpha-1 (K) | kappa*m (K*D) | kappa (K*D) | 2a-1 (K*D) | 2b+kappa*m^2 (K*D)]
+// One workgroup; thread k owns component k.
+__global__ __launch_bounds__(64) void mog_expected_params_kernel(const double* __restrict__ eta,
+                                                                 int K, int D,
+                                                                 float* __restrict__ Wmat,
+                                                                 float* __restrict__ cvec) {
+    __shared__ double alpha_sum;
+    const int k = threadIdx.x;
+    const double LOG_2PI = 1.8378770664093454835606594728112;
+    double a_k = k < K ? eta[k] + 1.0 : 0.0;
+    double tot = wave_allsum_f64(a_k);
+    if (k == 0) alpha_sum = tot;
+    __syncthreads();
+    if (k >= K) return;
+    double c = digamma_f64(a_k) - digamma_f64(alpha_sum);
+    const int64_t KD = (int64_t)K * D;
+    for (int d = 0; d < D; ++d) {
+        const int64_t i = (int64_t)k * D + d;
+        const double kappa = eta[K + KD + i];
+        const double m = eta[K + i] / kappa;
+        const double a = 0.5 * (eta[K + 2 * KD + i] + 1.0);
+        const double b = 0.5 * (eta[K + 3 * KD + i] - kappa * m * m);
+        const double T = a / b;
+        c += 0.5 * (digamma_f64(a) - log(b)) - 0.5 * LOG_2PI - 0.5 * T * m * m - 0.5 / kappa;
+        Wmat[(int64_t)k * 2 * D + d] = (float)(T * m);
+        Wmat[(int64_t)k * 2 * D + D + d] = (float)(-0.5 * T);
+    }
+    cvec[k] = (float)c;
+}
+
+// eta <- (1-rho) eta + rho (eta0 + scale * message(stats)), stats = [K][R | Sx | Sxx]
+__global__ void mog_natgrad_kernel(double* __restrict__ eta, const double* __restrict__ eta0,
+                                   const double* __restrict__ stats, int K, int D, double scale,
+                                   double rho) {
+    const int64_t KD = (int64_t)K * D;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K + 4 * KD) return;
+    double msg;
+    if (i < K) {
+        msg = stats[i * (1 + 2 * D)];
+    } else {
+        const int64_t j = i - K;
+        const int part = (int)(j / KD);
+        const int64_t kd = j % KD;
+        const int64_t k = kd / D, d = kd % D;
+        const double* row = stats + k * (1 + 2 * D);
+        msg = part == 0 ? row[1 + d] : (part == 3 ? row[1 + D + d] : row[0]);
+    }
+    eta[i] = (1.0 - rho) * eta[i] + rho * (eta0[i] + scale * msg);
+}
+
+}  // namespace
+
+extern "C" {
+
+int bsc_mog_expected_params(bsc_ctx* ctx, const double* eta, int32_t K, int32_t D, float* Wmat,
+                            float* c) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(eta && Wmat && c, "bsc_mog_expected_params: null pointer");
+    BSC_REQUIRE(K >= 1 && K <= MK && D >= 1, "bsc_mog_expected_params: K=%d (<=%d) D=%d", K, MK, D);
+    hipLaunchKernelGGL(mog_expected_params_kernel, dim3(1), dim3(64), 0, ctx->stream, eta, (int)K,
+                       (int)D, Wmat, c);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_mog_natgrad(bsc_ctx* ctx, double* eta, const double* eta0, const double* stats, int32_t K,
+                    int32_t D, double scale, double rho) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(eta && eta0 && stats && K >= 1 && D >= 1, "bsc_mog_natgrad: bad arguments");
+    const int64_t n = K + 4 * (int64_t)K * D;
+    hipLaunchKernelGGL(mog_natgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, eta, eta0, stats, (int)K, (int)D, scale, rho);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_mog_estep(bsc_ctx* ctx, const float* X, int64_t ldx, int64_t N, int32_t D, int32_t K,
+                  const float* Wmat, const float* c, double* stats, double* lse) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(N >= 0 && ((X != nullptr) || N == 0) && Wmat && c && stats && lse,
+                "bsc_mog_estep: null pointer");
+    if (D < 1 || D > MD || K < 1 || K > MK)
+        return bsc_fail(BSC_ERR_UNSUPPORTED,
+                        "bsc_mog_estep: D=%d K=%d outside the MFMA tile limits (D<=%d, K<=%d)", D,
+                        K, MD, MK);
+    BSC_REQUIRE(ldx >= D && ldx < ((int64_t)1 << 26), "bsc_mog_estep: bad ldx=%lld", (long long)ldx);
+    BSC_REQUIRE(((uintptr_t)X & 3) == 0, "bsc_mog_estep: X must be 4-byte aligned");
+    const int64_t n_tiles = (N + MT - 1) / MT;
+    const int64_t max_waves = 2 * 4 * (int64_t)ctx->cu_count;
+    int n_iter = 0, n_blocks = 1;
+    if (n_tiles > 0) {
+        const int64_t it = (n_tiles + max_waves - 1) / max_waves;
+        const int64_t waves = (n_tiles + it - 1) / it;
+        n_iter = (int)it;
+        n_blocks = (int)((waves + MOG_WAVES - 1) / MOG_WAVES);
+    }
+    void* ws = nullptr;
+    int rc = bsc_workspace(ctx, (size_t)n_blocks * MOG_SLAB * sizeof(float), &ws);
+    if (rc != BSC_OK) return rc;
+    ctx->slab_rows = 0;
+    {
+        bsc_prof_scope prof(ctx);
+        hipLaunchKernelGGL(mog_estep_kernel, dim3(n_blocks), dim3(MOG_BLOCK), 0, ctx->stream, X, ldx,
+                           N, (int)D, Wmat, c, (int)K, (float*)ws, n_iter);
+    }
+    BSC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mog_reduce_kernel, dim3((MOG_SLAB + 63) / 64), dim3(1024), 0, ctx->stream,
+                       (const float*)ws, n_blocks, (int)K, (int)D, stats, lse);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+}  // extern "C"

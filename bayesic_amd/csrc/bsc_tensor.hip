@@ -218,6 +218,41 @@ __global__ void eye_kernel(T* out, int64_t n) {
     if (i < n * n) out[i] = (i / n == i % n) ? (T)1 : (T)0;
 }
 
+// log det of a symmetric positive-definite matrix by an in-place float64 Cholesky
+// in the workspace, one workgroup per matrix (parameter-side: D x D, once per
+// update -- not a data-sized operation).  Non-SPD input yields NaN.
+template <typename T>
+__global__ __launch_bounds__(1024) void logdet_spd_kernel(const T* __restrict__ A, int64_t n,
+                                                          int64_t s_b, int64_t s_r, int64_t s_c,
+                                                          double* __restrict__ work,
+                                                          T* __restrict__ out) {
+    __shared__ double pivot;
+    __shared__ double red[16];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int64_t b = blockIdx.x;
+    double* L = work + b * n * n;
+    const T* src = A + b * s_b;
+    for (int64_t i = tid; i < n * n; i += nt) L[i] = (double)src[(i / n) * s_r + (i % n) * s_c];
+    __syncthreads();
+    double logsum = 0.0;
+    for (int64_t j = 0; j < n; ++j) {
+        if (tid == 0) pivot = sqrt(L[j * n + j]);
+        __syncthreads();
+        const double d = pivot;
+        if (tid == 0) logsum += log(d);
+        for (int64_t i = j + 1 + tid; i < n; i += nt) L[i * n + j] /= d;
+        __syncthreads();
+        const int64_t m = n - j - 1;   // trailing block is m x m, lower triangle only
+        for (int64_t t = tid; t < m * m; t += nt) {
+            const int64_t i = j + 1 + t / m, k = j + 1 + t % m;
+            if (k <= i) L[i * n + k] -= L[i * n + j] * L[k * n + j];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out[b] = (T)(2.0 * logsum);
+    (void)red;
+}
+
 int fill_dims(Dims& d, int rank, const int64_t* shape, int64_t* total, const char* who) {
     BSC_REQUIRE(rank >= 0 && rank <= MAXR, "%s: rank %d exceeds %d", who, rank, MAXR);
     d.rank = rank;
@@ -436,6 +471,27 @@ int bsc_sum(bsc_ctx* ctx, int dtype, int rank_keep, const int64_t* host_keep_sha
                                a.partial, a.splits, a.n_out, (double*)out);
         BSC_LAUNCH_CHECK();
     }
+    return BSC_OK;
+}
+
+int bsc_logdet_spd(bsc_ctx* ctx, int dtype, int64_t batch, int64_t n, const void* A, int64_t s_b,
+                   int64_t s_r, int64_t s_c, void* out) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(dtype == BSC_F32 || dtype == BSC_F64, "bsc_logdet_spd: unknown dtype %d", dtype);
+    BSC_REQUIRE(batch >= 0 && n >= 0 && out, "bsc_logdet_spd: bad arguments");
+    if (batch == 0) return BSC_OK;
+    BSC_REQUIRE(A || n == 0, "bsc_logdet_spd: A is null");
+    void* ws = nullptr;
+    int rc = bsc_workspace(ctx, (size_t)batch * n * n * sizeof(double) + 8, &ws);
+    if (rc != BSC_OK) return rc;
+    ctx->slab_rows = 0;
+    if (dtype == BSC_F32)
+        hipLaunchKernelGGL(logdet_spd_kernel<float>, dim3((unsigned)batch), dim3(1024), 0,
+                           ctx->stream, (const float*)A, n, s_b, s_r, s_c, (double*)ws, (float*)out);
+    else
+        hipLaunchKernelGGL(logdet_spd_kernel<double>, dim3((unsigned)batch), dim3(1024), 0,
+                           ctx->stream, (const double*)A, n, s_b, s_r, s_c, (double*)ws, (double*)out);
+    BSC_LAUNCH_CHECK();
     return BSC_OK;
 }
 

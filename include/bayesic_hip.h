@@ -153,6 +153,30 @@ int bsc_natgrad_update(bsc_ctx* ctx, double* eta, const double* eta0,
  * stats[0]=n, stats[1]=sum x, stats[2]=sum x^2 (float64). */
 int bsc_suffstats_normal(bsc_ctx* ctx, const float* x, int64_t n, double* stats);
 
+/* ---- mixture of Gaussians: discrete latent marginalised by summation ------
+ * (ABSENT in reference; README.md:43,72; statistics per
+ * bayesic/distribution/base.py:329-332).  For every row of X[N,D]:
+ *     logit_k = c[k] + sum_d (Wmat[k,d] x_d + Wmat[k,D+d] x_d^2)
+ *     r_k     = softmax_k(logit)
+ * and, summed over rows in float64 (fixed order):
+ *     stats[k] = [sum r_k | sum r_k x (D) | sum r_k x^2 (D)]   ([K, 1+2D])
+ *     lse[0]   = sum_n logsumexp_k(logit_nk)
+ * Both contractions run on fp32 MFMA.  Limits: D <= 16, K <= 64 (one tile). */
+int bsc_mog_estep(bsc_ctx* ctx, const float* X, int64_t ldx, int64_t N, int32_t D, int32_t K,
+                  const float* Wmat, const float* c, double* stats, double* lse);
+
+/* Mean-field global parameters of the mixture: Dirichlet over weights and a
+ * Normal-Gamma per (component, column), as one natural-parameter vector
+ *   eta = [alpha-1 (K) | kappa*m (K*D) | kappa (K*D) | 2a-1 (K*D) | 2b+kappa*m^2 (K*D)].
+ * bsc_mog_expected_params writes the float32 logit coefficients Wmat [K, 2D] and
+ * c [K] (expectations under q; digamma in float64).  bsc_mog_natgrad applies
+ *   eta <- (1-rho) eta + rho (eta0 + scale * message(stats))
+ * (README.md:36,75-77) straight from the [K, 1+2D] statistics. */
+int bsc_mog_expected_params(bsc_ctx* ctx, const double* eta, int32_t K, int32_t D, float* Wmat,
+                            float* c);
+int bsc_mog_natgrad(bsc_ctx* ctx, double* eta, const double* eta0, const double* stats, int32_t K,
+                    int32_t D, double scale, double rho);
+
 /* ---- executable primitives of the algebra front end -----------------------
  * The five-op IR that Einsum lowering emits plus element-wise nodes:
  * _sum bayesic/algebra.py:1284-1294, _mul :1297-1309, _dimshuffle :1312-1326 and
@@ -199,6 +223,12 @@ int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, 
                              int64_t K, const void* A, int64_t sa_b, int64_t sa_m, int64_t sa_k,
                              const void* B, int64_t sb_b, int64_t sb_k, int64_t sb_n, void* C,
                              int64_t sc_b, int64_t sc_m, int64_t sc_n);
+
+/* out[b] = log det A[b] for symmetric positive-definite A[b] (n x n, strides in
+ * elements), by float64 Cholesky -- the T.logdet of MultivariateNormal's
+ * log-normaliser, bayesic/distribution/core.py:49-52.  NaN when not SPD. */
+int bsc_logdet_spd(bsc_ctx* ctx, int dtype, int64_t batch, int64_t n, const void* A, int64_t s_b,
+                   int64_t s_r, int64_t s_c, void* out);
 
 /* out[n,n] = identity, contiguous. */
 int bsc_eye(bsc_ctx* ctx, int dtype, void* out, int64_t n);

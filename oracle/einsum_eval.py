@@ -110,6 +110,10 @@ class NumpyBackend(Backend):
     def diagonal(self, x, axis1, axis2):
         return np.diagonal(x, 0, axis1, axis2)
 
+    def logdet(self, x):
+        sign, value = np.linalg.slogdet(np.asarray(x, dtype=np.float64))
+        return value.astype(x.dtype)
+
 
 def einsum_semantics(e, inputs, dtype=np.float64):
     """Evaluate an (un-lowered) Einsum from its definition; factors that are not

@@ -252,3 +252,109 @@ def blr_init_lam(D):
     lam[D:2 * D] = math.log(0.1)
     lam[2 * D + 1] = math.log(0.1)
     return lam
+
+
+# --------------------------------------------------------------------------
+# Config 3: mixture of Gaussians, diagonal precisions, discrete latent
+# marginalised by summation (README.md:43,72), natural-gradient SVI on the
+# global parameters (README.md:36,75-77; Hoffman et al. ref [4]).
+#
+#   z_n ~ Cat(pi), x_nd | z_n=k ~ N(mu_kd, 1/tau_kd)
+#   pi ~ Dir(alpha0), (mu_kd, tau_kd) ~ NormalGamma(m0, kappa0, a0, b0)
+#   q(pi) = Dir(alpha), q(mu_kd, tau_kd) = NormalGamma(m_kd, kappa_kd, a_kd, b_kd)
+#
+# Natural parameters (so that the conjugate update is additive):
+#   eta_pi[k]      = alpha_k - 1                          <- + sum_n r_nk
+#   eta1[k,d]      = kappa m                               <- + sum_n r_nk x_nd
+#   eta2[k,d]      = kappa                                 <- + sum_n r_nk
+#   eta3[k,d]      = 2a - 1                                <- + sum_n r_nk
+#   eta4[k,d]      = 2b + kappa m^2                        <- + sum_n r_nk x_nd^2
+# flat layout: [eta_pi (K) | eta1 (K*D) | eta2 (K*D) | eta3 (K*D) | eta4 (K*D)]
+# --------------------------------------------------------------------------
+
+def mog_prior_eta(K, D, alpha0=1.0, m0=0.0, kappa0=0.01, a0=1.0, b0=1.0):
+    return np.concatenate([np.full(K, alpha0 - 1.0), np.full(K * D, kappa0 * m0),
+                           np.full(K * D, kappa0), np.full(K * D, 2.0 * a0 - 1.0),
+                           np.full(K * D, 2.0 * b0 + kappa0 * m0 * m0)])
+
+
+def mog_unpack(eta, K, D):
+    eta = np.asarray(eta, dtype=np.float64)
+    alpha = eta[:K] + 1.0
+    e1, e2, e3, e4 = (eta[K + i * K * D: K + (i + 1) * K * D].reshape(K, D) for i in range(4))
+    kappa = e2
+    m = e1 / kappa
+    a = 0.5 * (e3 + 1.0)
+    b = 0.5 * (e4 - kappa * m * m)
+    return alpha, m, kappa, a, b
+
+
+def mog_expected_params(eta, K, D):
+    """Coefficients of the per-row logits: logit_nk = c_k + sum_d (A_kd x_nd^2 + B_kd x_nd).
+    Returns float32 Wmat [K, 2D] = [B | A] (x features first, then x^2) and c [K]."""
+    from scipy.special import digamma
+    alpha, m, kappa, a, b = mog_unpack(eta, K, D)
+    T = a / b                                            # E[tau]
+    elog_pi = digamma(alpha) - digamma(alpha.sum())
+    c = elog_pi + (0.5 * (digamma(a) - np.log(b)) - 0.5 * LOG_2PI
+                   - 0.5 * T * m * m - 0.5 / kappa).sum(axis=1)
+    Wmat = np.concatenate([T * m, -0.5 * T], axis=1)
+    return Wmat.astype(np.float32), c.astype(np.float32)
+
+
+def mog_local_step(X, Wmat, c, chunk=65536):
+    """Marginalise z row by row.  float32 operands, float64 arithmetic.
+    Returns stats [K, 1 + 2D] = [sum r | sum r x | sum r x^2] and
+    sum_n logsumexp_k(logit_nk) (the local part of the bound)."""
+    K, twoD = Wmat.shape
+    D = twoD // 2
+    W64, c64 = Wmat.astype(np.float64), c.astype(np.float64)
+    stats = np.zeros((K, 1 + 2 * D))
+    lse_total = 0.0
+    for i in range(0, X.shape[0], chunk):
+        Xc = np.asarray(X[i:i + chunk], dtype=np.float32).astype(np.float64)
+        F = np.concatenate([Xc, Xc * Xc], axis=1)          # [n, 2D]
+        logit = F @ W64.T + c64[None, :]
+        mx = logit.max(axis=1, keepdims=True)
+        e = np.exp(logit - mx)
+        s = e.sum(axis=1, keepdims=True)
+        R = e / s
+        lse_total += float((mx[:, 0] + np.log(s[:, 0])).sum())
+        stats[:, 0] += R.sum(axis=0)
+        stats[:, 1:] += R.T @ F
+    return stats, lse_total
+
+
+def mog_message(stats, K, D):
+    """Map summed statistics to the natural-parameter increment (flat layout)."""
+    Rk, Sx, Sxx = stats[:, 0], stats[:, 1:1 + D], stats[:, 1 + D:]
+    Rkd = np.repeat(Rk[:, None], D, axis=1)
+    return np.concatenate([Rk, Sx.ravel(), Rkd.ravel(), Rkd.ravel(), Sxx.ravel()])
+
+
+def mog_svi_step(eta, eta0, X, n_total, rho, K, D):
+    """One SVI update on one mini-batch: local step (marginalise z), then
+    eta <- (1-rho) eta + rho (eta0 + N/B * message)."""
+    Wmat, c = mog_expected_params(eta, K, D)
+    stats, lse = mog_local_step(X, Wmat, c)
+    new = natgrad_update(eta, eta0, mog_message(stats, K, D), n_total / X.shape[0], rho)
+    return new, stats, lse
+
+
+def make_cfg3(n=10_000_000, d=16, k=64):
+    centres = np.random.RandomState(3).standard_normal((k, d)) * 4.0
+    labels = np.random.RandomState(4).randint(k, size=n)
+    X = centres[labels] + np.random.RandomState(5).standard_normal((n, d))
+    return X.astype(np.float32), centres, labels
+
+
+def mog_init_eta(X_sample, K, D, seed=0, alpha0=1.0, kappa0=0.01, a0=1.0, b0=1.0):
+    """Prior plus pseudo-observations at K randomly chosen rows (breaks symmetry)."""
+    rs = np.random.RandomState(seed)
+    picks = np.asarray(X_sample, np.float64)[rs.choice(len(X_sample), K, replace=False)]
+    eta = mog_prior_eta(K, D, alpha0, 0.0, kappa0, a0, b0).reshape(-1)
+    stats = np.zeros((K, 1 + 2 * D))
+    stats[:, 0] = 1.0
+    stats[:, 1:1 + D] = picks
+    stats[:, 1 + D:] = picks * picks + 1.0
+    return eta + mog_message(stats, K, D)

@@ -230,7 +230,8 @@ def test_suffstats_normal_and_conjugate_update_cfg1(ctx):
     eta0 = svi.normal_gamma_to_natural(0.0, 1.0, 1.0, 1.0)
     eta = ctx.to_device(eta0, f64).clone()
     msg = ctx.to_device(np.array([sx, n, n, sxx]), f64)
-    ctx.call("bsc_natgrad_update", ptr(eta), ptr(ctx.to_device(eta0, f64)), ptr(msg), 4, 1.0, 1.0)
+    eta0d = ctx.to_device(eta0, f64)
+    ctx.call("bsc_natgrad_update", ptr(eta), ptr(eta0d), ptr(msg), 4, 1.0, 1.0)
     ctx.sync()
     got = svi.normal_gamma_from_natural(eta.cpu().numpy())
     want = svi.normal_gamma_posterior_closed_form(x, 0.0, 1.0, 1.0, 1.0)

@@ -1,0 +1,121 @@
+"""GPU parity for BASELINE config 3 (mixture of Gaussians, discrete latent
+marginalised by summation) vs the float64 oracle.
+
+Tolerance: float32 operands, fp32 MFMA contractions (exact-f32 fma chains), fast
+exp/log in the softmax (~2 ulp), float64 cross-tile finish: statistics within
+2e-5 of the scale of the sums; the bound term rtol 2e-6; parameters derived in
+float64 from identical inputs rtol 1e-10 (digamma: series vs scipy)."""
+import numpy as np
+import numpy.testing as npt
+import pytest
+import torch
+
+from oracle import svi
+
+pytestmark = pytest.mark.gpu
+
+
+def _estep(ctx, X, Wmat, c):
+    from bayesic_amd._ffi import ptr
+    K, twoD = Wmat.shape
+    D = twoD // 2
+    # keep every device buffer referenced until the (asynchronous) call has finished
+    Xd = ctx.to_device(X) if X.shape[0] else ctx.zeros((1, D))
+    Wd, cd = ctx.to_device(Wmat), ctx.to_device(c)
+    stats, lse = ctx.zeros((K, 1 + 2 * D), torch.float64), ctx.zeros(1, torch.float64)
+    ctx.call("bsc_mog_estep", ptr(Xd), D, X.shape[0], D, K, ptr(Wd), ptr(cd), ptr(stats), ptr(lse))
+    ctx.sync()
+    return stats.cpu().numpy(), lse.item()
+
+
+@pytest.mark.parametrize("N,D,K", [(32, 16, 64), (1000, 16, 64), (1003, 16, 64), (7, 16, 64),
+                                   (5000, 16, 33), (4097, 5, 64), (333, 1, 2), (20000, 12, 40),
+                                   (0, 16, 64)])
+def test_estep_matches_oracle(ctx, N, D, K):
+    rs = np.random.RandomState(N + D + K)
+    centres = rs.standard_normal((K, D)) * 3
+    X = (centres[rs.randint(K, size=N)] + rs.standard_normal((N, D))).astype(np.float32)
+    T = rs.uniform(0.5, 2.0, (K, D))
+    Wmat = np.concatenate([T * centres, -0.5 * T], axis=1).astype(np.float32)
+    c = (rs.standard_normal(K) - 0.5 * (T * centres ** 2).sum(1)).astype(np.float32)
+    stats, lse = _estep(ctx, X, Wmat, c)
+    want, lse_ref = svi.mog_local_step(X, Wmat, c) if N else (np.zeros((K, 1 + 2 * D)), 0.0)
+    X64 = X.astype(np.float64)
+    scale = np.concatenate([[max(N, 1)], np.abs(X64).sum(0) + 1e-9, (X64 ** 2).sum(0) + 1e-9])
+    assert (np.abs(stats - want) <= 2e-5 * scale[None, :] + 1e-9).all(), \
+        np.abs((stats - want) / scale[None, :]).max()
+    npt.assert_allclose(stats[:, 0].sum(), N, rtol=1e-6, atol=1e-6)   # responsibilities sum to 1
+    npt.assert_allclose(lse, lse_ref, rtol=2e-6, atol=1e-4)
+
+
+def test_estep_exact_on_separated_integer_data(ctx):
+    """Well-separated clusters: r is exactly one-hot in float32, so every statistic is
+    an exact integer sum -- any row/component/feature mix-up in the MFMA operand
+    layouts shows up as a wrong integer."""
+    K, D, N = 64, 16, 64 * 40
+    k = np.arange(K)
+    centres = np.zeros((K, D))
+    centres[k, k % D] = 100.0 * (1 + k // D)              # distinct, far apart
+    labels = np.arange(N) % K
+    offs = (np.arange(N)[:, None] * 7 + np.arange(D)[None, :] * 3) % 5 - 2
+    X = (centres[labels] + offs).astype(np.float32)
+    T = np.ones((K, D))
+    Wmat = np.concatenate([T * centres, -0.5 * T], axis=1).astype(np.float32)
+    c = (-0.5 * (centres ** 2).sum(1)).astype(np.float32)
+    stats, _ = _estep(ctx, X, Wmat, c)
+    want = np.zeros((K, 1 + 2 * D))
+    for n in range(N):
+        want[labels[n], 0] += 1
+        want[labels[n], 1:1 + D] += X[n]
+        want[labels[n], 1 + D:] += X[n].astype(np.float64) ** 2
+    npt.assert_array_equal(stats, want)
+
+
+def test_expected_params_and_natgrad_match_oracle(ctx):
+    from bayesic_amd._ffi import ptr
+    K, D = 37, 9
+    rs = np.random.RandomState(2)
+    X = rs.standard_normal((500, D)).astype(np.float32) * 2
+    eta0 = svi.mog_prior_eta(K, D)
+    eta = svi.mog_init_eta(X, K, D, seed=3) + rs.uniform(0, 5, K + 4 * K * D) * \
+        np.concatenate([np.ones(K), np.zeros(K * D), np.ones(2 * K * D), np.zeros(K * D)])
+    f64 = torch.float64
+    etad = ctx.to_device(eta, f64)
+    Wmat, c = ctx.zeros((K, 2 * D)), ctx.zeros(K)
+    ctx.call("bsc_mog_expected_params", ptr(etad), K, D, ptr(Wmat), ptr(c))
+    ctx.sync()
+    Wr, cr = svi.mog_expected_params(eta, K, D)
+    npt.assert_allclose(Wmat.cpu().numpy(), Wr, rtol=1e-6)
+    npt.assert_allclose(c.cpu().numpy(), cr, rtol=1e-6, atol=1e-6)
+    stats = rs.uniform(0, 10, (K, 1 + 2 * D))
+    eta0d, statsd = ctx.to_device(eta0, f64), ctx.to_device(stats, f64)
+    ctx.call("bsc_mog_natgrad", ptr(etad), ptr(eta0d), ptr(statsd), K, D, 3.5, 0.3)
+    ctx.sync()
+    want = svi.natgrad_update(eta, eta0, svi.mog_message(stats, K, D), 3.5, 0.3)
+    npt.assert_allclose(etad.cpu().numpy(), want, rtol=1e-13)
+
+
+def test_svi_steps_track_the_oracle_and_recover_clusters(ctx):
+    from bayesic_amd.svi.mog import MoGNatGradSVI
+    K, D = 8, 16
+    X, centres, _ = svi.make_cfg3(40000, D, K)
+    eta0 = svi.mog_prior_eta(K, D)
+    eta = svi.mog_init_eta(X[:4000], K, D, seed=1)
+    model = MoGNatGradSVI(X, K, eta0, eta, n_total=len(X), ctx=ctx)
+    for t in range(1, 9):
+        model.step()
+        eta, stats, lse = svi.mog_svi_step(eta, eta0, X, len(X), (t + 1.0) ** -0.6, K, D)
+        ctx.sync()
+        npt.assert_allclose(model.lse.item(), lse, rtol=1e-5)
+        npt.assert_allclose(model.eta.cpu().numpy(), eta, rtol=2e-4, atol=2e-3)
+    _, m, _, _, _ = svi.mog_unpack(model.eta.cpu().numpy(), K, D)
+    dist = np.linalg.norm(m[:, None, :] - centres[None], axis=2)
+    assert (dist.min(axis=0) < 0.5).sum() >= K - 2       # (local optima may merge a pair)
+
+
+def test_unsupported_sizes_fail_loudly(ctx):
+    from bayesic_amd._ffi import BayesicHipError, ptr
+    X, W, c = ctx.zeros((8, 17)), ctx.zeros((4, 34)), ctx.zeros(4)
+    stats, lse = ctx.zeros(4 * 35, torch.float64), ctx.zeros(1, torch.float64)
+    with pytest.raises(BayesicHipError, match="tile limits"):
+        ctx.call("bsc_mog_estep", ptr(X), 17, 8, 17, 4, ptr(W), ptr(c), ptr(stats), ptr(lse))
