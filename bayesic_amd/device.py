@@ -89,7 +89,9 @@ class Context:
         return Event(self)
 
     def call(self, name, *args):
-        _ffi.check(getattr(self.lib, name)(self.handle, *args), name)
+        """Invoke entry point `name`; torch tensors are passed as device pointers."""
+        raw = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
+        _ffi.check(getattr(self.lib, name)(self.handle, *raw), name)
 
 
 class Event:

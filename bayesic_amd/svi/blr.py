@@ -24,7 +24,6 @@ import math
 import torch
 
 from ..device import default_context
-from .._ffi import ptr
 
 
 class BLRReparamSVI:
@@ -105,13 +104,13 @@ class BLRReparamSVI:
     # -- unfused phases (also the multi-sample-group path) ---------------------
     def sample(self, step):
         c = self.cur
-        self.ctx.call("bsc_blr_sample", ptr(self._lam[c]), self.D, self.S, self.seed, step,
-                      ptr(self._eps[c]), ptr(self._W[c]), ptr(self._xi[c]))
+        self.ctx.call("bsc_blr_sample", self._lam[c], self.D, self.S, self.seed, step,
+                      self._eps[c], self._W[c], self._xi[c])
         self._drawn = True
 
     def data_pass(self):
-        self.ctx.call("bsc_blr_data_pass", ptr(self.X), self.X.stride(0), ptr(self.y), self.B,
-                      self.D, ptr(self.W), self.S, ptr(self.Q), ptr(self.G))
+        self.ctx.call("bsc_blr_data_pass", self.X, self.X.stride(0), self.y, self.B,
+                      self.D, self.W, self.S, self.Q, self.G)
 
     def all_reduce(self):
         if self.world > 1:
@@ -121,13 +120,13 @@ class BLRReparamSVI:
         """Fused gradient + Adam + next draw; flips the double buffer."""
         c, n = self.cur, 1 - self.cur
         t = self.t + 1
-        self.ctx.call("bsc_blr_fused_update", ptr(stats) if stats is not None else None,
-                      ptr(self._lam[c]), ptr(self._lam[n]), ptr(self.m1), ptr(self.m2),
-                      ptr(self._eps[c]), ptr(self._W[c]), ptr(self._xi[c]), self.D, self.S,
+        self.ctx.call("bsc_blr_fused_update", stats,
+                      self._lam[c], self._lam[n], self.m1, self.m2,
+                      self._eps[c], self._W[c], self._xi[c], self.D, self.S,
                       self.batch_rows, self.n_total / self.batch_rows, self.alpha0, self.beta0,
                       t, self.lr, 0.9, 0.999, 1e-8, self.seed, t,
-                      ptr(self._eps[n]), ptr(self._W[n]), ptr(self._xi[n]), ptr(self.elbo),
-                      ptr(self.grad))
+                      self._eps[n], self._W[n], self._xi[n], self.elbo,
+                      self.grad)
         self.t = t
 
     def step(self):
@@ -135,8 +134,8 @@ class BLRReparamSVI:
         if not self._drawn:
             self.sample(self.t)  # Philox step index == number of completed updates
         if self.fused and self.world == 1 and self.S <= 8:
-            self.ctx.call("bsc_blr_data_pass_partial", ptr(self.X), self.X.stride(0),
-                          ptr(self.y), self.B, self.D, ptr(self.W), self.S)
+            self.ctx.call("bsc_blr_data_pass_partial", self.X, self.X.stride(0),
+                          self.y, self.B, self.D, self.W, self.S)
             self._finish(None)
         else:
             self.data_pass()

@@ -9,7 +9,6 @@ bound term when data-parallel) -> natural-gradient step.  All on the device.
 """
 import torch
 
-from .._ffi import ptr
 from ..device import default_context
 
 
@@ -48,12 +47,12 @@ class MoGNatGradSVI:
         self.ctx.reserve((2 * self.ctx.info()["cu_count"] + 8) * (64 * 33 + 1) * 4)
 
     def expected_params(self):
-        self.ctx.call("bsc_mog_expected_params", ptr(self.eta), self.K, self.D, ptr(self.Wmat),
-                      ptr(self.c))
+        self.ctx.call("bsc_mog_expected_params", self.eta, self.K, self.D, self.Wmat,
+                      self.c)
 
     def local_step(self):
-        self.ctx.call("bsc_mog_estep", ptr(self.X), self.X.stride(0), self.B, self.D, self.K,
-                      ptr(self.Wmat), ptr(self.c), ptr(self.stats), ptr(self.lse))
+        self.ctx.call("bsc_mog_estep", self.X, self.X.stride(0), self.B, self.D, self.K,
+                      self.Wmat, self.c, self.stats, self.lse)
 
     def step(self, rho=None):
         """One SVI update; rho defaults to the Robbins-Monro schedule (t+1)^-0.6."""
@@ -64,5 +63,5 @@ class MoGNatGradSVI:
         self.local_step()
         if self.world > 1:
             torch.distributed.all_reduce(self.buf, group=self.group)
-        self.ctx.call("bsc_mog_natgrad", ptr(self.eta), ptr(self.eta0), ptr(self.stats), self.K,
+        self.ctx.call("bsc_mog_natgrad", self.eta, self.eta0, self.stats, self.K,
                       self.D, self.n_total / self.batch_rows, float(rho))

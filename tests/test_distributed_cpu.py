@@ -1,0 +1,44 @@
+"""N>1 data-parallel host logic on CPU: two gloo ranks on row shards must
+reproduce the single-process update (config 2 and config 3 drivers).  See
+tests/_dist_worker.py for what is real and what is a test double."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from oracle import svi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_two_gloo_ranks_equal_single_process(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    out = str(tmp_path / "rank%d.npz")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), out],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    # every rank applied the identical update
+    np.testing.assert_array_equal(r0["lam"], r1["lam"])
+    np.testing.assert_array_equal(r0["eta"], r1["eta"])
+    # ... and it is the single-process update on the whole mini-batch
+    X, y, _ = svi.make_cfg2(900, 16)
+    lam = svi.blr_init_lam(16)
+    m1, m2 = np.zeros_like(lam), np.zeros_like(lam)
+    for t in range(1, 4):
+        lam, m1, m2, elbo, _ = svi.blr_step(lam, m1, m2, t, X, y, 4, 11, 9000, 0.02)
+    np.testing.assert_allclose(r0["lam"], lam, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(r0["elbo"][0], elbo, rtol=1e-10)
+    Xm, _, _ = svi.make_cfg3(1200, 4, 3)
+    eta0 = svi.mog_prior_eta(3, 4)
+    eta = svi.mog_init_eta(Xm[:300], 3, 4, seed=2)
+    for t in range(1, 4):
+        eta, _, lse = svi.mog_svi_step(eta, eta0, Xm, 12000, (t + 1.0) ** -0.6, 3, 4)
+    np.testing.assert_allclose(r0["eta"], eta, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(r0["lse"][0], lse, rtol=1e-10)
