@@ -65,6 +65,12 @@ SIGNATURES = {
     "bsc_mog_expected_params": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "bsc_mog_natgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,
                                 c_double]),
+    "bsc_bbvi_sample": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_uint64, c_uint32,
+                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bsc_logreg_bbvi_loglik": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                       c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
+    "bsc_bbvi_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                              c_double, c_double, c_double, c_void_p, c_void_p, c_void_p]),
     "bsc_elemwise": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int64), c_void_p,
                              POINTER(c_int64), c_int, POINTER(c_void_p), POINTER(c_int64)]),
     "bsc_convert": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int64), c_void_p,

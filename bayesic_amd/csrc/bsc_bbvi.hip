@@ -1,0 +1,371 @@
+// Black-box VI for hierarchical logistic regression (BASELINE config 5).
+//
+// ABSENT in the reference: spec is README.md:52 ("the gradient estimator from
+// Black box variational inference [3] -- ... the control variate one") with
+// README.md:69-79 for mini-batching; in bayesic.algebra terms the data-sized
+// contraction is dot(W, X.T) (cfg 5).
+//
+// logreg_loglik_kernel: ONE read of X[N,D], y[N], g[N] gives, for S = 64 Monte
+// Carlo draws of (w, b) at once,
+//     l_ns  = x_n . Wz[s] + Bz[g_n, s]
+//     ell_s = sum_n ( y_n l_ns - softplus(l_ns) )
+// 32 flop/B: close to the HBM/FP32 ridge, so the contraction runs on
+// v_mfma_f32_16x16x4_f32 (exact f32) and everything else is cheap.  A workgroup
+// (4 waves) owns 32-row tiles staged in LDS by coalesced 1-KiB row loads; wave w
+// owns samples 16w..16w+15 and keeps its slice of Wz in 64 registers as the MFMA
+// B operand for the whole kernel.  The k order inside a contraction is free, so
+// k-step s of lane group k reads column 16(s/4) + 4k + (s%4): one ds_read_b128
+// feeds four MFMAs.  LDS row stride 264 floats makes those reads conflict-free.
+#include "bsc_common.h"
+
+namespace {
+
+constexpr int LS = 64;            // samples
+constexpr int LD = 256;           // column capacity
+constexpr int LT = 32;            // rows per tile
+constexpr int LSTR = LD + 8;      // LDS row stride (floats)
+constexpr int LR_BLOCK = 256;
+constexpr int TILE_FLOATS = LT * LSTR + 2 * LT;   // rows + y + g
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Stage {   // one wave's share of a tile in registers: 8 rows x 16 B per lane
+    float4 x[8];
+    float yv;
+    int gv;
+};
+
+__device__ __forceinline__ void stage_load(Stage& st, const float* __restrict__ X, int64_t ldx,
+                                           const float* __restrict__ y, const int* __restrict__ g,
+                                           int64_t row0, int64_t N, int D, int wave, int lane) {
+    const int64_t rem = N - row0;
+    uint64_t xb = 0, yb = 0;
+    if (rem > 0) {
+        xb = ((uint64_t)(rem - 1) * (uint64_t)ldx + (uint64_t)D) * 4u;
+        yb = (uint64_t)rem * 4u;
+    }
+    const unsigned xrec = xb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)xb;
+    const unsigned yrec = yb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)yb;
+    const int64_t safe0 = rem > 0 ? row0 : 0;
+    auto xs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + safe0 * ldx), 0, xrec, 0x00020000);
+    auto ys = __builtin_amdgcn_make_buffer_rsrc((void*)(y + safe0), 0, yrec, 0x00020000);
+    auto gs = __builtin_amdgcn_make_buffer_rsrc((void*)(g + safe0), 0, yrec, 0x00020000);
+    const int row_bytes = (int)(ldx * 4);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(xs, 16 * lane, (8 * wave + r) * row_bytes, 0);
+        float4 f = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
+                               __uint_as_float(v[3]));
+        if (4 * lane >= D) f = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.x[r] = f;
+    }
+    // wave 0 also brings the tile's y and g (lanes 0-31: y, lanes 32-63: g)
+    st.yv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ys, 4 * (lane & 31), 0, 0));
+    st.gv = (int)__builtin_amdgcn_raw_buffer_load_b32(gs, 4 * (lane & 31), 0, 0);
+}
+
+__device__ __forceinline__ void stage_store(const Stage& st, float* tile, int wave, int lane) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        *reinterpret_cast<float4*>(tile + (8 * wave + r) * LSTR + 4 * lane) = st.x[r];
+    if (wave == 0) {
+        if (lane < 32) tile[LT * LSTR + lane] = st.yv;
+        else reinterpret_cast<int*>(tile)[LT * LSTR + LT + (lane & 31)] = st.gv;
+    }
+}
+
+__global__ __launch_bounds__(LR_BLOCK, 2) void logreg_loglik_kernel(
+    const float* __restrict__ X, int64_t ldx, const float* __restrict__ y,
+    const int* __restrict__ g, int64_t N, int D, const float* __restrict__ Wz,
+    const float* __restrict__ Bz, int n_groups, float* __restrict__ slab, int n_iter) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+
+    // B operand: Wz[sample 16*wave + i16][column of (k-step s, lane group kq)]
+    float wreg[LD / 4];
+#pragma unroll
+    for (int s = 0; s < LD / 4; ++s) {
+        const int col = 16 * (s >> 2) + 4 * kq + (s & 3);
+        wreg[s] = col < D ? Wz[(int64_t)(16 * wave + i16) * D + col] : 0.f;
+    }
+    float acc_ll = 0.f;
+
+    int64_t tile = blockIdx.x;
+    const int64_t stride = gridDim.x;
+    Stage st;
+    stage_load(st, X, ldx, y, g, tile * LT, N, D, wave, lane);
+    stage_store(st, lds, wave, lane);
+    __syncthreads();
+    int cur = 0;
+    for (int it = 0; it < n_iter; ++it) {
+        stage_load(st, X, ldx, y, g, (tile + stride) * LT, N, D, wave, lane);   // prefetch
+        const float* t = lds + cur * TILE_FLOATS;
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int q = 0; q < LD / 16; ++q) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const float4 a = *reinterpret_cast<const float4*>(t + (16 * rb + i16) * LSTR + 16 * q + 4 * kq);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wreg[4 * q + 0], acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wreg[4 * q + 1], acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wreg[4 * q + 2], acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wreg[4 * q + 3], acc[rb], 0, 0, 0);
+            }
+        }
+        // C/D map of 16x16x4: col = lane & 15 (sample), row = 4 * (lane >> 4) + reg
+        const int64_t row0 = tile * LT;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * rb + 4 * kq + r;
+                if (row0 + row < N) {
+                    const float yv = t[LT * LSTR + row];
+                    int gi = reinterpret_cast<const int*>(t)[LT * LSTR + LT + row];
+                    gi = gi < 0 ? 0 : (gi >= n_groups ? n_groups - 1 : gi);
+                    const float l = acc[rb][r] + Bz[(int64_t)gi * LS + 16 * wave + i16];
+                    // y l - softplus(l),  softplus(l) = max(l,0) + log1p(exp(-|l|))
+                    acc_ll += yv * l - (fmaxf(l, 0.f) + log1pf(__expf(-fabsf(l))));
+                }
+            }
+        stage_store(st, lds + (cur ^ 1) * TILE_FLOATS, wave, lane);
+        __syncthreads();
+        cur ^= 1;
+        tile += stride;
+    }
+    // lanes with the same sample (lane & 15) hold different rows: fold bits 4,5
+    acc_ll += __shfl_xor(acc_ll, 16);
+    acc_ll += __shfl_xor(acc_ll, 32);
+    if (lane < 16) slab[(int64_t)blockIdx.x * LS + 16 * wave + lane] = acc_ll;
+}
+
+__global__ __launch_bounds__(1024) void loglik_reduce_kernel(const float* __restrict__ slab,
+                                                             int n_rows, double* __restrict__ ell) {
+    __shared__ double part[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double sum = 0.0;
+    constexpr int BATCH = 16;
+    for (int b0 = wave; b0 < n_rows; b0 += 16 * BATCH) {
+        float v[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const int b = b0 + 16 * j;
+            v[j] = b < n_rows ? slab[(int64_t)b * LS + lane] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) sum += (double)v[j];
+    }
+    part[wave][lane] = sum;
+    __syncthreads();
+    if (wave == 0) {
+        double tot = part[0][lane];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) tot += part[k][lane];
+        ell[lane] = tot;
+    }
+}
+
+// ---- parameter side (float64, tiny) -----------------------------------------
+
+__device__ __forceinline__ void philox4(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+#pragma clang fp contract(off)
+// z = mu + exp(rho) * eps (Philox stream 2); writes eps [S,P] f64, Wz [S,D] f32,
+// Bz [G,S] f32 (transposed so a row's 64 intercepts are one 256-B run), zeta [S] f64
+__global__ void bbvi_sample_kernel(const double* __restrict__ lam, int D, int G, int S,
+                                   uint64_t seed, uint32_t step, double* __restrict__ eps,
+                                   float* __restrict__ Wz, float* __restrict__ Bz,
+                                   double* __restrict__ zeta) {
+    const int P = D + G + 1;
+    const int n_blocks = (P + 3) / 4;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * n_blocks) return;
+    const int s = idx / n_blocks, b = idx % n_blocks;
+    uint32_t c[4] = {(uint32_t)b, (uint32_t)s, 2u, step};
+    philox4(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const double two_m32 = 2.3283064365386963e-10, two_pi = 6.283185307179586476925286766559;
+    const double u0 = ((double)c[0] + 0.5) * two_m32, u1 = ((double)c[1] + 0.5) * two_m32;
+    const double u2 = ((double)c[2] + 0.5) * two_m32, u3 = ((double)c[3] + 0.5) * two_m32;
+    const double r0 = sqrt(-2.0 * log(u0)), r1 = sqrt(-2.0 * log(u2));
+    const double t0 = two_pi * u1, t1 = two_pi * u3;
+    const double z4[4] = {r0 * cos(t0), r0 * sin(t0), r1 * cos(t1), r1 * sin(t1)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = 4 * b + j;
+        if (i >= P) break;
+        eps[(int64_t)s * P + i] = z4[j];
+        const double sd = exp(lam[P + i]);
+        const double z = lam[i] + sd * z4[j];
+        if (i < D) Wz[(int64_t)s * D + i] = (float)z;
+        else if (i < D + G) Bz[(int64_t)(i - D) * S + s] = (float)z;
+        else zeta[s] = z;
+    }
+}
+
+// One workgroup.  f_s, the scalar control variate and the score-function gradient.
+constexpr int BB_BLOCK = 1024;
+constexpr int BB_MAX_S = 64;
+
+__global__ __launch_bounds__(BB_BLOCK) void bbvi_grad_kernel(
+    const double* __restrict__ lam, const double* __restrict__ eps, const double* __restrict__ ell,
+    int D, int G, int S, double scale, double a0, double b0, double log_prior_const,
+    double* __restrict__ elbo, double* __restrict__ grad, double* __restrict__ f_out) {
+    __shared__ double f[BB_MAX_S];
+    __shared__ double red[16][4];
+    __shared__ double cv;
+    const int P = D + G + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double LOG_2PI = 1.8378770664093454835606594728112;
+    // f_s: wave per sample (strided), lanes over parameters, fixed order
+    for (int s = wave; s < S; s += 16) {
+        const double zeta = lam[P - 1] + exp(lam[2 * P - 1]) * eps[(int64_t)s * P + P - 1];
+        const double tau = exp(zeta);
+        double part = 0.0;
+        for (int i = lane; i < P; i += 64) {
+            const double e = eps[(int64_t)s * P + i], rho = lam[P + i];
+            const double z = lam[i] + exp(rho) * e;
+            double lp;
+            if (i < D) lp = -0.5 * LOG_2PI - 0.5 * z * z;
+            else if (i < D + G) lp = -0.5 * LOG_2PI + 0.5 * zeta - 0.5 * tau * z * z;
+            else lp = log_prior_const + a0 * zeta - b0 * tau;
+            const double lq = -0.5 * LOG_2PI - rho - 0.5 * e * e;
+            part += lp - lq;
+        }
+        part = wave_allsum_f64(part);
+        if (lane == 0) f[s] = scale * ell[s] + part;
+    }
+    __syncthreads();
+    // control variate a = sum_i Cov(f h_i, h_i) / sum_i Var(h_i) over the 2P score components
+    double cov = 0.0, var = 0.0;
+    for (int i = tid; i < 2 * P; i += BB_BLOCK) {
+        const int p = i < P ? i : i - P;
+        const double inv_sd = exp(-lam[P + p]);
+        double mh = 0.0, mfh = 0.0;
+        for (int s = 0; s < S; ++s) {
+            const double e = eps[(int64_t)s * P + p];
+            const double h = i < P ? e * inv_sd : e * e - 1.0;
+            mh += h;
+            mfh += f[s] * h;
+        }
+        mh /= S;
+        mfh /= S;
+        double c = 0.0, v = 0.0;
+        for (int s = 0; s < S; ++s) {
+            const double e = eps[(int64_t)s * P + p];
+            const double h = i < P ? e * inv_sd : e * e - 1.0;
+            c += (f[s] * h - mfh) * (h - mh);
+            v += (h - mh) * (h - mh);
+        }
+        cov += c / (S - 1);
+        var += v / (S - 1);
+    }
+    cov = wave_allsum_f64(cov);
+    var = wave_allsum_f64(var);
+    if (lane == 0) { red[wave][0] = cov; red[wave][1] = var; }
+    __syncthreads();
+    if (tid == 0) {
+        double c = 0.0, v = 0.0, fm = 0.0;
+        for (int k = 0; k < 16; ++k) { c += red[k][0]; v += red[k][1]; }
+        cv = c / v;
+        for (int s = 0; s < S; ++s) fm += f[s];
+        elbo[0] = fm / S;
+        if (f_out) for (int s = 0; s < S; ++s) f_out[s] = f[s];
+    }
+    __syncthreads();
+    const double a = cv;
+    for (int i = tid; i < 2 * P; i += BB_BLOCK) {
+        const int p = i < P ? i : i - P;
+        const double inv_sd = exp(-lam[P + p]);
+        double gsum = 0.0;
+        for (int s = 0; s < S; ++s) {
+            const double e = eps[(int64_t)s * P + p];
+            const double h = i < P ? e * inv_sd : e * e - 1.0;
+            gsum += (f[s] - a) * h;
+        }
+        grad[i] = gsum / S;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bsc_logreg_bbvi_loglik(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y,
+                           const int32_t* g, int64_t N, int32_t D, int32_t n_groups,
+                           const float* Wz, const float* Bz, int32_t S, double* ell) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(N >= 0 && ((X && y && g) || N == 0) && Wz && Bz && ell,
+                "bsc_logreg_bbvi_loglik: null pointer");
+    if (S != LS || D < 4 || D > LD || (D % 4) != 0)
+        return bsc_fail(BSC_ERR_UNSUPPORTED,
+                        "bsc_logreg_bbvi_loglik: needs S == %d and D %% 4 == 0 in [4,%d] (got S=%d D=%d)",
+                        LS, LD, S, D);
+    BSC_REQUIRE(n_groups >= 1, "bsc_logreg_bbvi_loglik: n_groups=%d", n_groups);
+    BSC_REQUIRE(ldx >= D && ldx % 4 == 0 && ldx < ((int64_t)1 << 26),
+                "bsc_logreg_bbvi_loglik: bad ldx=%lld", (long long)ldx);
+    BSC_REQUIRE(((uintptr_t)X & 15) == 0, "bsc_logreg_bbvi_loglik: X must be 16-byte aligned");
+    const int64_t n_tiles = (N + LT - 1) / LT;
+    const int64_t max_blocks = 2 * (int64_t)ctx->cu_count;
+    int n_iter = 0, n_blocks = 1;
+    if (n_tiles > 0) {
+        const int64_t it = (n_tiles + max_blocks - 1) / max_blocks;
+        n_iter = (int)it;
+        n_blocks = (int)((n_tiles + it - 1) / it);
+    }
+    void* ws = nullptr;
+    int rc = bsc_workspace(ctx, (size_t)n_blocks * LS * sizeof(float), &ws);
+    if (rc != BSC_OK) return rc;
+    ctx->slab_rows = 0;
+    {
+        bsc_prof_scope prof(ctx);
+        hipLaunchKernelGGL(logreg_loglik_kernel, dim3(n_blocks), dim3(LR_BLOCK), 0, ctx->stream, X,
+                           ldx, y, (const int*)g, N, (int)D, Wz, Bz, (int)n_groups, (float*)ws, n_iter);
+    }
+    BSC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loglik_reduce_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const float*)ws,
+                       n_blocks, ell);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_bbvi_sample(bsc_ctx* ctx, const double* lam, int32_t D, int32_t G, int32_t S, uint64_t seed,
+                    uint32_t step, double* eps, float* Wz, float* Bz, double* zeta) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(lam && eps && Wz && Bz && zeta && D >= 1 && G >= 1 && S >= 1,
+                "bsc_bbvi_sample: bad arguments");
+    const int n = S * ((D + G + 1 + 3) / 4);
+    hipLaunchKernelGGL(bbvi_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, lam,
+                       (int)D, (int)G, (int)S, seed, step, eps, Wz, Bz, zeta);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_bbvi_grad(bsc_ctx* ctx, const double* lam, const double* eps, const double* ell, int32_t D,
+                  int32_t G, int32_t S, double scale, double a0, double b0, double* elbo,
+                  double* grad, double* f_out) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(lam && eps && ell && elbo && grad, "bsc_bbvi_grad: null pointer");
+    BSC_REQUIRE(D >= 1 && G >= 1 && S >= 2 && S <= BB_MAX_S, "bsc_bbvi_grad: D=%d G=%d S=%d (2..%d)",
+                D, G, S, BB_MAX_S);
+    BSC_REQUIRE(a0 > 0 && b0 > 0, "bsc_bbvi_grad: a0, b0 must be positive");
+    const double log_prior_const = a0 * log(b0) - lgamma(a0);
+    hipLaunchKernelGGL(bbvi_grad_kernel, dim3(1), dim3(BB_BLOCK), 0, ctx->stream, lam, eps, ell,
+                       (int)D, (int)G, (int)S, scale, a0, b0, log_prior_const, elbo, grad, f_out);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+}  // extern "C"

@@ -177,6 +177,28 @@ int bsc_mog_expected_params(bsc_ctx* ctx, const double* eta, int32_t K, int32_t 
 int bsc_mog_natgrad(bsc_ctx* ctx, double* eta, const double* eta0, const double* stats, int32_t K,
                     int32_t D, double scale, double rho);
 
+/* ---- black-box VI, score-function gradient with control variate ------------
+ * (ABSENT in reference; README.md:52 -> ref [3]; config 5: hierarchical logistic
+ * regression y_n ~ Bernoulli(sigmoid(x_n.w + b_{g_n})), z = [w (D) | b (G) | log tau],
+ * q(z) = N(mu, diag e^{2 rho}), lam = [mu (P) | rho (P)], P = D+G+1.)
+ *
+ * bsc_bbvi_sample: z_s = mu + e^rho eps_s (Philox stream 2) -> eps [S,P] f64,
+ *   Wz [S,D] f32, Bz [G,S] f32 (transposed), zeta [S] f64.
+ * bsc_logreg_bbvi_loglik: ONE pass over X[N,D], y[N] (0/1 as float), g[N] (int32):
+ *   ell[s] = sum_n ( y_n l_ns - softplus(l_ns) ),  l_ns = x_n.Wz[s] + Bz[g_n,s]
+ *   (float64 out, fixed order).  fp32 MFMA.  Requires S == 64, D % 4 == 0, D <= 256.
+ * bsc_bbvi_grad: f_s = scale*ell_s + log p(z_s) - log q(z_s); control variate
+ *   a = sum_i Cov(f h_i, h_i) / sum_i Var(h_i); grad = mean_s (f_s - a) h_s with
+ *   h_s = [eps/sigma | eps^2 - 1]; elbo = mean_s f_s.  f_out (may be NULL): f [S]. */
+int bsc_bbvi_sample(bsc_ctx* ctx, const double* lam, int32_t D, int32_t G, int32_t S, uint64_t seed,
+                    uint32_t step, double* eps, float* Wz, float* Bz, double* zeta);
+int bsc_logreg_bbvi_loglik(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y,
+                           const int32_t* g, int64_t N, int32_t D, int32_t n_groups,
+                           const float* Wz, const float* Bz, int32_t S, double* ell);
+int bsc_bbvi_grad(bsc_ctx* ctx, const double* lam, const double* eps, const double* ell, int32_t D,
+                  int32_t G, int32_t S, double scale, double a0, double b0, double* elbo,
+                  double* grad, double* f_out);
+
 /* ---- executable primitives of the algebra front end -----------------------
  * The five-op IR that Einsum lowering emits plus element-wise nodes:
  * _sum bayesic/algebra.py:1284-1294, _mul :1297-1309, _dimshuffle :1312-1326 and

@@ -358,3 +358,91 @@ def mog_init_eta(X_sample, K, D, seed=0, alpha0=1.0, kappa0=0.01, a0=1.0, b0=1.0
     stats[:, 1:1 + D] = picks
     stats[:, 1 + D:] = picks * picks + 1.0
     return eta + mog_message(stats, K, D)
+
+
+# --------------------------------------------------------------------------
+# Config 5: hierarchical logistic regression, black-box VI with the
+# score-function gradient and a control variate (README.md:52 -> ref [3]).
+#
+#   y_n ~ Bernoulli(sigmoid(x_n.w + b_{g_n})),  w_d ~ N(0,1),
+#   b_g | tau ~ N(0, 1/tau),  tau ~ Gamma(a0, b0),  zeta = log tau
+#   z = [w (D) | b (G) | zeta],  q(z) = N(mu, diag exp(2 rho)),  lam = [mu (P) | rho (P)]
+# --------------------------------------------------------------------------
+
+def bbvi_sample(lam, P, S, seed, step=0):
+    """z_s = mu + exp(rho) * eps_s, eps from Philox stream 2.  Returns eps [S,P], z [S,P]."""
+    lam = np.asarray(lam, dtype=np.float64)
+    eps = philox.normal_draws(seed, S, P, stream=2, step=step)
+    return eps, lam[:P][None, :] + np.exp(lam[P:])[None, :] * eps
+
+
+def logreg_loglik(X, y, g, Wz, Bz, chunk=65536):
+    """ell[s] = sum_n [ y_n l_ns - softplus(l_ns) ],  l_ns = x_n . Wz[s] + Bz[g_n, s].
+    float32 operands, float64 arithmetic."""
+    S = Wz.shape[0]
+    W64, B64 = Wz.astype(np.float64), Bz.astype(np.float64)
+    ell = np.zeros(S)
+    for i in range(0, X.shape[0], chunk):
+        Xc = np.asarray(X[i:i + chunk], np.float32).astype(np.float64)
+        yc = np.asarray(y[i:i + chunk], np.float32).astype(np.float64)
+        L = Xc @ W64.T + B64[np.asarray(g[i:i + chunk])]
+        ell += (yc[:, None] * L - np.logaddexp(0.0, L)).sum(axis=0)
+    return ell
+
+
+def bbvi_log_prior(z, D, G, a0=1.0, b0=1.0):
+    w, b, zeta = z[:, :D], z[:, D:D + G], z[:, D + G]
+    lp_w = (-0.5 * LOG_2PI - 0.5 * w * w).sum(axis=1)
+    lp_b = (-0.5 * LOG_2PI + 0.5 * zeta[:, None] - 0.5 * np.exp(zeta)[:, None] * b * b).sum(axis=1)
+    lp_zeta = a0 * math.log(b0) - math.lgamma(a0) + a0 * zeta - b0 * np.exp(zeta)  # incl. Jacobian
+    return lp_w + lp_b + lp_zeta
+
+
+def bbvi_elbo_and_grad(lam, eps, ell, D, G, scale, a0=1.0, b0=1.0):
+    """Score-function estimator with the scalar control variate of SURVEY 8(a) A14:
+        f_s = scale*ell_s + log p(z_s) - log q(z_s)
+        h_s = grad_lam log q(z_s) = [eps/sigma | eps^2 - 1]
+        a   = sum_i Cov_s(f h_i, h_i) / sum_i Var_s(h_i)
+        g   = mean_s (f_s - a) h_s ;   ELBO estimate = mean_s f_s."""
+    lam = np.asarray(lam, dtype=np.float64)
+    P = D + G + 1
+    S = eps.shape[0]
+    rho = lam[P:]
+    z = lam[:P][None, :] + np.exp(rho)[None, :] * eps
+    log_q = (-0.5 * LOG_2PI - rho[None, :] - 0.5 * eps * eps).sum(axis=1)
+    f = scale * ell + bbvi_log_prior(z, D, G, a0, b0) - log_q
+    h = np.concatenate([eps / np.exp(rho)[None, :], eps * eps - 1.0], axis=1)   # [S, 2P]
+    fh = f[:, None] * h
+    cov = ((fh - fh.mean(0)) * (h - h.mean(0))).sum(0) / (S - 1)
+    var = ((h - h.mean(0)) ** 2).sum(0) / (S - 1)
+    a = cov.sum() / var.sum()
+    grad = ((f - a)[:, None] * h).mean(axis=0)
+    return f.mean(), grad, a, f
+
+
+def make_cfg5(n=1_000_000, d=256, n_groups=1000):
+    X = np.random.RandomState(1234).standard_normal((n, d)).astype(np.float32)
+    w_true = np.random.RandomState(1).standard_normal(d) / 16.0
+    b_true = np.random.RandomState(7).standard_normal(n_groups) * 0.5
+    g = np.random.RandomState(6).randint(n_groups, size=n).astype(np.int32)
+    logits = X.astype(np.float64) @ w_true + b_true[g]
+    y = (np.random.RandomState(8).uniform(size=n) < 1.0 / (1.0 + np.exp(-logits))).astype(np.float32)
+    return X, y, g, w_true, b_true
+
+
+def bbvi_init_lam(P):
+    lam = np.zeros(2 * P)
+    lam[P:] = math.log(0.05)
+    return lam
+
+
+def bbvi_step(lam, m1, m2, t, X, y, g, D, G, S, seed, n_total, lr):
+    P = D + G + 1
+    eps, z = bbvi_sample(lam, P, S, seed, step=t - 1)
+    Wz = z[:, :D].astype(np.float32)
+    Bz = np.ascontiguousarray(z[:, D:D + G].T).astype(np.float32)     # [G, S]
+    ell = logreg_loglik(X, y, g, Wz, Bz)
+    # the likelihood sees float32-rounded w, b (what the device streams); priors and log q use float64 z
+    elbo, grad, a, f = bbvi_elbo_and_grad(lam, eps, ell, D, G, n_total / X.shape[0])
+    lam, m1, m2 = adam_ascent(lam, grad, m1, m2, t, lr)
+    return lam, m1, m2, elbo, grad, ell

@@ -1,0 +1,117 @@
+"""GPU parity for BASELINE config 5 (BBVI, hierarchical logistic regression) vs
+the float64 oracle.
+
+Tolerance: float32 operands, exact-f32 MFMA fma chains (K = 256), fast exp +
+log1p in softplus, float32 per-lane partial sums, float64 finish: each ell_s
+within 2e-5 * sum_n (|l_ns| + 1); parameter-side results (float64 both sides)
+rtol 1e-9."""
+import math
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+import torch
+
+from oracle import philox, svi
+
+pytestmark = pytest.mark.gpu
+
+
+def _loglik(ctx, X, y, g, Wz, Bz):
+    D, G, S = X.shape[1], Bz.shape[0], Wz.shape[0]
+    Xd = ctx.to_device(X) if X.shape[0] else ctx.zeros((1, D))
+    yd = ctx.to_device(y) if X.shape[0] else ctx.zeros(1)
+    gd = torch.as_tensor(g, dtype=torch.int32).to(ctx.device) if X.shape[0] else \
+        torch.zeros(1, dtype=torch.int32, device=ctx.device)
+    Wd, Bd = ctx.to_device(Wz), ctx.to_device(Bz)
+    ell = ctx.zeros(S, torch.float64)
+    ctx.call("bsc_logreg_bbvi_loglik", Xd, D, yd, gd, X.shape[0], D, G, Wd, Bd, S, ell)
+    ctx.sync()
+    return ell.cpu().numpy()
+
+
+@pytest.mark.parametrize("N,D,G", [(32, 256, 7), (1000, 256, 50), (1003, 256, 1000), (5, 256, 3),
+                                   (4099, 64, 11), (777, 4, 2), (20000, 252, 100), (0, 256, 4)])
+def test_loglik_matches_oracle(ctx, N, D, G):
+    rs = np.random.RandomState(N + D + G)
+    X = rs.standard_normal((N, D)).astype(np.float32)
+    g = rs.randint(G, size=N).astype(np.int32)
+    y = (rs.uniform(size=N) < 0.4).astype(np.float32)
+    Wz = (rs.standard_normal((64, D)) / math.sqrt(D)).astype(np.float32)
+    Bz = rs.standard_normal((G, 64)).astype(np.float32)
+    ell = _loglik(ctx, X, y, g, Wz, Bz)
+    want = svi.logreg_loglik(X, y, g, Wz, Bz) if N else np.zeros(64)
+    L = np.abs(X.astype(np.float64) @ Wz.astype(np.float64).T + Bz.astype(np.float64)[g]) if N else \
+        np.zeros((1, 64))
+    bound = (L + 1.0).sum(axis=0)
+    assert (np.abs(ell - want) <= 2e-5 * bound + 1e-9).all(), np.abs((ell - want) / bound).max()
+
+
+def test_loglik_operand_layout_with_exact_integers(ctx):
+    """Integer X, W with l = 0 for every (row, sample) except through one column per
+    sample: any mix-up of k order, sample or row mapping changes which rows count."""
+    N, D, G = 96, 256, 4
+    X = np.zeros((N, D), np.float32)
+    X[np.arange(N), (np.arange(N) * 7) % D] = 1.0            # row n has a single 1 in column c(n)
+    Wz = np.zeros((64, D), np.float32)
+    for s in range(64):
+        Wz[s, (s * 5) % D] = 40.0                            # sample s looks at column 5s
+    Bz = np.full((G, 64), -20.0, np.float32)
+    g = (np.arange(N) % G).astype(np.int32)
+    y = np.ones(N, np.float32)
+    ell = _loglik(ctx, X, y, g, Wz, Bz)
+    want = svi.logreg_loglik(X, y, g, Wz, Bz)                # rows hit: l=+20 -> ~0 ; else l=-20 -> ~-20
+    npt.assert_allclose(ell, want, rtol=1e-6)
+    assert len(set(np.round(want, 3))) > 1
+
+
+def test_sample_and_grad_match_oracle(ctx):
+    D, G, S = 24, 9, 64
+    P = D + G + 1
+    rs = np.random.RandomState(3)
+    lam = svi.bbvi_init_lam(P) + 0.05 * rs.standard_normal(2 * P)
+    f64 = torch.float64
+    lamd = ctx.to_device(lam, f64)
+    eps, Wz, Bz, zeta = ctx.zeros(S * P, f64), ctx.zeros(S * D), ctx.zeros(G * S), ctx.zeros(S, f64)
+    ctx.call("bsc_bbvi_sample", lamd, D, G, S, 99, 5, eps, Wz, Bz, zeta)
+    ctx.sync()
+    e_ref, z_ref = svi.bbvi_sample(lam, P, S, 99, step=5)
+    npt.assert_allclose(eps.cpu().numpy().reshape(S, P), e_ref, rtol=1e-12, atol=1e-14)
+    npt.assert_allclose(Wz.cpu().numpy().reshape(S, D), z_ref[:, :D].astype(np.float32), rtol=1e-6)
+    npt.assert_allclose(Bz.cpu().numpy().reshape(G, S), z_ref[:, D:D + G].T.astype(np.float32), rtol=1e-6)
+    npt.assert_allclose(zeta.cpu().numpy(), z_ref[:, P - 1], rtol=1e-12)
+    ell = rs.uniform(-900, -700, S)
+    elld = ctx.to_device(ell, f64)
+    elbo, grad, f = ctx.zeros(1, f64), ctx.zeros(2 * P, f64), ctx.zeros(S, f64)
+    ctx.call("bsc_bbvi_grad", lamd, eps, elld, D, G, S, 2.5, 1.3, 0.8, elbo, grad, f)
+    ctx.sync()
+    e_want, g_want, a, f_want = svi.bbvi_elbo_and_grad(lam, e_ref, ell, D, G, 2.5, 1.3, 0.8)
+    npt.assert_allclose(f.cpu().numpy(), f_want, rtol=1e-11)
+    npt.assert_allclose(elbo.item(), e_want, rtol=1e-11)
+    npt.assert_allclose(grad.cpu().numpy(), g_want, rtol=1e-8, atol=1e-9 * np.abs(g_want).max())
+
+
+def test_bbvi_steps_track_the_oracle(ctx):
+    from bayesic_amd.svi.bbvi import LogRegBBVI
+    X, y, g, _, _ = svi.make_cfg5(5000, 256, 20)
+    D, G, S = 256, 20, 64
+    model = LogRegBBVI(X, y, g, G, n_total=50000, n_samples=S, seed=7, lr=0.01, ctx=ctx)
+    lam = svi.bbvi_init_lam(D + G + 1)
+    m1, m2 = np.zeros_like(lam), np.zeros_like(lam)
+    for t in range(1, 5):
+        model.step()
+        lam, m1, m2, elbo, grad, ell = svi.bbvi_step(lam, m1, m2, t, X, y, g, D, G, S, 7, 50000, 0.01)
+        ctx.sync()
+        npt.assert_allclose(model.ell.cpu().numpy(), ell, rtol=1e-5)
+        npt.assert_allclose(model.elbo.item(), elbo, rtol=1e-5)
+        # Adam normalises the step, so parameters agree to ~lr * relative gradient error
+        npt.assert_allclose(model.lam.cpu().numpy(), lam, atol=2e-3)
+
+
+def test_unsupported_shapes_fail_loudly(ctx):
+    from bayesic_amd._ffi import BayesicHipError
+    X, y = ctx.zeros((8, 256)), ctx.zeros(8)
+    g = torch.zeros(8, dtype=torch.int32, device=ctx.device)
+    W, Bz, ell = ctx.zeros((8, 256)), ctx.zeros((2, 8)), ctx.zeros(8, torch.float64)
+    with pytest.raises(BayesicHipError, match="S == 64"):
+        ctx.call("bsc_logreg_bbvi_loglik", X, 256, y, g, 8, 256, 2, W, Bz, 8, ell)
