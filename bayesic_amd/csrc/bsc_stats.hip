@@ -92,9 +92,97 @@ __global__ void natgrad_update_kernel(double* __restrict__ eta, const double* __
     eta[i] = (1.0 - rho) * eta[i] + rho * (eta0[i] + scale * message[i]);
 }
 
+// ---- Dirichlet expectation for LDA-style nodes (config 4) ---------------------
+// out[r, c] = exp( E[log theta_rc] ) = exp( digamma(lam[r,c]) - digamma(sum_c lam[r,c]) )
+// (Hoffman, Blei, Bach 2010; the local/global expectations of README.md:69-79's
+// "SVI [4]" applied to a Dirichlet-Multinomial model).  Row sums in float64, fixed
+// order: one workgroup per row for the sum, then an element-wise pass.
+
+__device__ double digamma_f64_stats(double x) {
+    double acc = 0.0;
+    while (x < 8.0) {
+        acc -= 1.0 / x;
+        x += 1.0;
+    }
+    const double inv = 1.0 / x, inv2 = inv * inv;
+    const double series = inv2 * (1.0 / 12.0 - inv2 * (1.0 / 120.0 - inv2 * (1.0 / 252.0 - inv2 *
+                          (1.0 / 240.0 - inv2 * (5.0 / 660.0 - inv2 * (691.0 / 32760.0))))));
+    return acc + log(x) - 0.5 * inv - series;
+}
+
+__global__ __launch_bounds__(1024) void row_sum_kernel(const float* __restrict__ lam, int64_t cols,
+                                                       int64_t ld, double* __restrict__ row_psi) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = lam + (int64_t)blockIdx.x * ld;
+    double acc = 0.0;
+    for (int64_t c = tid; c < cols; c += 1024) acc += (double)row[c];
+    acc = wave_allsum_f64(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        row_psi[blockIdx.x] = digamma_f64_stats(t);
+    }
+}
+
+__global__ __launch_bounds__(256) void dirichlet_expect_kernel(const float* __restrict__ lam,
+                                                               int64_t rows, int64_t cols,
+                                                               int64_t ld,
+                                                               const double* __restrict__ row_psi,
+                                                               float* __restrict__ out) {
+    const int64_t n = rows * cols;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / cols, c = i - r * cols;
+        out[i] = (float)exp(digamma_f64_stats((double)lam[r * ld + c]) - row_psi[r]);
+    }
+}
+
+__global__ void natgrad_update_f32_kernel(float* __restrict__ eta, float eta0,
+                                          const float* __restrict__ message, int64_t n,
+                                          float scale, float rho) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        eta[i] = (1.0f - rho) * eta[i] + rho * (eta0 + scale * message[i]);
+}
+
 }  // namespace
 
 extern "C" {
+
+int bsc_dirichlet_expectation(bsc_ctx* ctx, const float* lam, int64_t rows, int64_t cols,
+                              int64_t ld, float* out) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(lam && out && rows >= 1 && cols >= 1 && ld >= cols && rows <= 65535 * 32,
+                "bsc_dirichlet_expectation: bad arguments");
+    void* ws = nullptr;
+    int rc = bsc_workspace(ctx, (size_t)rows * sizeof(double), &ws);
+    if (rc != BSC_OK) return rc;
+    ctx->slab_rows = 0;
+    hipLaunchKernelGGL(row_sum_kernel, dim3((unsigned)rows), dim3(1024), 0, ctx->stream, lam, cols,
+                       ld, (double*)ws);
+    BSC_LAUNCH_CHECK();
+    int64_t blocks = (rows * cols + 255) / 256;
+    if (blocks > 8 * (int64_t)ctx->cu_count) blocks = 8 * (int64_t)ctx->cu_count;
+    hipLaunchKernelGGL(dirichlet_expect_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       lam, rows, cols, ld, (const double*)ws, out);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_natgrad_update_f32(bsc_ctx* ctx, float* eta, float eta0, const float* message, int64_t n,
+                           float scale, float rho) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(eta && message && n > 0, "bsc_natgrad_update_f32: bad arguments");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8 * (int64_t)ctx->cu_count) blocks = 8 * (int64_t)ctx->cu_count;
+    hipLaunchKernelGGL(natgrad_update_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       eta, eta0, message, n, scale, rho);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
 
 int bsc_suffstats_normal(bsc_ctx* ctx, const float* x, int64_t n, double* stats) {
     BSC_CHECK_CTX(ctx);

@@ -146,6 +146,17 @@ int bsc_adam_ascent(bsc_ctx* ctx, double* lam, const double* grad, double* m1,
 int bsc_natgrad_update(bsc_ctx* ctx, double* eta, const double* eta0,
                        const double* message, int64_t n, double scale, double rho);
 
+/* Dirichlet expectation out[r,c] = exp(digamma(lam[r,c]) - digamma(sum_c lam[r,c]))
+ * (float32 in/out, float64 inside) and the float32 form of the natural-gradient
+ * step with a scalar prior, eta <- (1-rho) eta + rho (eta0 + scale * message):
+ * the K x V global parameter of the LDA-style Dirichlet-Multinomial model
+ * (BASELINE config 4; its sufficient statistics are the two contractions
+ * Bt * dot(Th.T, C / dot(Th, Bt)) evaluated through bsc_gemm_strided_batched). */
+int bsc_dirichlet_expectation(bsc_ctx* ctx, const float* lam, int64_t rows, int64_t cols,
+                              int64_t ld, float* out);
+int bsc_natgrad_update_f32(bsc_ctx* ctx, float* eta, float eta0, const float* message, int64_t n,
+                           float scale, float rho);
+
 /* ---- summed sufficient statistics of iid draws ---------------------------
  * ExpFamIndependentObservations.sufficient_statistics,
  * bayesic/distribution/base.py:328-332; Normal t(x)=(x,x^2),

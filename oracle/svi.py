@@ -446,3 +446,32 @@ def bbvi_step(lam, m1, m2, t, X, y, g, D, G, S, seed, n_total, lr):
     elbo, grad, a, f = bbvi_elbo_and_grad(lam, eps, ell, D, G, n_total / X.shape[0])
     lam, m1, m2 = adam_ascent(lam, grad, m1, m2, t, lr)
     return lam, m1, m2, elbo, grad, ell
+
+
+# --------------------------------------------------------------------------
+# Config 4: LDA-style Dirichlet-Multinomial, fixed-gamma local step (one
+# iteration), natural-gradient SVI on lambda [K, V] (Hoffman, Blei, Bach 2010;
+# README.md:69-79 -> ref [4]).  C [docs, V] are word counts.
+#   Th = exp(E[log theta]) from gamma [docs, K];  Bt = exp(E[log beta]) from lambda
+#   phinorm = Th Bt ;  sstats = Bt * (Th^T (C / phinorm))
+#   lambda <- (1-rho) lambda + rho (eta + (docs_total / docs) * sstats)
+# --------------------------------------------------------------------------
+
+def dirichlet_expectation(alpha):
+    from scipy.special import digamma
+    a = np.asarray(alpha, dtype=np.float64)
+    return np.exp(digamma(a) - digamma(a.sum(axis=1, keepdims=True)))
+
+
+def lda_sstats(C, Th, Bt):
+    C64, Th64, Bt64 = (np.asarray(v, np.float32).astype(np.float64) for v in (C, Th, Bt))
+    phinorm = Th64 @ Bt64
+    return Bt64 * (Th64.T @ (C64 / phinorm))
+
+
+def lda_svi_step(lam, gamma, C, eta, docs_total, rho):
+    Th = dirichlet_expectation(gamma).astype(np.float32)
+    Bt = dirichlet_expectation(lam).astype(np.float32)
+    ss = lda_sstats(C, Th, Bt)
+    new = (1.0 - rho) * np.asarray(lam, np.float64) + rho * (eta + docs_total / C.shape[0] * ss)
+    return new, ss
