@@ -61,6 +61,8 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
     ctx->cu_count = prop.multiProcessorCount;
     // tuning knob for A/B runs in one process; not part of the ABI contract
     if (const char* e = getenv("BSC_BLR_TILE_ROWS")) ctx->blr_tile_rows = atoi(e) == 4 ? 4 : 8;
+    if (const char* e = getenv("BSC_BLR_WAVES_PER_SIMD")) ctx->blr_waves_per_simd = atoi(e);
+    if (const char* e = getenv("BSC_BLR_NT")) ctx->blr_nt_loads = atoi(e);
     *out = ctx;
     return BSC_OK;
 }

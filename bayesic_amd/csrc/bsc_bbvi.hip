@@ -53,7 +53,7 @@ __device__ __forceinline__ void stage_load(Stage& st, const float* __restrict__ 
     const int row_bytes = (int)(ldx * 4);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        auto v = __builtin_amdgcn_raw_buffer_load_b128(xs, 16 * lane, (8 * wave + r) * row_bytes, 0);
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(xs, 16 * lane, (8 * wave + r) * row_bytes, 2);  // nt
         float4 f = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
                                __uint_as_float(v[3]));
         if (4 * lane >= D) f = make_float4(0.f, 0.f, 0.f, 0.f);

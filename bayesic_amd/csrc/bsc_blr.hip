@@ -63,7 +63,7 @@ __device__ __forceinline__ int lane_value(int lane) {
 // tiles past the end -- read as zeros without touching memory.  No ragged-tail
 // code path and a trip count that is the same for every wave.  Everything but
 // the 16*lane byte offset is wave-uniform.
-template <int ROWS, bool FULL>
+template <int ROWS, bool FULL, bool NT>
 __device__ __forceinline__ void load_tile(Tile<ROWS>& t, const float* __restrict__ X,
                                           int64_t ldx, const float* __restrict__ y,
                                           int64_t row0, int64_t B, int D, int lane) {
@@ -82,7 +82,8 @@ __device__ __forceinline__ void load_tile(Tile<ROWS>& t, const float* __restrict
     const int row_bytes = (int)(ldx * 4);
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-        auto v = __builtin_amdgcn_raw_buffer_load_b128(xs, lane_off, r * row_bytes, 0);
+        // NT: non-temporal (aux = 2) -- X is read exactly once per pass
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(xs, lane_off, r * row_bytes, NT ? 2 : 0);
         float4 f = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]),
                                __uint_as_float(v[2]), __uint_as_float(v[3]));
         if (!FULL && 4 * lane >= D) f = make_float4(0.f, 0.f, 0.f, 0.f);  // next row's bytes
@@ -185,7 +186,7 @@ __device__ __forceinline__ void compute_tile(const Tile<ROWS>& t, const float4 (
 
 // FULL: D == 256, every lane owns four live columns.  ROWS: tile height.
 // n_iter: tiles per wave (same for every wave; tiles past the end read zeros).
-template <bool FULL, int ROWS>
+template <bool FULL, int ROWS, bool NT>
 __global__ __launch_bounds__(PASS_BLOCK, Geo<ROWS>::OCC) void blr_pass_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ y, int64_t B, int D,
     const float* __restrict__ W, int S, float* __restrict__ slab, int n_iter) {
@@ -216,11 +217,11 @@ __global__ __launch_bounds__(PASS_BLOCK, Geo<ROWS>::OCC) void blr_pass_kernel(
     const int64_t stride = (int64_t)gridDim.x * PASS_WAVES;
     int64_t tile = (int64_t)blockIdx.x * PASS_WAVES + wave;
     Tile<ROWS> ta, tb;
-    load_tile<ROWS, FULL>(ta, X, ldx, y, tile * ROWS, B, D, lane);
+    load_tile<ROWS, FULL, NT>(ta, X, ldx, y, tile * ROWS, B, D, lane);
     for (int k = 0; k + 1 < n_iter; k += 2) {
-        load_tile<ROWS, FULL>(tb, X, ldx, y, (tile + stride) * ROWS, B, D, lane);
+        load_tile<ROWS, FULL, NT>(tb, X, ldx, y, (tile + stride) * ROWS, B, D, lane);
         compute_tile<ROWS>(ta, w, acc, qacc, wl, lane);
-        load_tile<ROWS, FULL>(ta, X, ldx, y, (tile + 2 * stride) * ROWS, B, D, lane);
+        load_tile<ROWS, FULL, NT>(ta, X, ldx, y, (tile + 2 * stride) * ROWS, B, D, lane);
         compute_tile<ROWS>(tb, w, acc, qacc, wl, lane);
         tile += 2 * stride;
     }
@@ -692,7 +693,9 @@ struct PassGrid {
 PassGrid pass_grid(bsc_ctx* ctx, int64_t B) {
     const int rows = ctx->blr_tile_rows;
     const int64_t n_tiles = (B + rows - 1) / rows;
-    const int64_t max_waves = (int64_t)(rows == 8 ? Geo<8>::OCC : Geo<4>::OCC) * 4 * ctx->cu_count;
+    int occ = rows == 8 ? Geo<8>::OCC : Geo<4>::OCC;
+    if (ctx->blr_waves_per_simd > 0 && ctx->blr_waves_per_simd < occ) occ = ctx->blr_waves_per_simd;
+    const int64_t max_waves = (int64_t)occ * 4 * ctx->cu_count;
     PassGrid g;
     if (n_tiles <= 0) {
         g.n_blocks = 1;
@@ -722,24 +725,28 @@ int check_pass_args(const float* X, int64_t ldx, const float* y, int64_t B, int3
     return BSC_OK;
 }
 
-template <int ROWS>
+template <int ROWS, bool NT>
 void launch_pass_rows(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B,
                       int D, const float* W, int sg, PassGrid g, float* slab) {
     if (D == GCOLS)
-        hipLaunchKernelGGL((blr_pass_kernel<true, ROWS>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0,
+        hipLaunchKernelGGL((blr_pass_kernel<true, ROWS, NT>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0,
                            ctx->stream, X, ldx, y, B, D, W, sg, slab, g.n_iter);
     else
-        hipLaunchKernelGGL((blr_pass_kernel<false, ROWS>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0,
-                           ctx->stream, X, ldx, y, B, D, W, sg, slab, g.n_iter);
+        hipLaunchKernelGGL((blr_pass_kernel<false, ROWS, NT>), dim3(g.n_blocks), dim3(PASS_BLOCK),
+                           0, ctx->stream, X, ldx, y, B, D, W, sg, slab, g.n_iter);
 }
 
 void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B, int D,
                  const float* W, int sg, PassGrid g, float* slab) {
     bsc_prof_scope prof(ctx);  // times the pass kernel alone
-    if (ctx->blr_tile_rows == 8)
-        launch_pass_rows<8>(ctx, X, ldx, y, B, D, W, sg, g, slab);
-    else
-        launch_pass_rows<4>(ctx, X, ldx, y, B, D, W, sg, g, slab);
+    const bool nt = ctx->blr_nt_loads != 0;
+    if (ctx->blr_tile_rows == 8) {
+        if (nt) launch_pass_rows<8, true>(ctx, X, ldx, y, B, D, W, sg, g, slab);
+        else launch_pass_rows<8, false>(ctx, X, ldx, y, B, D, W, sg, g, slab);
+    } else {
+        if (nt) launch_pass_rows<4, true>(ctx, X, ldx, y, B, D, W, sg, g, slab);
+        else launch_pass_rows<4, false>(ctx, X, ldx, y, B, D, W, sg, g, slab);
+    }
 }
 
 }  // namespace

@@ -18,6 +18,8 @@ struct bsc_ctx {
     size_t workspace_bytes = 0;
     int cu_count = 256;
     int blr_tile_rows = 8;  // pass-kernel tile height: 8 (2 waves/SIMD, default) or 4 (3 waves/SIMD)
+    int blr_waves_per_simd = 0;  // tuning: cap resident waves per SIMD (0 = kernel's own limit)
+    int blr_nt_loads = 1;        // non-temporal loads of X (read once per pass): +9% measured
     int slab_rows = 0;  // block partials left in `workspace` by bsc_blr_data_pass_partial
     // optional per-kernel timing of the dominant kernel (bsc_ctx_profile)
     bool profile = false;

@@ -75,7 +75,7 @@ __device__ __forceinline__ void load_rows(XRow& t, const float* __restrict__ X, 
     const int off = (lane & 31) * (int)(ldx * 4);
 #pragma unroll
     for (int c4 = 0; c4 < MD / 4; ++c4) {
-        auto v = __builtin_amdgcn_raw_buffer_load_b128(xs, off + 16 * c4, 0, 0);
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(xs, off + 16 * c4, 0, 2);  // nt: read once
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float f = __uint_as_float(v[j]);

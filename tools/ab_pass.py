@@ -26,11 +26,14 @@ def main():
     y = torch.randn(B, generator=g, device=dev)
     W = torch.randn((S, D), generator=g, device=dev) / 16
     ctxs = {}
-    for rows in (4, 8):
+    variants = [(8, 0, 0), (8, 1, 0), (8, 0, 1), (8, 1, 1), (4, 0, 0), (4, 2, 0), (4, 0, 1)]
+    for rows, wps, nt in variants:
         os.environ["BSC_BLR_TILE_ROWS"] = str(rows)
-        ctxs[rows] = Context(0)
-        ctxs[rows].reserve(8 << 20)
-    res = {4: [], 8: []}
+        os.environ["BSC_BLR_WAVES_PER_SIMD"] = str(wps)
+        os.environ["BSC_BLR_NT"] = str(nt)
+        ctxs[(rows, wps, nt)] = Context(0)
+        ctxs[(rows, wps, nt)].reserve(16 << 20)
+    res = {k: [] for k in ctxs}
     for rows, c in ctxs.items():     # warm-up
         for _ in range(5):
             c.call("bsc_blr_data_pass_partial", ptr(X), D, ptr(y), B, D, ptr(W), S)
@@ -44,10 +47,10 @@ def main():
             c.profile(False)
             res[rows].append(ms / n * 1e3)
     bytes_ = 4.0 * B * D + 4.0 * B
-    for rows in (4, 8):
-        a = np.array(res[rows])
-        print("rows=%d  per-launch us: median %.1f  min %.1f  max %.1f  -> %.0f GB/s (median)"
-              % (rows, np.median(a), a.min(), a.max(), bytes_ / np.median(a) / 1e3))
+    for key in ctxs:
+        a = np.array(res[key])
+        print("rows=%d waves/SIMD cap=%d nt=%d  per-launch us: median %.1f  min %.1f  max %.1f  -> %.0f GB/s (median)"
+              % (key + (np.median(a), a.min(), a.max(), bytes_ / np.median(a) / 1e3)))
 
 
 if __name__ == "__main__":
