@@ -146,6 +146,87 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
     C[b * sc_b + (idx / N) * sc_m + (idx % N) * sc_n] = v;
 }
 
+// Matrix-vector shapes (N == 1 after orienting): y[m] = sum_k A[m,k] x[k].  Pure
+// streaming: the matrix is read once.  Two access patterns, chosen by which stride
+// of A is 1, both with float64 accumulation and a fixed-order two-stage finish:
+//   K_CONTIG  (A[m, :] contiguous, e.g. X w):   a wave per row group, lanes along k;
+//   M_CONTIG  (A[:, k] contiguous, e.g. X^T y): lane <-> output m, waves split k.
+struct GemvArgs {
+    const float* A;
+    const float* x;
+    float* y;
+    double* partial;   // [splits][M]
+    int64_t M, K, sa_m, sa_k, sx, sy;
+    int splits;
+};
+
+__global__ __launch_bounds__(256) void gemv_kcontig_kernel(GemvArgs g) {
+    // one wave per output row; K is contiguous: 16-byte loads when aligned
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= g.M) return;
+    const float* row = g.A + m * g.sa_m;
+    double acc = 0.0;
+    const bool vec = g.sa_k == 1 && g.sx == 1 && (((uintptr_t)row | (uintptr_t)g.x) & 15) == 0;
+    int64_t k0 = 0;
+    if (vec) {
+        const int64_t k4 = g.K / 4;
+        for (int64_t i = lane; i < k4; i += 64) {
+            const float4 a = reinterpret_cast<const float4*>(row)[i];
+            const float4 b = reinterpret_cast<const float4*>(g.x)[i];
+            acc += (double)a.x * b.x + (double)a.y * b.y + (double)a.z * b.z + (double)a.w * b.w;
+        }
+        k0 = k4 * 4;
+    }
+    for (int64_t k = k0 + lane; k < g.K; k += 64) acc += (double)row[k * g.sa_k] * g.x[k * g.sx];
+    acc = wave_allsum_f64(acc);
+    if (lane == 0) g.y[m * g.sy] = (float)acc;
+}
+
+__global__ __launch_bounds__(256) void gemv_mcontig_kernel(GemvArgs g) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t groups = (g.M + 63) / 64;
+    const int64_t grp = blockIdx.x % groups;
+    const int split = (int)(blockIdx.x / groups);
+    const int64_t m = grp * 64 + lane;
+    const int64_t chunk = (g.K + g.splits - 1) / g.splits;
+    const int64_t k0 = split * chunk, k1 = (k0 + chunk < g.K) ? k0 + chunk : g.K;
+    double acc = 0.0;
+    if (m < g.M) {
+        const float* col = g.A + m * g.sa_m;
+        constexpr int U = 8;   // loads in flight per lane
+        int64_t k = k0 + wave;
+        for (; k + 4 * (U - 1) < k1; k += 4 * U) {
+            float a[U], b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                a[u] = col[(k + 4 * u) * g.sa_k];
+                b[u] = g.x[(k + 4 * u) * g.sx];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += (double)a[u] * b[u];
+        }
+        for (; k < k1; k += 4) acc += (double)col[k * g.sa_k] * g.x[k * g.sx];
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && m < g.M) {
+        const double tot = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+        if (g.splits > 1) g.partial[(int64_t)split * g.M + m] = tot;
+        else g.y[m * g.sy] = (float)tot;
+    }
+}
+
+__global__ void gemv_finish_kernel(const double* partial, int splits, int64_t M, float* y,
+                                   int64_t sy) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    double tot = 0.0;
+    for (int s = 0; s < splits; ++s) tot += partial[(int64_t)s * M + m];
+    y[m * sy] = (float)tot;
+}
+
 // float64 (and the degenerate shapes): one thread per output, k-ordered fma chain.
 template <typename T>
 __global__ void gemm_naive_kernel(int64_t M, int64_t N, int64_t K, const T* A, int64_t sa_b,
@@ -190,6 +271,50 @@ int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, 
                                (const float*)A, sa_b, sa_m, sa_k, (const float*)B, sb_b, sb_k, sb_n,
                                (float*)C, sc_b, sc_m, sc_n);
         BSC_LAUNCH_CHECK();
+        return BSC_OK;
+    }
+    if (batch == 1 && (N == 1 || M == 1) && K >= 64) {
+        // matrix-vector: orient so that the matrix is "A[m,k]" and the vector "x[k]"
+        GemvArgs v;
+        if (N == 1) {
+            v.A = (const float*)A; v.M = M; v.sa_m = sa_m; v.sa_k = sa_k;
+            v.x = (const float*)B; v.sx = sb_k; v.sy = sc_m;
+        } else {
+            v.A = (const float*)B; v.M = N; v.sa_m = sb_n; v.sa_k = sb_k;
+            v.x = (const float*)A; v.sx = sa_k; v.sy = sc_n;
+        }
+        v.K = K;
+        v.y = (float*)C;
+        v.partial = nullptr;
+        v.splits = 1;
+        bsc_prof_scope prof(ctx);
+        if (v.sa_k == 1 || (v.sa_m != 1 && v.sa_k < v.sa_m)) {
+            hipLaunchKernelGGL(gemv_kcontig_kernel, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0,
+                               ctx->stream, v);
+            BSC_LAUNCH_CHECK();
+            return BSC_OK;
+        }
+        const int64_t groups = (v.M + 63) / 64;
+        int64_t splits = (4 * (int64_t)ctx->cu_count) / groups;
+        if (splits > K / 256) splits = K / 256;
+        if (splits < 1) splits = 1;
+        if (splits > 2048) splits = 2048;
+        v.splits = (int)splits;
+        if (splits > 1) {
+            void* ws = nullptr;
+            int rc = bsc_workspace(ctx, (size_t)splits * v.M * sizeof(double), &ws);
+            if (rc != BSC_OK) return rc;
+            v.partial = (double*)ws;
+            ctx->slab_rows = 0;
+        }
+        hipLaunchKernelGGL(gemv_mcontig_kernel, dim3((unsigned)(groups * splits)), dim3(256), 0,
+                           ctx->stream, v);
+        BSC_LAUNCH_CHECK();
+        if (splits > 1) {
+            hipLaunchKernelGGL(gemv_finish_kernel, dim3((unsigned)((v.M + 255) / 256)), dim3(256), 0,
+                               ctx->stream, (const double*)v.partial, v.splits, v.M, v.y, v.sy);
+            BSC_LAUNCH_CHECK();
+        }
         return BSC_OK;
     }
     GemmArgs g;

@@ -14,13 +14,14 @@
 //                                                       (backward, 64 x rows x 32)
 // Both contractions are dense with no padding waste at K=64, D=16, so both run on
 // v_mfma_f32_32x32x2_f32 (exact f32).  A wave owns 32-row tiles:
-//   forward  D[row][comp]  = A(features: lane = row, k = feature pair) * B(W, in registers)
-//   softmax  across the 32 lanes of each half-wave (DPP + one permlane16 swap per row)
-//   backward D[comp][feat] = A(r) * B(features from LDS)
-// and the responsibility tile is ALREADY laid out as the next MFMA's A operand:
-// accumulator register q of lane l holds row (q&3)+8(q>>2)+4(l>>5) for component
-// l&31, i.e. exactly A[i = comp][k = l>>5] of the row pair (rho, rho+4) -- no lane
-// movement, no LDS round trip for r.
+//   forward  D[comp][row]  = A(W, in registers) * B(features: lane = row, k = feature pair)
+//            so lane (row, half) holds 32 of the row's 64 logits in its own registers
+//   softmax  in-lane max/sum over those 32 + ONE permlane32 swap with the other half
+//            (PMC showed the first version, with rows in registers and components on
+//            lanes, spent 1240 VALU instructions per tile on cross-lane reductions
+//            against 64 MFMAs: profiles/r01_e_mog_bbvi_pmc.txt)
+//   r is transposed through wave-private LDS ([row][comp], 16-byte writes)
+//   backward D[comp][feat] = A(r: lane = comp, k = row of the pair) * B(features from LDS)
 #include "bsc_common.h"
 
 namespace {
@@ -32,6 +33,8 @@ constexpr int MT = 32;        // rows per tile
 constexpr int MOG_BLOCK = 256;
 constexpr int MOG_WAVES = MOG_BLOCK / BSC_WAVE;
 constexpr int XT_STRIDE = MD + 4;                    // LDS row stride of the x tile
+constexpr int RT_STRIDE = MK + 4;                    // LDS row stride of the r tile [row][comp]
+constexpr int WAVE_LDS = MT * XT_STRIDE + MT * RT_STRIDE;
 constexpr int MOG_SLAB = MK * (1 + MF) + 1;          // [comp][R | S(32)] + L
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -40,22 +43,20 @@ __device__ __forceinline__ int drow(int q, int lane) {  // C/D row of accumulato
     return (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
 }
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_max(float v) { return fmaxf(v, dpp_f32<CTRL>(v)); }
-
-// all-reduce over the 32 lanes of each half-wave
-__device__ __forceinline__ float half_allmax(float v) {
-    v = dpp_max<DPP_QUAD_XOR1>(v);
-    v = dpp_max<DPP_QUAD_XOR2>(v);
-    v = dpp_max<DPP_ROW_ROR4>(v);
-    v = dpp_max<DPP_ROW_ROR8>(v);
+// sum over the 32 lanes of each half-wave, result in every lane of the half
+__device__ __forceinline__ float half32_allsum(float v) {
+    v = row16_allsum(v);
     auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ float swap32_max(float v) {   // max with the lane 32 away
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-__device__ __forceinline__ float half_allsum(float v) {
-    v = row16_allsum(v);
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+__device__ __forceinline__ float swap32_sum(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
@@ -88,21 +89,28 @@ __device__ __forceinline__ void load_rows(XRow& t, const float* __restrict__ X, 
 __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
     const float* __restrict__ X, int64_t ldx, int64_t N, int D, const float* __restrict__ Wmat,
     const float* __restrict__ cvec, int K, float* __restrict__ slab, int n_iter) {
-    __shared__ __attribute__((aligned(16))) float lds[MOG_WAVES * (MT * XT_STRIDE) > MOG_WAVES * MOG_SLAB
-                                                          ? MOG_WAVES * (MT * XT_STRIDE)
+    __shared__ __attribute__((aligned(16))) float lds[MOG_WAVES * WAVE_LDS > MOG_WAVES * MOG_SLAB
+                                                          ? MOG_WAVES * WAVE_LDS
                                                           : MOG_WAVES * MOG_SLAB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    float* xt = lds + wave * (MT * XT_STRIDE);
+    float* xt = lds + wave * WAVE_LDS;
+    float* rt = xt + MT * XT_STRIDE;
 
-    // B operand of the forward product: W[comp = 32cb + l31][feature 2s + half]
+    // A operand of the forward product: W[comp = 32cb + l31][feature 2s + half]
     float wreg[2][MF / 2];
-    float bias[2];
+    f32x16 bias_q[2];   // bias of the component each accumulator register holds
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int comp = 32 * cb + drow(q, lane);
+            bias_q[cb][q] = comp < K ? cvec[comp] : -1.0e30f;
+        }
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         const int comp = 32 * cb + l31;
-        bias[cb] = comp < K ? cvec[comp] : -1.0e30f;
 #pragma unroll
         for (int s = 0; s < MF / 2; ++s) {
             const int f = 2 * s + half;            // f < 16: x_f ; else x^2_{f-16}
@@ -118,7 +126,11 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int q = 0; q < 16; ++q) S[cb][q] = 0.f;
-    float rsum[2] = {0.f, 0.f};
+    f32x16 rsum[2];   // per-lane (i.e. per-row-slot) partial sums of r, folded over lanes at the end
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rsum[cb][q] = 0.f;
     float lse_acc = 0.f;
 
     const int64_t stride = (int64_t)gridDim.x * MOG_WAVES;
@@ -136,42 +148,64 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
                 *reinterpret_cast<float4*>(xt + l31 * XT_STRIDE + 4 * c4) =
                     make_float4(cur.x[4 * c4], cur.x[4 * c4 + 1], cur.x[4 * c4 + 2], cur.x[4 * c4 + 3]);
         }
-        // forward: logits[row][comp]
+        // forward: logits[comp][row] -- lane (row = l31, half) gets comps 32cb + drow(q, lane)
         f32x16 logit[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) logit[cb][q] = bias[cb];
+            for (int q = 0; q < 16; ++q) logit[cb][q] = bias_q[cb][q];   // C operand carries the bias
 #pragma unroll
         for (int s = 0; s < MF / 2; ++s) {
             const int t = s & 7;
             float a = half ? cur.x[2 * t + 1] : cur.x[2 * t];
             if (s >= 8) a = a * a;
-            logit[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[0][s], logit[0], 0, 0, 0);
-            logit[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[1][s], logit[1], 0, 0, 0);
+            logit[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[0][s], a, logit[0], 0, 0, 0);
+            logit[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[1][s], a, logit[1], 0, 0, 0);
         }
-        // softmax over the 64 components of every row; rows past N get r = 0
+        // softmax over the row's 64 components: 32 in this lane, 32 in lane ^ 32
+        const bool valid = row0 + l31 < N;
+        float m = -3.0e38f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const bool valid = row0 + drow(q, lane) < N;
-            const float m = half_allmax(fmaxf(logit[0][q], logit[1][q]));
-            const float e0 = __expf(logit[0][q] - m), e1 = __expf(logit[1][q] - m);
-            const float s = half_allsum(e0 + e1);
-            const float inv = valid ? 1.0f / s : 0.f;
-            logit[0][q] = e0 * inv;
-            logit[1][q] = e1 * inv;
-            rsum[0] += logit[0][q];
-            rsum[1] += logit[1][q];
-            if (valid && l31 == 0) lse_acc += m + __logf(s);
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) m = fmaxf(m, logit[cb][q]);
+        m = swap32_max(m);
+        float ssum = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                logit[cb][q] = __expf(logit[cb][q] - m);
+                ssum += logit[cb][q];
+            }
+        ssum = swap32_sum(ssum);
+        const float inv = valid ? 1.0f / ssum : 0.f;
+        if (valid && half == 0) lse_acc += m + __logf(ssum);
+        // r -> LDS as [row][comp]: registers 4g..4g+3 are 4 consecutive components
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                logit[cb][q] *= inv;
+                rsum[cb][q] += logit[cb][q];
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *reinterpret_cast<float4*>(rt + l31 * RT_STRIDE + 32 * cb + 8 * gq + 4 * half) =
+                    make_float4(logit[cb][4 * gq], logit[cb][4 * gq + 1], logit[cb][4 * gq + 2],
+                                logit[cb][4 * gq + 3]);
         }
         wave_lds_sync();
-        // backward: S[comp][feat] += r[row][comp] * f[row][feat]
+        // backward: S[comp][feat] += r[row][comp] * f[row][feat], two rows per MFMA
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            float b = xt[drow(q, lane) * XT_STRIDE + (lane & (MD - 1))];
+        for (int t = 0; t < MT / 2; ++t) {
+            const int row = 2 * t + half;
+            float b = xt[row * XT_STRIDE + (lane & (MD - 1))];
             if (lane & MD) b = b * b;               // features 16..31 are the squares
-            S[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(logit[0][q], b, S[0], 0, 0, 0);
-            S[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(logit[1][q], b, S[1], 0, 0, 0);
+            const float r0 = rt[row * RT_STRIDE + l31];
+            const float r1 = rt[row * RT_STRIDE + 32 + l31];
+            S[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0, b, S[0], 0, 0, 0);
+            S[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r1, b, S[1], 0, 0, 0);
         }
         wave_lds_sync();   // the next tile overwrites xt
         cur = nxt;
@@ -188,12 +222,13 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
             const int comp = 32 * cb + drow(q, lane);
             ep[comp * (1 + MF) + 1 + l31] = S[cb][q];
         }
-        float r = rsum[cb];
-        r += __shfl_xor(r, 32);                   // the two row halves of the same component
-        if (half == 0) ep[(32 * cb + l31) * (1 + MF)] = r;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {            // R[comp]: fold the 32 row-lanes of this half
+            const float r = half32_allsum(rsum[cb][q]);
+            if (l31 == 0) ep[(32 * cb + drow(q, lane)) * (1 + MF)] = r;
+        }
     }
-    float l = lse_acc;
-    l += __shfl_xor(l, 32);
+    const float l = wave_allsum(lse_acc);   // one row per lane of the lower half
     if (lane == 0) ep[MK * (1 + MF)] = l;
     __syncthreads();
     float* out = slab + (int64_t)blockIdx.x * MOG_SLAB;

@@ -157,3 +157,21 @@ def test_config_shaped_expressions_on_device(dev):
     npt.assert_allclose(run(dev, Bm * dot(Th.T, C), Bm=Bv, Th=Thv, C=Cv),
                         Bv.astype(np.float64) * (Thv.astype(np.float64).T @ Cv.astype(np.float64)),
                         rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,d", [(1000, 300), (70000, 256), (64, 64), (5000, 7)])
+def test_matrix_vector_paths(dev, n, d):
+    """X w, X^T y and the vector-matrix forms take the streaming GEMV kernels."""
+    rs = np.random.RandomState(n + d)
+    Xv = rs.standard_normal((n, d)).astype(np.float32)
+    wv = rs.standard_normal(d).astype(np.float32)
+    yv = rs.standard_normal(n).astype(np.float32)
+    X, w, y = var("X", 2), var("w", 1), var("y", 1)
+    X64 = Xv.astype(np.float64)
+    tol = dict(rtol=1e-5, atol=1e-5 * np.sqrt(max(n, d)))
+    npt.assert_allclose(run(dev, dot(X, w), X=Xv, w=wv), X64 @ wv, **tol)
+    npt.assert_allclose(run(dev, dot(X.T, y), X=Xv, y=yv), X64.T @ yv, **tol)
+    npt.assert_allclose(run(dev, dot(y, X), X=Xv, y=yv), yv @ X64, **tol)
+    npt.assert_allclose(run(dev, dot(w, X.T), X=Xv, w=wv), wv @ X64.T, **tol)
+    got = run(dev, dot(X.T, y), X=Xv, y=yv)
+    assert (got == run(dev, dot(X.T, y), X=Xv, y=yv)).all()

@@ -40,6 +40,8 @@ def timed(ctx, fn, reps, warm=3):
 
 def main():
     quick = "--quick" in sys.argv
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
+    want = lambda name: not only or any(o in name for o in only)
     ctx = Context(0)
     dev = ctx.device
     g = torch.Generator(device=dev).manual_seed(0)
@@ -53,63 +55,67 @@ def main():
         out.append(rec)
         print(json.dumps(rec), flush=True)
 
-    # ---- config 2: BLR reparam pass ------------------------------------------
-    N, D, S = 1_000_000, 256, 8
-    X = torch.randn((N, D), generator=g, device=dev)
-    y = torch.randn(N, generator=g, device=dev)
-    W = torch.randn((S, D), generator=g, device=dev) / 16
     ctx.reserve(64 << 20)
-    w, k = timed(ctx, lambda: ctx.call("bsc_blr_data_pass_partial", X, D, y, N, D, W, S), 20)
-    row("cfg2 blr_pass 1Mx256 S=8", w, k, 4.0 * N * D + 4 * N, 4.0 * N * D * S, "hbm")
+    if want("cfg2"):
+        # ---- config 2: BLR reparam pass ------------------------------------------
+        N, D, S = 1_000_000, 256, 8
+        X = torch.randn((N, D), generator=g, device=dev)
+        y = torch.randn(N, generator=g, device=dev)
+        W = torch.randn((S, D), generator=g, device=dev) / 16
+        w, k = timed(ctx, lambda: ctx.call("bsc_blr_data_pass_partial", X, D, y, N, D, W, S), 50, warm=20)
+        row("cfg2 blr_pass 1Mx256 S=8", w, k, 4.0 * N * D + 4 * N, 4.0 * N * D * S, "hbm")
 
-    # ---- config 2': conjugate statistic X^T X through the executor -----------------
-    be = DeviceBackend(ctx)
-    Xs = A.var("X", 2)
-    gram = A.dot(Xs.T, Xs).compile(be).device_fn
-    w, k = timed(ctx, lambda: gram(X=X), 5)
-    row("cfg2' gram X^T X 256x256x1M", w, k, 4.0 * N * D, 2.0 * N * D * D, "f32-mfma")
-    xty = A.dot(Xs.T, A.var("y", 1)).compile(be).device_fn
-    w, k = timed(ctx, lambda: xty(X=X, y=y), 5)
-    row("cfg2' X^T y", w, k, 4.0 * N * D, 2.0 * N * D, "hbm")
-    del X, y
+        # ---- config 2': conjugate statistic X^T X through the executor -----------------
+        be = DeviceBackend(ctx)
+        Xs = A.var("X", 2)
+        gram = A.dot(Xs.T, Xs).compile(be).device_fn
+        w, k = timed(ctx, lambda: gram(X=X), 5)
+        row("cfg2' gram X^T X 256x256x1M", w, k, 4.0 * N * D, 2.0 * N * D * D, "f32-mfma")
+        xty = A.dot(Xs.T, A.var("y", 1)).compile(be).device_fn
+        w, k = timed(ctx, lambda: xty(X=X, y=y), 5)
+        row("cfg2' X^T y", w, k, 4.0 * N * D, 2.0 * N * D, "hbm")
+        del X, y
 
-    # ---- config 3: MoG E-step + statistics ----------------------------------------
-    N3, D3, K3 = (2_000_000 if quick else 10_000_000), 16, 64
-    X3 = torch.randn((N3, D3), generator=g, device=dev) * 3
-    Wm = torch.randn((K3, 2 * D3), generator=g, device=dev) * 0.1
-    Wm[:, D3:] = -0.5
-    c = torch.zeros(K3, device=dev)
-    stats, lse = torch.zeros(K3 * (1 + 2 * D3), dtype=torch.float64, device=dev), \
-        torch.zeros(1, dtype=torch.float64, device=dev)
-    w, k = timed(ctx, lambda: ctx.call("bsc_mog_estep", X3, D3, N3, D3, K3, Wm, c, stats, lse), 10)
-    row("cfg3 mog_estep %dMx16 K=64" % (N3 // 1_000_000), w, k, 4.0 * N3 * D3, 8.0 * K3 * D3 * N3,
-        "f32-mfma")
-    del X3
+    if want("cfg3"):
+        # ---- config 3: MoG E-step + statistics ----------------------------------------
+        N3, D3, K3 = (2_000_000 if quick else 10_000_000), 16, 64
+        X3 = torch.randn((N3, D3), generator=g, device=dev) * 3
+        Wm = torch.randn((K3, 2 * D3), generator=g, device=dev) * 0.1
+        Wm[:, D3:] = -0.5
+        c = torch.zeros(K3, device=dev)
+        stats = torch.zeros(K3 * (1 + 2 * D3), dtype=torch.float64, device=dev)
+        lse = torch.zeros(1, dtype=torch.float64, device=dev)
+        w, k = timed(ctx, lambda: ctx.call("bsc_mog_estep", X3, D3, N3, D3, K3, Wm, c, stats, lse), 20, warm=10)
+        row("cfg3 mog_estep %dMx16 K=64" % (N3 // 1_000_000), w, k, 4.0 * N3 * D3,
+            8.0 * K3 * D3 * N3, "f32-mfma")
+        del X3
 
-    # ---- config 5: BBVI log-likelihood pass ------------------------------------------
-    N5, D5, G5, S5 = 1_000_000, 256, 1000, 64
-    X5 = torch.randn((N5, D5), generator=g, device=dev)
-    y5 = (torch.rand(N5, generator=g, device=dev) < 0.4).float()
-    g5 = torch.randint(0, G5, (N5,), generator=g, device=dev, dtype=torch.int32)
-    Wz = torch.randn((S5, D5), generator=g, device=dev) / 16
-    Bz = torch.randn((G5, S5), generator=g, device=dev)
-    ell = torch.zeros(S5, dtype=torch.float64, device=dev)
-    w, k = timed(ctx, lambda: ctx.call("bsc_logreg_bbvi_loglik", X5, D5, y5, g5, N5, D5, G5, Wz, Bz,
-                                       S5, ell), 10)
-    row("cfg5 logreg_loglik 1Mx256 S=64", w, k, 4.0 * N5 * D5 + 8.0 * N5, 2.0 * N5 * D5 * S5,
-        "hbm/f32-mfma")
-    del X5
+    if want("cfg5"):
+        # ---- config 5: BBVI log-likelihood pass ------------------------------------------
+        N5, D5, G5, S5 = 1_000_000, 256, 1000, 64
+        X5 = torch.randn((N5, D5), generator=g, device=dev)
+        y5 = (torch.rand(N5, generator=g, device=dev) < 0.4).float()
+        g5 = torch.randint(0, G5, (N5,), generator=g, device=dev, dtype=torch.int32)
+        Wz = torch.randn((S5, D5), generator=g, device=dev) / 16
+        Bz = torch.randn((G5, S5), generator=g, device=dev)
+        ell = torch.zeros(S5, dtype=torch.float64, device=dev)
+        w, k = timed(ctx, lambda: ctx.call("bsc_logreg_bbvi_loglik", X5, D5, y5, g5, N5, D5, G5, Wz,
+                                           Bz, S5, ell), 20, warm=10)
+        row("cfg5 logreg_loglik 1Mx256 S=64", w, k, 4.0 * N5 * D5 + 8.0 * N5, 2.0 * N5 * D5 * S5,
+            "hbm/f32-mfma")
+        del X5
 
-    # ---- config 4: LDA local step on one GPU's shard -----------------------------------
-    from bayesic_amd.svi.lda import LDAFixedGammaSVI
-    docs, V, K4 = (1000 if quick else 6250), 100_000, 128
-    C = torch.poisson(torch.full((docs, V), 0.05, device=dev), generator=g)
-    gamma = torch.rand((docs, K4), generator=g, device=dev) + 0.5
-    lam = torch.rand((K4, V), generator=g, device=dev) + 0.5
-    model = LDAFixedGammaSVI(C, gamma, lam, docs_total=50_000, ctx=ctx)
-    w, _ = timed(ctx, model.step, 3, warm=1)
-    row("cfg4 lda_step %dx100k K=128 (whole step)" % docs, w, float("nan"), 4.0 * docs * V,
-        4.0 * docs * V * K4, "f32-mfma")
+    if want("cfg4"):
+        # ---- config 4: LDA local step on one GPU's shard -----------------------------------
+        from bayesic_amd.svi.lda import LDAFixedGammaSVI
+        docs, V, K4 = (1000 if quick else 6250), 100_000, 128
+        C = torch.poisson(torch.full((docs, V), 0.05, device=dev), generator=g)
+        gamma = torch.rand((docs, K4), generator=g, device=dev) + 0.5
+        lam = torch.rand((K4, V), generator=g, device=dev) + 0.5
+        model = LDAFixedGammaSVI(C, gamma, lam, docs_total=50_000, ctx=ctx)
+        w, _ = timed(ctx, model.step, 3, warm=1)
+        row("cfg4 lda_step %dx100k K=128 (whole step)" % docs, w, float("nan"), 4.0 * docs * V,
+            4.0 * docs * V * K4, "f32-mfma")
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w"), indent=1)
 
