@@ -95,7 +95,8 @@ int bsc_ctx_reserve(bsc_ctx* ctx, size_t bytes) {
 
 int bsc_ctx_profile(bsc_ctx* ctx, int enable) {
     BSC_CHECK_CTX(ctx);
-    ctx->profile = enable != 0;
+    ctx->profile = enable > 0 ? enable : 0;
+    ctx->profile_tick = 0;
     return BSC_OK;
 }
 

@@ -257,9 +257,9 @@ __global__ __launch_bounds__(PASS_BLOCK, Geo<ROWS>::OCC) void blr_pass_kernel(
 // Loads are issued in batches of 16 before any add: the partials were written by
 // another kernel, so every load is a MALL/HBM round trip (~0.4 us) and a
 // load-add-load-add chain would serialise them.
+template <int BATCH = 16>
 __device__ __forceinline__ double slab_column_sum(const float* __restrict__ p, int first,
                                                   int step, int n_rows) {
-    constexpr int BATCH = 16;
     double sum = 0.0;
     for (int b0 = first; b0 < n_rows; b0 += step * BATCH) {
         float v[BATCH];
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(RED_BLOCK) void blr_slab_reduce_kernel(
     const int wave = threadIdx.x >> 6;
     const int i = blockIdx.x * BSC_WAVE + lane;
     double sum = 0.0;
-    if (i < SLAB_STRIDE) sum = slab_column_sum(slab + i, wave, RED_WAVES, n_blocks);
+    if (i < SLAB_STRIDE) sum = slab_column_sum<32>(slab + i, wave, RED_WAVES, n_blocks);
     part[wave][lane] = sum;
     __syncthreads();
     if (wave == 0 && i < SLAB_STRIDE) {
@@ -357,6 +357,33 @@ __global__ void philox_normal_kernel(uint64_t seed, uint32_t stream, uint32_t st
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (4 * b + j < n_params) eps[(int64_t)s * n_params + 4 * b + j] = z[j];
+}
+
+// eps for `n_steps` consecutive Philox steps in one launch:
+// eps[(k*S + s)*(D+1) + d], d < D from stream 0, d == D from stream 1 (the layout
+// bsc_blr_sample writes for one step).  The noise does not depend on the
+// parameters, so it is produced ahead of time and kept out of the update's
+// latency chain.
+__global__ void blr_noise_kernel(int D, int S, uint64_t seed, uint32_t step0, int n_steps,
+                                 double* __restrict__ eps) {
+    const int n_blocks = (D + 3) / 4;
+    const int per_step = S * n_blocks + S;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)per_step * n_steps) return;
+    const int k = (int)(idx / per_step), r = (int)(idx % per_step);
+    double* out = eps + (int64_t)k * S * (D + 1);
+    double z[4];
+    if (r < S * n_blocks) {
+        const int s = r / n_blocks, b = r % n_blocks;
+        philox_normal4(seed, (uint32_t)b, (uint32_t)s, 0u, step0 + (uint32_t)k, z);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * b + j < D) out[(int64_t)s * (D + 1) + 4 * b + j] = z[j];
+    } else {
+        const int s = r - S * n_blocks;
+        philox_normal4(seed, 0u, (uint32_t)s, 1u, step0 + (uint32_t)k, z);
+        out[(int64_t)s * (D + 1) + D] = z[0];
+    }
 }
 
 // Draws for Philox block `pb` (columns 4pb..4pb+3) of sample s, given m, rho
@@ -494,6 +521,7 @@ struct FusedArgs {
     const float* W;
     const double* xi;
     double* eps_next;      // nullptr: no next draw
+    int eps_next_ready;    // 1: eps_next already holds the noise of next_step (bsc_blr_noise)
     float* W_next;
     double* xi_next;
     double* elbo;
@@ -532,18 +560,25 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
         const int d = d0 + dl;
         double gm = 0.0, gr = 0.0;
         if (a.slab) {  // S <= 8: lane <-> (column dl, sample sl) of one 256-B slab run
-            red[wave][lane] =
-                slab_column_sum(a.slab + 64 * blockIdx.x + lane, wave, FUSED_WAVES, a.n_slab);
+            // issue the small operand loads first so that they fly together with the slab
+            const bool live = sl < S && d < D;
+            double wv = 0.0, xs = 0.0, ev = 0.0;
+            if (wave == 0 && live) {
+                wv = (double)a.W[(int64_t)sl * D + d];
+                xs = a.xi[sl];
+                ev = a.eps[(int64_t)sl * (D + 1) + d];
+            }
+            red[wave][lane] = slab_column_sum<32>(a.slab + 64 * blockIdx.x + lane, wave,
+                                                  FUSED_WAVES, a.n_slab);
             __syncthreads();
             if (wave != 0) return;
             double g = red[0][lane];
 #pragma unroll
             for (int k = 1; k < FUSED_WAVES; ++k) g += red[k][lane];
-            if (sl < S && d < D) {
-                const double wv = (double)a.W[(int64_t)sl * D + d];
-                const double dw = exp(-a.xi[sl]) * (a.scale * g - wv);
+            if (live) {
+                const double dw = exp(-xs) * (a.scale * g - wv);
                 gm = dw;
-                gr = dw * a.eps[(int64_t)sl * (D + 1) + d];
+                gr = dw * ev;
             }
         } else {
             if (wave != 0) return;
@@ -557,6 +592,13 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
                 }
             }
         }
+        // parameter state of this column (loads overlap the shuffles below)
+        double p_m = 0.0, p_rho = 0.0, p_m1 = 0.0, p_m2 = 0.0, p_r1 = 0.0, p_r2 = 0.0;
+        if (sl == 0 && d < D) {
+            p_m = a.lam_in[d]; p_rho = a.lam_in[D + d];
+            p_m1 = a.m1[d]; p_m2 = a.m2[d];
+            p_r1 = a.m1[D + d]; p_r2 = a.m2[D + d];
+        }
         // fold the 8 sample lanes (lane bits 0-2)
 #pragma unroll
         for (int off = 1; off < 8; off <<= 1) {
@@ -566,15 +608,15 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
         double* new_m = sh;        // [8]
         double* new_rho = sh + 8;  // [8]
         if (sl == 0 && d < D) {
-            const double rho = a.lam_in[D + d];
+            const double rho = p_rho;
             const double g_m = gm * inv_S;
             const double g_r = gr * inv_S * exp(rho) + 1.0;
             a.grad[d] = g_m;
             a.grad[D + d] = g_r;
-            double m1 = a.m1[d], m2 = a.m2[d];
-            const double nm = adam_ascent_one(a.lam_in[d], g_m, m1, m2, a);
+            double m1 = p_m1, m2 = p_m2;
+            const double nm = adam_ascent_one(p_m, g_m, m1, m2, a);
             a.m1[d] = m1; a.m2[d] = m2;
-            double r1 = a.m1[D + d], r2 = a.m2[D + d];
+            double r1 = p_r1, r2 = p_r2;
             const double nr = adam_ascent_one(rho, g_r, r1, r2, a);
             a.m1[D + d] = r1; a.m2[D + d] = r2;
             a.lam_out[d] = nm;
@@ -583,7 +625,15 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
             new_rho[dl] = nr;
         }
         wave_lds_sync();
-        if (a.eps_next) {
+        if (a.eps_next && a.eps_next_ready) {
+            // noise precomputed: w = m + e^rho * eps for this lane's (column, sample)
+            for (int s = sl; s < S; s += 8)
+                if (d < D) {
+                    const double sd = exp(new_rho[dl]);
+                    const double wv = new_m[dl] + sd * a.eps_next[(int64_t)s * (D + 1) + d];
+                    a.W_next[(int64_t)s * D + d] = (float)wv;
+                }
+        } else if (a.eps_next) {
             // two Philox blocks per sample cover the 8 columns
             for (int i = lane; i < 2 * S; i += BSC_WAVE) {
                 const int s = i >> 1, pb = 2 * blockIdx.x + (i & 1);
@@ -600,8 +650,8 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
     double* wsq = sh + FIN_MAX_S;       // [S]
     double* misc = sh + 2 * FIN_MAX_S;  // [1]=new a [2]=new b
     if (a.slab) {  // S <= 8: thread -> (sample tid&7, slab-row group tid>>3)
-        double part = slab_column_sum(a.slab + SLAB_G + (tid & 7), tid >> 3, FUSED_BLOCK / 8,
-                                      a.n_slab);
+        double part = slab_column_sum<8>(a.slab + SLAB_G + (tid & 7), tid >> 3, FUSED_BLOCK / 8,
+                                         a.n_slab);
         // fold the 8 row groups of this wave (lane bits 3-5), then the 16 waves
         part += __shfl_xor(part, 8);
         part += __shfl_xor(part, 16);
@@ -678,9 +728,15 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
         misc[2] = nb;
     }
     __syncthreads();
-    if (a.eps_next)
+    if (a.eps_next && a.eps_next_ready) {
+        for (int s = tid; s < S; s += FUSED_BLOCK) {
+            const double sd = exp(misc[2]);
+            a.xi_next[s] = misc[1] + sd * a.eps_next[(int64_t)s * (D + 1) + D];
+        }
+    } else if (a.eps_next) {
         for (int s = tid; s < S; s += FUSED_BLOCK)
             blr_draw_scale(misc[1], misc[2], D, s, a.seed, a.next_step, a.eps_next, a.xi_next);
+    }
 }
 
 // Grid and per-wave trip count: fill the resident wave slots, then balance so
@@ -775,6 +831,17 @@ int bsc_blr_sample(bsc_ctx* ctx, const double* lam, int32_t D, int32_t S, uint64
     return BSC_OK;
 }
 
+int bsc_blr_noise(bsc_ctx* ctx, int32_t D, int32_t S, uint64_t seed, uint32_t step0,
+                  int32_t n_steps, double* eps) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(eps && D > 0 && S > 0 && n_steps > 0, "bsc_blr_noise: bad arguments");
+    const int64_t n = (int64_t)(S * ((D + 3) / 4) + S) * n_steps;
+    hipLaunchKernelGGL(blr_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, (int)D, (int)S, seed, step0, (int)n_steps, eps);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
 int bsc_blr_data_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B,
                       int32_t D, const float* W, int32_t S, double* Q, double* G) {
     BSC_CHECK_CTX(ctx);
@@ -834,8 +901,8 @@ int bsc_blr_fused_update(bsc_ctx* ctx, const double* stats, const double* lam_in
                          const double* xi, int32_t D, int32_t S, double batch_rows, double scale,
                          double alpha0, double beta0, int64_t t, double lr, double beta1,
                          double beta2, double adam_eps, uint64_t seed, uint32_t next_step,
-                         double* eps_next, float* W_next, double* xi_next, double* elbo,
-                         double* grad) {
+                         double* eps_next, int32_t eps_next_ready, float* W_next, double* xi_next,
+                         double* elbo, double* grad) {
     BSC_CHECK_CTX(ctx);
     BSC_REQUIRE(lam_in && lam_out && m1 && m2 && eps && W && xi && elbo && grad,
                 "bsc_blr_fused_update: null pointer");
@@ -862,6 +929,7 @@ int bsc_blr_fused_update(bsc_ctx* ctx, const double* stats, const double* lam_in
     a.lam_in = lam_in; a.lam_out = lam_out; a.m1 = m1; a.m2 = m2;
     a.eps = eps; a.W = W; a.xi = xi;
     a.eps_next = eps_next; a.W_next = W_next; a.xi_next = xi_next;
+    a.eps_next_ready = eps_next_ready != 0;
     a.elbo = elbo; a.grad = grad;
     a.D = D; a.S = S;
     a.batch_rows = batch_rows; a.scale = scale; a.alpha0 = alpha0; a.beta0 = beta0;

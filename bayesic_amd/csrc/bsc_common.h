@@ -22,7 +22,8 @@ struct bsc_ctx {
     int blr_nt_loads = 1;        // non-temporal loads of X (read once per pass): +9% measured
     int slab_rows = 0;  // block partials left in `workspace` by bsc_blr_data_pass_partial
     // optional per-kernel timing of the dominant kernel (bsc_ctx_profile)
-    bool profile = false;
+    int profile = 0;        // 0 = off, n = time every n-th launch of a dominant kernel
+    int profile_tick = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;  // recorded pairs
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;    // reusable pairs
 };
@@ -32,7 +33,8 @@ struct bsc_prof_scope {
     bsc_ctx* ctx;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     explicit bsc_prof_scope(bsc_ctx* c) : ctx(c) {
-        if (!ctx->profile) return;
+        if (ctx->profile <= 0) return;
+        if ((ctx->profile_tick++ % ctx->profile) != 0) return;
         if (!ctx->prof_pool.empty()) {
             ev = ctx->prof_pool.back();
             ctx->prof_pool.pop_back();

@@ -55,9 +55,10 @@ class Context:
     def reserve(self, nbytes):
         _ffi.check(self.lib.bsc_ctx_reserve(self.handle, nbytes), "bsc_ctx_reserve")
 
-    def profile(self, enable=True):
-        """Time the dominant kernel of each entry point with hipEvents on the ctx stream."""
-        _ffi.check(self.lib.bsc_ctx_profile(self.handle, int(bool(enable))), "bsc_ctx_profile")
+    def profile(self, every=1):
+        """Time the dominant kernel of each entry point with hipEvents on the ctx stream;
+        `every` = 0/False: off, n: every n-th launch."""
+        _ffi.check(self.lib.bsc_ctx_profile(self.handle, int(every)), "bsc_ctx_profile")
 
     def profile_read(self):
         """(total_ms, launches) of the dominant kernel since the last read; syncs."""

@@ -27,6 +27,8 @@ from ..device import default_context
 
 
 class BLRReparamSVI:
+    NOISE_BLOCK = 32
+
     def __init__(self, X, y, n_total=None, n_samples=8, seed=1234, lr=1e-2, alpha0=1.0,
                  beta0=1.0, ctx=None, group=None, lam0=None, fused=True):
         self.ctx = ctx or default_context()
@@ -65,7 +67,10 @@ class BLRReparamSVI:
             self._lam[0, 2 * D + 1] = math.log(0.1)
         else:
             self._lam[0].copy_(torch.as_tensor(lam0, dtype=f64))
-        self._eps = torch.zeros((2, S * (D + 1)), dtype=f64, device=dev)
+        # noise ring: NOISE_BLOCK steps are drawn per launch, two blocks resident
+        self._ring = 2 * self.NOISE_BLOCK
+        self._eps = torch.zeros((self._ring, S * (D + 1)), dtype=f64, device=dev)
+        self._noise_upto = 0   # noise of Philox steps [0, _noise_upto) has been requested
         self._W = torch.zeros((2, S * D), dtype=torch.float32, device=dev)
         self._xi = torch.zeros((2, S), dtype=f64, device=dev)
         self.m1 = torch.zeros(2 * D + 2, dtype=f64, device=dev)
@@ -95,7 +100,17 @@ class BLRReparamSVI:
 
     @property
     def eps(self):
-        return self._eps[self.cur]
+        return self._eps[self.t % self._ring]
+
+    def _ensure_noise(self, step):
+        """Noise of Philox step `step` is in ring row step % ring (drawn a block ahead)."""
+        nb = self.NOISE_BLOCK
+        while self._noise_upto <= step:
+            start = self._noise_upto
+            r0 = start % self._ring
+            self.ctx.call("bsc_blr_noise", self.D, self.S, self.seed, start, nb,
+                          self._eps[r0:r0 + nb])
+            self._noise_upto = start + nb
 
     @property
     def xi(self):
@@ -104,8 +119,9 @@ class BLRReparamSVI:
     # -- unfused phases (also the multi-sample-group path) ---------------------
     def sample(self, step):
         c = self.cur
+        self._ensure_noise(step)        # (bsc_blr_sample rewrites this row with the same values)
         self.ctx.call("bsc_blr_sample", self._lam[c], self.D, self.S, self.seed, step,
-                      self._eps[c], self._W[c], self._xi[c])
+                      self._eps[step % self._ring], self._W[c], self._xi[c])
         self._drawn = True
 
     def data_pass(self):
@@ -119,13 +135,14 @@ class BLRReparamSVI:
     def _finish(self, stats):
         """Fused gradient + Adam + next draw; flips the double buffer."""
         c, n = self.cur, 1 - self.cur
-        t = self.t + 1
+        t = self.t + 1                  # Adam step count; Philox step of the NEXT draw
+        self._ensure_noise(t)
         self.ctx.call("bsc_blr_fused_update", stats,
                       self._lam[c], self._lam[n], self.m1, self.m2,
-                      self._eps[c], self._W[c], self._xi[c], self.D, self.S,
+                      self._eps[self.t % self._ring], self._W[c], self._xi[c], self.D, self.S,
                       self.batch_rows, self.n_total / self.batch_rows, self.alpha0, self.beta0,
                       t, self.lr, 0.9, 0.999, 1e-8, self.seed, t,
-                      self._eps[n], self._W[n], self._xi[n], self.elbo,
+                      self._eps[t % self._ring], 1, self._W[n], self._xi[n], self.elbo,
                       self.grad)
         self.t = t
 

@@ -64,9 +64,11 @@ int bsc_d2h(bsc_ctx* ctx, void* host_dst, const void* src, size_t bytes); /* syn
 int bsc_memset(bsc_ctx* ctx, void* dst, int value, size_t bytes);
 
 /* Per-kernel timing of the dominant kernel of each entry point, with hipEvents
- * recorded on the ctx stream immediately around that one launch.  Off by
- * default.  bsc_ctx_profile_read synchronises, returns the summed duration and
- * the launch count since the last read, and resets both. */
+ * recorded on the ctx stream immediately around that one launch.  enable = 0: off
+ * (default); enable = n >= 1: time every n-th such launch (an event pair costs a
+ * few microseconds of stream time, so a sampling period keeps the perturbation of
+ * a timed region small).  bsc_ctx_profile_read synchronises, returns the summed
+ * duration and the number of TIMED launches since the last read, and resets both. */
 int bsc_ctx_profile(bsc_ctx* ctx, int enable);
 int bsc_ctx_profile_read(bsc_ctx* ctx, double* host_total_ms, int64_t* host_launches);
 
@@ -88,6 +90,13 @@ int bsc_philox_normal(bsc_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t ste
  * (w_s = m + e^rho * eps_s, rounded), xi[S] f64. */
 int bsc_blr_sample(bsc_ctx* ctx, const double* lam, int32_t D, int32_t S,
                    uint64_t seed, uint32_t step, double* eps, float* W, double* xi);
+
+/* The same noise for n_steps consecutive Philox steps [step0, step0+n_steps) in
+ * one launch: eps[(k*S + s)*(D+1) + d].  The noise does not depend on the
+ * parameters, so a driver produces it ahead of time (off the update's latency
+ * chain) and hands it to bsc_blr_fused_update with eps_next_ready = 1. */
+int bsc_blr_noise(bsc_ctx* ctx, int32_t D, int32_t S, uint64_t seed, uint32_t step0,
+                  int32_t n_steps, double* eps);
 
 /* ---- the mini-batch data pass (ABSENT in reference; README.md:51,69-79;
  *      likelihood decomposition bayesic/distribution/base.py:47-69) --------
@@ -124,15 +133,18 @@ int bsc_blr_elbo_grad(bsc_ctx* ctx, const double* lam, const double* eps,
  * -> ELBO + pathwise gradient (as bsc_blr_elbo_grad) -> Adam ascent step t
  * (as bsc_adam_ascent) written to lam_out (lam_in is not modified; m1, m2
  * updated in place) -> when the *_next buffers are non-NULL, the reparameterised
- * draws of Philox step `next_step` from lam_out (as bsc_blr_sample).  The caller
+ * draws of Philox step `next_step` from lam_out (as bsc_blr_sample); with
+ * eps_next_ready != 0 eps_next is an INPUT already holding that step's noise
+ * (bsc_blr_noise) and only W_next / xi_next are written.  The caller
  * double-buffers lam and the draws: *_next must not alias eps/W/xi. */
 int bsc_blr_fused_update(bsc_ctx* ctx, const double* stats, const double* lam_in,
                          double* lam_out, double* m1, double* m2, const double* eps,
                          const float* W, const double* xi, int32_t D, int32_t S,
                          double batch_rows, double scale, double alpha0, double beta0,
                          int64_t t, double lr, double beta1, double beta2, double adam_eps,
-                         uint64_t seed, uint32_t next_step, double* eps_next, float* W_next,
-                         double* xi_next, double* elbo, double* grad);
+                         uint64_t seed, uint32_t next_step, double* eps_next,
+                         int32_t eps_next_ready, float* W_next, double* xi_next, double* elbo,
+                         double* grad);
 
 /* ---- parameter updates --------------------------------------------------- */
 

@@ -40,6 +40,11 @@ class OracleContext:
     def _np(t):
         return t.numpy()
 
+    def bsc_blr_noise(self, D, S, seed, step0, n_steps, eps):
+        for k in range(n_steps):
+            e, _, _ = svi.blr_sample(np.zeros(2 * D + 2), D, S, seed, step=step0 + k)
+            eps[k].copy_(torch.from_numpy(e.ravel()))
+
     def bsc_blr_sample(self, lam, D, S, seed, step, eps, W, xi):
         e, w, x = svi.blr_sample(lam.numpy(), D, S, seed, step=step)
         eps.copy_(torch.from_numpy(e.ravel()))
@@ -56,7 +61,7 @@ class OracleContext:
 
     def bsc_blr_fused_update(self, stats, lam_in, lam_out, m1, m2, eps, W, xi, D, S, batch_rows,
                              scale, alpha0, beta0, t, lr, b1, b2, adam_eps, seed, next_step,
-                             eps_n, W_n, xi_n, elbo, grad):
+                             eps_n, eps_ready, W_n, xi_n, elbo, grad):
         if stats is None:
             Q, G = self._pending
         else:

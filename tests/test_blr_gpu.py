@@ -283,7 +283,7 @@ def test_fused_update_from_stats_matches_oracle(ctx, D, S):
     elbo, grad = ctx.zeros(1, f64), ctx.zeros(2 * D + 2, f64)
     ctx.call("bsc_blr_fused_update", ptr(stats), ptr(lam_in), ptr(lam_out), ptr(m1d), ptr(m2d),
              ptr(epsd), ptr(Wd), ptr(xid), D, S, B, scale, 1.5, 0.7, t, lr, 0.9, 0.999, 1e-8,
-             77, t, ptr(eps_n), ptr(W_n), ptr(xi_n), ptr(elbo), ptr(grad))
+             77, t, ptr(eps_n), 0, ptr(W_n), ptr(xi_n), ptr(elbo), ptr(grad))
     ctx.sync()
     e_ref, g_ref = svi.blr_elbo_and_grad(lam, eps, W, xi, Q, G, B, scale, 1.5, 0.7)
     lam_ref, m1r, m2r = svi.adam_ascent(lam, g_ref, m1, m2, t, lr)
@@ -327,8 +327,34 @@ def test_fused_update_requires_pending_partials(ctx):
     with pytest.raises(BayesicHipError, match="pending"):
         ctx.call("bsc_blr_fused_update", None, ptr(lam_in), ptr(lam_out), ptr(m1), ptr(m2),
                  ptr(eps), ptr(W), ptr(xi), D, S, 16.0, 1.0, 1.0, 1.0, 1, 0.01, 0.9, 0.999, 1e-8,
-                 1, 1, None, None, None, ptr(elbo), ptr(grad))
+                 1, 1, None, 0, None, None, ptr(elbo), ptr(grad))
     with pytest.raises(BayesicHipError, match="differ"):
         ctx.call("bsc_blr_fused_update", ptr(Q), ptr(lam_in), ptr(lam_in), ptr(m1), ptr(m2),
                  ptr(eps), ptr(W), ptr(xi), D, S, 16.0, 1.0, 1.0, 1.0, 1, 0.01, 0.9, 0.999, 1e-8,
-                 1, 1, None, None, None, ptr(elbo), ptr(grad))
+                 1, 1, None, 0, None, None, ptr(elbo), ptr(grad))
+
+
+def test_noise_ring_wraps_and_matches_per_step_sampling(ctx):
+    """The driver draws noise 32 steps per launch into a 64-row ring; 70 updates cross
+    both a block boundary and the wrap-around.  Also checks bsc_blr_noise against the
+    oracle's per-step draws and the eps_next_ready path of the fused finish."""
+    from bayesic_amd._ffi import ptr
+    from bayesic_amd.svi.blr import BLRReparamSVI
+    D, S = 16, 4
+    noise = ctx.zeros((5, S * (D + 1)), torch.float64)
+    ctx.call("bsc_blr_noise", D, S, 321, 7, 5, noise)
+    ctx.sync()
+    for k in range(5):
+        e, _, _ = svi.blr_sample(svi.blr_init_lam(D), D, S, 321, step=7 + k)
+        np.testing.assert_allclose(noise[k].cpu().numpy().reshape(S, D + 1), e, rtol=1e-12, atol=1e-14)
+    X, y, _ = svi.make_cfg2(800, D)
+    model = BLRReparamSVI(X, y, n_total=8000, n_samples=S, seed=321, lr=0.01, ctx=ctx)
+    lam = svi.blr_init_lam(D)
+    m1, m2 = np.zeros_like(lam), np.zeros_like(lam)
+    for t in range(1, 71):
+        model.step()
+        lam, m1, m2, elbo, _ = svi.blr_step(lam, m1, m2, t, X, y, S, 321, 8000, 0.01)
+        if t in (1, 31, 32, 33, 63, 64, 65, 70):
+            ctx.sync()
+            np.testing.assert_allclose(model.elbo.item(), elbo, rtol=1e-6)
+            np.testing.assert_allclose(model.lam.cpu().numpy(), lam, atol=5e-4)

@@ -33,7 +33,7 @@ def timed(ctx, fn, reps, warm=3):
     e1.record()
     wall = e0.elapsed_ms(e1) / reps * 1e-3
     ms, n = ctx.profile_read()
-    ctx.profile(False)
+    ctx.profile(0)
     kern = (ms / n * 1e-3) if n else float("nan")
     return wall, kern
 

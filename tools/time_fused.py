@@ -23,7 +23,7 @@ ctx.call("bsc_blr_data_pass", ptr(X), D, ptr(y), B, D, ptr(W[0]), S, ptr(stats[:
 def fused(use_slab, draw):
     ctx.call("bsc_blr_fused_update", None if use_slab else ptr(stats), ptr(lam[0]), ptr(lam[1]), ptr(m1), ptr(m2),
              ptr(eps[0]), ptr(W[0]), ptr(xi[0]), D, S, float(B), 1.0, 1.0, 1.0, 1, 1e-3, 0.9, 0.999, 1e-8, 1, 1,
-             ptr(eps[1]) if draw else None, ptr(W[1]) if draw else None, ptr(xi[1]) if draw else None, ptr(elbo), ptr(grad))
+             ptr(eps[1]) if draw else None, 0, ptr(W[1]) if draw else None, ptr(xi[1]) if draw else None, ptr(elbo), ptr(grad))
 
 def timeit(fn, n=50):
     for _ in range(5): fn()
