@@ -20,9 +20,10 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LDA = BM + 4;  // +4 floats: staggers rows for the k-contiguous fill
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDA = BM + 4;  // LDS row stride: 528 B keeps 16-byte rows aligned and staggers banks
 constexpr int GEMM_BLOCK = 256;
+constexpr int TILE = BK * LDA;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -34,39 +35,71 @@ struct GemmArgs {
     int64_t sa_b, sa_m, sa_k, sb_b, sb_k, sb_n, sc_b, sc_m, sc_n;
     int tiles_m, tiles_n, splits;
     int64_t k_chunk;   // multiple of BK
+    int vec_a, vec_b;  // 16-byte loads allowed along the operand's contiguous axis
 };
 
-// Fill one [BK][BM] LDS tile from a (rows = m, k) operand with strides (s_m, s_k).
-// M_CONTIG: consecutive threads walk m (stride s_m == 1); else they walk k.
-template <bool M_CONTIG>
-__device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ src, int64_t s_m,
+// A [BK x 128] operand tile travels global -> registers -> LDS (k-major rows of
+// 128).  MN_CONTIG: the operand's m (or n) axis has stride 1, a thread takes 4
+// consecutive m of one k (one ds_write_b128); otherwise its k axis has stride 1
+// (or nothing has), a thread takes 4 consecutive k of one m (four ds_write_b32).
+struct Staged {
+    float4 v[4];
+};
+
+template <bool MN_CONTIG>
+__device__ __forceinline__ void stage_load(Staged& st, const float* __restrict__ src, int64_t s_m,
                                            int64_t s_k, int64_t m0, int64_t M, int64_t k0,
-                                           int64_t k_end, int tid) {
-    if (M_CONTIG) {
-        const int m = tid & (BM - 1);
+                                           int64_t k_end, int vec, int tid) {
 #pragma unroll
-        for (int kk = tid >> 7; kk < BK; kk += GEMM_BLOCK / BM) {
-            const int64_t gm = m0 + m, gk = k0 + kk;
-            float v = 0.f;
-            if (gm < M && gk < k_end) v = src[gm * s_m + gk * s_k];
-            lds[kk * LDA + m] = v;
+    for (int p = 0; p < 4; ++p) {
+        int64_t gm, gk;
+        if (MN_CONTIG) {
+            gm = m0 + 4 * (tid & 31);
+            gk = k0 + (tid >> 5) + 8 * p;
+        } else {
+            gk = k0 + 4 * (tid & 7);
+            gm = m0 + (tid >> 3) + 32 * p;
         }
-    } else {
-        const int kk = tid & (BK - 1);
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* ptr = src + gm * s_m + gk * s_k;
+        const int64_t step = MN_CONTIG ? s_m : s_k;
+        const bool inside = MN_CONTIG ? (gm + 3 < M && gk < k_end) : (gk + 3 < k_end && gm < M);
+        if (inside && vec) {
+            f = *reinterpret_cast<const float4*>(ptr);
+        } else {
+            const int64_t lim = MN_CONTIG ? M - gm : k_end - gk;
+            const bool other = MN_CONTIG ? gk < k_end : gm < M;
+            if (other) {
+                if (lim > 0) f.x = ptr[0];
+                if (lim > 1) f.y = ptr[step];
+                if (lim > 2) f.z = ptr[2 * step];
+                if (lim > 3) f.w = ptr[3 * step];
+            }
+        }
+        st.v[p] = f;
+    }
+}
+
+template <bool MN_CONTIG>
+__device__ __forceinline__ void stage_store(const Staged& st, float* lds, int tid) {
 #pragma unroll
-        for (int m = tid >> 4; m < BM; m += GEMM_BLOCK / BK) {
-            const int64_t gm = m0 + m, gk = k0 + kk;
-            float v = 0.f;
-            if (gm < M && gk < k_end) v = src[gm * s_m + gk * s_k];
-            lds[kk * LDA + m] = v;
+    for (int p = 0; p < 4; ++p) {
+        if (MN_CONTIG) {
+            const int m = 4 * (tid & 31), k = (tid >> 5) + 8 * p;
+            *reinterpret_cast<float4*>(lds + k * LDA + m) = st.v[p];
+        } else {
+            const int k = 4 * (tid & 7), m = (tid >> 3) + 32 * p;
+            lds[(k + 0) * LDA + m] = st.v[p].x;
+            lds[(k + 1) * LDA + m] = st.v[p].y;
+            lds[(k + 2) * LDA + m] = st.v[p].z;
+            lds[(k + 3) * LDA + m] = st.v[p].w;
         }
     }
 }
 
 template <bool A_M_CONTIG, bool B_N_CONTIG>
-__global__ __launch_bounds__(GEMM_BLOCK) void gemm_f32_mfma_kernel(GemmArgs g) {
-    __shared__ float As[BK * LDA];
-    __shared__ float Bs[BK * LDA];
+__global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_mfma_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];   // As[2], Bs[2]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves
@@ -89,10 +122,21 @@ __global__ __launch_bounds__(GEMM_BLOCK) void gemm_f32_mfma_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fr = lane & 31, fk = lane >> 5;  // operand fragment: row/col fr, k offset fk
+    Staged sa, sb;
+    stage_load<A_M_CONTIG>(sa, A, g.sa_m, g.sa_k, m0, g.M, k_begin, k_end, g.vec_a, tid);
+    stage_load<B_N_CONTIG>(sb, B, g.sb_n, g.sb_k, n0, g.N, k_begin, k_end, g.vec_b, tid);
+    stage_store<A_M_CONTIG>(sa, lds, tid);
+    stage_store<B_N_CONTIG>(sb, lds + 2 * TILE, tid);
+    __syncthreads();
+    int cur = 0;
     for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
-        stage_tile<A_M_CONTIG>(As, A, g.sa_m, g.sa_k, m0, g.M, k0, k_end, tid);
-        stage_tile<B_N_CONTIG>(Bs, B, g.sb_n, g.sb_k, n0, g.N, k0, k_end, tid);
-        __syncthreads();
+        const bool more = k0 + BK < k_end;
+        if (more) {   // next tile's global loads fly during this tile's MFMAs
+            stage_load<A_M_CONTIG>(sa, A, g.sa_m, g.sa_k, m0, g.M, k0 + BK, k_end, g.vec_a, tid);
+            stage_load<B_N_CONTIG>(sb, B, g.sb_n, g.sb_k, n0, g.N, k0 + BK, k_end, g.vec_b, tid);
+        }
+        const float* As = lds + cur * TILE;
+        const float* Bs = lds + 2 * TILE + cur * TILE;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float a[2], bq[2];
@@ -106,7 +150,12 @@ __global__ __launch_bounds__(GEMM_BLOCK) void gemm_f32_mfma_kernel(GemmArgs g) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
         }
+        if (more) {   // the other buffer was last read one step ago, behind a barrier
+            stage_store<A_M_CONTIG>(sa, lds + (cur ^ 1) * TILE, tid);
+            stage_store<B_N_CONTIG>(sb, lds + 2 * TILE + (cur ^ 1) * TILE, tid);
+        }
         __syncthreads();
+        cur ^= 1;
     }
 
     // C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -354,6 +403,14 @@ int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, 
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)splits, (unsigned)batch);
     const bool a_m = (sa_m == 1) || (sa_k != 1 && M >= K);   // which axis consecutive threads walk
     const bool b_n = (sb_n == 1) || (sb_k != 1 && N >= K);
+    // 16-byte loads along the contiguous axis need that stride to be 1, the other
+    // strides multiples of 4 elements and the base 16-byte aligned
+    auto vec_ok = [](const void* p, bool mn, int64_t s_mn, int64_t s_k, int64_t s_b) {
+        const int64_t unit = mn ? s_mn : s_k, other = mn ? s_k : s_mn;
+        return (int)(unit == 1 && other % 4 == 0 && s_b % 4 == 0 && ((uintptr_t)p & 15) == 0);
+    };
+    g.vec_a = vec_ok(A, a_m, sa_m, sa_k, sa_b);
+    g.vec_b = vec_ok(B, b_n, sb_n, sb_k, sb_b);
     {
         bsc_prof_scope prof(ctx);
         if (a_m && b_n)
