@@ -559,8 +559,20 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
         const int dl = lane >> 3, sl = lane & 7;  // slab order within the run is [d][s]
         const int d = d0 + dl;
         double gm = 0.0, gr = 0.0;
+        // every small operand of wave 0 is requested before the slab so that the whole
+        // workgroup pays one memory round trip, not one per dependent stage
+        double p_m = 0.0, p_rho = 0.0, p_m1 = 0.0, p_m2 = 0.0, p_r1 = 0.0, p_r2 = 0.0;
+        double e_next = 0.0;
+        const bool pre_noise = a.eps_next && a.eps_next_ready;
+        if (wave == 0) {
+            if (sl == 0 && d < D) {
+                p_m = a.lam_in[d]; p_rho = a.lam_in[D + d];
+                p_m1 = a.m1[d]; p_m2 = a.m2[d];
+                p_r1 = a.m1[D + d]; p_r2 = a.m2[D + d];
+            }
+            if (pre_noise && sl < S && d < D) e_next = a.eps_next[(int64_t)sl * (D + 1) + d];
+        }
         if (a.slab) {  // S <= 8: lane <-> (column dl, sample sl) of one 256-B slab run
-            // issue the small operand loads first so that they fly together with the slab
             const bool live = sl < S && d < D;
             double wv = 0.0, xs = 0.0, ev = 0.0;
             if (wave == 0 && live) {
@@ -592,13 +604,6 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
                 }
             }
         }
-        // parameter state of this column (loads overlap the shuffles below)
-        double p_m = 0.0, p_rho = 0.0, p_m1 = 0.0, p_m2 = 0.0, p_r1 = 0.0, p_r2 = 0.0;
-        if (sl == 0 && d < D) {
-            p_m = a.lam_in[d]; p_rho = a.lam_in[D + d];
-            p_m1 = a.m1[d]; p_m2 = a.m2[d];
-            p_r1 = a.m1[D + d]; p_r2 = a.m2[D + d];
-        }
         // fold the 8 sample lanes (lane bits 0-2)
 #pragma unroll
         for (int off = 1; off < 8; off <<= 1) {
@@ -625,13 +630,13 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
             new_rho[dl] = nr;
         }
         wave_lds_sync();
-        if (a.eps_next && a.eps_next_ready) {
+        if (pre_noise) {
             // noise precomputed: w = m + e^rho * eps for this lane's (column, sample)
             for (int s = sl; s < S; s += 8)
                 if (d < D) {
                     const double sd = exp(new_rho[dl]);
-                    const double wv = new_m[dl] + sd * a.eps_next[(int64_t)s * (D + 1) + d];
-                    a.W_next[(int64_t)s * D + d] = (float)wv;
+                    const double en = s == sl ? e_next : a.eps_next[(int64_t)s * (D + 1) + d];
+                    a.W_next[(int64_t)s * D + d] = (float)(new_m[dl] + sd * en);
                 }
         } else if (a.eps_next) {
             // two Philox blocks per sample cover the 8 columns
@@ -649,6 +654,32 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
     double* Qs = sh;                    // [S]
     double* wsq = sh + FIN_MAX_S;       // [S]
     double* misc = sh + 2 * FIN_MAX_S;  // [1]=new a [2]=new b
+    __shared__ double terms[3 * FIN_MAX_S];
+    const bool pre_noise = a.eps_next && a.eps_next_ready;
+    // request every small operand first (one memory round trip for the workgroup)
+    double x_s = 0.0, e_sD = 0.0, e_next = 0.0;           // thread s < S
+    if (tid < S) {
+        x_s = a.xi[tid];
+        e_sD = a.eps[(int64_t)tid * (D + 1) + D];
+        if (pre_noise) e_next = a.eps_next[(int64_t)tid * (D + 1) + D];
+    }
+    double av = 0.0, bv = 0.0, am1 = 0.0, am2 = 0.0, bm1 = 0.0, bm2 = 0.0;  // thread 0
+    if (tid == 0) {
+        av = a.lam_in[2 * D]; bv = a.lam_in[2 * D + 1];
+        am1 = a.m1[2 * D]; am2 = a.m2[2 * D];
+        bm1 = a.m1[2 * D + 1]; bm2 = a.m2[2 * D + 1];
+    }
+    double rho_part = 0.0;
+    for (int d = tid; d < D; d += FUSED_BLOCK) rho_part += a.lam_in[D + d];
+    // |w_s|^2: wave-per-sample, fixed order (first 4 loads of each lane issued here)
+    float wpre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (wave < S) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = lane + BSC_WAVE * j;
+            if (d < D) wpre[j] = a.W[(int64_t)wave * D + d];
+        }
+    }
     if (a.slab) {  // S <= 8: thread -> (sample tid&7, slab-row group tid>>3)
         double part = slab_column_sum<8>(a.slab + SLAB_G + (tid & 7), tid >> 3, FUSED_BLOCK / 8,
                                          a.n_slab);
@@ -657,54 +688,55 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);
         if (lane < 8) red[wave][lane] = part;
-        __syncthreads();
-        if (tid < 8) {
-            double t = 0.0;
-            for (int k = 0; k < FUSED_WAVES; ++k) t += red[k][tid];
-            Qs[tid] = t;
-        }
     } else {
         for (int s = tid; s < S; s += FUSED_BLOCK) Qs[s] = a.stats[s];
     }
-    // |w_s|^2: wave-per-sample, fixed order
     for (int s = wave; s < S; s += FUSED_WAVES) {
         double part = 0.0;
-        for (int d = lane; d < D; d += BSC_WAVE) {
+        int d = lane;
+        if (s == wave) {  // the prefetched columns, same ascending order as the loop below
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (d < D) part += (double)wpre[j] * (double)wpre[j];
+                d += BSC_WAVE;
+            }
+        }
+        for (; d < D; d += BSC_WAVE) {
             const double wv = (double)a.W[(int64_t)s * D + d];
             part += wv * wv;
         }
         part = wave_allsum_f64(part);
         if (lane == 0) wsq[s] = part;
     }
-    {
-        double part = 0.0;
-        for (int d = tid; d < D; d += FUSED_BLOCK) part += a.lam_in[D + d];
-        part = wave_allsum_f64(part);
-        if (lane == 0) red[wave][32] = part;  // column 32: clear of the Q staging columns
-    }
+    rho_part = wave_allsum_f64(rho_part);
+    if (lane == 0) red[wave][32] = rho_part;  // column 32: clear of the Q staging columns
     __syncthreads();
-    // per-sample terms in parallel (one thread per sample), then a fixed-order sum
-    __shared__ double terms[3 * FIN_MAX_S];
+    if (a.slab && tid < 8) {
+        double t = 0.0;
+        for (int k = 0; k < FUSED_WAVES; ++k) t += red[k][tid];
+        Qs[tid] = t;
+    }
+    // per-sample terms in parallel (one thread per sample; thread s wrote Qs[s] itself),
+    // then a fixed-order sum
     double* t_dxi = terms;              // [S]
     double* t_dxe = t_dxi + FIN_MAX_S;  // [S]
     double* t_f = t_dxe + FIN_MAX_S;    // [S]
     if (tid < S) {
         const int s = tid;
-        const double x = a.xi[s], e = exp(-x);
+        const double x = x_s, e = exp(-x);
         const double dxi = -0.5 * (a.scale * a.batch_rows + (double)D) - a.alpha0 +
                            e * (0.5 * a.scale * Qs[s] + 0.5 * wsq[s] + a.beta0);
         const double loglik = a.scale * (-0.5 * a.batch_rows * (LOG_2PI + x) - 0.5 * e * Qs[s]);
         const double logpw = -0.5 * (double)D * (LOG_2PI + x) - 0.5 * e * wsq[s];
         const double logpxi = a.log_prior_const - a.alpha0 * x - a.beta0 * e;
         t_dxi[s] = dxi;
-        t_dxe[s] = dxi * a.eps[(int64_t)s * (D + 1) + D];
+        t_dxe[s] = dxi * e_sD;
         t_f[s] = loglik + logpw + logpxi;
     }
     __syncthreads();
     if (tid == 0) {
         double sum_rho = 0.0;
         for (int k = 0; k < FUSED_WAVES; ++k) sum_rho += red[k][32];
-        const double av = a.lam_in[2 * D], bv = a.lam_in[2 * D + 1];
         double fa = 0.0, fb = 0.0, fsum = 0.0;
         for (int s = 0; s < S; ++s) {
             fa += t_dxi[s];
@@ -716,23 +748,18 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
         a.grad[2 * D] = g_a;
         a.grad[2 * D + 1] = g_b;
         a.elbo[0] = fsum * inv_S + sum_rho + bv + 0.5 * (double)(D + 1) * (1.0 + LOG_2PI);
-        double m1 = a.m1[2 * D], m2 = a.m2[2 * D];
-        const double na = adam_ascent_one(av, g_a, m1, m2, a);
-        a.m1[2 * D] = m1; a.m2[2 * D] = m2;
-        double b1 = a.m1[2 * D + 1], b2 = a.m2[2 * D + 1];
-        const double nb = adam_ascent_one(bv, g_b, b1, b2, a);
-        a.m1[2 * D + 1] = b1; a.m2[2 * D + 1] = b2;
+        const double na = adam_ascent_one(av, g_a, am1, am2, a);
+        a.m1[2 * D] = am1; a.m2[2 * D] = am2;
+        const double nb = adam_ascent_one(bv, g_b, bm1, bm2, a);
+        a.m1[2 * D + 1] = bm1; a.m2[2 * D + 1] = bm2;
         a.lam_out[2 * D] = na;
         a.lam_out[2 * D + 1] = nb;
         misc[1] = na;
         misc[2] = nb;
     }
     __syncthreads();
-    if (a.eps_next && a.eps_next_ready) {
-        for (int s = tid; s < S; s += FUSED_BLOCK) {
-            const double sd = exp(misc[2]);
-            a.xi_next[s] = misc[1] + sd * a.eps_next[(int64_t)s * (D + 1) + D];
-        }
+    if (pre_noise) {
+        if (tid < S) a.xi_next[tid] = misc[1] + exp(misc[2]) * e_next;
     } else if (a.eps_next) {
         for (int s = tid; s < S; s += FUSED_BLOCK)
             blr_draw_scale(misc[1], misc[2], D, s, a.seed, a.next_step, a.eps_next, a.xi_next);

@@ -20,10 +20,10 @@ stats = torch.zeros(S*(D+1), dtype=f64, device=dev)
 ctx.call("bsc_blr_sample", ptr(lam[0]), D, S, 1, 0, ptr(eps[0]), ptr(W[0]), ptr(xi[0]))
 ctx.call("bsc_blr_data_pass", ptr(X), D, ptr(y), B, D, ptr(W[0]), S, ptr(stats[:S]), ptr(stats[S:]))
 
-def fused(use_slab, draw):
+def fused(use_slab, draw, ready=0):
     ctx.call("bsc_blr_fused_update", None if use_slab else ptr(stats), ptr(lam[0]), ptr(lam[1]), ptr(m1), ptr(m2),
              ptr(eps[0]), ptr(W[0]), ptr(xi[0]), D, S, float(B), 1.0, 1.0, 1.0, 1, 1e-3, 0.9, 0.999, 1e-8, 1, 1,
-             ptr(eps[1]) if draw else None, 0, ptr(W[1]) if draw else None, ptr(xi[1]) if draw else None, ptr(elbo), ptr(grad))
+             ptr(eps[1]) if draw else None, ready, ptr(W[1]) if draw else None, ptr(xi[1]) if draw else None, ptr(elbo), ptr(grad))
 
 def timeit(fn, n=50):
     for _ in range(5): fn()
@@ -41,9 +41,10 @@ partial(); ctx.sync()
 print("fused(stats, draw)   %.1f us" % timeit(lambda: fused(False, True)))
 print("fused(stats, nodraw) %.1f us" % timeit(lambda: fused(False, False)))
 print("fused(slab,  draw)   %.1f us  (slab L2/MALL-warm: re-read back to back)" % timeit(lambda: fused(True, True)))
+print("fused(slab,  ready noise) %.1f us" % timeit(lambda: fused(True, True, 1)))
 print("fused(slab,  nodraw) %.1f us" % timeit(lambda: fused(True, False)))
 tp = timeit(partial, 20)
-def both(): partial(); fused(True, True)
+def both(): partial(); fused(True, True, 1)
 tb = timeit(both, 20)
 print("pass alone %.1f us; pass+fused %.1f us -> fused adds %.1f us" % (tp, tb, tb - tp))
 ctx.call("bsc_blr_sample", ptr(lam[0]), D, S, 1, 0, ptr(eps[0]), ptr(W[0]), ptr(xi[0]))
