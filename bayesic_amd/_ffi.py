@@ -81,6 +81,10 @@ SIGNATURES = {
                             POINTER(c_int64), c_void_p, POINTER(c_int64)]),
     "bsc_sum": (c_int, [c_void_p, c_int, c_int, POINTER(c_int64), POINTER(c_int64), c_int,
                         POINTER(c_int64), POINTER(c_int64), c_void_p, c_void_p]),
+    "bsc_map_reduce": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int64), c_int,
+                               POINTER(c_int64), c_int, POINTER(c_void_p), POINTER(c_int64),
+                               POINTER(c_int64), POINTER(c_int32), POINTER(c_double), c_double,
+                               c_double, c_int, c_double, c_void_p, POINTER(c_int64)]),
     "bsc_gemm_strided_batched": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64,
                                          c_void_p, c_int64, c_int64, c_int64,
                                          c_void_p, c_int64, c_int64, c_int64,

@@ -76,7 +76,12 @@ class Backend(object):
             done[key] = value
             return value
 
-        return visit(expr)
+        try:
+            return visit(expr)
+        finally:
+            # `visit` refers to itself, so `done` would otherwise keep every intermediate
+            # value alive until the cyclic garbage collector runs
+            done.clear()
 
     def compile(self, expr):
         types = expr.input_types

@@ -10,6 +10,24 @@ csrc/bsc_gemm.hip.  0-d integer bookkeeping (``X.shape[i]``, ``X.size``, the ``n
 of ``eye(n)``, Python literal scalars) stays on the host as ``HostScalar`` until
 it meets a device tensor.
 
+Fusion: unary element-wise nodes and n-ary add / mul are
+not launched when they are met.  They become a ``Lazy`` value -- an operand list
+with a unary op per operand, a combine op, a scale/shift and a unary post op --
+that is folded into whichever node consumes it: another add / mul of the same
+kind splices its operands, ``_dimshuffle`` re-views every operand, ``_sum`` and a
+full contraction (``_tensordot`` with no free axes) become ONE ``bsc_map_reduce``
+launch that reads every operand once and writes only the result.  Anything else
+(GEMM operands, ``_diagonal``, ``logdet``, the function result) forces the value
+with one fused element-wise launch.  So ``sum(exp(X) * Y)`` or
+``C * dot(Th, B) ** -1`` never write an intermediate the size of the data.
+
+Memory plan: the intermediates of a compiled expression are allocated on its
+first evaluation and reused by every later one (same shapes), so the hot path
+makes no allocator calls except for the result, which always gets fresh storage
+because the caller owns it.  (Measured need: with one allocator request per
+intermediate, the LDA statistic at 6250 x 100k made ~25 device mallocs per
+evaluation through block splitting, 6 ms -> 60+ ms.)
+
 dtype rules (the reference's came from Theano and are pinned by no test):
 float32 unless any operand is float64; Python scalars take the dtype of the
 tensors they meet; integer arrays are converted to float64 on upload.
@@ -40,6 +58,32 @@ class HostScalar(object):
         return 0
 
 
+class Lazy(object):
+    """post(scale * COMBINE_i pre_i(t_i) + shift), not yet computed.
+
+    ``terms`` is a list of (tensor, pre_op, pre_arg); every tensor has rank
+    ``len(shape)`` and extent 1 where it broadcasts."""
+
+    __slots__ = ("combine", "terms", "scale", "shift", "post", "shape", "dtype")
+
+    def __init__(self, combine, terms, shape, dtype, scale=1.0, shift=0.0, post=None):
+        self.combine, self.terms, self.shape, self.dtype = combine, terms, tuple(shape), dtype
+        self.scale, self.shift, self.post = scale, shift, post
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def dim(self):
+        return len(self.shape)
+
+    @property
+    def plain(self):
+        """No scale, shift or post op: the operand list can be spliced into a
+        consumer that combines the same way."""
+        return self.post is None and self.scale == 1.0 and self.shift == 0.0
+
+
 def _i64(values):
     values = list(values)
     return (ctypes.c_int64 * max(len(values), 1))(*values)
@@ -48,7 +92,15 @@ def _i64(values):
 class DeviceBackend(Backend):
     name = "mi355x-hip"
 
-    def __init__(self, ctx=None):
+    _MAX_PLANS = 64
+
+    def __init__(self, ctx=None, fuse=True):
+        self._plans = {}          # id(expr) -> [expr, [flat buffers in allocation order]]
+        self._plan = None         # buffers of the evaluation in progress
+        self._cursor = 0
+        """fuse=False launches every element-wise node on its own (the unfused
+        baseline of tools/bench_fusion.py); results are identical up to rounding."""
+        self.fuse = bool(fuse)
         self.ctx = ctx if ctx is not None else default_context()
         if not isinstance(self.ctx, Context):
             raise TypeError("ctx must be a bayesic_amd.device.Context")
@@ -71,6 +123,7 @@ class DeviceBackend(Backend):
         return torch.from_numpy(a).to(self.ctx.device)
 
     def to_host(self, value):
+        value = self._force(value)
         if isinstance(value, HostScalar):
             return np.asarray(value.value)
         self.ctx.sync()
@@ -89,22 +142,43 @@ class DeviceBackend(Backend):
     def _host_int(self, v):
         if isinstance(v, HostScalar):
             return int(v.value)
+        v = self._force(v)
         self.ctx.sync()
         return int(v.item())
 
     def eye(self, n):
         n = self._host_int(n)
-        out = torch.empty((n, n), dtype=torch.float32, device=self.ctx.device)
+        out = self._empty((n, n), torch.float32)
         self.ctx.call("bsc_eye", 0, _ffi.ptr(out), n)
         return out
 
     # -- helpers ----------------------------------------------------------------------
+    def _empty(self, shape, dtype):
+        """Uninitialised device tensor; inside evaluate() the k-th request reuses the
+        k-th buffer of the previous evaluation of the same expression."""
+        shape = tuple(int(n) for n in shape)
+        if self._plan is None:
+            return torch.empty(shape, dtype=dtype, device=self.ctx.device)
+        numel = math.prod(shape)
+        k = self._cursor
+        self._cursor += 1
+        if k < len(self._plan):
+            buf = self._plan[k]
+            if buf is not None and buf.dtype == dtype and buf.numel() == numel:
+                return buf.view(shape)
+        buf = torch.empty((numel,), dtype=dtype, device=self.ctx.device)
+        if k < len(self._plan):
+            self._plan[k] = buf
+        else:
+            self._plan.append(buf)
+        return buf.view(shape)
+
     def _upload_scalar(self, s, dtype, ndim):
         t = torch.tensor(float(s.value), dtype=dtype, device=self.ctx.device)
         return t.reshape((1,) * ndim)
 
     def _convert(self, t, dtype):
-        out = torch.empty(t.shape, dtype=dtype, device=self.ctx.device)
+        out = self._empty(t.shape, dtype)
         self.ctx.call("bsc_convert", _DT[t.dtype], _DT[dtype], t.dim(), _i64(t.shape),
                       _ffi.ptr(t), _i64(t.stride()), _ffi.ptr(out), _i64(out.stride()))
         return out
@@ -145,22 +219,15 @@ class DeviceBackend(Backend):
         raise ValueError("unknown elementwise op %r" % op_name)
 
     def _elemwise(self, op_name, args):
+        """Immediate element-wise launch (binary pow with a tensor exponent)."""
+        args = [self._force(a) for a in args]
         if all(isinstance(a, HostScalar) for a in args):
             return HostScalar(self._host_elemwise(op_name, [a.value for a in args]))
-        if op_name in ("add", "mul") and len(args) > 8:      # kernel takes up to 8 inputs
-            head = self._elemwise(op_name, args[:8])
-            return self._elemwise(op_name, [head] + list(args[8:]))
         args, dtype, ndim = self._common(args)
         if ndim > _MAX_RANK:
             raise _ffi.BayesicHipError("rank %d exceeds the kernels' limit %d" % (ndim, _MAX_RANK))
-        shape = []
-        for axis in range(ndim):
-            extents = {a.shape[axis] for a in args}
-            big = extents - {1}
-            if len(big) > 1:
-                raise ValueError("shapes do not broadcast on axis %d: %s" % (axis, sorted(extents)))
-            shape.append(big.pop() if big else 1)
-        out = torch.empty(shape, dtype=dtype, device=self.ctx.device)
+        shape = self._broadcast_shape([a.shape for a in args], ndim)
+        out = self._empty(shape, dtype)
         strides = []
         for a in args:
             strides += [0 if (a.shape[ax] == 1 and shape[ax] != 1) else a.stride(ax)
@@ -170,37 +237,169 @@ class DeviceBackend(Backend):
                       _i64(out.stride()), len(args), ptrs, _i64(strides))
         return out
 
+    @staticmethod
+    def _broadcast_shape(shapes, ndim):
+        shape = []
+        for axis in range(ndim):
+            extents = {s[axis] for s in shapes}
+            big = extents - {1}
+            if len(big) > 1:
+                raise ValueError("shapes do not broadcast on axis %d: %s" % (axis, sorted(extents)))
+            shape.append(big.pop() if big else 1)
+        return shape
+
+    # -- deferred element-wise values -------------------------------------------------
+    def _launch(self, lazy, red_axes=()):
+        """One bsc_map_reduce launch: the value of `lazy`, summed over red_axes."""
+        rank = lazy.ndim
+        if rank > _MAX_RANK:
+            raise _ffi.BayesicHipError("rank %d exceeds the kernels' limit %d" % (rank, _MAX_RANK))
+        red = sorted(a % rank for a in red_axes) if rank else []
+        keep = [a for a in range(rank) if a not in red]
+        shape = lazy.shape
+        terms = lazy.terms
+        out = self._empty([shape[a] for a in keep], lazy.dtype)
+
+        def strides(t, axes):
+            return [0 if (t.shape[ax] == 1 and shape[ax] != 1) else t.stride(ax) for ax in axes]
+
+        keep_strides, red_strides = [], []
+        for t, _, _ in terms:
+            keep_strides += strides(t, keep)
+            red_strides += strides(t, red)
+        n = len(terms)
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _, _ in terms])
+        pre_ops = (ctypes.c_int32 * n)(*[_OPS[op or "copy"] for _, op, _ in terms])
+        pre_args = (ctypes.c_double * n)(*[float(arg) for _, _, arg in terms])
+        post_op, post_arg = lazy.post if lazy.post is not None else ("copy", 0.0)
+        self.ctx.call("bsc_map_reduce", _DT[lazy.dtype], _OPS[lazy.combine], len(keep),
+                      _i64(shape[a] for a in keep), len(red), _i64(shape[a] for a in red), n, ptrs,
+                      _i64(keep_strides), _i64(red_strides), pre_ops, pre_args, float(lazy.scale),
+                      float(lazy.shift), _OPS[post_op], float(post_arg), _ffi.ptr(out),
+                      _i64(out.stride()))
+        return out
+
+    def _force(self, v):
+        return self._launch(v) if isinstance(v, Lazy) else v
+
+    def _unary(self, op_name, x, arg=0.0):
+        if isinstance(x, Lazy):
+            if x.post is None and self.fuse:
+                return Lazy(x.combine, x.terms, x.shape, x.dtype, x.scale, x.shift, (op_name, arg))
+            x = self._force(x)
+        out = Lazy("mul", [(x, op_name, arg)], x.shape, x.dtype)
+        return out if self.fuse else self._launch(out)
+
+    def _combine(self, op_name, args):
+        """n-ary add / mul as a deferred value; host scalars fold into scale / shift."""
+        mul = op_name == "mul"
+        host = [a.value for a in args if isinstance(a, HostScalar)]
+        rest = [a for a in args if not isinstance(a, HostScalar)]
+        if not rest:
+            return HostScalar(self._host_elemwise(op_name, host))
+        coef = (math.prod(host) if mul else sum(host)) if host else (1.0 if mul else 0.0)
+        ndim = max(a.dim() for a in rest)
+        dtype = torch.float64 if any(a.dtype == torch.float64 for a in rest) else torch.float32
+        terms = []
+        for a in rest:
+            if a.dim() != ndim:                       # numpy-style left padding
+                a = self._force(a)
+                a = a.reshape((1,) * (ndim - a.dim()) + tuple(a.shape))
+            if isinstance(a, Lazy):
+                single = len(a.terms) == 1
+                if a.post is None and (a.combine == op_name or single) and \
+                        (a.plain or (mul and a.shift == 0.0) or (not mul and a.scale == 1.0)):
+                    # splice: (s * prod) * rest == s * (prod * rest);  (sum + c) + rest likewise
+                    if mul:
+                        coef = coef * a.scale
+                    else:
+                        coef = coef + a.shift
+                    terms += a.terms
+                    continue
+                a = self._force(a)
+            terms.append((a, None, 0.0))
+        terms = [(t if t.dtype == dtype else self._convert(t, dtype), op, arg)
+                 for t, op, arg in terms]
+        while len(terms) > 8:                         # the kernel takes up to 8 operands
+            head = Lazy(op_name, terms[:8], self._broadcast_shape([t.shape for t, _, _ in terms[:8]],
+                                                                  ndim), dtype)
+            terms = [(self._launch(head), None, 0.0)] + terms[8:]
+        shape = self._broadcast_shape([t.shape for t, _, _ in terms], ndim)
+        out = Lazy(op_name, terms, shape, dtype, scale=coef if mul else 1.0,
+                   shift=0.0 if mul else coef)
+        return out if self.fuse else self._launch(out)
+
+    def evaluate(self, expr, inputs):
+        entry = self._plans.get(id(expr))
+        if entry is None or entry[0] is not expr:
+            if len(self._plans) >= self._MAX_PLANS:
+                self._plans.pop(next(iter(self._plans)))
+            entry = self._plans[id(expr)] = [expr, []]
+        self._plan, self._cursor = entry[1], 0
+        try:
+            out = self._force(Backend.evaluate(self, expr, inputs))
+        finally:
+            plan, self._plan = self._plan, None
+        if isinstance(out, torch.Tensor):
+            # the caller owns the result: its storage leaves the plan
+            where = out.untyped_storage().data_ptr()
+            for k, buf in enumerate(plan):
+                if buf is not None and buf.untyped_storage().data_ptr() == where:
+                    plan[k] = None
+        return out
+
     # -- hooks --------------------------------------------------------------------------
     def elemwise(self, op_name, *args):
-        return self._elemwise(op_name, list(args))
+        args = list(args)
+        if all(isinstance(a, HostScalar) for a in args):
+            return HostScalar(self._host_elemwise(op_name, [a.value for a in args]))
+        if op_name in ("add", "mul"):
+            return self._combine(op_name, args)
+        if op_name == "pow":
+            if isinstance(args[1], HostScalar):
+                return self._unary("pow", args[0], float(args[1].value))
+            return self._elemwise("pow", args)
+        return self._unary(op_name, args[0])
 
     def mul(self, *factors):
-        return self._elemwise("mul", list(factors))
+        return self._combine("mul", list(factors))
 
     def sum(self, x, axes):
         if isinstance(x, HostScalar):
             return x
+        if isinstance(x, Lazy):
+            return self._launch(x, axes)
         axes = [a % x.dim() for a in axes]
         keep = [a for a in range(x.dim()) if a not in axes]
-        out = torch.empty([x.shape[a] for a in keep], dtype=x.dtype, device=self.ctx.device)
+        out = self._empty([x.shape[a] for a in keep], x.dtype)
         self.ctx.call("bsc_sum", _DT[x.dtype], len(keep), _i64(x.shape[a] for a in keep),
                       _i64(x.stride(a) for a in keep), len(axes), _i64(x.shape[a] for a in axes),
                       _i64(x.stride(a) for a in axes), _ffi.ptr(x), _ffi.ptr(out))
         return out
 
-    def dimshuffle(self, x, axes):
-        if isinstance(x, HostScalar):
-            return x          # broadcast axes of a scalar are re-created where it is used
+    @staticmethod
+    def _view_dimshuffle(x, axes):
         y = x.permute([a for a in axes if a != "x"])
         for position, a in enumerate(axes):
             if a == "x":
                 y = y.unsqueeze(position)
         return y
 
+    def dimshuffle(self, x, axes):
+        if isinstance(x, HostScalar):
+            return x          # broadcast axes of a scalar are re-created where it is used
+        if isinstance(x, Lazy):     # element-wise values commute with views: re-view every operand
+            terms = [(self._view_dimshuffle(t, axes), op, arg) for t, op, arg in x.terms]
+            shape = [1 if a == "x" else x.shape[a] for a in axes]
+            return Lazy(x.combine, terms, shape, x.dtype, x.scale, x.shift, x.post)
+        return self._view_dimshuffle(x, axes)
+
     def diagonal(self, x, axis1, axis2):
+        x = self._force(x)
         return torch.diagonal(x, 0, axis1, axis2)     # view; the diagonal axis goes last
 
     def logdet(self, x):
+        x = self._force(x)
         lead = list(x.shape[:-2])
         n = x.shape[-1]
         if x.shape[-2] != n:
@@ -208,7 +407,7 @@ class DeviceBackend(Backend):
         xb = x.reshape([-1, n, n]) if x.dim() != 3 else x     # view when possible
         if not (x.dim() == 3 or xb.data_ptr() == x.data_ptr()):
             xb = self._contiguous(x).reshape([-1, n, n])
-        out = torch.empty(lead, dtype=x.dtype, device=self.ctx.device)
+        out = self._empty(lead, x.dtype)
         self.ctx.call("bsc_logdet_spd", _DT[x.dtype], xb.shape[0], n, _ffi.ptr(xb), xb.stride(0),
                       xb.stride(1), xb.stride(2), _ffi.ptr(out))
         return out
@@ -228,7 +427,30 @@ class DeviceBackend(Backend):
         stride = live[-1][1]
         return extent, stride
 
+    def _dot_products(self, x, y, x_dot, y_dot, x_batch, y_batch):
+        """_tensordot with no free axes: out[batch] = sum_dot x * y in one fused pass
+        (operands may be deferred element-wise values; nothing is materialised)."""
+        # line y's axes up with x's, then it is sum(x * y) over x's dot axes
+        order = [None] * x.dim()
+        for ax, ay in zip(list(x_batch) + list(x_dot), list(y_batch) + list(y_dot)):
+            order[ax] = ay
+        y = self.dimshuffle(y, order)
+        for ax in range(x.dim()):
+            if x.shape[ax] != y.shape[ax]:
+                raise ValueError("tensordot: contracted / batch extents differ (%d vs %d)"
+                                 % (x.shape[ax], y.shape[ax]))
+        prod = self._combine("mul", [x, y])
+        out = self._launch(prod, x_dot)               # kept axes in x's axis order
+        kept = [a for a in range(x.dim()) if a not in x_dot]
+        perm = [kept.index(a) for a in x_batch]
+        return out.permute(perm) if perm != sorted(perm) else out
+
     def tensordot(self, x, y, x_dot, y_dot, x_batch, y_batch):
+        free_x = x.dim() - len(x_dot) - len(x_batch)
+        free_y = y.dim() - len(y_dot) - len(y_batch)
+        if free_x == 0 and free_y == 0 and self.fuse:      # (batched) dot products
+            return self._dot_products(x, y, x_dot, y_dot, x_batch, y_batch)
+        x, y = self._force(x), self._force(y)
         (x, y), dtype, _ = self._common([x, y]) if x.dtype != y.dtype else ((x, y), x.dtype, 0)
         x_other = [a for a in range(x.dim()) if a not in x_dot and a not in x_batch]
         y_other = [a for a in range(y.dim()) if a not in y_dot and a not in y_batch]
@@ -249,7 +471,7 @@ class DeviceBackend(Backend):
         if k != k2 or xb != yb:
             raise ValueError("tensordot: contracted / batch extents differ (%d vs %d, %d vs %d)"
                              % (k, k2, xb, yb))
-        out = torch.empty(out_shape, dtype=dtype, device=self.ctx.device)
+        out = self._empty(out_shape, dtype)
         self.ctx.call("bsc_gemm_strided_batched", _DT[dtype], xb, m, n, k,
                       _ffi.ptr(x), sxb, sxm, sxk, _ffi.ptr(y), syb, syk, syn,
                       _ffi.ptr(out), m * n, n, 1)

@@ -63,6 +63,16 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
     if (const char* e = getenv("BSC_BLR_TILE_ROWS")) ctx->blr_tile_rows = atoi(e) == 4 ? 4 : 8;
     if (const char* e = getenv("BSC_BLR_WAVES_PER_SIMD")) ctx->blr_waves_per_simd = atoi(e);
     if (const char* e = getenv("BSC_BLR_NT")) ctx->blr_nt_loads = atoi(e);
+    if (const char* e = getenv("BSC_FUSED_MAP_BLOCKS_PER_CU")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) ctx->fused_map_blocks_per_cu = v;
+    }
+    if (const char* e = getenv("BSC_FUSED_MAP_UNROLL")) ctx->fused_map_unroll = atoi(e) == 1 ? 1 : 2;
+    if (const char* e = getenv("BSC_FUSED_NT_STORE")) ctx->fused_nt_store = atoi(e) != 0;
+    if (const char* e = getenv("BSC_FUSED_WAVES_PER_CU")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) ctx->fused_waves_per_cu = v;
+    }
     *out = ctx;
     return BSC_OK;
 }

@@ -1,0 +1,690 @@
+// Fused pointwise map with an optional trailing reduction: the executor's fusion
+// of element-wise chains (elemwise / add / _mul: bayesic/algebra.py:195-233,
+// 1297-1309, 1435-1448) with a following _sum (:1284-1294) into ONE pass over the
+// operands.  The reference leaves this to Theano's graph
+// optimiser; here the host plan folds unary ops into the consumer's operand list:
+//
+//   v(keep, red) = post( scale * COMBINE_i pre_i( in_i[keep, red] ) + shift )
+//   out[keep]    = sum_red v(keep, red)        (rank_red == 0: out[keep] = v(keep))
+//
+// All HBM-bound: every operand element is read once, nothing intermediate is
+// written.  Reductions accumulate in float64 in a fixed order (lane-strided
+// partial -> butterfly -> split partials summed in split order).
+#include "bsc_common.h"
+
+namespace {
+
+constexpr int MAXR = BSC_MAX_RANK;
+constexpr int MAXIN = 8;
+
+struct Dims {
+    int rank;
+    int64_t shape[MAXR];
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// streaming 16-byte load: the operands of a fused map are used once
+__device__ __forceinline__ float4 load4_nt(const float* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+struct MapArgs {
+    Dims keep, red;
+    int64_t n_out, n_red;
+    int n_in, combine, post_op;
+    double scale, shift, post_arg;
+    int pre_op[MAXIN];
+    double pre_arg[MAXIN];
+    int64_t keep_strides[MAXIN][MAXR];
+    int64_t red_strides[MAXIN][MAXR];
+    int64_t out_strides[MAXR];
+    const void* in[MAXIN];
+    void* out;
+    double* partial;  // [splits][n_out] when splits > 1
+    int splits;
+    int nt_store;     // dense map: streaming stores
+};
+
+__device__ __forceinline__ void unravel(int64_t flat, const Dims& d, int64_t (&idx)[MAXR]) {
+    if (d.rank <= 1) {  // the host coalesces axes, so this is the common case
+#pragma unroll
+        for (int a = 0; a < MAXR; ++a) idx[a] = 0;
+        idx[0] = flat;
+        return;
+    }
+#pragma unroll
+    for (int a = MAXR - 1; a >= 0; --a) {
+        if (a < d.rank) {
+            const int64_t s = d.shape[a];
+            const int64_t q = flat / s;
+            idx[a] = flat - q * s;
+            flat = q;
+        } else {
+            idx[a] = 0;
+        }
+    }
+}
+
+__device__ __forceinline__ int64_t dot_strides(const int64_t (&idx)[MAXR], const int64_t* strides,
+                                               int rank) {
+    int64_t off = 0;
+#pragma unroll
+    for (int a = 0; a < MAXR; ++a)
+        if (a < rank) off += idx[a] * strides[a];
+    return off;
+}
+
+template <typename T>
+__device__ __forceinline__ T apply_unary(int op, T x, double arg) {
+    switch (op) {
+        case BSC_OP_LOG: return log(x);
+        case BSC_OP_EXP: return exp(x);
+        case BSC_OP_ABS: return fabs(x);
+        case BSC_OP_POW:
+            if (arg == -1.0) return (T)1 / x;
+            if (arg == 2.0) return x * x;
+            if (arg == 0.5) return sqrt(x);
+            if (arg == 1.0) return x;
+            return pow(x, (T)arg);
+        default: return x;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ T finish_value(const MapArgs& a, T v) {
+    if (a.scale != 1.0) v *= (T)a.scale;
+    if (a.shift != 0.0) v += (T)a.shift;
+    return apply_unary<T>(a.post_op, v, a.post_arg);
+}
+
+// value at (kept offsets koff[i], reduce index ridx)
+template <typename T>
+__device__ __forceinline__ T map_value(const MapArgs& a, const int64_t (&koff)[MAXIN],
+                                       const int64_t (&ridx)[MAXR]) {
+    T v = a.combine == BSC_OP_MUL ? (T)1 : (T)0;
+#pragma unroll
+    for (int k = 0; k < MAXIN; ++k) {
+        if (k < a.n_in) {
+            const int64_t off = koff[k] + dot_strides(ridx, a.red_strides[k], a.red.rank);
+            const T x = apply_unary<T>(a.pre_op[k], static_cast<const T*>(a.in[k])[off], a.pre_arg[k]);
+            v = a.combine == BSC_OP_MUL ? v * x : v + x;
+        }
+    }
+    return finish_value<T>(a, v);
+}
+
+// ---- pure map ------------------------------------------------------------------
+
+template <typename T>
+__global__ __launch_bounds__(256) void map_strided_kernel(MapArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t zero[MAXR] = {0, 0, 0, 0, 0, 0};
+    for (int64_t flat = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; flat < a.n_out;
+         flat += stride) {
+        int64_t idx[MAXR], koff[MAXIN];
+        unravel(flat, a.keep, idx);
+#pragma unroll
+        for (int k = 0; k < MAXIN; ++k)
+            koff[k] = k < a.n_in ? dot_strides(idx, a.keep_strides[k], a.keep.rank) : 0;
+        static_cast<T*>(a.out)[dot_strides(idx, a.out_strides, a.keep.rank)] =
+            map_value<T>(a, koff, zero);
+    }
+}
+
+// every operand dense in the output's order (or one broadcast value): 16 B per lane,
+// U float4 per operand in flight
+template <int U>
+__global__ __launch_bounds__(256) void map_dense_f32_kernel(MapArgs a, int64_t n4, int scalar_mask) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float id = a.combine == BSC_OP_MUL ? 1.f : 0.f;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += stride * U) {
+        float4 u[MAXIN][U];
+#pragma unroll
+        for (int k = 0; k < MAXIN; ++k) {   // all loads first
+            if (k >= a.n_in) continue;
+            if (scalar_mask & (1 << k)) {
+                const float s = static_cast<const float*>(a.in[k])[0];
+#pragma unroll
+                for (int j = 0; j < U; ++j) u[k][j] = make_float4(s, s, s, s);
+            } else {
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int64_t i = i0 + stride * j;
+                    u[k][j] = load4_nt(static_cast<const float*>(a.in[k]) + 4 * (i < n4 ? i : n4 - 1));
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            float4 v = make_float4(id, id, id, id);
+#pragma unroll
+            for (int k = 0; k < MAXIN; ++k) {
+                if (k >= a.n_in) continue;
+                const int op = a.pre_op[k];
+                const double arg = a.pre_arg[k];
+                const float x0 = apply_unary<float>(op, u[k][j].x, arg);
+                const float x1 = apply_unary<float>(op, u[k][j].y, arg);
+                const float x2 = apply_unary<float>(op, u[k][j].z, arg);
+                const float x3 = apply_unary<float>(op, u[k][j].w, arg);
+                if (a.combine == BSC_OP_MUL) { v.x *= x0; v.y *= x1; v.z *= x2; v.w *= x3; }
+                else { v.x += x0; v.y += x1; v.z += x2; v.w += x3; }
+            }
+            v.x = finish_value<float>(a, v.x); v.y = finish_value<float>(a, v.y);
+            v.z = finish_value<float>(a, v.z); v.w = finish_value<float>(a, v.w);
+            const int64_t i = i0 + stride * j;
+            if (i < n4) {
+                const f32x4 w = {v.x, v.y, v.z, v.w};
+                if (a.nt_store) __builtin_nontemporal_store(w, static_cast<f32x4*>(a.out) + i);
+                else static_cast<f32x4*>(a.out)[i] = w;
+            }
+        }
+    }
+}
+
+// ---- map + reduce ----------------------------------------------------------------
+
+// Variant A: the fastest-varying operand axis is a REDUCED one.  One wave per
+// (output, split); lanes stride over the flattened reduce index, 4 elements in
+// flight per lane.
+template <typename T>
+__global__ __launch_bounds__(256) void map_reduce_wave_kernel(MapArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t job = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (job >= a.n_out * a.splits) return;
+    const int64_t o = job % a.n_out;
+    const int split = (int)(job / a.n_out);
+    int64_t kidx[MAXR], koff[MAXIN];
+    unravel(o, a.keep, kidx);
+#pragma unroll
+    for (int k = 0; k < MAXIN; ++k)
+        koff[k] = k < a.n_in ? dot_strides(kidx, a.keep_strides[k], a.keep.rank) : 0;
+    const int64_t chunk = (a.n_red + a.splits - 1) / a.splits;
+    const int64_t r0 = split * chunk;
+    const int64_t r1 = (r0 + chunk < a.n_red) ? r0 + chunk : a.n_red;
+    double acc = 0.0;
+    int64_t r = r0 + lane;
+    for (; r + 192 < r1; r += 256) {
+        T v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int64_t ridx[MAXR];
+            unravel(r + 64 * j, a.red, ridx);
+            v[j] = map_value<T>(a, koff, ridx);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += (double)v[j];
+    }
+    for (; r < r1; r += 64) {
+        int64_t ridx[MAXR];
+        unravel(r, a.red, ridx);
+        acc += (double)map_value<T>(a, koff, ridx);
+    }
+    acc = wave_allsum_f64(acc);
+    if (lane == 0) {
+        if (a.splits > 1) a.partial[(int64_t)split * a.n_out + o] = acc;
+        else static_cast<T*>(a.out)[dot_strides(kidx, a.out_strides, a.keep.rank)] = (T)acc;
+    }
+}
+
+// Variant A, dense: every operand is a dense run along the single reduce axis and
+// 16-byte aligned there; 16 B per lane per load.
+template <int N, int U>
+__global__ __launch_bounds__(256) void map_reduce_wave_dense_f32_kernel(MapArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t job = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (job >= a.n_out * a.splits) return;
+    const int64_t o = job % a.n_out;
+    const int split = (int)(job / a.n_out);
+    int64_t kidx[MAXR];
+    unravel(o, a.keep, kidx);
+    const float* base[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        base[k] = static_cast<const float*>(a.in[k]) + dot_strides(kidx, a.keep_strides[k], a.keep.rank);
+    const int64_t n4 = a.n_red / 4;                       // host guarantees n_red % 4 == 0
+    double acc = 0.0;
+    const float id = a.combine == BSC_OP_MUL ? 1.f : 0.f;
+    // U float4 per operand in flight per lane.  The splits of one output interleave
+    // (split s takes every splits-th 4-KB piece) so that all waves in flight read one
+    // moving window of memory -- DRAM pages stay open; private chunks per wave halve the
+    // bandwidth.  Pieces past the end are clamped to a valid address and dropped.
+    // (U = 1 for rows of up to 64 float4, where deeper unrolling would only re-read.)
+    const int64_t r1 = n4;
+    for (int64_t rb = (int64_t)split * 64 * U + lane; rb < r1; rb += (int64_t)a.splits * 64 * U) {
+        float4 u[N][U];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int64_t r = rb + 64 * j;
+                u[k][j] = load4_nt(base[k] + 4 * (r < r1 ? r : r1 - 1));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            float4 v = make_float4(id, id, id, id);
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const int op = a.pre_op[k];
+                const double arg = a.pre_arg[k];
+                const float x0 = apply_unary<float>(op, u[k][j].x, arg);
+                const float x1 = apply_unary<float>(op, u[k][j].y, arg);
+                const float x2 = apply_unary<float>(op, u[k][j].z, arg);
+                const float x3 = apply_unary<float>(op, u[k][j].w, arg);
+                if (a.combine == BSC_OP_MUL) { v.x *= x0; v.y *= x1; v.z *= x2; v.w *= x3; }
+                else { v.x += x0; v.y += x1; v.z += x2; v.w += x3; }
+            }
+            if (rb + 64 * j < r1) {
+                acc += (double)finish_value<float>(a, v.x);
+                acc += (double)finish_value<float>(a, v.y);
+                acc += (double)finish_value<float>(a, v.z);
+                acc += (double)finish_value<float>(a, v.w);
+            }
+        }
+    }
+    acc = wave_allsum_f64(acc);
+    if (lane == 0) {
+        if (a.splits > 1) a.partial[(int64_t)split * a.n_out + o] = acc;
+        else static_cast<float*>(a.out)[dot_strides(kidx, a.out_strides, a.keep.rank)] = (float)acc;
+    }
+}
+
+// Variant B, dense: one kept axis and one reduce axis, every operand dense along
+// the kept axis and 16-byte aligned there.  Lane <-> 4 consecutive
+// outputs, a wave covers 256 outputs per row; the four waves of a block and
+// `splits` blocks divide the reduce range, 4 rows in flight per lane.
+template <int N>
+__global__ __launch_bounds__(256) void map_reduce_lane_dense_f32_kernel(MapArgs a) {
+    __shared__ double red[4][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_groups = (a.n_out + 255) / 256;
+    const int64_t group = blockIdx.x % n_groups;
+    const int split = (int)(blockIdx.x / n_groups);
+    const int64_t o = group * 256 + 4 * lane;           // n_out % 4 == 0 (host)
+    const int64_t r1 = a.n_red;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const float id = a.combine == BSC_OP_MUL ? 1.f : 0.f;
+    if (o < a.n_out) {
+        // a block takes 4*U consecutive rows per step (wave w row w, w+4, ...), the splits
+        // of one output group interleave: one moving window of memory for the whole grid
+        constexpr int U = 4;
+        for (int64_t rb = (int64_t)split * 4 * U + wave; rb < r1; rb += (int64_t)a.splits * 4 * U) {
+            float4 u[N][U];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const float* base = static_cast<const float*>(a.in[k]) + o * a.keep_strides[k][0];
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int64_t r = rb + 4 * j < r1 ? rb + 4 * j : r1 - 1;
+                    u[k][j] = load4_nt(base + r * a.red_strides[k][0]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                float4 v = make_float4(id, id, id, id);
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    const int op = a.pre_op[k];
+                    const double arg = a.pre_arg[k];
+                    const float x0 = apply_unary<float>(op, u[k][j].x, arg);
+                    const float x1 = apply_unary<float>(op, u[k][j].y, arg);
+                    const float x2 = apply_unary<float>(op, u[k][j].z, arg);
+                    const float x3 = apply_unary<float>(op, u[k][j].w, arg);
+                    if (a.combine == BSC_OP_MUL) { v.x *= x0; v.y *= x1; v.z *= x2; v.w *= x3; }
+                    else { v.x += x0; v.y += x1; v.z += x2; v.w += x3; }
+                }
+                if (rb + 4 * j < r1) {
+                    acc[0] += (double)finish_value<float>(a, v.x);
+                    acc[1] += (double)finish_value<float>(a, v.y);
+                    acc[2] += (double)finish_value<float>(a, v.z);
+                    acc[3] += (double)finish_value<float>(a, v.w);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[wave][lane][c] = acc[c];
+    __syncthreads();
+    if (wave == 0 && o < a.n_out) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double tot = ((red[0][lane][c] + red[1][lane][c]) + red[2][lane][c]) + red[3][lane][c];
+            if (a.splits > 1) a.partial[(int64_t)split * a.n_out + o + c] = tot;
+            else static_cast<float*>(a.out)[(o + c) * a.out_strides[0]] = (float)tot;
+        }
+    }
+}
+
+// Variant B: the fastest-varying operand axis is a KEPT one.  Lane <-> output, so a
+// wave reads 64 consecutive elements per reduce step; the four waves of a block
+// and `splits` blocks divide the reduce range.
+template <typename T>
+__global__ __launch_bounds__(256) void map_reduce_lane_kernel(MapArgs a) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_groups = (a.n_out + 63) / 64;
+    const int64_t group = blockIdx.x % n_groups;
+    const int split = (int)(blockIdx.x / n_groups);
+    const int64_t o = group * 64 + lane;
+    const int64_t chunk = (a.n_red + a.splits - 1) / a.splits;
+    const int64_t r0 = split * chunk;
+    const int64_t r1 = (r0 + chunk < a.n_red) ? r0 + chunk : a.n_red;
+    double acc = 0.0;
+    int64_t kidx[MAXR] = {0, 0, 0, 0, 0, 0};
+    if (o < a.n_out) {
+        int64_t koff[MAXIN];
+        unravel(o, a.keep, kidx);
+        #pragma unroll
+    for (int k = 0; k < MAXIN; ++k)
+        koff[k] = k < a.n_in ? dot_strides(kidx, a.keep_strides[k], a.keep.rank) : 0;
+        int64_t r = r0 + wave;
+        for (; r + 12 < r1; r += 16) {
+            T v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int64_t ridx[MAXR];
+                unravel(r + 4 * j, a.red, ridx);
+                v[j] = map_value<T>(a, koff, ridx);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += (double)v[j];
+        }
+        for (; r < r1; r += 4) {
+            int64_t ridx[MAXR];
+            unravel(r, a.red, ridx);
+            acc += (double)map_value<T>(a, koff, ridx);
+        }
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && o < a.n_out) {
+        const double tot = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+        if (a.splits > 1) a.partial[(int64_t)split * a.n_out + o] = tot;
+        else static_cast<T*>(a.out)[dot_strides(kidx, a.out_strides, a.keep.rank)] = (T)tot;
+    }
+}
+
+// Sum of the split partials, fixed order.  Few outputs with many splits (a full
+// reduction has 1 output and thousands of splits): one wave per output, lanes
+// stride over the splits with 4 loads in flight, float64 butterfly.  Many outputs:
+// one thread per output (the splits are few then).
+template <typename T>
+__global__ __launch_bounds__(256) void map_reduce_finish_kernel(MapArgs a, int wave_per_output) {
+    int64_t o;
+    double tot = 0.0;
+    if (wave_per_output) {
+        const int lane = threadIdx.x & 63;
+        o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (o >= a.n_out) return;
+        const double* p = a.partial + o;
+        int s = lane;
+        for (; s + 192 < a.splits; s += 256) {
+            double v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = p[(int64_t)(s + 64 * j) * a.n_out];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tot += v[j];
+        }
+        for (; s < a.splits; s += 64) tot += p[(int64_t)s * a.n_out];
+        tot = wave_allsum_f64(tot);
+        if (lane != 0) return;
+    } else {
+        o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (o >= a.n_out) return;
+        for (int s = 0; s < a.splits; ++s) tot += a.partial[(int64_t)s * a.n_out + o];
+    }
+    int64_t kidx[MAXR];
+    unravel(o, a.keep, kidx);
+    static_cast<T*>(a.out)[dot_strides(kidx, a.out_strides, a.keep.rank)] = (T)tot;
+}
+
+// ---- host: axis coalescing ----------------------------------------------------------
+
+// One group of axes (kept or reduced) with the strides of every operand (and of
+// the output for the kept group).  Size-1 axes are dropped; neighbours (outer,
+// inner) merge when every stride row satisfies outer == inner * extent(inner).
+struct AxisGroup {
+    int rank = 0;
+    int64_t shape[MAXR];
+    int64_t strides[MAXIN + 1][MAXR];
+};
+
+void coalesce(AxisGroup& g, int n_rows) {
+    int out = 0;
+    for (int a = 0; a < g.rank; ++a) {
+        if (g.shape[a] == 1) continue;
+        bool merge = out > 0;
+        if (merge)
+            for (int k = 0; k < n_rows; ++k)
+                if (g.strides[k][out - 1] != g.strides[k][a] * g.shape[a]) merge = false;
+        if (merge) {
+            g.shape[out - 1] *= g.shape[a];
+            for (int k = 0; k < n_rows; ++k) g.strides[k][out - 1] = g.strides[k][a];
+        } else {
+            g.shape[out] = g.shape[a];
+            for (int k = 0; k < n_rows; ++k) g.strides[k][out] = g.strides[k][a];
+            ++out;
+        }
+    }
+    g.rank = out;
+}
+
+int64_t iabs(int64_t v) { return v < 0 ? -v : v; }
+
+}  // namespace
+
+extern "C" {
+
+int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
+                   const int64_t* host_keep_shape, int rank_red, const int64_t* host_red_shape,
+                   int n_in, const void* const* host_in, const int64_t* host_in_keep_strides,
+                   const int64_t* host_in_red_strides, const int32_t* host_pre_op,
+                   const double* host_pre_arg, double scale, double shift, int post_op,
+                   double post_arg, void* out, const int64_t* host_out_strides) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(dtype == BSC_F32 || dtype == BSC_F64, "bsc_map_reduce: unknown dtype %d", dtype);
+    BSC_REQUIRE(combine == BSC_OP_ADD || combine == BSC_OP_MUL,
+                "bsc_map_reduce: combine must be BSC_OP_ADD or BSC_OP_MUL, got %d", combine);
+    BSC_REQUIRE(rank_keep >= 0 && rank_keep <= MAXR && rank_red >= 0 && rank_red <= MAXR,
+                "bsc_map_reduce: rank exceeds %d", MAXR);
+    BSC_REQUIRE(n_in >= 1 && n_in <= MAXIN && host_in && host_pre_op && host_pre_arg && out,
+                "bsc_map_reduce: bad operands");
+    auto unary_ok = [](int op) {
+        return op == BSC_OP_COPY || op == BSC_OP_LOG || op == BSC_OP_EXP || op == BSC_OP_ABS ||
+               op == BSC_OP_POW;
+    };
+    BSC_REQUIRE(unary_ok(post_op), "bsc_map_reduce: post op %d is not unary", post_op);
+    AxisGroup keep, red;
+    keep.rank = rank_keep;
+    red.rank = rank_red;
+    int64_t n_out = 1, n_red = 1;
+    for (int a = 0; a < rank_keep; ++a) {
+        BSC_REQUIRE(host_keep_shape[a] >= 0, "bsc_map_reduce: negative extent");
+        keep.shape[a] = host_keep_shape[a];
+        n_out *= keep.shape[a];
+        keep.strides[n_in][a] = host_out_strides[a];
+    }
+    for (int a = 0; a < rank_red; ++a) {
+        BSC_REQUIRE(host_red_shape[a] >= 0, "bsc_map_reduce: negative extent");
+        red.shape[a] = host_red_shape[a];
+        n_red *= red.shape[a];
+    }
+    MapArgs m{};
+    for (int k = 0; k < n_in; ++k) {
+        BSC_REQUIRE(host_in[k] != nullptr || n_out * n_red == 0, "bsc_map_reduce: input %d is null", k);
+        BSC_REQUIRE(unary_ok(host_pre_op[k]), "bsc_map_reduce: pre op %d is not unary", host_pre_op[k]);
+        m.in[k] = host_in[k];
+        m.pre_op[k] = host_pre_op[k];
+        m.pre_arg[k] = host_pre_arg[k];
+        for (int a = 0; a < rank_keep; ++a) keep.strides[k][a] = host_in_keep_strides[k * rank_keep + a];
+        for (int a = 0; a < rank_red; ++a) red.strides[k][a] = host_in_red_strides[k * rank_red + a];
+    }
+    if (n_out == 0) return BSC_OK;
+    coalesce(keep, n_in + 1);
+    coalesce(red, n_in);
+    m.keep.rank = keep.rank;
+    m.red.rank = red.rank;
+    for (int a = 0; a < MAXR; ++a) {
+        m.keep.shape[a] = a < keep.rank ? keep.shape[a] : 1;
+        m.red.shape[a] = a < red.rank ? red.shape[a] : 1;
+        m.out_strides[a] = a < keep.rank ? keep.strides[n_in][a] : 0;
+        for (int k = 0; k < n_in; ++k) {
+            m.keep_strides[k][a] = a < keep.rank ? keep.strides[k][a] : 0;
+            m.red_strides[k][a] = a < red.rank ? red.strides[k][a] : 0;
+        }
+    }
+    m.n_out = n_out;
+    m.n_red = n_red;
+    m.n_in = n_in;
+    m.combine = combine;
+    m.post_op = post_op;
+    m.post_arg = post_arg;
+    m.scale = scale;
+    m.shift = shift;
+    m.out = out;
+    m.splits = 1;
+    m.partial = nullptr;
+    m.nt_store = ctx->fused_nt_store;
+
+    if (rank_red == 0) {
+        // ---- pure map ----
+        bool dense = dtype == BSC_F32 && keep.rank <= 1 && (n_out % 4) == 0 &&
+                     (((uintptr_t)out) & 15) == 0 && (keep.rank == 0 || m.out_strides[0] == 1);
+        int scalar_mask = 0;
+        for (int k = 0; k < n_in && dense; ++k) {
+            const int64_t s = keep.rank ? m.keep_strides[k][0] : 0;
+            if (s == 0) scalar_mask |= 1 << k;
+            else if (s != 1 || (((uintptr_t)m.in[k]) & 15) != 0) dense = false;
+        }
+        if (dense && n_out >= 4) {
+            const int64_t n4 = n_out / 4;
+            int64_t blocks = (n4 + 255) / 256;
+            const int64_t cap = (int64_t)ctx->cu_count * ctx->fused_map_blocks_per_cu;
+            if (blocks > cap) blocks = cap;
+            if (ctx->fused_map_unroll == 1)
+                hipLaunchKernelGGL(map_dense_f32_kernel<1>, dim3((unsigned)blocks), dim3(256), 0,
+                                   ctx->stream, m, n4, scalar_mask);
+            else
+                hipLaunchKernelGGL(map_dense_f32_kernel<2>, dim3((unsigned)blocks), dim3(256), 0,
+                                   ctx->stream, m, n4, scalar_mask);
+        } else {
+            int64_t blocks = (n_out + 255) / 256;
+            const int64_t cap = (int64_t)ctx->cu_count * 8;
+            if (blocks > cap) blocks = cap;
+            if (dtype == BSC_F32)
+                hipLaunchKernelGGL(map_strided_kernel<float>, dim3((unsigned)blocks), dim3(256), 0,
+                                   ctx->stream, m);
+            else
+                hipLaunchKernelGGL(map_strided_kernel<double>, dim3((unsigned)blocks), dim3(256), 0,
+                                   ctx->stream, m);
+        }
+        BSC_LAUNCH_CHECK();
+        return BSC_OK;
+    }
+
+    // ---- map + reduce: which operand axis varies fastest? ----
+    int64_t min_keep = INT64_MAX, min_red = INT64_MAX;
+    for (int k = 0; k < n_in; ++k) {
+        for (int a = 0; a < keep.rank; ++a) {
+            const int64_t s = iabs(m.keep_strides[k][a]);
+            if (s != 0 && s < min_keep) min_keep = s;
+        }
+        for (int a = 0; a < red.rank; ++a) {
+            const int64_t s = iabs(m.red_strides[k][a]);
+            if (s != 0 && s < min_red) min_red = s;
+        }
+    }
+    const bool lanes_over_outputs = min_keep < min_red && n_out >= 16;
+    // dense variants (16 B per lane): one reduce axis, and for the lane variant one kept axis
+    bool dense_lane = lanes_over_outputs && dtype == BSC_F32 && n_in <= 3 && keep.rank == 1 && red.rank == 1 &&
+                      (n_out % 4) == 0 && m.out_strides[0] == 1;
+    bool dense_wave = !lanes_over_outputs && dtype == BSC_F32 && n_in <= 3 && red.rank == 1 &&
+                      (n_red % 4) == 0;
+    for (int k = 0; k < n_in; ++k) {
+        if (dense_lane && (m.keep_strides[k][0] != 1 || (((uintptr_t)m.in[k]) & 15) != 0 ||
+                           m.red_strides[k][0] % 4 != 0))
+            dense_lane = false;
+        if (dense_wave) {
+            if (m.red_strides[k][0] != 1 || (((uintptr_t)m.in[k]) & 15) != 0) dense_wave = false;
+            for (int a = 0; a < keep.rank; ++a)
+                if (m.keep_strides[k][a] % 4 != 0) dense_wave = false;
+        }
+    }
+    // split the reduce range until about fused_waves_per_cu waves per CU are in flight
+    // (a block is 4 waves: 4 (output, split) jobs in the wave kernels, one output group
+    // in the lane kernels)
+    const int64_t outs_per_block = lanes_over_outputs ? (dense_lane ? 256 : 64) : 4;
+    const int64_t jobs = (n_out + outs_per_block - 1) / outs_per_block;
+    int64_t splits = 1;
+    const int64_t want_blocks = (int64_t)ctx->cu_count * ctx->fused_waves_per_cu / 4;
+    if (jobs < want_blocks) {
+        splits = lanes_over_outputs ? want_blocks / jobs : (want_blocks * 4) / n_out;
+        const int64_t max_splits = n_red / (lanes_over_outputs ? 64 : 4096);
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        if (splits > 16384) splits = 16384;
+    }
+    m.splits = (int)splits;
+    if (splits > 1) {
+        void* ws = nullptr;
+        int rc = bsc_workspace(ctx, (size_t)splits * n_out * sizeof(double), &ws);
+        if (rc != BSC_OK) return rc;
+        m.partial = (double*)ws;
+        ctx->slab_rows = 0;
+    }
+    if (lanes_over_outputs) {
+        const int64_t blocks = jobs * splits;
+        if (dense_lane) {
+#define BSC_LANE(NV)                                                                             \
+    case NV:                                                                                     \
+        hipLaunchKernelGGL(map_reduce_lane_dense_f32_kernel<NV>, dim3((unsigned)blocks), dim3(256), \
+                           0, ctx->stream, m);                                                   \
+        break;
+            switch (n_in) { BSC_LANE(1) BSC_LANE(2) BSC_LANE(3) }
+#undef BSC_LANE
+        } else if (dtype == BSC_F32)
+            hipLaunchKernelGGL(map_reduce_lane_kernel<float>, dim3((unsigned)blocks), dim3(256), 0,
+                               ctx->stream, m);
+        else
+            hipLaunchKernelGGL(map_reduce_lane_kernel<double>, dim3((unsigned)blocks), dim3(256), 0,
+                               ctx->stream, m);
+    } else {
+        // the wave kernels run four (output, split) jobs per block
+        const int64_t blocks = (n_out * splits + 3) / 4;
+        if (dense_wave) {
+#define BSC_WAVE_CASE(NV)                                                                        \
+    case NV:                                                                                     \
+        if (n_red <= 256 * splits)                                                               \
+            hipLaunchKernelGGL((map_reduce_wave_dense_f32_kernel<NV, 1>), dim3((unsigned)blocks), \
+                               dim3(256), 0, ctx->stream, m);                                    \
+        else                                                                                     \
+            hipLaunchKernelGGL((map_reduce_wave_dense_f32_kernel<NV, 4>), dim3((unsigned)blocks), \
+                               dim3(256), 0, ctx->stream, m);                                    \
+        break;
+            switch (n_in) { BSC_WAVE_CASE(1) BSC_WAVE_CASE(2) BSC_WAVE_CASE(3) }
+#undef BSC_WAVE_CASE
+        } else if (dtype == BSC_F32)
+            hipLaunchKernelGGL(map_reduce_wave_kernel<float>, dim3((unsigned)blocks), dim3(256), 0,
+                               ctx->stream, m);
+        else
+            hipLaunchKernelGGL(map_reduce_wave_kernel<double>, dim3((unsigned)blocks), dim3(256), 0,
+                               ctx->stream, m);
+    }
+    BSC_LAUNCH_CHECK();
+    if (splits > 1) {
+        const int wave_per_output = n_out < 4096;
+        const unsigned blocks = (unsigned)(wave_per_output ? (n_out + 3) / 4 : (n_out + 255) / 256);
+        if (dtype == BSC_F32)
+            hipLaunchKernelGGL(map_reduce_finish_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               m, wave_per_output);
+        else
+            hipLaunchKernelGGL(map_reduce_finish_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               m, wave_per_output);
+        BSC_LAUNCH_CHECK();
+    }
+    return BSC_OK;
+}
+
+}  // extern "C"

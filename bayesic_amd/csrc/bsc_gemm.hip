@@ -307,8 +307,18 @@ int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, 
     BSC_REQUIRE(batch >= 0 && M >= 0 && N >= 0 && K >= 0, "bsc_gemm_strided_batched: negative extent");
     if (batch == 0 || M == 0 || N == 0) return BSC_OK;
     BSC_REQUIRE(C && ((A && B) || K == 0), "bsc_gemm_strided_batched: null pointer");
-    BSC_REQUIRE(batch <= 65535, "bsc_gemm_strided_batched: batch %lld exceeds 65535",
-                (long long)batch);
+    if (batch > 65535) {  // the batch index is a grid dimension: run 65535 batches per launch
+        const size_t es = dtype == BSC_F64 ? 8 : 4;
+        for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+            const int64_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
+            int rc = bsc_gemm_strided_batched(
+                ctx, dtype, nb, M, N, K, A ? (const char*)A + (size_t)(b0 * sa_b) * es : nullptr, sa_b,
+                sa_m, sa_k, B ? (const char*)B + (size_t)(b0 * sb_b) * es : nullptr, sb_b, sb_k, sb_n,
+                (char*)C + (size_t)(b0 * sc_b) * es, sc_b, sc_m, sc_n);
+            if (rc != BSC_OK) return rc;
+        }
+        return BSC_OK;
+    }
     if (dtype == BSC_F64 || K == 0) {
         const dim3 grid((unsigned)((M * N + 255) / 256), (unsigned)batch);
         if (dtype == BSC_F64)

@@ -128,90 +128,6 @@ __global__ __launch_bounds__(256) void convert_kernel(Dims d, int64_t total, con
     }
 }
 
-// ---- sums --------------------------------------------------------------------
-
-struct SumArgs {
-    Dims keep, red;
-    int64_t n_out, n_red;
-    int64_t keep_strides[MAXR];
-    int64_t red_strides[MAXR];
-    const void* in;
-    void* out;
-    double* partial;  // [splits][n_out] when splits > 1
-    int splits;
-};
-
-// Variant A: the fastest-varying input axis is a REDUCED one.  One wave per
-// (output, split); lanes stride over the flattened reduce index.
-template <typename T>
-__global__ __launch_bounds__(256) void sum_wave_kernel(SumArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t job = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (job >= a.n_out * a.splits) return;
-    const int64_t o = job % a.n_out;
-    const int split = (int)(job / a.n_out);
-    int64_t kidx[MAXR];
-    unravel(o, a.keep, kidx);
-    const T* base = static_cast<const T*>(a.in) + dot_strides(kidx, a.keep_strides, a.keep.rank);
-    const int64_t chunk = (a.n_red + a.splits - 1) / a.splits;
-    const int64_t r0 = split * chunk;
-    const int64_t r1 = (r0 + chunk < a.n_red) ? r0 + chunk : a.n_red;
-    double acc = 0.0;
-    for (int64_t r = r0 + lane; r < r1; r += 64) {
-        int64_t ridx[MAXR];
-        unravel(r, a.red, ridx);
-        acc += (double)base[dot_strides(ridx, a.red_strides, a.red.rank)];
-    }
-    acc = wave_allsum_f64(acc);
-    if (lane == 0) {
-        if (a.splits > 1) a.partial[(int64_t)split * a.n_out + o] = acc;
-        else static_cast<T*>(a.out)[o] = (T)acc;
-    }
-}
-
-// Variant B: the fastest-varying input axis is a KEPT one.  Lane <-> output, so a
-// wave reads 64 consecutive elements per reduce step; the four waves of a block
-// and `splits` blocks divide the reduce range.
-template <typename T>
-__global__ __launch_bounds__(256) void sum_lane_kernel(SumArgs a) {
-    __shared__ double red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t n_groups = (a.n_out + 63) / 64;
-    const int64_t group = blockIdx.x % n_groups;
-    const int split = (int)(blockIdx.x / n_groups);
-    const int64_t o = group * 64 + lane;
-    const int64_t chunk = (a.n_red + a.splits - 1) / a.splits;
-    const int64_t r0 = split * chunk;
-    const int64_t r1 = (r0 + chunk < a.n_red) ? r0 + chunk : a.n_red;
-    double acc = 0.0;
-    if (o < a.n_out) {
-        int64_t kidx[MAXR];
-        unravel(o, a.keep, kidx);
-        const T* base = static_cast<const T*>(a.in) + dot_strides(kidx, a.keep_strides, a.keep.rank);
-        for (int64_t r = r0 + wave; r < r1; r += 4) {
-            int64_t ridx[MAXR];
-            unravel(r, a.red, ridx);
-            acc += (double)base[dot_strides(ridx, a.red_strides, a.red.rank)];
-        }
-    }
-    red[wave][lane] = acc;
-    __syncthreads();
-    if (wave == 0 && o < a.n_out) {
-        const double tot = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
-        if (a.splits > 1) a.partial[(int64_t)split * a.n_out + o] = tot;
-        else static_cast<T*>(a.out)[o] = (T)tot;
-    }
-}
-
-template <typename T>
-__global__ void sum_finish_kernel(const double* partial, int splits, int64_t n_out, T* out) {
-    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= n_out) return;
-    double tot = 0.0;
-    for (int s = 0; s < splits; ++s) tot += partial[(int64_t)s * n_out + o];
-    out[o] = (T)tot;
-}
-
 template <typename T>
 __global__ void eye_kernel(T* out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -401,77 +317,24 @@ int bsc_convert(bsc_ctx* ctx, int src_dtype, int dst_dtype, int rank, const int6
 int bsc_sum(bsc_ctx* ctx, int dtype, int rank_keep, const int64_t* host_keep_shape,
             const int64_t* host_in_keep_strides, int rank_red, const int64_t* host_red_shape,
             const int64_t* host_in_red_strides, const void* in, void* out) {
+    // the one-operand case of the fused map-reduce (csrc/bsc_fused.hip)
     BSC_CHECK_CTX(ctx);
-    BSC_REQUIRE(dtype == BSC_F32 || dtype == BSC_F64, "bsc_sum: unknown dtype %d", dtype);
+    BSC_REQUIRE(rank_keep >= 0 && rank_keep <= MAXR && rank_red >= 0 && rank_red <= MAXR,
+                "bsc_sum: rank exceeds %d", MAXR);
     BSC_REQUIRE(out != nullptr, "bsc_sum: out is null");
-    SumArgs a{};
-    int rc = fill_dims(a.keep, rank_keep, host_keep_shape, &a.n_out, "bsc_sum(keep)");
-    if (rc != BSC_OK) return rc;
-    rc = fill_dims(a.red, rank_red, host_red_shape, &a.n_red, "bsc_sum(reduce)");
-    if (rc != BSC_OK) return rc;
-    if (a.n_out == 0) return BSC_OK;
-    BSC_REQUIRE(in != nullptr || a.n_red == 0, "bsc_sum: in is null");
-    int64_t min_keep = INT64_MAX, min_red = INT64_MAX;
-    for (int ax = 0; ax < MAXR; ++ax) {
-        a.keep_strides[ax] = ax < rank_keep ? host_in_keep_strides[ax] : 0;
-        a.red_strides[ax] = ax < rank_red ? host_in_red_strides[ax] : 0;
-        if (ax < rank_keep && a.keep.shape[ax] > 1) {
-            int64_t s = a.keep_strides[ax] < 0 ? -a.keep_strides[ax] : a.keep_strides[ax];
-            if (s != 0 && s < min_keep) min_keep = s;
-        }
-        if (ax < rank_red && a.red.shape[ax] > 1) {
-            int64_t s = a.red_strides[ax] < 0 ? -a.red_strides[ax] : a.red_strides[ax];
-            if (s != 0 && s < min_red) min_red = s;
-        }
+    int64_t out_strides[MAXR + 1], n_out = 1, n_red = 1;
+    for (int a = rank_keep - 1; a >= 0; --a) {
+        out_strides[a] = n_out;
+        n_out *= host_keep_shape[a];
     }
-    a.in = in;
-    a.out = out;
-    const bool lanes_over_outputs = min_keep < min_red && a.n_out >= 16;
-    // split the reduce range when there are too few outputs to fill the chip
-    const int64_t jobs = lanes_over_outputs ? (a.n_out + 63) / 64 : (a.n_out + 3) / 4;
-    int64_t splits = 1;
-    const int64_t want_blocks = (int64_t)ctx->cu_count * 4;
-    if (jobs < want_blocks) {
-        splits = want_blocks / jobs;
-        const int64_t max_splits = a.n_red / (lanes_over_outputs ? 64 : 1024);
-        if (splits > max_splits) splits = max_splits;
-        if (splits < 1) splits = 1;
-        if (splits > 4096) splits = 4096;
-    }
-    a.splits = (int)splits;
-    a.partial = nullptr;
-    if (splits > 1) {
-        void* ws = nullptr;
-        rc = bsc_workspace(ctx, (size_t)splits * a.n_out * sizeof(double), &ws);
-        if (rc != BSC_OK) return rc;
-        a.partial = (double*)ws;
-        ctx->slab_rows = 0;
-    }
-    if (lanes_over_outputs) {
-        const int64_t blocks = ((a.n_out + 63) / 64) * splits;
-        if (dtype == BSC_F32)
-            hipLaunchKernelGGL(sum_lane_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL(sum_lane_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
-    } else {
-        const int64_t blocks = (a.n_out * splits + 3) / 4;
-        if (dtype == BSC_F32)
-            hipLaunchKernelGGL(sum_wave_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL(sum_wave_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
-    }
-    BSC_LAUNCH_CHECK();
-    if (splits > 1) {
-        const unsigned blocks = (unsigned)((a.n_out + 255) / 256);
-        if (dtype == BSC_F32)
-            hipLaunchKernelGGL(sum_finish_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream,
-                               a.partial, a.splits, a.n_out, (float*)out);
-        else
-            hipLaunchKernelGGL(sum_finish_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream,
-                               a.partial, a.splits, a.n_out, (double*)out);
-        BSC_LAUNCH_CHECK();
-    }
-    return BSC_OK;
+    for (int a = 0; a < rank_red; ++a) n_red *= host_red_shape[a];
+    BSC_REQUIRE(in != nullptr || n_out * n_red == 0, "bsc_sum: in is null");
+    const void* ins[1] = {in};
+    const int32_t pre_op[1] = {BSC_OP_COPY};
+    const double pre_arg[1] = {0.0};
+    return bsc_map_reduce(ctx, dtype, BSC_OP_ADD, rank_keep, host_keep_shape, rank_red,
+                          host_red_shape, 1, ins, host_in_keep_strides, host_in_red_strides, pre_op,
+                          pre_arg, 1.0, 0.0, BSC_OP_COPY, 0.0, out, out_strides);
 }
 
 int bsc_logdet_spd(bsc_ctx* ctx, int dtype, int64_t batch, int64_t n, const void* A, int64_t s_b,

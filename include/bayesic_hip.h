@@ -260,6 +260,22 @@ int bsc_sum(bsc_ctx* ctx, int dtype, int rank_keep, const int64_t* host_keep_sha
             const int64_t* host_in_keep_strides, int rank_red, const int64_t* host_red_shape,
             const int64_t* host_in_red_strides, const void* in, void* out);
 
+/* Fused pointwise map with an optional trailing sum: one pass over the operands
+ * for a chain elemwise -> add/_mul -> elemwise -> _sum (bayesic/algebra.py:195-233,
+ * 1284-1309, 1435-1448), which the reference leaves to Theano's graph optimiser.
+ *   v(keep, red) = post( scale * COMBINE_i pre_i( in_i[keep, red] ) + shift )
+ *   out[keep]    = sum over red of v(keep, red)     (rank_red == 0: out[keep] = v(keep))
+ * combine is BSC_OP_ADD or BSC_OP_MUL; pre_op[i] and post_op are BSC_OP_COPY, LOG,
+ * EXP, ABS or POW (x ** arg, arg taken from pre_arg[i] / post_arg).  in_keep_strides
+ * is [n_in][rank_keep], in_red_strides [n_in][rank_red] (0 broadcasts); sums
+ * accumulate in float64 in a fixed order. */
+int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
+                   const int64_t* host_keep_shape, int rank_red, const int64_t* host_red_shape,
+                   int n_in, const void* const* host_in, const int64_t* host_in_keep_strides,
+                   const int64_t* host_in_red_strides, const int32_t* host_pre_op,
+                   const double* host_pre_arg, double scale, double shift, int post_op,
+                   double post_arg, void* out, const int64_t* host_out_strides);
+
 /* C[b,m,n] = sum_k A[b,m,k] * B[b,k,n], every stride free (so transposed and
  * broadcast operands cost nothing).  float32 runs on v_mfma_f32_32x32x2_f32 with
  * a deterministic split-K when M*N is small against K (XtX: M=N=256, K=1e6);

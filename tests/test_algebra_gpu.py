@@ -90,6 +90,25 @@ def test_batched_tensordot_on_device(dev):
     npt.assert_allclose(run(dev, e2, S=T.S_), np.einsum("uiv,uiw->uvw", T.S_, T.S_), rtol=1e-5)
 
 
+def test_batched_tensordot_more_batches_than_a_grid_dimension(dev):
+    """70 000 batches of a 2x3 . 3x2 product (the batch index is a grid dimension
+    of at most 65 535) -- also with fusion off, where batched dot products take the
+    GEMM path as well."""
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    rs = np.random.RandomState(5)
+    A_ = rs.standard_normal((70000, 2, 3)).astype(np.float32)
+    B_ = rs.standard_normal((70000, 3, 2)).astype(np.float32)
+    S1, S2 = var("S1", 3), var("S2", 3)
+    e = tensordot(S1, S2, [2], [1], [0], [0])
+    want = np.einsum("bik,bkj->bij", A_.astype(np.float64), B_)
+    npt.assert_allclose(run(dev, e, S1=A_, S2=B_), want, rtol=1e-5, atol=1e-6)
+    e2 = tensordot(S1, S1, [1, 2], [1, 2], [0], [0])          # batched dot products
+    want2 = (A_.astype(np.float64) ** 2).sum(axis=(1, 2))
+    npt.assert_allclose(run(dev, e2, S1=A_), want2, rtol=1e-5)
+    unfused = DeviceBackend(dev.ctx, fuse=False)
+    npt.assert_allclose(e2.compile(unfused)(S1=A_), want2, rtol=1e-5)
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (33, 17, 5), (128, 128, 16), (130, 257, 1000),
                                    (256, 256, 40000), (64, 16, 100003), (5, 300, 2), (300, 5, 777)])
 def test_gemm_shapes_incl_split_k(dev, M, N, K):

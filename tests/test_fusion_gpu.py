@@ -1,0 +1,275 @@
+"""GPU parity of the fused map(+reduce) kernel (bsc_map_reduce) and of the
+executor's deferred element-wise values against numpy,
+plus the launch counts that show the fusion really happens: a chain
+elemwise -> _mul -> _sum must be ONE launch that writes only its result.
+
+Tolerances: rtol 1e-5 wherever a sum is involved (the reference's own,
+bayesic/tests/test_algebra.py:82), 2e-6 for device libm vs numpy otherwise.
+"""
+import ctypes
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from bayesic_amd.algebra import *            # noqa: F401,F403
+import builtins
+
+pytestmark = pytest.mark.gpu
+
+OPS = {"add": 0, "mul": 1, "log": 2, "exp": 3, "pow": 4, "abs_": 5, "copy": 6}
+NP_UNARY = {"copy": lambda x, a: x, "log": lambda x, a: np.log(x), "exp": lambda x, a: np.exp(x),
+            "abs_": lambda x, a: np.abs(x), "pow": lambda x, a: np.power(x, a)}
+
+
+@pytest.fixture(scope="module")
+def dev(ctx):
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    return DeviceBackend(ctx)
+
+
+def _i64(v):
+    v = list(v)
+    return (ctypes.c_int64 * builtins.max(len(v), 1))(*v)
+
+
+def map_reduce(ctx, arrays, pre, combine, red_axes, scale=1.0, shift=0.0, post=("copy", 0.0),
+               views=None):
+    """Direct C-ABI call.  arrays: numpy arrays of one rank (extent 1 broadcasts);
+    views[i]: optional function applied to the uploaded tensor (strided views)."""
+    import torch
+    dtype = arrays[0].dtype
+    rank = arrays[0].ndim
+    shape = [builtins.max(a.shape[ax] for a in arrays) for ax in range(rank)]
+    tens = []
+    for i, a in enumerate(arrays):
+        t = ctx.to_device(np.ascontiguousarray(a) if views is None or views[i] is None else a)
+        tens.append(t)
+    red = sorted(red_axes)
+    keep = [a for a in range(rank) if a not in red]
+    out = torch.empty([shape[a] for a in keep], dtype=tens[0].dtype, device=ctx.device)
+
+    def strides(t, axes):
+        return [0 if (t.shape[ax] == 1 and shape[ax] != 1) else t.stride(ax) for ax in axes]
+
+    ks, rs = [], []
+    for t in tens:
+        ks += strides(t, keep)
+        rs += strides(t, red)
+    n = len(tens)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tens])
+    pre_ops = (ctypes.c_int32 * n)(*[OPS[p[0]] for p in pre])
+    pre_args = (ctypes.c_double * n)(*[float(p[1]) for p in pre])
+    ctx.call("bsc_map_reduce", 0 if dtype == np.float32 else 1, OPS[combine], len(keep),
+             _i64(shape[a] for a in keep), len(red), _i64(shape[a] for a in red), n, ptrs,
+             _i64(ks), _i64(rs), pre_ops, pre_args, float(scale), float(shift), OPS[post[0]],
+             float(post[1]), out, _i64(out.stride()))
+    ctx.sync()
+    return out.cpu().numpy()
+
+
+def expected(arrays, pre, combine, red_axes, scale=1.0, shift=0.0, post=("copy", 0.0)):
+    vals = [NP_UNARY[p[0]](a.astype(np.float64), p[1]) for a, p in zip(arrays, pre)]
+    v = vals[0]
+    for u in vals[1:]:
+        v = v * u if combine == "mul" else v + u
+    v = NP_UNARY[post[0]](scale * v + shift, post[1])
+    v = np.broadcast_to(v, np.broadcast_shapes(*[a.shape for a in arrays]))
+    return v.sum(axis=tuple(red_axes)) if red_axes else v
+
+
+RNG = np.random.RandomState(11)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,red", [
+    ((1024,), ()),                # dense map, 16-byte path
+    ((37, 53), ()),               # ragged map
+    ((64, 4096), (1,)),           # reduce the fast axis (wave variant, dense)
+    ((64, 4099), (1,)),           # ragged reduce length (wave variant, scalar loads)
+    ((4096, 96), (0,)),           # reduce the slow axis (lane variant)
+    ((8, 300000), (1,)),          # few outputs: split reduction
+    ((300000, 8), (0,)),          # few outputs, lane variant (below 16 outputs -> wave)
+    ((20, 30, 40), (0, 2)),       # two reduced axes around a kept one
+    ((6, 5, 4, 3, 2, 7), (1, 3, 5)),
+    ((0, 5), (0,)),               # empty reduction -> zeros
+])
+def test_map_reduce_matches_numpy(ctx, dtype, shape, red):
+    a = (RNG.rand(*shape) + 0.5).astype(dtype)
+    b = RNG.standard_normal(shape).astype(dtype)
+    c = (RNG.rand(*[1 if i % 2 else s for i, s in enumerate(shape)]) + 0.5).astype(dtype)  # broadcasts
+    pre = [("log", 0), ("exp", 0), ("pow", -1.0)]
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == np.float32 else dict(rtol=1e-12, atol=1e-12)
+    for combine in ("mul", "add"):
+        got = map_reduce(ctx, [a, b, c], pre, combine, red, scale=0.5, shift=0.25, post=("abs_", 0))
+        want = expected([a, b, c], pre, combine, red, scale=0.5, shift=0.25, post=("abs_", 0))
+        assert got.shape == want.shape
+        npt.assert_allclose(got, want, **tol)
+
+
+def test_map_reduce_strided_views_and_determinism(ctx):
+    import torch
+    a = RNG.standard_normal((300, 200)).astype(np.float32)
+    ta = ctx.to_device(a)
+    out1 = torch.empty(200, dtype=torch.float32, device=ctx.device)
+    out2 = torch.empty(200, dtype=torch.float32, device=ctx.device)
+    tt = ta.t()                                   # [200, 300] view, reduce axis 1 has stride 200
+    for out in (out1, out2):
+        ptrs = (ctypes.c_void_p * 2)(tt.data_ptr(), tt.data_ptr())
+        ctx.call("bsc_map_reduce", 0, OPS["mul"], 1, _i64([200]), 1, _i64([300]), 2, ptrs,
+                 _i64([tt.stride(0)] * 2), _i64([tt.stride(1)] * 2),
+                 (ctypes.c_int32 * 2)(OPS["copy"], OPS["copy"]), (ctypes.c_double * 2)(0, 0),
+                 1.0, 0.0, OPS["copy"], 0.0, out, _i64([1]))
+    ctx.sync()
+    npt.assert_array_equal(out1.cpu().numpy(), out2.cpu().numpy())        # fixed order
+    npt.assert_allclose(out1.cpu().numpy(), (a.astype(np.float64) ** 2).sum(axis=0), rtol=1e-5)
+
+
+def test_map_reduce_rejects_bad_arguments(ctx):
+    from bayesic_amd._ffi import BayesicHipError
+    import torch
+    t = torch.zeros(8, device=ctx.device)
+    args = lambda combine, pre, post: (
+        "bsc_map_reduce", 0, combine, 1, _i64([8]), 0, _i64([]), 1,
+        (ctypes.c_void_p * 1)(t.data_ptr()), _i64([1]), _i64([]), (ctypes.c_int32 * 1)(pre),
+        (ctypes.c_double * 1)(0.0), 1.0, 0.0, post, 0.0, t, _i64([1]))
+    with pytest.raises(BayesicHipError):
+        ctx.call(*args(OPS["log"], OPS["copy"], OPS["copy"]))     # combine must be add / mul
+    with pytest.raises(BayesicHipError):
+        ctx.call(*args(OPS["mul"], OPS["add"], OPS["copy"]))      # pre op must be unary
+    with pytest.raises(BayesicHipError):
+        ctx.call(*args(OPS["mul"], OPS["copy"], OPS["mul"]))      # post op must be unary
+
+
+# ---- executor level --------------------------------------------------------------
+
+class Counting(object):
+    """Counts C-ABI calls issued through a context while an expression runs."""
+
+    def __init__(self, ctx):
+        self.ctx, self.calls = ctx, []
+
+    def __enter__(self):
+        self._orig = self.ctx.call
+        def call(name, *a):
+            self.calls.append(name)
+            return self._orig(name, *a)
+        self.ctx.call = call
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.call = self._orig
+
+    def count(self, name):
+        return self.calls.count(name)
+
+
+def test_chain_into_sum_is_one_launch(dev):
+    X, Y = var("X", ndim=2), var("Y", ndim=2)
+    X_ = RNG.standard_normal((700, 300)).astype(np.float32)
+    Y_ = RNG.standard_normal((700, 300)).astype(np.float32)
+    f = sum(exp(X) * Y).compile(dev)              # lowered: _tensordot(exp(X), Y, [0,1], [0,1])
+    with Counting(dev.ctx) as c:
+        got = f(X=X_, Y=Y_)
+    assert c.count("bsc_map_reduce") == 1
+    assert c.count("bsc_elemwise") == 0 and c.count("bsc_gemm_strided_batched") == 0
+    npt.assert_allclose(got, (np.exp(X_.astype(np.float64)) * Y_).sum(), rtol=1e-5)
+
+    g = sum(exp(X) * Y, axis=0).compile(dev)      # -> a batched full contraction or _sum(_mul)
+    with Counting(dev.ctx) as c:
+        got = g(X=X_, Y=Y_)
+    assert c.count("bsc_map_reduce") == 1 and c.count("bsc_elemwise") == 0
+    npt.assert_allclose(got, (np.exp(X_.astype(np.float64)) * Y_).sum(axis=0), rtol=1e-5, atol=1e-4)
+
+
+def test_elementwise_trees_fuse_and_match_numpy(dev):
+    X, Y, Z, x = var("X", ndim=2), var("Y", ndim=2), var("Z", ndim=2), var("x", ndim=1)
+    X_ = (RNG.rand(64, 48) + 0.5).astype(np.float32)
+    Y_ = RNG.standard_normal((64, 48)).astype(np.float32)
+    Z_ = (RNG.rand(64, 48) + 0.5).astype(np.float32)
+    x_ = (RNG.rand(48) + 0.5).astype(np.float32)
+    cases = [
+        (X / Y, X_ / Y_, 1),                                        # mul(X, pow(Y,-1))
+        (exp(X * Y) * Z, np.exp(X_ * Y_) * Z_, 2),                  # post op, then a second launch
+        (log(abs(Y) + 1), np.log(np.abs(Y_) + 1), 1),
+        (2 * exp(X) * log(Z) * 3, 2 * np.exp(X_) * np.log(Z_) * 3, 1),
+        (X * dimshuffle(log(x), "x", 0), X_ * np.log(x_)[None, :], 1),   # a view of a deferred value
+        ((X + Y) * Z, (X_ + Y_) * Z_, 2),
+        (exp(X).T * Y.T, np.exp(X_).T * Y_.T, 1),
+        (X + Y + Z + 1, X_ + Y_ + Z_ + 1, 1),
+        (X - 2 * Y, X_ - 2 * Y_, 2),
+    ]
+    for expr, want, launches in cases:
+        f = expr.compile(dev)
+        with Counting(dev.ctx) as c:
+            got = f(**{n: {"X": X_, "Y": Y_, "Z": Z_, "x": x_}[n] for n in expr.input_types})
+        npt.assert_allclose(got, want, rtol=3e-6, atol=1e-6, err_msg=repr(expr))
+        assert c.count("bsc_map_reduce") + c.count("bsc_elemwise") == launches, (repr(expr), c.calls)
+
+
+def test_more_than_eight_factors(dev):
+    vs = [var("v%d" % i, ndim=1) for i in range(11)]
+    vals = {"v%d" % i: (RNG.rand(100) + 0.5).astype(np.float32) for i in range(11)}
+    e = vs[0]
+    for v in vs[1:]:
+        e = e * v
+    want = np.prod([vals["v%d" % i].astype(np.float64) for i in range(11)], axis=0)
+    npt.assert_allclose(e.compile(dev)(**vals), want, rtol=1e-5)
+
+
+def test_batched_dot_products_take_the_fused_path(dev):
+    S1, S2 = var("S1", ndim=3), var("S2", ndim=3)
+    A = RNG.standard_normal((7, 50, 30)).astype(np.float32)
+    B = RNG.standard_normal((7, 50, 30)).astype(np.float32)
+    idx = [("out", 0), ("sum", 0), ("sum", 1)]
+    e = einsum([(S1, idx), (S2, idx)], 1)                  # out_b = sum_ij S1_bij S2_bij
+    f = e.compile(dev)
+    with Counting(dev.ctx) as c:
+        got = f(S1=A, S2=B)
+    assert c.count("bsc_map_reduce") == 1 and c.count("bsc_gemm_strided_batched") == 0
+    npt.assert_allclose(got, np.einsum("bij,bij->b", A.astype(np.float64), B), rtol=1e-5, atol=1e-4)
+
+
+def test_lda_statistic_has_no_data_sized_elementwise_intermediate(dev):
+    Th, Bm, C = var("Th", ndim=2), var("Bm", ndim=2), var("C", ndim=2)
+    docs, V, K = 96, 640, 16
+    Th_ = (RNG.rand(docs, K) + 0.1).astype(np.float32)
+    Bm_ = (RNG.rand(K, V) + 0.1).astype(np.float32)
+    C_ = RNG.poisson(0.3, (docs, V)).astype(np.float32)
+    e = Bm * dot(Th.T, C / dot(Th, Bm))
+    f = e.compile(dev)
+    with Counting(dev.ctx) as c:
+        got = f(Th=Th_, Bm=Bm_, C=C_)
+    # two GEMMs, one fused C * P**-1, one fused Bm * (...)
+    assert c.count("bsc_gemm_strided_batched") == 2
+    assert c.count("bsc_map_reduce") == 2 and c.count("bsc_elemwise") == 0
+    want = Bm_ * (Th_.T.astype(np.float64) @ (C_ / (Th_.astype(np.float64) @ Bm_)))
+    npt.assert_allclose(got, want, rtol=2e-5)
+
+
+def test_memory_plan_reuses_intermediates_but_never_the_result(dev):
+    """Intermediates of a compiled expression are allocated once; the result always
+    gets storage of its own (a second call must not overwrite the first result),
+    and a change of input shapes re-plans."""
+    X, Y = var("X", ndim=2), var("Y", ndim=2)
+    e = dot(exp(X), Y.T) * 2 + 1                   # exp(X) is forced (GEMM operand), result is fused
+    f = e.compile(dev).device_fn
+    rs = np.random.RandomState(3)
+    outs, wants = [], []
+    for shape in [(40, 30), (40, 30), (17, 9), (40, 30)]:
+        X_ = rs.standard_normal(shape).astype(np.float32)
+        Y_ = rs.standard_normal(shape).astype(np.float32)
+        outs.append(f(X=dev.from_host(X_, "float32", 2), Y=dev.from_host(Y_, "float32", 2)))
+        wants.append(np.exp(X_.astype(np.float64)) @ Y_.T * 2 + 1)
+    dev.ctx.sync()
+    ptrs = {o.untyped_storage().data_ptr() for o in outs}
+    assert len(ptrs) == len(outs)                  # four live results, four storages
+    for o, w in zip(outs, wants):
+        npt.assert_allclose(o.cpu().numpy(), w, rtol=2e-5, atol=1e-5)
+    plan = dev._plans[id(e)][1]
+    live = [b for b in plan if b is not None]
+    assert len(live) >= 1                          # the forced exp(X) stays in the plan
+    before = [b.data_ptr() for b in live]
+    X_ = rs.standard_normal((40, 30)).astype(np.float32)
+    f(X=dev.from_host(X_, "float32", 2), Y=dev.from_host(X_, "float32", 2))
+    assert [b.data_ptr() for b in dev._plans[id(e)][1] if b is not None][:len(before)] == before
