@@ -1,0 +1,318 @@
+// Fixed-gamma local step of the LDA-style Dirichlet-Multinomial model (BASELINE
+// config 4; SURVEY.md 8(b) names the entry bsc_lda_sstats):
+//
+//   sstats[k,v] = Bt[k,v] * sum_d Th[d,k] * C[d,v] / (sum_k' Th[d,k'] Bt[k',v])
+//
+// i.e. the algebra expression  Bt * dot(Th.T, C / dot(Th, Bt))  whose lowered
+// form (bayesic/algebra.py:553-765) is two _tensordot GEMMs around an
+// element-wise division.  Run through the generic executor that costs two
+// docs x V intermediates (2.5 GB each per GPU at config 4); here both
+// contractions and the division happen in ONE pass over C, and neither
+// phinorm nor the ratio ever leaves the registers.
+//
+// Bound: fp32 MFMA (4*docs*V*K flops on 4*docs*V bytes = 128 flop/B at K=128).
+//
+// Workgroup = 4 waves = 128 vocabulary columns (32 per wave) x a range of
+// documents, walked 32 at a time:
+//   phase 1  P[32 d, 32 v] = Th[32 d, K] . Bt[K, 32 v]     (Bt column block in
+//            registers for the whole kernel, Th tile from LDS)
+//   ratio    R = C / P   in the MFMA result layout (C tile staged through LDS)
+//   phase 2  S[K, 32 v] += Th[32 d, K]^T . R[32 d, 32 v]
+// The result layout of v_mfma_f32_32x32x2_f32 (lane = column, 16 rows per lane)
+// is exactly its B-operand layout when the contraction index is taken to be
+// those rows, so R feeds phase 2 straight from registers.
+#include "bsc_common.h"
+
+namespace {
+
+constexpr int LDA_BLOCK = 256;
+constexpr int DT = 32;        // documents per step
+constexpr int VT = 128;       // vocabulary columns per workgroup
+constexpr int TH_LD = 132;    // Th tile row stride in LDS: 16-byte rows, conflict-free b128 reads
+constexpr int C_LD = VT + 4;  // C tile row stride
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct LdaArgs {
+    const float* C;
+    const float* Th;
+    const float* Bt;
+    float* out;        // sstats [K, V] (ld = ldo) when splits == 1, else partial [splits][K][V]
+    int64_t ldc, ldth, ldb, ldo;
+    int64_t docs, V;
+    int64_t docs_per_split;   // multiple of DT
+    int splits;
+    int vec_c, vec_th;        // 16-byte global loads allowed
+};
+
+// global -> registers for one step: Th tile [32][K] and C tile [32][128]
+template <int KT>
+struct Staged {
+    float4 th[KT];   // 32 * 32KT / 4 float4 over 256 threads
+    float4 c[4];
+};
+
+template <int KT>
+__device__ __forceinline__ void stage_load(Staged<KT>& st, const LdaArgs& a, int64_t d0, int64_t d_end,
+                                           int64_t v_base, int tid) {
+    constexpr int K = 32 * KT;
+#pragma unroll
+    for (int p = 0; p < KT; ++p) {
+        const int idx = tid + LDA_BLOCK * p;
+        const int row = idx / (K / 4), c4 = idx % (K / 4);
+        const int64_t d = d0 + row;
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d < d_end) {
+            const float* src = a.Th + d * a.ldth + 4 * c4;
+            if (a.vec_th) f = *reinterpret_cast<const float4*>(src);
+            else f = make_float4(src[0], src[1], src[2], src[3]);
+        }
+        st.th[p] = f;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int idx = tid + LDA_BLOCK * p;
+        const int row = idx >> 5, c4 = idx & 31;
+        const int64_t d = d0 + row, v = v_base + 4 * c4;
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d < d_end) {
+            const float* src = a.C + d * a.ldc + v;
+            if (a.vec_c && v + 3 < a.V) {
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+                f = make_float4(t.x, t.y, t.z, t.w);
+            } else {
+                if (v < a.V) f.x = src[0];
+                if (v + 1 < a.V) f.y = src[1];
+                if (v + 2 < a.V) f.z = src[2];
+                if (v + 3 < a.V) f.w = src[3];
+            }
+        }
+        st.c[p] = f;
+    }
+}
+
+template <int KT>
+__device__ __forceinline__ void stage_store(const Staged<KT>& st, float* th, float* ct, int tid) {
+    constexpr int K = 32 * KT;
+#pragma unroll
+    for (int p = 0; p < KT; ++p) {
+        const int idx = tid + LDA_BLOCK * p;
+        const int row = idx / (K / 4), c4 = idx % (K / 4);
+        *reinterpret_cast<float4*>(th + row * TH_LD + 4 * c4) = st.th[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int idx = tid + LDA_BLOCK * p;
+        const int row = idx >> 5, c4 = idx & 31;
+        *reinterpret_cast<float4*>(ct + row * C_LD + 4 * c4) = st.c[p];
+    }
+}
+
+// K = 32 * KT topics.
+//
+// MFMA operand maps (v_mfma_f32_32x32x2_f32, D = A.B + C, lane l, h = l >> 5, j = l & 31):
+//   A[i = j][kk = h],  B[kk = h][col = j],  D[row = (r&3) + 8(r>>2) + 4h][col = j] in register r.
+// phase 1: i = document, col = v; the K contraction is split between the lane halves
+//   (half h owns k = (K/2) h + t) so a lane's A values are contiguous in LDS (b128 reads).
+// phase 2: col = v, contraction over the 32 documents two at a time: step r pairs the
+//   documents row_r + 4h -- exactly what register r of P holds -- and i = topic with the
+//   interleaved map k = KT * i + kt, so one b128 read of Th[d][KT*i ..] feeds the KT tiles.
+template <int KT>
+__global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_kernel(LdaArgs a) {
+    constexpr int K = 32 * KT;
+    __shared__ __attribute__((aligned(16))) float th_s[2][DT * TH_LD];
+    __shared__ __attribute__((aligned(16))) float c_s[2][DT * C_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int64_t v_base = (int64_t)blockIdx.x * VT;
+    const int64_t v = v_base + 32 * wave + j;
+    const bool v_ok = v < a.V;
+    const int split = blockIdx.y;
+    const int64_t d_begin = (int64_t)split * a.docs_per_split;
+    const int64_t d_end = d_begin + a.docs_per_split < a.docs ? d_begin + a.docs_per_split : a.docs;
+
+    // Bt column block of this lane: k = (K/2) h + t
+    float bt[K / 2];
+#pragma unroll
+    for (int t = 0; t < K / 2; ++t)
+        bt[t] = v_ok ? a.Bt[(int64_t)((K / 2) * h + t) * a.ldb + v] : 0.f;
+
+    f32x16 S[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
+
+    Staged<KT> st;
+    if (d_begin < d_end) {
+        stage_load<KT>(st, a, d_begin, d_end, v_base, tid);
+        stage_store<KT>(st, th_s[0], c_s[0], tid);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int64_t d0 = d_begin; d0 < d_end; d0 += DT) {
+        const bool more = d0 + DT < d_end;
+        if (more) stage_load<KT>(st, a, d0 + DT, d_end, v_base, tid);
+        const float* th = th_s[cur];
+        const float* ct = c_s[cur];
+
+        // ---- phase 1: P = Th . Bt --------------------------------------------------
+        f32x16 P;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P[r] = 0.f;
+        const float* arow = th + j * TH_LD + (K / 2) * h;
+#pragma unroll
+        for (int t4 = 0; t4 < K / 8; ++t4) {
+            const float4 av = *reinterpret_cast<const float4*>(arow + 4 * t4);
+            P = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bt[4 * t4 + 0], P, 0, 0, 0);
+            P = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bt[4 * t4 + 1], P, 0, 0, 0);
+            P = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bt[4 * t4 + 2], P, 0, 0, 0);
+            P = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bt[4 * t4 + 3], P, 0, 0, 0);
+        }
+
+        // ---- ratio in the result layout; padded rows / columns contribute nothing ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float c = ct[row * C_LD + 32 * wave + j];
+            P[r] = (v_ok && d0 + row < d_end) ? c / P[r] : 0.f;
+        }
+
+        // ---- phase 2: S += Th^T . R ----------------------------------------------
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float* src = th + row * TH_LD + KT * j;
+            float av[KT];
+            if constexpr (KT == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(src);
+                av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+            } else if constexpr (KT == 2) {
+                const float2 t = *reinterpret_cast<const float2*>(src);
+                av[0] = t.x; av[1] = t.y;
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) av[kt] = src[kt];
+            }
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+                S[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kt], P[r], S[kt], 0, 0, 0);
+        }
+
+        if (more) stage_store<KT>(st, th_s[cur ^ 1], c_s[cur ^ 1], tid);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: S[kt] register r is topic k = KT * row_r + kt, column v --------------
+    if (!v_ok) return;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int64_t k = KT * row + kt;
+            if (a.splits == 1)
+                a.out[k * a.ldo + v] = S[kt][r] * a.Bt[k * a.ldb + v];
+            else
+                a.out[((int64_t)split * K + k) * a.V + v] = S[kt][r];
+        }
+}
+
+// sstats = Bt * (sum of the split partials), fixed order
+__global__ __launch_bounds__(256) void lda_reduce_kernel(const float* __restrict__ partial, int splits,
+                                                         int64_t K, int64_t V,
+                                                         const float* __restrict__ Bt, int64_t ldb,
+                                                         float* __restrict__ out, int64_t ldo) {
+    const int64_t n = K * V;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float tot = partial[i];
+        for (int s = 1; s < splits; ++s) tot += partial[(int64_t)s * n + i];
+        const int64_t k = i / V, v = i - k * V;
+        out[k * ldo + v] = tot * Bt[k * ldb + v];
+    }
+}
+
+template <int KT>
+void launch_lda(bsc_ctx* ctx, const LdaArgs& a, dim3 grid) {
+    hipLaunchKernelGGL(lda_sstats_kernel<KT>, grid, dim3(LDA_BLOCK), 0, ctx->stream, a);
+}
+
+}  // namespace
+
+extern "C" {
+
+int bsc_lda_sstats(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int64_t V, int32_t K,
+                   const float* Th, int64_t ldth, const float* Bt, int64_t ldb, float* sstats,
+                   int64_t ldo) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(docs >= 0 && V >= 0 && K > 0, "bsc_lda_sstats: bad extents");
+    if (K % 32 != 0 || K > 128)
+        return bsc_fail(BSC_ERR_UNSUPPORTED,
+                        "bsc_lda_sstats: K must be 32, 64, 96 or 128 (got %d); use the algebra "
+                        "executor for other topic counts", K);
+    if (V == 0) return BSC_OK;
+    BSC_REQUIRE(Bt && sstats && (docs == 0 || (C && Th)), "bsc_lda_sstats: null pointer");
+    BSC_REQUIRE(ldc >= V && ldth >= K && ldb >= V && ldo >= V, "bsc_lda_sstats: leading dimension");
+    LdaArgs a{};
+    a.C = C; a.Th = Th; a.Bt = Bt;
+    a.ldc = ldc; a.ldth = ldth; a.ldb = ldb; a.ldo = ldo;
+    a.docs = docs; a.V = V;
+    a.vec_c = (ldc % 4 == 0) && (((uintptr_t)C) & 15) == 0;
+    a.vec_th = (ldth % 4 == 0) && (((uintptr_t)Th) & 15) == 0;
+    const int64_t n_vt = (V + VT - 1) / VT;
+    // Split the documents so that the grid fills whole rounds of the 2 x CU resident
+    // workgroups (782 column tiles on 512 slots would leave a quarter of the chip idle).
+    const int64_t slots = 2 * (int64_t)ctx->cu_count;
+    const int64_t steps = (docs + DT - 1) / DT;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int s = 1; s <= 8; ++s) {
+        if (s > 1 && steps / s < 8) break;
+        const int64_t wgs = n_vt * s;
+        const double eff = (double)wgs / (double)(slots * ((wgs + slots - 1) / slots));
+        if (eff > best_eff + 0.02) {
+            best_eff = eff;
+            best = s;
+        }
+    }
+    a.splits = best;
+    a.docs_per_split = ((steps + best - 1) / best) * DT;
+    if (a.docs_per_split == 0) a.docs_per_split = DT;
+    float* partial = nullptr;
+    if (best > 1) {
+        void* ws = nullptr;
+        int rc = bsc_workspace(ctx, (size_t)best * K * V * sizeof(float), &ws);
+        if (rc != BSC_OK) return rc;
+        ctx->slab_rows = 0;
+        partial = (float*)ws;
+        a.out = partial;
+    } else {
+        a.out = sstats;
+    }
+    const dim3 grid((unsigned)n_vt, (unsigned)best);
+    {
+        bsc_prof_scope prof(ctx);  // times the fused kernel alone
+        switch (K / 32) {
+            case 1: launch_lda<1>(ctx, a, grid); break;
+            case 2: launch_lda<2>(ctx, a, grid); break;
+            case 3: launch_lda<3>(ctx, a, grid); break;
+            default: launch_lda<4>(ctx, a, grid); break;
+        }
+    }
+    BSC_LAUNCH_CHECK();
+    if (best > 1) {
+        int64_t blocks = ((int64_t)K * V + 255) / 256;
+        const int64_t cap = (int64_t)ctx->cu_count * 8;
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(lda_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                           partial, best, (int64_t)K, V, Bt, ldb, sstats, ldo);
+        BSC_LAUNCH_CHECK();
+    }
+    return BSC_OK;
+}
+
+}  // extern "C"

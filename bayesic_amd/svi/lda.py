@@ -6,10 +6,13 @@ GEMMs (cfg 4):
 
     sstats = Bt * dot(Th.T, C / dot(Th, Bt))
 
-The expression is built ONCE with the algebra front end and evaluated by the
-MI355X backend (fp32 MFMA GEMM + fused element-wise kernels); the Dirichlet
-expectation and the natural-gradient step on lambda [K, V] are their own
-kernels.  Data-parallel over documents: one all-reduce of sstats (K*V float32,
+Two device paths compute it.  ``via="kernel"`` (default when K is 32, 64, 96 or
+128) is bsc_lda_sstats: both contractions and the division in one pass over C,
+no docs x V intermediate.  ``via="executor"`` builds the expression ONCE with
+the algebra front end and evaluates it on the MI355X backend (two fp32 MFMA
+GEMMs + fused element-wise launches) -- any K, and the cross-check of the fused
+kernel.  The Dirichlet expectation and the natural-gradient step on lambda
+[K, V] are their own kernels.  Data-parallel over documents: one all-reduce of sstats (K*V float32,
 51.2 MB at K=128, V=100k) per update.
 """
 import torch
@@ -20,7 +23,7 @@ from ..device import default_context
 
 
 class LDAFixedGammaSVI:
-    def __init__(self, C, gamma, lam0, eta=0.01, docs_total=None, ctx=None, group=None):
+    def __init__(self, C, gamma, lam0, eta=0.01, docs_total=None, ctx=None, group=None, via=None):
         self.ctx = ctx or default_context()
         dev = self.ctx.device
         f32 = torch.float32
@@ -53,15 +56,30 @@ class LDAFixedGammaSVI:
         self.expr = Bm * A.dot(Th.T, Cv / A.dot(Th, Bm))
         self.backend = DeviceBackend(self.ctx)
         self._sstats_fn = self.expr.compile(self.backend).device_fn
-        self.sstats = None
+        if via is None:
+            via = "kernel" if self.K in (32, 64, 96, 128) else "executor"
+        if via not in ("kernel", "executor"):
+            raise ValueError("via must be 'kernel' or 'executor'")
+        self.via = via
+        self.C = self.C if self.C.stride(1) == 1 else self.C.contiguous()
+        self.sstats = torch.zeros((self.K, self.V), dtype=f32, device=dev)
         self.t = 0
+
+    def local_step(self):
+        """sstats = Bt * dot(Th.T, C / dot(Th, Bt)) for the current lambda."""
+        self.ctx.call("bsc_dirichlet_expectation", self.lam, self.K, self.V, self.V, self.Bt)
+        if self.via == "kernel":
+            self.ctx.call("bsc_lda_sstats", self.C, self.C.stride(0), self.docs, self.V, self.K,
+                          self.Th, self.K, self.Bt, self.V, self.sstats, self.V)
+        else:
+            self.sstats = self._sstats_fn(Th=self.Th, C=self.C, Bm=self.Bt)
+        return self.sstats
 
     def step(self, rho=None):
         self.t += 1
         if rho is None:
             rho = (self.t + 1.0) ** -0.7
-        self.ctx.call("bsc_dirichlet_expectation", self.lam, self.K, self.V, self.V, self.Bt)
-        self.sstats = self._sstats_fn(Th=self.Th, C=self.C, Bm=self.Bt)
+        self.local_step()
         if self.world > 1:
             torch.distributed.all_reduce(self.sstats, group=self.group)
         self.ctx.call("bsc_natgrad_update_f32", self.lam, self.eta, self.sstats, self.lam.numel(),

@@ -169,6 +169,18 @@ int bsc_dirichlet_expectation(bsc_ctx* ctx, const float* lam, int64_t rows, int6
 int bsc_natgrad_update_f32(bsc_ctx* ctx, float* eta, float eta0, const float* message, int64_t n,
                            float scale, float rho);
 
+/* Fixed-gamma local step of the LDA-style Dirichlet-Multinomial model (BASELINE
+ * config 4): sstats[k,v] = Bt[k,v] * sum_d Th[d,k] C[d,v] / (sum_k' Th[d,k'] Bt[k',v]),
+ * the algebra expression Bt * dot(Th.T, C / dot(Th, Bt)) (lowered by
+ * bayesic/algebra.py:553-765 to two _tensordot GEMMs around a division) in ONE pass
+ * over the count matrix C[docs, V]: neither docs x V intermediate is written.
+ * Th[docs, K] = exp(E[log theta]), Bt[K, V] = exp(E[log beta]) (bsc_dirichlet_expectation);
+ * all float32, row-major with leading dimensions in elements; fp32 MFMA.
+ * K must be 32, 64, 96 or 128 (else BSC_ERR_UNSUPPORTED -- the executor path is general). */
+int bsc_lda_sstats(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int64_t V, int32_t K,
+                   const float* Th, int64_t ldth, const float* Bt, int64_t ldb, float* sstats,
+                   int64_t ldo);
+
 /* ---- summed sufficient statistics of iid draws ---------------------------
  * ExpFamIndependentObservations.sufficient_statistics,
  * bayesic/distribution/base.py:328-332; Normal t(x)=(x,x^2),

@@ -45,3 +45,75 @@ def test_lda_steps_match_oracle(ctx, docs, V, K):
         lam_ref = model.lam.cpu().numpy().astype(np.float64)
     # total expected counts are conserved by the local step: sum_kv sstats = sum_dv C
     npt.assert_allclose(model.sstats.double().sum().item(), C.astype(np.float64).sum(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("docs,V,K", [
+    (32, 128, 128),        # one full tile
+    (1, 1, 32),            # a single cell
+    (45, 130, 64),         # ragged documents and vocabulary
+    (700, 1000, 96),       # K = 96 (three topic tiles), V not a multiple of 4
+    (5000, 3000, 128),     # several document splits and the partial reduction
+    (0, 77, 128),          # no documents: zeros
+])
+def test_fused_lda_statistics_match_oracle_and_executor(ctx, docs, V, K):
+    """bsc_lda_sstats (both contractions + the division in one pass) against the float64
+    oracle and against the same expression run through the algebra executor."""
+    from bayesic_amd import algebra as A
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    rs = np.random.RandomState(docs + V + K)
+    C = rs.poisson(0.3, (docs, V)).astype(np.float32)
+    Th = (rs.rand(docs, K) + 0.05).astype(np.float32)
+    Bt = (rs.rand(K, V) + 0.05).astype(np.float32)
+    dC, dTh, dBt = ctx.to_device(C), ctx.to_device(Th), ctx.to_device(Bt)
+    out = torch.full((K, V), float("nan"), dtype=torch.float32, device=ctx.device)
+    ctx.call("bsc_lda_sstats", dC, V, docs, V, K, dTh, K, dBt, V, out, V)
+    ctx.sync()
+    got = out.cpu().numpy()
+    want = svi.lda_sstats(C, Th, Bt) if docs else np.zeros((K, V))
+    npt.assert_allclose(got, want, rtol=3e-5, atol=1e-6)
+    if docs:
+        Thv, Cv, Bm = A.var("Th", 2), A.var("C", 2), A.var("Bm", 2)
+        f = (Bm * A.dot(Thv.T, Cv / A.dot(Thv, Bm))).compile(DeviceBackend(ctx)).device_fn
+        ex = f(Th=dTh, C=dC, Bm=dBt)
+        ctx.sync()
+        npt.assert_allclose(got, ex.cpu().numpy(), rtol=3e-5, atol=1e-6)
+    # run-to-run identical (fixed reduction order)
+    out2 = torch.empty_like(out)
+    ctx.call("bsc_lda_sstats", dC, V, docs, V, K, dTh, K, dBt, V, out2, V)
+    ctx.sync()
+    npt.assert_array_equal(got, out2.cpu().numpy())
+
+
+def test_fused_lda_statistics_strided_operands_and_limits(ctx):
+    from bayesic_amd._ffi import BayesicHipError
+    rs = np.random.RandomState(9)
+    docs, V, K = 100, 203, 32
+    Cb = rs.poisson(0.3, (docs, V + 5)).astype(np.float32)       # leading dimensions > extents,
+    Thb = (rs.rand(docs, K + 3) + 0.05).astype(np.float32)       # not multiples of 4: scalar loads
+    Btb = (rs.rand(K, V + 1) + 0.05).astype(np.float32)
+    dC, dTh, dBt = ctx.to_device(Cb), ctx.to_device(Thb), ctx.to_device(Btb)
+    out = torch.zeros((K, V + 2), dtype=torch.float32, device=ctx.device)
+    ctx.call("bsc_lda_sstats", dC, V + 5, docs, V, K, dTh, K + 3, dBt, V + 1, out, V + 2)
+    ctx.sync()
+    want = svi.lda_sstats(Cb[:, :V], Thb[:, :K], Btb[:, :V])
+    npt.assert_allclose(out.cpu().numpy()[:, :V], want, rtol=3e-5, atol=1e-6)
+    assert (out.cpu().numpy()[:, V:] == 0).all()                 # padding columns untouched
+    with pytest.raises(BayesicHipError):                         # unsupported topic count: no fallback
+        ctx.call("bsc_lda_sstats", dC, V + 5, docs, V, 48, dTh, K + 3, dBt, V + 1, out, V + 2)
+
+
+def test_lda_driver_paths_agree(ctx):
+    from bayesic_amd.svi.lda import LDAFixedGammaSVI
+    rs = np.random.RandomState(1)
+    docs, V, K = 300, 900, 64
+    C = rs.poisson(0.3, (docs, V)).astype(np.float32)
+    gamma = rs.gamma(100.0, 0.01, (docs, K)).astype(np.float32)
+    lam = rs.gamma(100.0, 0.01, (K, V)).astype(np.float32)
+    a = LDAFixedGammaSVI(C, gamma, lam, ctx=ctx, via="kernel")
+    b = LDAFixedGammaSVI(C, gamma, lam, ctx=ctx, via="executor")
+    assert LDAFixedGammaSVI(C, gamma, lam, ctx=ctx).via == "kernel"
+    for _ in range(2):
+        a.step()
+        b.step()
+    ctx.sync()
+    npt.assert_allclose(a.lam.cpu().numpy(), b.lam.cpu().numpy(), rtol=3e-5)

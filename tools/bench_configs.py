@@ -113,9 +113,17 @@ def main():
         gamma = torch.rand((docs, K4), generator=g, device=dev) + 0.5
         lam = torch.rand((K4, V), generator=g, device=dev) + 0.5
         model = LDAFixedGammaSVI(C, gamma, lam, docs_total=50_000, ctx=ctx)
-        w, _ = timed(ctx, model.step, 3, warm=1)
-        row("cfg4 lda_step %dx100k K=128 (whole step)" % docs, w, float("nan"), 4.0 * docs * V,
+        w, k = timed(ctx, lambda: ctx.call("bsc_lda_sstats", model.C, V, docs, V, K4, model.Th, K4,
+                                           model.Bt, V, model.sstats, V), 5, warm=2)
+        row("cfg4 lda_sstats %dx100k K=128 (fused kernel)" % docs, w, k, 4.0 * docs * V,
             4.0 * docs * V * K4, "f32-mfma")
+        w, _ = timed(ctx, model.step, 3, warm=1)
+        row("cfg4 lda_step %dx100k K=128 (whole step, fused kernel)" % docs, w, float("nan"),
+            4.0 * docs * V, 4.0 * docs * V * K4, "f32-mfma")
+        ex = LDAFixedGammaSVI(C, gamma, lam, docs_total=50_000, ctx=ctx, via="executor")
+        w, _ = timed(ctx, ex.step, 3, warm=1)
+        row("cfg4 lda_step %dx100k K=128 (whole step, executor: 2 GEMMs + fused elementwise)" % docs,
+            w, float("nan"), 4.0 * docs * V, 4.0 * docs * V * K4, "f32-mfma")
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w"), indent=1)
 
