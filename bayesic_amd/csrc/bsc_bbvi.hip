@@ -23,16 +23,15 @@ namespace {
 constexpr int LS = 64;            // samples
 constexpr int LD = 256;           // column capacity
 constexpr int LT = 32;            // rows per tile
-constexpr int LSTR = LD + 8;      // LDS row stride (floats)
+constexpr int LSTR = LD + 4;      // LDS row stride (floats): 16 rows x 16 B reads hit 8 distinct 4-bank groups per 8 lanes
 constexpr int LR_BLOCK = 256;
-constexpr int TILE_FLOATS = LT * LSTR + 2 * LT;   // rows + y + g
+constexpr int TILE_FLOATS = LT * LSTR + LT;   // rows + y
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Stage {   // one wave's share of a tile in registers: 8 rows x 16 B per lane
     float4 x[8];
     float yv;
-    int gv;
 };
 
 template <bool FULL>
@@ -50,7 +49,6 @@ __device__ __forceinline__ void stage_load(Stage& st, const float* __restrict__ 
     const int64_t safe0 = rem > 0 ? row0 : 0;
     auto xs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + safe0 * ldx), 0, xrec, 0x00020000);
     auto ys = __builtin_amdgcn_make_buffer_rsrc((void*)(y + safe0), 0, yrec, 0x00020000);
-    auto gs = __builtin_amdgcn_make_buffer_rsrc((void*)(g + safe0), 0, yrec, 0x00020000);
     const int row_bytes = (int)(ldx * 4);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -60,19 +58,34 @@ __device__ __forceinline__ void stage_load(Stage& st, const float* __restrict__ 
         if (!FULL && 4 * lane >= D) f = make_float4(0.f, 0.f, 0.f, 0.f);
         st.x[r] = f;
     }
-    // wave 0 also brings the tile's y and g (lanes 0-31: y, lanes 32-63: g)
+    // wave 0 also brings the tile's y
     st.yv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ys, 4 * (lane & 31), 0, 0));
-    st.gv = (int)__builtin_amdgcn_raw_buffer_load_b32(gs, 4 * (lane & 31), 0, 0);
+}
+
+// The 8 group ids of the rows whose logits this lane ends up holding (MFMA result
+// rows 16 rb + 4 kq + r), clamped to [0, n_groups); rows past N read as group 0.
+__device__ __forceinline__ void load_groups(int (&gi)[8], const int* __restrict__ g, int64_t row0,
+                                            int64_t N, int kq, int n_groups) {
+    const int64_t rem = N - row0;
+    const uint64_t gb = rem > 0 ? (uint64_t)rem * 4u : 0;
+    const unsigned grec = gb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)gb;
+    auto gs = __builtin_amdgcn_make_buffer_rsrc((void*)(g + (rem > 0 ? row0 : 0)), 0, grec, 0x00020000);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(gs, 4 * (16 * rb + 4 * kq), 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int x = (int)v[r];
+            gi[4 * rb + r] = x < 0 ? 0 : (x >= n_groups ? n_groups - 1 : x);
+        }
+    }
 }
 
 __device__ __forceinline__ void stage_store(const Stage& st, float* tile, int wave, int lane) {
 #pragma unroll
     for (int r = 0; r < 8; ++r)
         *reinterpret_cast<float4*>(tile + (8 * wave + r) * LSTR + 4 * lane) = st.x[r];
-    if (wave == 0) {
-        if (lane < 32) tile[LT * LSTR + lane] = st.yv;
-        else reinterpret_cast<int*>(tile)[LT * LSTR + LT + (lane & 31)] = st.gv;
-    }
+    if (wave == 0 && lane < 32) tile[LT * LSTR + lane] = st.yv;
 }
 
 template <bool FULL>   // FULL: D == 256, no column masking
@@ -99,18 +112,39 @@ __global__ __launch_bounds__(LR_BLOCK, 2) void logreg_loglik_kernel(
     Stage st;
     stage_load<FULL>(st, X, ldx, y, g, tile * LT, N, D, wave, lane);
     stage_store(st, lds, wave, lane);
+    // The intercept b[g_n, s] is a gather that depends on the row's group id: requested
+    // when it is needed it costs a full memory round trip per tile with the MFMA pipe idle.
+    // So group ids run two tiles ahead and intercepts one tile ahead, in registers.
+    const float* bz_lane = Bz + 16 * wave + i16;
+    int gi[8];
+    float bz_a[8], bz_b[8];
+    load_groups(gi, g, tile * LT, N, kq, n_groups);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bz_a[e] = bz_lane[(int64_t)gi[e] * LS];
+    load_groups(gi, g, (tile + stride) * LT, N, kq, n_groups);
     __syncthreads();
     int cur = 0;
-    for (int it = 0; it < n_iter; ++it) {
+    // One tile.  bz_cur holds this tile's intercepts (requested a tile ago), bz_next
+    // receives the next tile's; the caller alternates the two register sets so that no
+    // copy (which would wait for the loads straight away) is needed.
+    auto one_tile = [&](const float (&bz_cur)[8], float (&bz_next)[8]) {
         stage_load<FULL>(st, X, ldx, y, g, (tile + stride) * LT, N, D, wave, lane);   // prefetch
         const float* t = lds + cur * TILE_FLOATS;
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        // A operands one k-group ahead in registers: the 8 MFMAs of group q (256 cycles)
+        // cover the LDS latency of group q+1.  The two row blocks alternate so that no
+        // MFMA waits on its predecessor (16x16x4: 32-cycle issue, 40-cycle dependent latency).
+        const float* ta = t + i16 * LSTR + 4 * kq;
+        float4 a0n = *reinterpret_cast<const float4*>(ta);
+        float4 a1n = *reinterpret_cast<const float4*>(ta + 16 * LSTR);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // the reads of group 0
 #pragma unroll
         for (int q = 0; q < LD / 16; ++q) {
-            // the two row blocks alternate so that no MFMA waits on its predecessor
-            // (16x16x4: 32-cycle issue, 40-cycle dependent-accumulator latency)
-            const float4 a0 = *reinterpret_cast<const float4*>(t + i16 * LSTR + 16 * q + 4 * kq);
-            const float4 a1 = *reinterpret_cast<const float4*>(t + (16 + i16) * LSTR + 16 * q + 4 * kq);
+            const float4 a0 = a0n, a1 = a1n;
+            if (q + 1 < LD / 16) {
+                a0n = *reinterpret_cast<const float4*>(ta + 16 * (q + 1));
+                a1n = *reinterpret_cast<const float4*>(ta + 16 * LSTR + 16 * (q + 1));
+            }
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wreg[4 * q + 0], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wreg[4 * q + 0], acc[1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wreg[4 * q + 1], acc[0], 0, 0, 0);
@@ -119,7 +153,14 @@ __global__ __launch_bounds__(LR_BLOCK, 2) void logreg_loglik_kernel(
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wreg[4 * q + 2], acc[1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wreg[4 * q + 3], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wreg[4 * q + 3], acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 LDS reads (group q+1) ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // ... then the 8 MFMAs of group q
         }
+        // next tile's intercepts (its group ids arrived during the MFMAs), then the ids
+        // of the tile after
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bz_next[e] = bz_lane[(int64_t)gi[e] * LS];
+        load_groups(gi, g, (tile + 2 * stride) * LT, N, kq, n_groups);
         // C/D map of 16x16x4: col = lane & 15 (sample), row = 4 * (lane >> 4) + reg
         const int64_t row0 = tile * LT;
 #pragma unroll
@@ -129,9 +170,7 @@ __global__ __launch_bounds__(LR_BLOCK, 2) void logreg_loglik_kernel(
                 const int row = 16 * rb + 4 * kq + r;
                 if (row0 + row < N) {
                     const float yv = t[LT * LSTR + row];
-                    int gi = reinterpret_cast<const int*>(t)[LT * LSTR + LT + row];
-                    gi = gi < 0 ? 0 : (gi >= n_groups ? n_groups - 1 : gi);
-                    const float l = acc[rb][r] + Bz[(int64_t)gi * LS + 16 * wave + i16];
+                    const float l = acc[rb][r] + bz_cur[4 * rb + r];
                     // y l - softplus(l),  softplus(l) = max(l,0) + log(1 + exp(-|l|)).  The
                     // hardware exp/log pair is accurate to ~1e-7 ABSOLUTE here (argument of
                     // the log is in (1, 2]), far inside the stated tolerance; log1pf would
@@ -143,6 +182,10 @@ __global__ __launch_bounds__(LR_BLOCK, 2) void logreg_loglik_kernel(
         __syncthreads();
         cur ^= 1;
         tile += stride;
+    };
+    for (int it = 0; it < n_iter; it += 2) {   // n_iter is even (host)
+        one_tile(bz_a, bz_b);
+        one_tile(bz_b, bz_a);
     }
     // lanes with the same sample (lane & 15) hold different rows: fold bits 4,5
     acc_ll += __shfl_xor(acc_ll, 16);
@@ -331,7 +374,7 @@ int bsc_logreg_bbvi_loglik(bsc_ctx* ctx, const float* X, int64_t ldx, const floa
     int n_iter = 0, n_blocks = 1;
     if (n_tiles > 0) {
         const int64_t it = (n_tiles + max_blocks - 1) / max_blocks;
-        n_iter = (int)it;
+        n_iter = (int)(it + (it & 1));   // even: the kernel alternates two register sets per tile pair
         n_blocks = (int)((n_tiles + it - 1) / it);
     }
     void* ws = nullptr;
