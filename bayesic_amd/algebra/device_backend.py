@@ -42,7 +42,8 @@ from .. import _ffi
 from ..device import Context, default_context
 from .backend import Backend
 
-_OPS = {"add": 0, "mul": 1, "log": 2, "exp": 3, "pow": 4, "abs_": 5, "copy": 6}
+_OPS = {"add": 0, "mul": 1, "log": 2, "exp": 3, "pow": 4, "abs_": 5, "copy": 6, "gammaln": 7,
+        "digamma": 8}
 _DT = {torch.float32: 0, torch.float64: 1}
 _MAX_RANK = 6
 
@@ -216,6 +217,11 @@ class DeviceBackend(Backend):
                     if not all(isinstance(v, int) and v >= 0 for v in values) else values[0] ** values[1]
             if op_name == "abs_":
                 return abs(values[0])
+            if op_name == "gammaln":
+                return math.lgamma(values[0])
+            if op_name == "digamma":
+                from scipy.special import digamma      # host scalars only (shape arithmetic)
+                return float(digamma(values[0]))
         raise ValueError("unknown elementwise op %r" % op_name)
 
     def _elemwise(self, op_name, args):

@@ -282,20 +282,8 @@ __global__ __launch_bounds__(1024) void mog_reduce_kernel(const float* __restric
     }
 }
 
-// digamma in float64: recurrence up to x >= 8, then the asymptotic series
 #pragma clang fp contract(off)
-__device__ double digamma_f64(double x) {
-    double acc = 0.0;
-    while (x < 8.0) {
-        acc -= 1.0 / x;
-        x += 1.0;
-    }
-    const double inv = 1.0 / x, inv2 = inv * inv;
-    // ln x - 1/2x - 1/12x^2 + 1/120x^4 - 1/252x^6 + 1/240x^8 - 5/660x^10 + 691/32760x^12
-    const double series = inv2 * (1.0 / 12.0 - inv2 * (1.0 / 120.0 - inv2 * (1.0 / 252.0 - inv2 *
-                          (1.0 / 240.0 - inv2 * (5.0 / 660.0 - inv2 * (691.0 / 32760.0))))));
-    return acc + log(x) - 0.5 * inv - series;
-}
+__device__ __forceinline__ double digamma_f64(double x) { return bsc_digamma_f64(x); }
 
 // eta layout: [alpha-1 (K) | kappa*m (K*D) | kappa (K*D) | 2a-1 (K*D) | 2b+kappa*m^2 (K*D)]
 // One workgroup; thread k owns component k.

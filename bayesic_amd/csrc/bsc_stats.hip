@@ -98,17 +98,7 @@ __global__ void natgrad_update_kernel(double* __restrict__ eta, const double* __
 // "SVI [4]" applied to a Dirichlet-Multinomial model).  Row sums in float64, fixed
 // order: one workgroup per row for the sum, then an element-wise pass.
 
-__device__ double digamma_f64_stats(double x) {
-    double acc = 0.0;
-    while (x < 8.0) {
-        acc -= 1.0 / x;
-        x += 1.0;
-    }
-    const double inv = 1.0 / x, inv2 = inv * inv;
-    const double series = inv2 * (1.0 / 12.0 - inv2 * (1.0 / 120.0 - inv2 * (1.0 / 252.0 - inv2 *
-                          (1.0 / 240.0 - inv2 * (5.0 / 660.0 - inv2 * (691.0 / 32760.0))))));
-    return acc + log(x) - 0.5 * inv - series;
-}
+__device__ __forceinline__ double digamma_f64_stats(double x) { return bsc_digamma_f64(x); }
 
 __global__ __launch_bounds__(1024) void row_sum_kernel(const float* __restrict__ lam, int64_t cols,
                                                        int64_t ld, double* __restrict__ row_psi) {

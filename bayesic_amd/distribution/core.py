@@ -62,6 +62,11 @@ class Normal(ExponentialFamily):
     def log_likelihood_data_term(self, data):
         return 0
 
+    def expected_sufficient_statistics(self, mean, variance):
+        """E[(x, x^2)] under N(mean, variance) -- what a mean-field message carries."""
+        mean, variance = A.wrap_if_literal(mean), A.wrap_if_literal(variance)
+        return mean, mean ** 2 + variance
+
 
 def _lead(n, *trailing):
     """Index list: n shared leading out axes followed by the given trailing indices."""

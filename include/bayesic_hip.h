@@ -251,7 +251,9 @@ typedef enum bsc_op {
     BSC_OP_EXP = 3,
     BSC_OP_POW = 4, /* in0 ** in1 */
     BSC_OP_ABS = 5,
-    BSC_OP_COPY = 6 /* materialise a strided view */
+    BSC_OP_COPY = 6, /* materialise a strided view */
+    BSC_OP_LGAMMA = 7,  /* log Gamma(x): unary, bsc_map_reduce only (log-normalisers of the */
+    BSC_OP_DIGAMMA = 8  /* Gamma / Dirichlet / Wishart nodes and their expectations)        */
 } bsc_op;
 
 /* out[i] = op(in_0[i], ..., in_{n-1}[i]) over the index space `shape`;
@@ -278,7 +280,7 @@ int bsc_sum(bsc_ctx* ctx, int dtype, int rank_keep, const int64_t* host_keep_sha
  *   v(keep, red) = post( scale * COMBINE_i pre_i( in_i[keep, red] ) + shift )
  *   out[keep]    = sum over red of v(keep, red)     (rank_red == 0: out[keep] = v(keep))
  * combine is BSC_OP_ADD or BSC_OP_MUL; pre_op[i] and post_op are BSC_OP_COPY, LOG,
- * EXP, ABS or POW (x ** arg, arg taken from pre_arg[i] / post_arg).  in_keep_strides
+ * EXP, ABS, LGAMMA, DIGAMMA or POW (x ** arg, arg taken from pre_arg[i] / post_arg).  in_keep_strides
  * is [n_in][rank_keep], in_red_strides [n_in][rank_red] (0 broadcasts); sums
  * accumulate in float64 in a fixed order. */
 int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,

@@ -61,6 +61,12 @@ class NumpyBackend(Backend):
                 return np.power(args[0], args[1])
             if op_name == "abs_":
                 return np.abs(args[0])
+            if op_name == "gammaln":
+                from scipy.special import gammaln
+                return gammaln(args[0])
+            if op_name == "digamma":
+                from scipy.special import digamma
+                return digamma(args[0])
         raise ValueError("unknown elementwise op %r" % op_name)
 
     def sum(self, x, axes):
