@@ -58,7 +58,11 @@ class Backend(object):
         raise NotImplementedError
 
     # -- tree walk -------------------------------------------------------------
-    def evaluate(self, expr, inputs):
+    def evaluate(self, expr, inputs, bindings=None):
+        """Post-order walk.  ``bindings`` maps sub-expressions (by value) to input
+        names: such a node is not computed but read from ``inputs`` -- how a mean-field
+        update substitutes E[t(z)] for the statistic t(z) of another latent
+        (bayesic_amd/inference/vmp.py)."""
         from .einsum_form import Einsum
         from .expr import var
         done = {}
@@ -67,7 +71,9 @@ class Backend(object):
             key = id(node)
             if key in done:
                 return done[key]
-            if isinstance(node, var):
+            if bindings and not isinstance(node, var) and node in bindings:
+                value = inputs[bindings[node]]
+            elif isinstance(node, var):
                 value = inputs[node.name]
             elif isinstance(node, Einsum):
                 value = visit(node.lowered())
@@ -83,19 +89,26 @@ class Backend(object):
             # value alive until the cyclic garbage collector runs
             done.clear()
 
-    def compile(self, expr):
-        types = expr.input_types
+    def compile(self, expr, bindings=None):
+        """``bindings``: {sub-expression: input name}; the named inputs (float, of the
+        sub-expression's ndim) replace those sub-expressions (see ``evaluate``)."""
+        types = dict(expr.input_types)
+        bindings = dict(bindings or {})
+        for sub, name in bindings.items():
+            types[name] = ("float32", sub.ndim)
         backend = self
 
         def device_fn(**device_inputs):
-            return backend.evaluate(expr, device_inputs)
+            return backend.evaluate(expr, device_inputs, bindings) if bindings \
+                else backend.evaluate(expr, device_inputs)
 
         def f(**inputs):
-            missing = [n for n in types if n not in inputs]
-            if missing:
-                raise TypeError("missing inputs: %s" % ", ".join(sorted(missing)))
-            bound = {n: backend.from_host(inputs[n], *types[n]) for n in types}
-            out = backend.to_host(device_fn(**bound))
+            # inputs that only occur inside bound sub-expressions are not needed
+            bound = {n: backend.from_host(inputs[n], *types[n]) for n in types if n in inputs}
+            try:
+                out = backend.to_host(device_fn(**bound))
+            except KeyError as e:
+                raise TypeError("missing input: %s" % e.args[0])
             if getattr(out, "ndim", 0) == 0 and expr.ndim > 0:
                 # a broadcast scalar (e.g. einsum([], 2)): all axes are broadcastable
                 out = out.reshape((1,) * expr.ndim)

@@ -111,6 +111,9 @@ class DeviceBackend(Backend):
         a = np.asarray(array)
         if a.ndim != ndim:
             raise ValueError("input has ndim %d, expected %d" % (a.ndim, ndim))
+        if ndim == 0 and np.dtype(dtype).kind == "f":
+            # scalar parameters travel as kernel arguments (double), not as device tensors
+            return HostScalar(float(a))
         if np.dtype(dtype).kind in "iub":
             if ndim == 0:
                 return HostScalar(int(a))
@@ -335,7 +338,7 @@ class DeviceBackend(Backend):
                    shift=0.0 if mul else coef)
         return out if self.fuse else self._launch(out)
 
-    def evaluate(self, expr, inputs):
+    def evaluate(self, expr, inputs, bindings=None):
         entry = self._plans.get(id(expr))
         if entry is None or entry[0] is not expr:
             if len(self._plans) >= self._MAX_PLANS:
@@ -343,7 +346,7 @@ class DeviceBackend(Backend):
             entry = self._plans[id(expr)] = [expr, []]
         self._plan, self._cursor = entry[1], 0
         try:
-            out = self._force(Backend.evaluate(self, expr, inputs))
+            out = self._force(Backend.evaluate(self, expr, inputs, bindings))
         finally:
             plan, self._plan = self._plan, None
         if isinstance(out, torch.Tensor):

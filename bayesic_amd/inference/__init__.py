@@ -1,0 +1,8 @@
+"""Conjugacy detection and mean-field / VMP update synthesis from a symbolic
+log-joint (the purpose bayesic/algebra.py:1-6 and
+README.md:30-37 state for the algebra front end)."""
+from .conjugacy import (NotConjugate, conjugate_coefficients, depends_on, expand_terms)
+from .vmp import GammaNode, MeanFieldVMP, NormalNode
+
+__all__ = ["NotConjugate", "conjugate_coefficients", "depends_on", "expand_terms",
+           "MeanFieldVMP", "NormalNode", "GammaNode"]

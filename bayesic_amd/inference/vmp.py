@@ -1,0 +1,178 @@
+"""Mean-field variational message passing synthesised from a symbolic log-joint.
+
+For every latent node the coefficients of its sufficient statistics are read off
+the log-joint once (``conjugate_coefficients``); an update of q(z) is then
+
+    eta_j(z)  <-  E_{q(others)}[ c_j ]
+
+(README.md:36: "a traditional variational message passing update (equivalently a
+unit-step natural gradient update)"), with rho < 1 giving the damped / stochastic
+natural-gradient step of README.md:69-79.  The expectation is taken by BINDING:
+c_j is multilinear in the other latents' statistics t_k(w) (that is what conjugacy
+of the whole blanket means), so evaluating it with every sub-expression t_k(w)
+replaced by the number E_q[t_k(w)] is exact.  The data-sized parts of c_j (sums over
+observations) run through the executor -- on the MI355X backend as fused map-reduce
+launches over the resident data.
+
+Model-writing rule (the usual VMP one): a latent must enter the log-joint only
+through the statistic expressions its node declares, e.g. ``mu ** 2`` and not
+``mu * mu`` for a Normal node -- the product form is bilinear in mu and binding
+E[mu] twice would give E[mu]^2.
+"""
+import math
+
+import numpy as np
+
+from .. import algebra as A
+from ..distribution.special import digamma  # noqa: F401  (documented dependency of GammaNode)
+from .conjugacy import conjugate_coefficients
+
+
+class LatentNode(object):
+    """A latent variable with an exponential-family variational distribution."""
+
+    def __init__(self, variable):
+        self.var = variable
+        self.eta = None
+
+    @property
+    def statistics(self):
+        raise NotImplementedError
+
+    def expectations(self):
+        """E_q[t_j(z)] for the current natural parameters, as numpy arrays."""
+        raise NotImplementedError
+
+
+class NormalNode(LatentNode):
+    """q(z) = N(mean, variance), element-wise over z's shape: t = (z, z^2),
+    eta = (mean / variance, -1 / (2 variance))."""
+
+    def __init__(self, variable, mean=0.0, variance=1.0):
+        LatentNode.__init__(self, variable)
+        self.set(mean, variance)
+
+    @property
+    def statistics(self):
+        return (self.var, self.var ** 2)
+
+    def set(self, mean, variance):
+        mean, variance = np.asarray(mean, np.float64), np.asarray(variance, np.float64)
+        self.eta = [mean / variance, -0.5 / variance]
+
+    @property
+    def variance(self):
+        return -0.5 / self.eta[1]
+
+    @property
+    def mean(self):
+        return self.eta[0] * self.variance
+
+    def expectations(self):
+        return [self.mean, self.mean ** 2 + self.variance]
+
+
+class GammaNode(LatentNode):
+    """q(z) = Gamma(shape a, rate b): t = (log z, z), eta = (a - 1, -b)."""
+
+    def __init__(self, variable, shape=1.0, rate=1.0):
+        LatentNode.__init__(self, variable)
+        self.eta = [np.asarray(shape, np.float64) - 1.0, -np.asarray(rate, np.float64)]
+
+    @property
+    def statistics(self):
+        return (A.log(self.var), self.var)
+
+    @property
+    def shape(self):
+        return self.eta[0] + 1.0
+
+    @property
+    def rate(self):
+        return -self.eta[1]
+
+    def expectations(self):
+        from scipy.special import digamma as psi       # parameter-sized, host side
+        return [psi(self.shape) - np.log(self.rate), self.shape / self.rate]
+
+
+class MeanFieldVMP(object):
+    """Coordinate-ascent mean field on a conjugate-exponential log-joint.
+
+    log_joint : scalar expression (or list of summands) over the data and latent vars
+    nodes     : LatentNode objects, updated in this order by ``sweep``
+    data      : {input name: array}; uploaded to the backend once
+    Raises NotConjugate at construction when a node is not conjugate in its blanket.
+    """
+
+    def __init__(self, log_joint, nodes, data, backend=None):
+        from ..algebra.backend import resolve_backend
+        self.backend = resolve_backend(backend)
+        self.nodes = list(nodes)
+        self._by_name = {n.var.name: n for n in self.nodes}
+        self._messages = {}
+        for node in self.nodes:
+            coefficients, _ = conjugate_coefficients(log_joint, node.var, node.statistics)
+            others = [m for m in self.nodes if m is not node]
+            compiled = []
+            for c in coefficients:
+                if c is None:
+                    compiled.append(None)
+                    continue
+                bindings = {}
+                for m in others:
+                    for k, t in enumerate(m.statistics):
+                        if t is m.var:
+                            continue                 # the identity statistic binds the var itself
+                        bindings[t] = "_E_%s_%d" % (m.var.name, k)
+                compiled.append((c, self.backend.compile(c, bindings), bindings))
+            self._messages[node.var.name] = compiled
+        types = {}
+        for compiled in self._messages.values():
+            for entry in compiled:
+                if entry is not None:
+                    types.update(entry[0].input_types)
+        self._data = {name: self.backend.from_host(value, *types[name])
+                      for name, value in data.items() if name in types}
+        missing = [n for n in types if n not in self._data and n not in self._by_name]
+        if missing:
+            raise TypeError("log-joint inputs neither given as data nor declared latent: %s"
+                            % ", ".join(sorted(missing)))
+
+    def _expectation_inputs(self, exclude):
+        values = {}
+        for m in self.nodes:
+            if m is exclude:
+                continue
+            for k, (t, e) in enumerate(zip(m.statistics, m.expectations())):
+                name = m.var.name if t is m.var else "_E_%s_%d" % (m.var.name, k)
+                values[name] = self.backend.from_host(np.asarray(e, np.float64), "float32", t.ndim)
+        return values
+
+    def message(self, name):
+        """E_q(others)[c_j] for node `name`: the natural parameters VMP assigns to it."""
+        node = self._by_name[name]
+        inputs = dict(self._data)
+        inputs.update(self._expectation_inputs(node))
+        out = []
+        for entry in self._messages[name]:
+            if entry is None:
+                out.append(None)
+                continue
+            c, f, _ = entry
+            needed = {k: v for k, v in inputs.items()}
+            out.append(np.asarray(self.backend.to_host(f.device_fn(**needed)), np.float64))
+        return out
+
+    def update(self, name, rho=1.0):
+        """eta <- (1 - rho) eta + rho * message; rho = 1 is the VMP update."""
+        node = self._by_name[name]
+        message = self.message(name)
+        for j, m in enumerate(message):
+            if m is not None:
+                node.eta[j] = (1.0 - rho) * node.eta[j] + rho * m.reshape(np.shape(node.eta[j]))
+        return node
+
+    def sweep(self, rho=1.0):
+        for node in self.nodes:
+            self.update(node.var.name, rho)

@@ -1,0 +1,163 @@
+"""Conjugacy detection with ``match`` and the mean-field / VMP updates synthesised from
+it (intent: bayesic/algebra.py:1-6, README.md:30-37).  The
+reference has no inference code, so the pins are closed-form posteriors and the
+textbook coordinate-ascent updates.  CPU: float64 numpy backend of the oracle."""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from bayesic_amd import algebra as A
+from bayesic_amd.distribution import Dirichlet, Normal
+from bayesic_amd.inference import (GammaNode, MeanFieldVMP, NormalNode, NotConjugate,
+                                   conjugate_coefficients, expand_terms)
+from oracle.einsum_eval import NumpyBackend
+
+B64 = NumpyBackend(np.float64)
+rs = np.random.RandomState(21)
+
+
+def run(expr, **inputs):
+    return expr.compile(B64)(**inputs)
+
+
+def f64(name, ndim):
+    return A.var(name, ndim, "float64")
+
+
+def test_expand_terms_distributes_products_and_sums_over_add():
+    X, Y, Z = f64("X", 2), f64("Y", 2), f64("Z", 2)
+    vals = dict(X=rs.standard_normal((3, 4)), Y=rs.standard_normal((3, 4)), Z=rs.standard_normal((3, 4)))
+    e = A.sum((X + Y) * (Z - 2 * X)) - 3 * A.sum(Y + 1)
+    terms = expand_terms(e)
+    assert len(terms) == 6
+    assert all(not isinstance(f, A.add) for t in terms if isinstance(t, A.Einsum)
+               for f, _ in t.factors_and_indices)
+    total = sum(float(run(t, **{k: vals[k] for k in t.input_types})) for t in terms)
+    npt.assert_allclose(total, run(e, **vals), rtol=1e-12)
+    assert expand_terms(X) == [X]
+    # a broadcast summand under a sum: sum_n (x_n + 1) mu  =  mu sum_n x_n  +  N mu
+    x, mu = f64("x", 1), f64("mu", 0)
+    xs = rs.standard_normal(7)
+    pieces = expand_terms(A.sum((x + 1) * mu))
+    assert len(pieces) == 2
+    npt.assert_allclose(sum(float(run(t, x=xs, mu=0.4)) for t in pieces), 0.4 * (xs.sum() + 7),
+                        rtol=1e-12)
+    (c, _), _ = conjugate_coefficients(A.sum((x + 1) * mu), mu, (mu, mu ** 2))
+    npt.assert_allclose(run(c, x=xs), xs.sum() + 7, rtol=1e-12)
+
+
+def normal_gamma_log_joint(x, mu, tau, m0, v0, a0, b0):
+    """x_n ~ N(mu, 1/tau), mu ~ N(m0, v0), tau ~ Gamma(a0, rate b0); constants dropped."""
+    N = A.shape(x, 0)
+    lik = A.sum(x * mu * tau) + A.sum(x * x * (-0.5 * tau)) \
+        - N * (0.5 * (mu ** 2) * tau - 0.5 * A.log(tau))
+    prior_mu = mu * (m0 / v0) + (mu ** 2) * (-0.5 / v0)
+    prior_tau = (a0 - 1.0) * A.log(tau) - b0 * tau
+    return lik + prior_mu + prior_tau
+
+
+def test_coefficients_of_the_normal_gamma_model():
+    x, mu, tau = f64("x", 1), f64("mu", 0), f64("tau", 0)
+    lj = normal_gamma_log_joint(x, mu, tau, 0.5, 4.0, 2.0, 3.0)
+    xs = rs.standard_normal(50) * 0.7 + 1.0
+    (c1, c2), rest = conjugate_coefficients(lj, mu, (mu, mu ** 2))
+    npt.assert_allclose(run(c1, x=xs, tau=1.7), 1.7 * xs.sum() + 0.5 / 4.0, rtol=1e-12)
+    npt.assert_allclose(run(c2, x=xs, tau=1.7), -0.5 * 50 * 1.7 - 0.5 / 4.0, rtol=1e-12)
+    assert all("mu" not in t.input_types for t in rest)
+    (d1, d2), _ = conjugate_coefficients(lj, tau, (A.log(tau), tau))
+    npt.assert_allclose(run(d1, x=xs), 0.5 * 50 + 2.0 - 1.0, rtol=1e-12)
+    # E[...] is taken by binding mu and mu ** 2 separately; here a point value binds both
+    npt.assert_allclose(run(d2, x=xs, mu=0.3), 0.3 * xs.sum() - 0.5 * (xs ** 2).sum()
+                        - 0.5 * 50 * 0.09 - 3.0, rtol=1e-12)
+
+
+def test_known_variance_normal_mean_lands_on_the_exact_posterior():
+    """Built from the Distribution nodes: one unit-step update IS the posterior
+    (README.md:36)."""
+    x, mu = f64("x", 1), f64("mu", 0)
+    v, m0, v0 = 2.5, -1.0, 9.0
+    xs = rs.standard_normal(200) * np.sqrt(v) + 3.0
+    lj = Normal().iid(1).log_likelihood(x, mean=mu, variance=v) \
+        + Normal().log_likelihood(mu, mean=m0, variance=v0)
+    node = NormalNode(mu)
+    vmp = MeanFieldVMP(lj, [node], {"x": xs}, backend=B64)
+    vmp.sweep()
+    post_prec = 1.0 / v0 + len(xs) / v
+    npt.assert_allclose(node.variance, 1.0 / post_prec, rtol=1e-12)
+    npt.assert_allclose(node.mean, (m0 / v0 + xs.sum() / v) / post_prec, rtol=1e-12)
+    # a damped step is the convex combination in natural parameters (SVI, README.md:69-79)
+    node2 = NormalNode(mu, mean=0.0, variance=1.0)
+    vmp2 = MeanFieldVMP(lj, [node2], {"x": xs}, backend=B64)
+    vmp2.update("mu", rho=0.25)
+    npt.assert_allclose(node2.eta[1], 0.75 * (-0.5) + 0.25 * (-0.5 * post_prec), rtol=1e-12)
+
+
+def reference_mean_field(xs, m0, v0, a0, b0, sweeps):
+    """Textbook coordinate ascent for q(mu) q(tau) (e.g. Bishop 10.1.3, independent priors)."""
+    N, sx, sxx = len(xs), xs.sum(), (xs ** 2).sum()
+    e_tau = 1.0
+    for _ in range(sweeps):
+        prec = 1.0 / v0 + N * e_tau
+        m = (m0 / v0 + e_tau * sx) / prec
+        e_mu, e_mu2 = m, m * m + 1.0 / prec
+        a = a0 + 0.5 * N
+        b = b0 + 0.5 * (sxx - 2.0 * e_mu * sx + N * e_mu2)
+        e_tau = a / b
+    return m, 1.0 / prec, a, b
+
+
+def test_mean_field_normal_gamma_matches_textbook_updates():
+    x, mu, tau = f64("x", 1), f64("mu", 0), f64("tau", 0)
+    xs = 2.0 + 1.5 * rs.standard_normal(500)
+    m0, v0, a0, b0 = 0.0, 100.0, 1.0, 1.0
+    lj = normal_gamma_log_joint(x, mu, tau, m0, v0, a0, b0)
+    q_mu, q_tau = NormalNode(mu), GammaNode(tau, shape=1.0, rate=1.0)
+    vmp = MeanFieldVMP(lj, [q_mu, q_tau], {"x": xs}, backend=B64)
+    for _ in range(15):
+        vmp.sweep()
+    m, v, a, b = reference_mean_field(xs, m0, v0, a0, b0, 15)
+    npt.assert_allclose([q_mu.mean, q_mu.variance, q_tau.shape, q_tau.rate], [m, v, a, b], rtol=1e-10)
+    # and it found the data: posterior mean ~ sample mean, E[tau] ~ 1 / sample variance
+    npt.assert_allclose(q_mu.mean, xs.mean(), rtol=1e-2)
+    npt.assert_allclose(q_tau.shape / q_tau.rate, 1.0 / xs.var(), rtol=2e-2)
+
+
+def test_dirichlet_categorical_counts():
+    X, theta = f64("X", 2), f64("theta", 1)
+    alpha0 = np.array([0.5, 1.0, 2.0, 4.0])
+    onehot = np.eye(4)[rs.randint(0, 4, 60)]
+    lj = A.sum(X * A.dimshuffle(A.log(theta), "x", 0)) \
+        + Dirichlet().log_likelihood(theta, concentration=A.constant(alpha0))
+    (c,), rest = conjugate_coefficients(lj, theta, (A.log(theta),))
+    npt.assert_allclose(run(c, X=onehot), onehot.sum(0) + alpha0 - 1.0, rtol=1e-12)
+
+
+def test_non_conjugate_terms_are_reported():
+    x, w = f64("x", 1), f64("w", 0)
+    lj = A.sum(A.log(1 + A.exp(x * w))) + w * 0.3
+    with pytest.raises(NotConjugate) as info:
+        conjugate_coefficients(lj, w, (w, w ** 2))
+    assert "w" in info.value.term.input_types
+    # bilinear use of a latent (mu * mu instead of the declared statistic mu ** 2)
+    mu = f64("mu", 0)
+    with pytest.raises(NotConjugate):
+        conjugate_coefficients(A.sum(x * mu * mu), mu, (mu, mu ** 2))
+    with pytest.raises(TypeError):          # an input that is neither data nor latent
+        MeanFieldVMP(A.sum(x * mu) + (mu ** 2) * w, [NormalNode(mu)], {"x": np.ones(3)}, backend=B64)
+
+
+@pytest.mark.gpu
+def test_mean_field_normal_gamma_on_device(ctx):
+    """BASELINE config 1's data (N = 10 000) through the MI355X backend: the data-sized
+    messages are fused map-reduce launches over the resident x; float32 data."""
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from oracle import svi
+    xs = np.asarray(svi.make_cfg1(), np.float32)
+    x, mu, tau = A.var("x", 1), A.var("mu", 0), A.var("tau", 0)
+    lj = normal_gamma_log_joint(x, mu, tau, 0.0, 100.0, 1.0, 1.0)
+    q_mu, q_tau = NormalNode(mu), GammaNode(tau)
+    vmp = MeanFieldVMP(lj, [q_mu, q_tau], {"x": xs}, backend=DeviceBackend(ctx))
+    for _ in range(10):
+        vmp.sweep()
+    m, v, a, b = reference_mean_field(xs.astype(np.float64), 0.0, 100.0, 1.0, 1.0, 10)
+    npt.assert_allclose([q_mu.mean, q_mu.variance, q_tau.shape, q_tau.rate], [m, v, a, b], rtol=2e-5)
