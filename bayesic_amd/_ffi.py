@@ -83,6 +83,8 @@ SIGNATURES = {
                         POINTER(c_int64), POINTER(c_int64), c_void_p, c_void_p]),
     "bsc_lda_sstats": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p,
                                c_int64, c_void_p, c_int64, c_void_p, c_int64]),
+    "bsc_lda_sstats_csc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32,
+                                   c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
     "bsc_map_reduce": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int64), c_int,
                                POINTER(c_int64), c_int, POINTER(c_void_p), POINTER(c_int64),
                                POINTER(c_int64), POINTER(c_int32), POINTER(c_double), c_double,

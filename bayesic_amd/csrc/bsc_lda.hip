@@ -236,6 +236,110 @@ __global__ __launch_bounds__(256) void lda_reduce_kernel(const float* __restrict
     }
 }
 
+// ---- sparse counts (compressed sparse COLUMN): one pass over the nonzeros ----------
+//
+// Real bag-of-words data is ~1 % dense; the dense kernel above spends its MFMAs on
+// zeros.  Here a workgroup owns 64 consecutive words (16 per wave); a word's
+// nonzeros (document id, count) are walked four at a time, one per 16-lane group,
+// each lane holding K/16 consecutive topics of that document's Th row:
+//   p = <Th[d,:], Bt[:,v]>  (in-lane partial + 4 DPP adds inside the 16-lane row)
+//   acc[k] += Th[d,k] * c / p
+// No atomics: a word belongs to one wave, groups combine in a fixed order at the end.
+// Bound: L2 -> CU traffic of the Th rows (4K bytes per nonzero; Th itself is
+// docs x K and stays L2-resident) and ~8 VALU instructions per nonzero.
+constexpr int CSC_WORDS = 64;          // words per workgroup
+constexpr int CSC_LD = CSC_WORDS + 1;  // Bt / result tile row stride in LDS
+
+struct LdaCscArgs {
+    const int64_t* colptr;
+    const int32_t* rowidx;
+    const float* vals;
+    const float* Th;
+    const float* Bt;
+    float* out;
+    int64_t ldth, ldb, ldo, docs, V;
+    int vec_th;
+};
+
+template <int KPL>   // topics per lane; K = 16 * KPL
+__global__ __launch_bounds__(LDA_BLOCK) void lda_sstats_csc_kernel(LdaCscArgs a) {
+    constexpr int K = 16 * KPL;
+    __shared__ float tile[K * CSC_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, gl = lane & 15;
+    const int64_t v_base = (int64_t)blockIdx.x * CSC_WORDS;
+
+    for (int i = tid; i < K * CSC_WORDS; i += LDA_BLOCK) {   // Bt[:, v_base .. +63], coalesced rows
+        const int k = i / CSC_WORDS, c = i % CSC_WORDS;
+        tile[k * CSC_LD + c] = v_base + c < a.V ? a.Bt[(int64_t)k * a.ldb + v_base + c] : 0.f;
+    }
+    __syncthreads();
+
+    for (int w = 0; w < CSC_WORDS / 4; ++w) {
+        const int c = 16 * wave + w;
+        const int64_t v = v_base + c;
+        if (v >= a.V) break;                                  // uniform per wave
+        float bt[KPL], acc[KPL];
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            bt[i] = tile[(gl * KPL + i) * CSC_LD + c];
+            acc[i] = 0.f;
+        }
+        const int64_t begin = a.colptr[v], end = a.colptr[v + 1];
+        for (int64_t j0 = begin; j0 < end; j0 += 8) {
+            // two nonzeros per 16-lane group in flight
+            float th[2][KPL], cnt[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t j = j0 + 4 * u + g;
+                const bool ok = j < end;
+                const int64_t jj = ok ? j : begin;            // a valid address either way
+                int64_t d = a.rowidx[jj];
+                d = d < 0 ? 0 : (d >= a.docs ? a.docs - 1 : d);
+                cnt[u] = ok ? a.vals[jj] : 0.f;
+                const float* row = a.Th + d * a.ldth + gl * KPL;
+                if (KPL % 4 == 0 && a.vec_th) {
+#pragma unroll
+                    for (int q = 0; q < KPL / 4; ++q) {
+                        const float4 t = reinterpret_cast<const float4*>(row)[q];
+                        th[u][4 * q + 0] = t.x; th[u][4 * q + 1] = t.y;
+                        th[u][4 * q + 2] = t.z; th[u][4 * q + 3] = t.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < KPL; ++i) th[u][i] = row[i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float p = 0.f;
+#pragma unroll
+                for (int i = 0; i < KPL; ++i) p += th[u][i] * bt[i];
+                p = row16_allsum(p);
+                const float r = cnt[u] != 0.f ? cnt[u] / p : 0.f;
+#pragma unroll
+                for (int i = 0; i < KPL; ++i) acc[i] += th[u][i] * r;
+            }
+        }
+        // the four groups saw disjoint nonzeros of this word: fold them (fixed order)
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            acc[i] += __shfl_xor(acc[i], 16);
+            acc[i] += __shfl_xor(acc[i], 32);
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) tile[(gl * KPL + i) * CSC_LD + c] = acc[i] * bt[i];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < K * CSC_WORDS; i += LDA_BLOCK) {
+        const int k = i / CSC_WORDS, c = i % CSC_WORDS;
+        if (v_base + c < a.V) a.out[(int64_t)k * a.ldo + v_base + c] = tile[k * CSC_LD + c];
+    }
+}
+
 template <int KT>
 void launch_lda(bsc_ctx* ctx, const LdaArgs& a, dim3 grid) {
     hipLaunchKernelGGL(lda_sstats_kernel<KT>, grid, dim3(LDA_BLOCK), 0, ctx->stream, a);
@@ -312,6 +416,36 @@ int bsc_lda_sstats(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int6
                            partial, best, (int64_t)K, V, Bt, ldb, sstats, ldo);
         BSC_LAUNCH_CHECK();
     }
+    return BSC_OK;
+}
+
+int bsc_lda_sstats_csc(bsc_ctx* ctx, const int64_t* colptr, const int32_t* rowidx, const float* vals,
+                       int64_t docs, int64_t V, int32_t K, const float* Th, int64_t ldth,
+                       const float* Bt, int64_t ldb, float* sstats, int64_t ldo) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(docs >= 0 && V >= 0 && K > 0, "bsc_lda_sstats_csc: bad extents");
+    if (K % 32 != 0 || K > 128)
+        return bsc_fail(BSC_ERR_UNSUPPORTED,
+                        "bsc_lda_sstats_csc: K must be 32, 64, 96 or 128 (got %d)", K);
+    if (V == 0) return BSC_OK;
+    BSC_REQUIRE(colptr && Bt && sstats, "bsc_lda_sstats_csc: null pointer");
+    BSC_REQUIRE(ldth >= K && ldb >= V && ldo >= V, "bsc_lda_sstats_csc: leading dimension");
+    LdaCscArgs a{};
+    a.colptr = colptr; a.rowidx = rowidx; a.vals = vals;
+    a.Th = Th; a.Bt = Bt; a.out = sstats;
+    a.ldth = ldth; a.ldb = ldb; a.ldo = ldo; a.docs = docs; a.V = V;
+    a.vec_th = (ldth % 4 == 0) && (((uintptr_t)Th) & 15) == 0;
+    const dim3 grid((unsigned)((V + CSC_WORDS - 1) / CSC_WORDS));
+    {
+        bsc_prof_scope prof(ctx);
+        switch (K / 32) {
+            case 1: hipLaunchKernelGGL(lda_sstats_csc_kernel<2>, grid, dim3(LDA_BLOCK), 0, ctx->stream, a); break;
+            case 2: hipLaunchKernelGGL(lda_sstats_csc_kernel<4>, grid, dim3(LDA_BLOCK), 0, ctx->stream, a); break;
+            case 3: hipLaunchKernelGGL(lda_sstats_csc_kernel<6>, grid, dim3(LDA_BLOCK), 0, ctx->stream, a); break;
+            default: hipLaunchKernelGGL(lda_sstats_csc_kernel<8>, grid, dim3(LDA_BLOCK), 0, ctx->stream, a); break;
+        }
+    }
+    BSC_LAUNCH_CHECK();
     return BSC_OK;
 }
 

@@ -11,8 +11,10 @@ Two device paths compute it.  ``via="kernel"`` (default when K is 32, 64, 96 or
 no docs x V intermediate.  ``via="executor"`` builds the expression ONCE with
 the algebra front end and evaluates it on the MI355X backend (two fp32 MFMA
 GEMMs + fused element-wise launches) -- any K, and the cross-check of the fused
-kernel.  The Dirichlet expectation and the natural-gradient step on lambda
-[K, V] are their own kernels.  Data-parallel over documents: one all-reduce of sstats (K*V float32,
+kernel.  ``via="csc"`` (default when C is a scipy.sparse matrix) keeps the counts
+in compressed-sparse-column form and walks only the nonzeros (bsc_lda_sstats_csc).
+The Dirichlet expectation and the natural-gradient step on lambda [K, V] are their
+own kernels.  Data-parallel over documents: one all-reduce of sstats (K*V float32,
 51.2 MB at K=128, V=100k) per update.
 """
 import torch
@@ -27,13 +29,32 @@ class LDAFixedGammaSVI:
         self.ctx = ctx or default_context()
         dev = self.ctx.device
         f32 = torch.float32
-        self.C = C if isinstance(C, torch.Tensor) else torch.as_tensor(C, dtype=f32).to(dev)
+        self._csc = None
+        try:
+            import scipy.sparse as sparse
+            is_sparse = sparse.issparse(C)
+        except ImportError:
+            is_sparse = False
+        if is_sparse:
+            if via not in (None, "csc"):
+                raise ValueError("sparse counts need via='csc'")
+            via = "csc"
+            csc = C.tocsc()
+            csc.sum_duplicates()
+            self._csc = (torch.as_tensor(csc.indptr.astype("int64")).to(dev),
+                         torch.as_tensor(csc.indices.astype("int32")).to(dev),
+                         torch.as_tensor(csc.data.astype("float32")).to(dev))
+            self.C = None
+            shape_C = csc.shape
+        else:
+            self.C = C if isinstance(C, torch.Tensor) else torch.as_tensor(C, dtype=f32).to(dev)
+            shape_C = tuple(self.C.shape)
         gamma = gamma if isinstance(gamma, torch.Tensor) else torch.as_tensor(gamma, dtype=f32).to(dev)
         self.lam = (lam0 if isinstance(lam0, torch.Tensor)
                     else torch.as_tensor(lam0, dtype=f32).to(dev)).clone().contiguous()
-        if self.C.dtype != f32 or gamma.dtype != f32 or self.lam.dtype != f32:
+        if (self.C is not None and self.C.dtype != f32) or gamma.dtype != f32 or self.lam.dtype != f32:
             raise TypeError("C, gamma and lambda must be float32")
-        self.docs, self.V = self.C.shape
+        self.docs, self.V = shape_C
         self.K = self.lam.shape[0]
         if gamma.shape != (self.docs, self.K) or self.lam.shape != (self.K, self.V):
             raise ValueError("shapes: C [docs, V], gamma [docs, K], lambda [K, V]")
@@ -58,17 +79,24 @@ class LDAFixedGammaSVI:
         self._sstats_fn = self.expr.compile(self.backend).device_fn
         if via is None:
             via = "kernel" if self.K in (32, 64, 96, 128) else "executor"
-        if via not in ("kernel", "executor"):
-            raise ValueError("via must be 'kernel' or 'executor'")
+        if via not in ("kernel", "executor", "csc"):
+            raise ValueError("via must be 'kernel', 'executor' or 'csc'")
+        if via == "csc" and self._csc is None:
+            raise ValueError("via='csc' needs a scipy.sparse count matrix")
         self.via = via
-        self.C = self.C if self.C.stride(1) == 1 else self.C.contiguous()
+        if self.C is not None and self.C.stride(1) != 1:
+            self.C = self.C.contiguous()
         self.sstats = torch.zeros((self.K, self.V), dtype=f32, device=dev)
         self.t = 0
 
     def local_step(self):
         """sstats = Bt * dot(Th.T, C / dot(Th, Bt)) for the current lambda."""
         self.ctx.call("bsc_dirichlet_expectation", self.lam, self.K, self.V, self.V, self.Bt)
-        if self.via == "kernel":
+        if self.via == "csc":
+            colptr, rowidx, vals = self._csc
+            self.ctx.call("bsc_lda_sstats_csc", colptr, rowidx, vals, self.docs, self.V, self.K,
+                          self.Th, self.K, self.Bt, self.V, self.sstats, self.V)
+        elif self.via == "kernel":
             self.ctx.call("bsc_lda_sstats", self.C, self.C.stride(0), self.docs, self.V, self.K,
                           self.Th, self.K, self.Bt, self.V, self.sstats, self.V)
         else:

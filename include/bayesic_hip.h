@@ -181,6 +181,14 @@ int bsc_lda_sstats(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int6
                    const float* Th, int64_t ldth, const float* Bt, int64_t ldb, float* sstats,
                    int64_t ldo);
 
+/* The same statistic from SPARSE counts in compressed-sparse-column form (column v =
+ * word v: colptr[V+1] offsets into rowidx (document ids) / vals (counts)): one pass over
+ * the nonzeros, no atomics, fixed summation order.  Real bag-of-words data is ~1 % dense
+ * (SURVEY.md 8(f) rank 4); explicit zeros contribute nothing.  Same K limits. */
+int bsc_lda_sstats_csc(bsc_ctx* ctx, const int64_t* colptr, const int32_t* rowidx, const float* vals,
+                       int64_t docs, int64_t V, int32_t K, const float* Th, int64_t ldth,
+                       const float* Bt, int64_t ldb, float* sstats, int64_t ldo);
+
 /* ---- summed sufficient statistics of iid draws ---------------------------
  * ExpFamIndependentObservations.sufficient_statistics,
  * bayesic/distribution/base.py:328-332; Normal t(x)=(x,x^2),

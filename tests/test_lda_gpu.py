@@ -117,3 +117,57 @@ def test_lda_driver_paths_agree(ctx):
         b.step()
     ctx.sync()
     npt.assert_allclose(a.lam.cpu().numpy(), b.lam.cpu().numpy(), rtol=3e-5)
+
+
+@pytest.mark.parametrize("docs,V,K,density", [
+    (64, 64, 128, 0.3),       # one word tile
+    (300, 1000, 64, 0.05),    # config-4-like density, ragged last tile (1000 = 15*64 + 40)
+    (1000, 130, 96, 0.01),    # very sparse, K = 96
+    (50, 70, 32, 1.0),        # fully dense stored as sparse
+    (40, 200, 128, 0.0),      # no nonzeros at all
+])
+def test_sparse_lda_statistics_match_dense_paths(ctx, docs, V, K, density):
+    """bsc_lda_sstats_csc (one pass over the nonzeros, compressed sparse column) against
+    the float64 oracle and the dense fused kernel."""
+    import scipy.sparse as sparse
+    rs = np.random.RandomState(docs + V + K)
+    mask = rs.rand(docs, V) < density
+    C = (rs.poisson(2.0, (docs, V)) + 1).astype(np.float32) * mask
+    Th = (rs.rand(docs, K) + 0.05).astype(np.float32)
+    Bt = (rs.rand(K, V) + 0.05).astype(np.float32)
+    csc = sparse.csc_matrix(C)
+    colptr = torch.as_tensor(csc.indptr.astype(np.int64)).to(ctx.device)
+    rowidx = torch.as_tensor(csc.indices.astype(np.int32)).to(ctx.device)
+    vals = torch.as_tensor(csc.data.astype(np.float32)).to(ctx.device)
+    dTh, dBt = ctx.to_device(Th), ctx.to_device(Bt)
+    out = torch.full((K, V), float("nan"), dtype=torch.float32, device=ctx.device)
+    ctx.call("bsc_lda_sstats_csc", colptr, rowidx, vals, docs, V, K, dTh, K, dBt, V, out, V)
+    ctx.sync()
+    got = out.cpu().numpy()
+    npt.assert_allclose(got, svi.lda_sstats(C, Th, Bt), rtol=3e-5, atol=1e-6)
+    dense = torch.empty_like(out)
+    ctx.call("bsc_lda_sstats", ctx.to_device(C), V, docs, V, K, dTh, K, dBt, V, dense, V)
+    ctx.sync()
+    npt.assert_allclose(got, dense.cpu().numpy(), rtol=3e-5, atol=1e-6)
+    out2 = torch.empty_like(out)                   # fixed order: run-to-run identical
+    ctx.call("bsc_lda_sstats_csc", colptr, rowidx, vals, docs, V, K, dTh, K, dBt, V, out2, V)
+    ctx.sync()
+    npt.assert_array_equal(got, out2.cpu().numpy())
+
+
+def test_lda_driver_with_sparse_counts(ctx):
+    import scipy.sparse as sparse
+    from bayesic_amd.svi.lda import LDAFixedGammaSVI
+    rs = np.random.RandomState(2)
+    docs, V, K = 200, 700, 64
+    C = (rs.poisson(0.05, (docs, V))).astype(np.float32)
+    gamma = rs.gamma(100.0, 0.01, (docs, K)).astype(np.float32)
+    lam = rs.gamma(100.0, 0.01, (K, V)).astype(np.float32)
+    a = LDAFixedGammaSVI(sparse.csr_matrix(C), gamma, lam, ctx=ctx)
+    b = LDAFixedGammaSVI(C, gamma, lam, ctx=ctx)
+    assert a.via == "csc" and b.via == "kernel"
+    for _ in range(2):
+        a.step()
+        b.step()
+    ctx.sync()
+    npt.assert_allclose(a.lam.cpu().numpy(), b.lam.cpu().numpy(), rtol=3e-5)
