@@ -85,6 +85,14 @@ SIGNATURES = {
                                c_int64, c_void_p, c_int64, c_void_p, c_int64]),
     "bsc_lda_sstats_csc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32,
                                    c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
+    "bsc_host_register": (c_int, [c_void_p, c_size_t]),
+    "bsc_host_unregister": (c_int, [c_void_p]),
+    "bsc_loader_create": (c_int, [c_void_p, c_int64, c_int32, c_int32, POINTER(c_void_p)]),
+    "bsc_loader_destroy": (c_int, [c_void_p]),
+    "bsc_loader_submit": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64]),
+    "bsc_loader_acquire": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p),
+                                   POINTER(c_int64)]),
+    "bsc_loader_release": (c_int, [c_void_p]),
     "bsc_map_reduce": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int64), c_int,
                                POINTER(c_int64), c_int, POINTER(c_void_p), POINTER(c_int64),
                                POINTER(c_int64), POINTER(c_int32), POINTER(c_double), c_double,

@@ -1,0 +1,146 @@
+// Mini-batch streaming: host memory -> HBM slots on a copy stream of its own, so
+// that batch t+1 crosses PCIe while the update of batch t runs on the context's
+// stream (README.md:69-79: "stochastic updates applied via subsampled
+// minibatches"; SURVEY.md 8(f) rank 4: the step before the path).  The update
+// kernels only ever see device-resident batches -- the hot path is unchanged.
+//
+// Slot life cycle:  submit (H2D queued on the copy stream, ordered after the
+// kernels that last read the slot)  ->  acquire (compute stream waits for the
+// copy)  ->  release (marks the point on the compute stream after which the slot
+// may be overwritten).  Host buffers should be page-locked (bsc_host_register or
+// pinned allocation): a pageable source makes the runtime stage the copy through
+// its own bounce buffer at a fraction of the PCIe rate.
+#include "bsc_common.h"
+
+#include <vector>
+
+struct bsc_loader {
+    bsc_ctx* ctx = nullptr;
+    hipStream_t copy_stream = nullptr;
+    int64_t max_rows = 0;
+    int32_t D = 0;
+    struct Slot {
+        float* X = nullptr;
+        float* y = nullptr;
+        int64_t rows = 0;
+        hipEvent_t copied = nullptr;     // recorded on the copy stream after the H2D
+        hipEvent_t consumed = nullptr;   // recorded on the compute stream at release
+        bool has_consumed = false;
+    };
+    std::vector<Slot> slots;
+    int64_t submitted = 0, acquired = 0, released = 0;   // monotone counters; slot = counter % n
+};
+
+extern "C" {
+
+int bsc_host_register(void* host_ptr, size_t bytes) {
+    BSC_REQUIRE(host_ptr != nullptr && bytes > 0, "bsc_host_register: bad arguments");
+    BSC_HIP(hipHostRegister(host_ptr, bytes, hipHostRegisterDefault));
+    return BSC_OK;
+}
+
+int bsc_host_unregister(void* host_ptr) {
+    BSC_REQUIRE(host_ptr != nullptr, "bsc_host_unregister: null pointer");
+    BSC_HIP(hipHostUnregister(host_ptr));
+    return BSC_OK;
+}
+
+int bsc_loader_create(bsc_ctx* ctx, int64_t max_rows, int32_t D, int32_t n_slots, bsc_loader** out) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(out != nullptr, "bsc_loader_create: out is null");
+    BSC_REQUIRE(max_rows > 0 && D > 0 && n_slots >= 2 && n_slots <= 16,
+                "bsc_loader_create: need max_rows > 0, D > 0, 2 <= n_slots <= 16");
+    bsc_loader* L = new bsc_loader();
+    L->ctx = ctx;
+    L->max_rows = max_rows;
+    L->D = D;
+    L->slots.resize(n_slots);
+    hipError_t err = hipStreamCreateWithFlags(&L->copy_stream, hipStreamNonBlocking);
+    for (auto& s : L->slots) {
+        if (err == hipSuccess) err = hipMalloc((void**)&s.X, (size_t)max_rows * D * sizeof(float));
+        if (err == hipSuccess) err = hipMalloc((void**)&s.y, (size_t)max_rows * sizeof(float));
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&s.copied, hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming);
+    }
+    if (err != hipSuccess) {
+        for (auto& s : L->slots) {
+            if (s.X) (void)hipFree(s.X);
+            if (s.y) (void)hipFree(s.y);
+            if (s.copied) (void)hipEventDestroy(s.copied);
+            if (s.consumed) (void)hipEventDestroy(s.consumed);
+        }
+        if (L->copy_stream) (void)hipStreamDestroy(L->copy_stream);
+        delete L;
+        return bsc_fail(BSC_ERR_HIP, "bsc_loader_create: %s", hipGetErrorString(err));
+    }
+    *out = L;
+    return BSC_OK;
+}
+
+int bsc_loader_destroy(bsc_loader* L) {
+    if (!L) return BSC_OK;
+    (void)hipStreamSynchronize(L->copy_stream);
+    (void)hipStreamSynchronize(L->ctx->stream);
+    for (auto& s : L->slots) {
+        (void)hipFree(s.X);
+        (void)hipFree(s.y);
+        (void)hipEventDestroy(s.copied);
+        (void)hipEventDestroy(s.consumed);
+    }
+    (void)hipStreamDestroy(L->copy_stream);
+    delete L;
+    return BSC_OK;
+}
+
+int bsc_loader_submit(bsc_loader* L, const float* host_X, int64_t ldx, const float* host_y,
+                      int64_t rows) {
+    BSC_REQUIRE(L != nullptr, "bsc_loader_submit: loader is null");
+    BSC_REQUIRE(host_X && host_y && rows > 0 && rows <= L->max_rows && ldx >= L->D,
+                "bsc_loader_submit: bad batch (rows=%lld, max_rows=%lld, ldx=%lld, D=%d)",
+                (long long)rows, (long long)L->max_rows, (long long)ldx, L->D);
+    const int64_t n = (int64_t)L->slots.size();
+    BSC_REQUIRE(L->submitted - L->released < n,
+                "bsc_loader_submit: all %lld slots are in flight (release one first)", (long long)n);
+    auto& s = L->slots[L->submitted % n];
+    // the copy may not overtake the kernels that last read this slot
+    if (s.has_consumed) BSC_HIP(hipStreamWaitEvent(L->copy_stream, s.consumed, 0));
+    if (ldx == L->D)
+        BSC_HIP(hipMemcpyAsync(s.X, host_X, (size_t)rows * L->D * sizeof(float), hipMemcpyHostToDevice,
+                               L->copy_stream));
+    else
+        BSC_HIP(hipMemcpy2DAsync(s.X, (size_t)L->D * sizeof(float), host_X, (size_t)ldx * sizeof(float),
+                                 (size_t)L->D * sizeof(float), (size_t)rows, hipMemcpyHostToDevice,
+                                 L->copy_stream));
+    BSC_HIP(hipMemcpyAsync(s.y, host_y, (size_t)rows * sizeof(float), hipMemcpyHostToDevice,
+                           L->copy_stream));
+    BSC_HIP(hipEventRecord(s.copied, L->copy_stream));
+    s.rows = rows;
+    L->submitted += 1;
+    return BSC_OK;
+}
+
+int bsc_loader_acquire(bsc_loader* L, const float** dX, const float** dy, int64_t* rows) {
+    BSC_REQUIRE(L != nullptr && dX && dy && rows, "bsc_loader_acquire: null argument");
+    BSC_REQUIRE(L->acquired < L->submitted, "bsc_loader_acquire: no submitted batch is waiting");
+    BSC_REQUIRE(L->acquired == L->released,
+                "bsc_loader_acquire: release the batch acquired before taking the next one");
+    auto& s = L->slots[L->acquired % (int64_t)L->slots.size()];
+    BSC_HIP(hipStreamWaitEvent(L->ctx->stream, s.copied, 0));
+    *dX = s.X;
+    *dy = s.y;
+    *rows = s.rows;
+    L->acquired += 1;
+    return BSC_OK;
+}
+
+int bsc_loader_release(bsc_loader* L) {
+    BSC_REQUIRE(L != nullptr, "bsc_loader_release: loader is null");
+    BSC_REQUIRE(L->released < L->acquired, "bsc_loader_release: nothing is acquired");
+    auto& s = L->slots[L->released % (int64_t)L->slots.size()];
+    BSC_HIP(hipEventRecord(s.consumed, L->ctx->stream));
+    s.has_consumed = true;
+    L->released += 1;
+    return BSC_OK;
+}
+
+}  // extern "C"

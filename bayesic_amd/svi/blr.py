@@ -42,6 +42,7 @@ class BLRReparamSVI:
         if self.X.stride(1) != 1:
             raise ValueError("X must be row-major (unit stride along columns)")
         self.B, self.D = self.X.shape
+        self._Xarg, self._yarg, self._ldx = self.X, self.y, self.X.stride(0)
         self.S = int(n_samples)
         self.seed = int(seed)
         self.lr = float(lr)
@@ -85,6 +86,24 @@ class BLRReparamSVI:
         # size the slab once so step() never allocates
         self.ctx.reserve((4 * self.ctx.info()["cu_count"] + 8) * (8 * 256 + 8) * 4)
 
+    def set_batch(self, X, y, rows=None, ldx=None):
+        """Point the next update at another device-resident mini-batch of the same width:
+        torch tensors, or raw device pointers with `rows` (and `ldx`, default D) -- what
+        MiniBatchLoader.acquire() returns.  The mini-batch scaling n_total / batch_rows
+        keeps the batch size the model was built with."""
+        if isinstance(X, torch.Tensor):
+            if X.dtype != torch.float32 or y.dtype != torch.float32 or X.dim() != 2 or \
+                    X.shape[1] != self.D or X.stride(1) != 1 or y.shape[0] != X.shape[0]:
+                raise ValueError("batch must be float32 X [rows, %d] row-major and y [rows]" % self.D)
+            self.X, self.y = X, y
+            self._Xarg, self._yarg, self._ldx, self.B = X, y, X.stride(0), X.shape[0]
+        else:
+            if rows is None:
+                raise ValueError("raw device pointers need `rows`")
+            self.X = self.y = None
+            self._Xarg, self._yarg = int(X), int(y)
+            self._ldx, self.B = int(ldx if ldx is not None else self.D), int(rows)
+
     # -- current views ---------------------------------------------------------
     @property
     def cur(self):
@@ -125,7 +144,7 @@ class BLRReparamSVI:
         self._drawn = True
 
     def data_pass(self):
-        self.ctx.call("bsc_blr_data_pass", self.X, self.X.stride(0), self.y, self.B,
+        self.ctx.call("bsc_blr_data_pass", self._Xarg, self._ldx, self._yarg, self.B,
                       self.D, self.W, self.S, self.Q, self.G)
 
     def all_reduce(self):
@@ -151,8 +170,8 @@ class BLRReparamSVI:
         if not self._drawn:
             self.sample(self.t)  # Philox step index == number of completed updates
         if self.fused and self.world == 1 and self.S <= 8:
-            self.ctx.call("bsc_blr_data_pass_partial", self.X, self.X.stride(0),
-                          self.y, self.B, self.D, self.W, self.S)
+            self.ctx.call("bsc_blr_data_pass_partial", self._Xarg, self._ldx,
+                          self._yarg, self.B, self.D, self.W, self.S)
             self._finish(None)
         else:
             self.data_pass()

@@ -73,6 +73,27 @@ int bsc_ctx_profile(bsc_ctx* ctx, int enable);
 int bsc_ctx_profile_read(bsc_ctx* ctx, double* host_total_ms, int64_t* host_launches);
 
 /* hipEvent wrappers so a ctypes caller can time the ctx stream. */
+/* ---- mini-batch streaming: host memory -> HBM slots on a copy stream --------------
+ * (README.md:69-79 "stochastic updates applied via subsampled minibatches"; the
+ * reference has no loader -- SURVEY.md 8(f) rank 4.)  While the update of batch t
+ * runs on the context's stream, batch t+1 crosses PCIe; the update kernels only ever
+ * see device-resident batches.  submit queues the copy (after the kernels that last
+ * read the slot), acquire makes the context's stream wait for the oldest submitted
+ * batch and returns its device pointers, release marks the point on the context's
+ * stream after which the slot may be overwritten.  At most n_slots batches may be
+ * between submit and release.  Host buffers should be page-locked
+ * (bsc_host_register); a pageable source is staged by the runtime at a fraction of
+ * the PCIe rate.  Not thread-safe. */
+typedef struct bsc_loader bsc_loader;
+int bsc_host_register(void* host_ptr, size_t bytes);
+int bsc_host_unregister(void* host_ptr);
+int bsc_loader_create(bsc_ctx* ctx, int64_t max_rows, int32_t D, int32_t n_slots, bsc_loader** out);
+int bsc_loader_destroy(bsc_loader* loader);
+int bsc_loader_submit(bsc_loader* loader, const float* host_X, int64_t ldx, const float* host_y,
+                      int64_t rows);
+int bsc_loader_acquire(bsc_loader* loader, const float** dX, const float** dy, int64_t* rows);
+int bsc_loader_release(bsc_loader* loader);
+
 int bsc_event_create(void** event);
 int bsc_event_destroy(void* event);
 int bsc_event_record(bsc_ctx* ctx, void* event);
