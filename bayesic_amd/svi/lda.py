@@ -73,10 +73,6 @@ class LDAFixedGammaSVI:
         self.Bt = torch.empty((self.K, self.V), dtype=f32, device=dev)
         self.ctx.call("bsc_dirichlet_expectation", gamma.contiguous(), self.docs, self.K, self.K,
                       self.Th)                          # gamma is fixed: Th is computed once
-        Th, Cv, Bm = A.var("Th", 2), A.var("C", 2), A.var("Bm", 2)
-        self.expr = Bm * A.dot(Th.T, Cv / A.dot(Th, Bm))
-        self.backend = DeviceBackend(self.ctx)
-        self._sstats_fn = self.expr.compile(self.backend).device_fn
         if via is None:
             via = "kernel" if self.K in (32, 64, 96, 128) else "executor"
         if via not in ("kernel", "executor", "csc"):
@@ -84,6 +80,11 @@ class LDAFixedGammaSVI:
         if via == "csc" and self._csc is None:
             raise ValueError("via='csc' needs a scipy.sparse count matrix")
         self.via = via
+        if via == "executor":
+            Th, Cv, Bm = A.var("Th", 2), A.var("C", 2), A.var("Bm", 2)
+            self.expr = Bm * A.dot(Th.T, Cv / A.dot(Th, Bm))
+            self.backend = DeviceBackend(self.ctx)
+            self._sstats_fn = self.expr.compile(self.backend).device_fn
         if self.C is not None and self.C.stride(1) != 1:
             self.C = self.C.contiguous()
         self.sstats = torch.zeros((self.K, self.V), dtype=f32, device=dev)

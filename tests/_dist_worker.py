@@ -94,6 +94,47 @@ class OracleContext:
         eta.copy_(torch.from_numpy(new))
 
 
+    # -- config 5 (BBVI) ---------------------------------------------------------
+    def bsc_bbvi_sample(self, lam, D, G, S, seed, step, eps, Wz, Bz, zeta):
+        P = D + G + 1
+        e, z = svi.bbvi_sample(lam.numpy(), P, S, seed, step=step)
+        eps.copy_(torch.from_numpy(e.ravel()))
+        Wz.copy_(torch.from_numpy(z[:, :D].astype(np.float32).ravel()))
+        Bz.copy_(torch.from_numpy(np.ascontiguousarray(z[:, D:D + G].T).astype(np.float32).ravel()))
+        zeta.copy_(torch.from_numpy(z[:, D + G].copy()))
+
+    def bsc_logreg_bbvi_loglik(self, X, ldx, y, g, N, D, G, Wz, Bz, S, ell):
+        out = svi.logreg_loglik(X.numpy(), y.numpy(), g.numpy(), Wz.numpy().reshape(S, D),
+                                Bz.numpy().reshape(G, S))
+        ell.copy_(torch.from_numpy(out))
+
+    def bsc_bbvi_grad(self, lam, eps, ell, D, G, S, scale, a0, b0, elbo, grad, f_out):
+        P = D + G + 1
+        e, g, _, f = svi.bbvi_elbo_and_grad(lam.numpy(), eps.numpy().reshape(S, P), ell.numpy(),
+                                            D, G, scale, a0, b0)
+        elbo[0] = float(e)
+        grad.copy_(torch.from_numpy(g))
+        f_out.copy_(torch.from_numpy(f))
+
+    def bsc_adam_ascent(self, lam, grad, m1, m2, n, t, lr, b1, b2, eps):
+        new, a, b = svi.adam_ascent(lam.numpy(), grad.numpy(), m1.numpy(), m2.numpy(), t, lr, b1, b2, eps)
+        lam.copy_(torch.from_numpy(new))
+        m1.copy_(torch.from_numpy(a))
+        m2.copy_(torch.from_numpy(b))
+
+    # -- config 4 (LDA) ------------------------------------------------------------
+    def bsc_dirichlet_expectation(self, lam, rows, cols, ld, out):
+        out.copy_(torch.from_numpy(svi.dirichlet_expectation(lam.numpy()).astype(np.float32)))
+
+    def bsc_lda_sstats(self, C, ldc, docs, V, K, Th, ldth, Bt, ldb, out, ldo):
+        out.copy_(torch.from_numpy(svi.lda_sstats(C.numpy(), Th.numpy(), Bt.numpy()).astype(np.float32)))
+
+    def bsc_natgrad_update_f32(self, eta, eta0, message, n, scale, rho):
+        new = (1.0 - rho) * eta.numpy().astype(np.float64) + \
+            rho * (eta0 + scale * message.numpy().astype(np.float64))
+        eta.copy_(torch.from_numpy(new.astype(np.float32)))
+
+
 def main():
     out_path = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -121,8 +162,36 @@ def main():
                         n_total=12000, ctx=OracleContext())
     for _ in range(3):
         mog.step()
+
+    # --- config 5 shape (small): one all-reduce of the S log-likelihoods ------------
+    from bayesic_amd.svi.bbvi import LogRegBBVI
+    from bayesic_amd.svi.lda import LDAFixedGammaSVI
+    X5, y5, g5, _, _ = svi.make_cfg5(600, 8, 5)
+    c5 = [0, 350, 600] if world == 2 else np.linspace(0, 600, world + 1).astype(int)
+    sl = slice(c5[rank], c5[rank + 1])
+    bb = LogRegBBVI(torch.from_numpy(X5[sl].copy()), torch.from_numpy(y5[sl].copy()),
+                    torch.from_numpy(g5[sl].copy()), 5, n_total=6000, n_samples=16, seed=5, lr=0.05,
+                    ctx=OracleContext())
+    assert bb.world == world and bb.batch_rows == 600.0
+    for _ in range(3):
+        bb.step()
+
+    # --- config 4 shape (small): one all-reduce of the K x V statistics --------------
+    rs = np.random.RandomState(9)
+    C4 = rs.poisson(0.3, (90, 40)).astype(np.float32)
+    gamma4 = rs.gamma(100.0, 0.01, (90, 32)).astype(np.float32)
+    lam4 = rs.gamma(100.0, 0.01, (32, 40)).astype(np.float32)
+    c4 = [0, 50, 90] if world == 2 else np.linspace(0, 90, world + 1).astype(int)
+    sl = slice(c4[rank], c4[rank + 1])
+    lda = LDAFixedGammaSVI(torch.from_numpy(C4[sl].copy()), torch.from_numpy(gamma4[sl].copy()),
+                           torch.from_numpy(lam4.copy()), eta=0.01, docs_total=900, ctx=OracleContext(),
+                           via="kernel")
+    assert lda.world == world and lda.batch_docs == 90.0
+    for _ in range(2):
+        lda.step()
     np.savez(out_path % rank, lam=lam, elbo=model.elbo.numpy(), eta=mog.eta.numpy(),
-             lse=mog.lse.numpy())
+             lse=mog.lse.numpy(), bbvi_lam=bb.lam.numpy(), bbvi_elbo=bb.elbo.numpy(),
+             lda_lam=lda.lam.numpy())
     dist.barrier()
     dist.destroy_process_group()
 

@@ -1,5 +1,5 @@
 """N>1 data-parallel host logic on CPU: two gloo ranks on row shards must
-reproduce the single-process update (config 2 and config 3 drivers).  See
+reproduce the single-process update (config 2, 3, 4 and 5 drivers).  See
 tests/_dist_worker.py for what is real and what is a test double."""
 import os
 import subprocess
@@ -42,3 +42,21 @@ def test_two_gloo_ranks_equal_single_process(tmp_path):
         eta, _, lse = svi.mog_svi_step(eta, eta0, Xm, 12000, (t + 1.0) ** -0.6, 3, 4)
     np.testing.assert_allclose(r0["eta"], eta, rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(r0["lse"][0], lse, rtol=1e-10)
+    # config 5: the S log-likelihoods are the only exchanged object
+    np.testing.assert_array_equal(r0["bbvi_lam"], r1["bbvi_lam"])
+    X5, y5, g5, _, _ = svi.make_cfg5(600, 8, 5)
+    lam5 = svi.bbvi_init_lam(8 + 5 + 1)
+    m1, m2 = np.zeros_like(lam5), np.zeros_like(lam5)
+    for t in range(1, 4):
+        lam5, m1, m2, elbo5, _, _ = svi.bbvi_step(lam5, m1, m2, t, X5, y5, g5, 8, 5, 16, 5, 6000, 0.05)
+    np.testing.assert_allclose(r0["bbvi_lam"], lam5, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(r0["bbvi_elbo"][0], elbo5, rtol=1e-9)
+    # config 4: the K x V statistics are all-reduced, every rank holds the same lambda
+    np.testing.assert_array_equal(r0["lda_lam"], r1["lda_lam"])
+    rs = np.random.RandomState(9)
+    C4 = rs.poisson(0.3, (90, 40)).astype(np.float32)
+    gamma4 = rs.gamma(100.0, 0.01, (90, 32)).astype(np.float32)
+    lam4 = rs.gamma(100.0, 0.01, (32, 40)).astype(np.float32).astype(np.float64)
+    for t in range(1, 3):
+        lam4, _ = svi.lda_svi_step(lam4.astype(np.float32), gamma4, C4, 0.01, 900, (t + 1.0) ** -0.7)
+    np.testing.assert_allclose(r0["lda_lam"], lam4, rtol=2e-6)
