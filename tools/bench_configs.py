@@ -76,6 +76,22 @@ def main():
         row("cfg2' X^T y", w, k, 4.0 * N * D, 2.0 * N * D, "hbm")
         del X, y
 
+    if want("gemm"):
+        # ---- the _tensordot GEMM on a plain square problem (reference point for its tiling) ----
+        for n in (4096, 4224, 8192):
+            Am = torch.randn((n, n), generator=g, device=dev)
+            Bm = torch.randn((n, n), generator=g, device=dev)
+            Cm = torch.empty((n, n), device=dev)
+            w, k = timed(ctx, lambda: ctx.call("bsc_gemm_strided_batched", 0, 1, n, n, n, Am, 0, n, 1,
+                                               Bm, 0, n, 1, Cm, 0, n, 1), 10, warm=3)
+            row("gemm %dx%dx%d f32 (A k-contiguous, B n-contiguous)" % (n, n, n), w, k, 12.0 * n * n,
+                2.0 * n ** 3, "f32-mfma")
+            w, k = timed(ctx, lambda: ctx.call("bsc_gemm_strided_batched", 0, 1, n, n, n, Am, 0, 1, n,
+                                               Bm, 0, n, 1, Cm, 0, n, 1), 10, warm=3)
+            row("gemm %dx%dx%d f32 (A m-contiguous, B n-contiguous)" % (n, n, n), w, k, 12.0 * n * n,
+                2.0 * n ** 3, "f32-mfma")
+            del Am, Bm, Cm
+
     if want("cfg3"):
         # ---- config 3: MoG E-step + statistics ----------------------------------------
         N3, D3, K3 = (2_000_000 if quick else 10_000_000), 16, 64
