@@ -253,6 +253,169 @@ __global__ __launch_bounds__(PASS_BLOCK, Geo<ROWS>::OCC) void blr_pass_kernel(
     }
 }
 
+// ---- variant with the forward pass on the MFMA pipe (D == 256) -------------------
+//
+// The kernel above keeps ~83 % of the VALU issue slots busy behind the HBM stream,
+// so it slows down on boxes whose sustained shader clock is lower (measured: pure-read
+// ceiling equal or higher, pass 10-20 % slower).  fp32 MFMA has the same peak as fp32
+// VALU on this part, but it is a SEPARATE pipe: putting the forward x.w products there
+// halves the VALU work and removes the transpose-reduce altogether.
+//
+// A wave owns 16-row tiles.  The tile is written to the wave's LDS region row-major
+// (stride 260 floats) and read back twice:
+//   forward   A operand of v_mfma_f32_16x16x4_f32: lane (i = l&15, kq = l>>4) reads
+//             X[row i][16 j + 4 kq .. +3] (one ds_read_b128 feeds 4 MFMAs); B operand
+//             = W[sample l&15][same columns], 64 registers loaded once; the result
+//             D[row 4 kq + reg][sample l&15] is the 16 x 8 block of dot products
+//             (columns 8..15 of the MFMA are idle).
+//   backward  lane l reads X[row][4l..4l+3] again (conflict-free) and the residuals by
+//             LDS broadcast: acc[s] += resid(row, s) * x, as above.
+// Only the prefetched NEXT tile lives in registers (64 VGPRs); 2 waves per SIMD.
+constexpr int MT_ROWS = 16;
+constexpr int MT_RS = GCOLS + 4;                         // LDS row stride (floats)
+constexpr int MT_WAVE_LDS = MT_ROWS * MT_RS + MT_ROWS * SG;   // tile + residual buffer
+
+typedef float mfma_f32x4 __attribute__((ext_vector_type(4)));
+
+struct MTile {
+    float4 x[MT_ROWS];
+    float4 yv;     // y[row0 + 4 kq .. + 3]: the rows of this lane's MFMA result registers
+};
+
+template <bool NT>
+__device__ __forceinline__ void load_mtile(MTile& t, const float* __restrict__ X, int64_t ldx,
+                                           const float* __restrict__ y, int64_t row0, int64_t B,
+                                           int lane) {
+    const int64_t rem = B - row0;
+    uint64_t xbytes = 0, ybytes = 0;
+    if (rem > 0) {
+        xbytes = ((uint64_t)(rem - 1) * (uint64_t)ldx + (uint64_t)GCOLS) * 4u;
+        ybytes = (uint64_t)rem * 4u;
+    }
+    const unsigned xrec = xbytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)xbytes;
+    const unsigned yrec = ybytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)ybytes;
+    const int64_t safe0 = rem > 0 ? row0 : 0;
+    auto xs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + safe0 * ldx), 0, xrec, 0x00020000);
+    auto ys = __builtin_amdgcn_make_buffer_rsrc((void*)(y + safe0), 0, yrec, 0x00020000);
+    const int lane_off = 16 * lane;
+    const int row_bytes = (int)(ldx * 4);
+#pragma unroll
+    for (int r = 0; r < MT_ROWS; ++r) {
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(xs, lane_off, r * row_bytes, NT ? 2 : 0);
+        t.x[r] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
+                             __uint_as_float(v[3]));
+    }
+    auto v = __builtin_amdgcn_raw_buffer_load_b128(ys, 16 * (lane >> 4), 0, 0);
+    t.yv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
+                       __uint_as_float(v[3]));
+}
+
+template <bool NT>
+__global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_mfma_kernel(
+    const float* __restrict__ X, int64_t ldx, const float* __restrict__ y, int64_t B,
+    const float* __restrict__ W, int S, float* __restrict__ slab, int n_iter) {
+    constexpr int LDS_FLOATS = PASS_WAVES * (MT_WAVE_LDS > SLAB_STRIDE ? MT_WAVE_LDS : SLAB_STRIDE);
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    float* tl = lds + wave * MT_WAVE_LDS;      // this wave's tile
+    float* rb = tl + MT_ROWS * MT_RS;          // residuals [row][sample]
+
+    // B operand: W[sample i16][16 j + 4 kq + c]; samples >= S (and MFMA columns 8..15) are zero
+    float wreg[GCOLS / 4];
+#pragma unroll
+    for (int j = 0; j < GCOLS / 16; ++j) {
+        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i16 < S) w4 = *reinterpret_cast<const float4*>(W + (int64_t)i16 * GCOLS + 16 * j + 4 * kq);
+        wreg[4 * j + 0] = w4.x; wreg[4 * j + 1] = w4.y;
+        wreg[4 * j + 2] = w4.z; wreg[4 * j + 3] = w4.w;
+    }
+    float4 acc[SG];
+#pragma unroll
+    for (int s = 0; s < SG; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float qacc = 0.f;
+    const bool live = i16 < SG;                 // lanes whose MFMA column is a sample
+
+    const int64_t stride = (int64_t)gridDim.x * PASS_WAVES;
+    int64_t tile = (int64_t)blockIdx.x * PASS_WAVES + wave;
+    MTile t;
+    load_mtile<NT>(t, X, ldx, y, tile * MT_ROWS, B, lane);
+    for (int k = 0; k < n_iter; ++k) {
+        // the tile to LDS, then its registers take the next tile (unconditional prefetch:
+        // tiles past the end read zeros without touching memory)
+#pragma unroll
+        for (int r = 0; r < MT_ROWS; ++r)
+            *reinterpret_cast<float4*>(tl + r * MT_RS + 4 * lane) = t.x[r];
+        const float4 yv = t.yv;
+        tile += stride;
+        load_mtile<NT>(t, X, ldx, y, tile * MT_ROWS, B, lane);
+        wave_lds_sync();
+
+        // forward on the MFMA pipe; two accumulators so that no MFMA waits on its predecessor
+        mfma_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = tl + i16 * MT_RS + 4 * kq;
+#pragma unroll
+        for (int j = 0; j < GCOLS / 16; j += 2) {
+            const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * j);
+            const float4 a1 = *reinterpret_cast<const float4*>(arow + 16 * j + 16);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wreg[4 * j + 0], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wreg[4 * j + 4], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wreg[4 * j + 1], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wreg[4 * j + 5], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wreg[4 * j + 2], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wreg[4 * j + 6], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wreg[4 * j + 3], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wreg[4 * j + 7], d1, 0, 0, 0);
+        }
+        // result register reg of lane (i16, kq) = dot(row 4 kq + reg, sample i16)
+        if (live) {
+            const float r0 = yv.x - (d0[0] + d1[0]), r1 = yv.y - (d0[1] + d1[1]);
+            const float r2 = yv.z - (d0[2] + d1[2]), r3 = yv.w - (d0[3] + d1[3]);
+            qacc = fmaf(r0, r0, qacc); qacc = fmaf(r1, r1, qacc);
+            qacc = fmaf(r2, r2, qacc); qacc = fmaf(r3, r3, qacc);
+            float* dst = rb + (4 * kq) * SG + i16;
+            dst[0] = r0; dst[SG] = r1; dst[2 * SG] = r2; dst[3 * SG] = r3;
+        }
+        wave_lds_sync();
+
+        // backward on the VALU: rows from LDS (row-major again), residuals by broadcast
+#pragma unroll
+        for (int r = 0; r < MT_ROWS; ++r) {
+            if ((r & 3) == 0 && r) asm volatile("" ::: "memory");   // four rows of reads in flight
+            const float4 x4 = *reinterpret_cast<const float4*>(tl + r * MT_RS + 4 * lane);
+            const float4 c0 = *reinterpret_cast<const float4*>(rb + r * SG);
+            const float4 c1 = *reinterpret_cast<const float4*>(rb + r * SG + 4);
+            axpy4(acc[0], c0.x, x4); axpy4(acc[1], c0.y, x4);
+            axpy4(acc[2], c0.z, x4); axpy4(acc[3], c0.w, x4);
+            axpy4(acc[4], c1.x, x4); axpy4(acc[5], c1.y, x4);
+            axpy4(acc[6], c1.z, x4); axpy4(acc[7], c1.w, x4);
+        }
+        wave_lds_sync();   // the next iteration overwrites the tile
+    }
+
+    // block reduction through LDS, fixed order over waves (same slab layout as above)
+    __syncthreads();
+    float* ep = lds + wave * SLAB_STRIDE;
+#pragma unroll
+    for (int s = 0; s < SG; ++s)
+        *reinterpret_cast<float4*>(ep + s * GCOLS + 4 * lane) = acc[s];
+    float qv = live ? qacc : 0.f;          // lane (i16 < 8, kq): rows 4 kq .. of sample i16
+    qv += __shfl_xor(qv, 16);
+    qv += __shfl_xor(qv, 32);
+    if (lane < SG) ep[SLAB_G + lane] = qv;
+    __syncthreads();
+    float* out = slab + (int64_t)blockIdx.x * SLAB_STRIDE;
+    for (int i = tid; i < SLAB_STRIDE; i += PASS_BLOCK) {
+        const int src = i < SLAB_G ? (i & 7) * GCOLS + (i >> 3) : i;
+        float v = lds[src];
+#pragma unroll
+        for (int k = 1; k < PASS_WAVES; ++k) v += lds[k * SLAB_STRIDE + src];
+        out[i] = v;
+    }
+}
+
 // float64 sum of p[b * SLAB_STRIDE] over slab rows b = first, first+step, ...
 // Loads are issued in batches of 16 before any add: the partials were written by
 // another kernel, so every load is a MALL/HBM round trip (~0.4 us) and a
@@ -773,10 +936,17 @@ struct PassGrid {
     int n_iter;
 };
 
-PassGrid pass_grid(bsc_ctx* ctx, int64_t B) {
-    const int rows = ctx->blr_tile_rows;
+// Tile height of the variant that will run: 16 = forward on the MFMA pipe (needs the full
+// 256-column layout and 16-byte aligned y), else the VALU kernel with 8- or 4-row tiles.
+int pass_rows(const bsc_ctx* ctx, int D, const float* y) {
+    if (ctx->blr_tile_rows == 16)
+        return (D == GCOLS && (((uintptr_t)y) & 15) == 0) ? 16 : 8;
+    return ctx->blr_tile_rows;
+}
+
+PassGrid pass_grid(bsc_ctx* ctx, int64_t B, int rows) {
     const int64_t n_tiles = (B + rows - 1) / rows;
-    int occ = rows == 8 ? Geo<8>::OCC : Geo<4>::OCC;
+    int occ = rows == 4 ? Geo<4>::OCC : 2;
     if (ctx->blr_waves_per_simd > 0 && ctx->blr_waves_per_simd < occ) occ = ctx->blr_waves_per_simd;
     const int64_t max_waves = (int64_t)occ * 4 * ctx->cu_count;
     PassGrid g;
@@ -823,7 +993,15 @@ void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int6
                  const float* W, int sg, PassGrid g, float* slab) {
     bsc_prof_scope prof(ctx);  // times the pass kernel alone
     const bool nt = ctx->blr_nt_loads != 0;
-    if (ctx->blr_tile_rows == 8) {
+    const int rows = pass_rows(ctx, D, y);
+    if (rows == 16) {
+        if (nt)
+            hipLaunchKernelGGL(blr_pass_mfma_kernel<true>, dim3(g.n_blocks), dim3(PASS_BLOCK), 0,
+                               ctx->stream, X, ldx, y, B, W, sg, slab, g.n_iter);
+        else
+            hipLaunchKernelGGL(blr_pass_mfma_kernel<false>, dim3(g.n_blocks), dim3(PASS_BLOCK), 0,
+                               ctx->stream, X, ldx, y, B, W, sg, slab, g.n_iter);
+    } else if (rows == 8) {
         if (nt) launch_pass_rows<8, true>(ctx, X, ldx, y, B, D, W, sg, g, slab);
         else launch_pass_rows<8, false>(ctx, X, ldx, y, B, D, W, sg, g, slab);
     } else {
@@ -875,7 +1053,7 @@ int bsc_blr_data_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y,
     int rc = check_pass_args(X, ldx, y, B, D, W, S, FIN_MAX_S);
     if (rc != BSC_OK) return rc;
     BSC_REQUIRE(Q && G, "bsc_blr_data_pass: null output");
-    const PassGrid g = pass_grid(ctx, B);
+    const PassGrid g = pass_grid(ctx, B, pass_rows(ctx, D, y));
     void* ws = nullptr;
     rc = bsc_workspace(ctx, (size_t)g.n_blocks * SLAB_STRIDE * sizeof(float), &ws);
     if (rc != BSC_OK) return rc;
@@ -898,7 +1076,7 @@ int bsc_blr_data_pass_partial(bsc_ctx* ctx, const float* X, int64_t ldx, const f
     BSC_CHECK_CTX(ctx);
     int rc = check_pass_args(X, ldx, y, B, D, W, S, SG);
     if (rc != BSC_OK) return rc;
-    const PassGrid g = pass_grid(ctx, B);
+    const PassGrid g = pass_grid(ctx, B, pass_rows(ctx, D, y));
     void* ws = nullptr;
     rc = bsc_workspace(ctx, (size_t)g.n_blocks * SLAB_STRIDE * sizeof(float), &ws);
     if (rc != BSC_OK) return rc;

@@ -17,7 +17,7 @@ struct bsc_ctx {
     void* workspace = nullptr;   // partial-sum slabs; grown on demand
     size_t workspace_bytes = 0;
     int cu_count = 256;
-    int blr_tile_rows = 8;  // pass-kernel tile height: 8 (2 waves/SIMD, default) or 4 (3 waves/SIMD)
+    int blr_tile_rows = 16;      // 16: forward on the MFMA pipe when D == 256 (else 8-row VALU tiles); 8 | 4: VALU variants
     int blr_waves_per_simd = 0;  // tuning: cap resident waves per SIMD (0 = kernel's own limit)
     int fused_map_blocks_per_cu = 8;  // bsc_map_reduce, pure map: grid cap (256-thread blocks)
     int fused_map_unroll = 2;         // float4 per operand in flight per lane (1 | 2); 2 is +18% measured

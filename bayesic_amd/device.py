@@ -67,6 +67,14 @@ class Context:
                    "bsc_ctx_profile_read")
         return float(ms.value), int(n.value)
 
+    def read_probe(self, tensor, reps=10):
+        """Best pure streaming-read rate (GB/s) over `tensor` on this device; syncs."""
+        out = ctypes.c_double()
+        _ffi.check(self.lib.bsc_hbm_read_probe(self.handle, tensor.data_ptr(),
+                                               tensor.numel() * tensor.element_size(), int(reps),
+                                               ctypes.byref(out)), "bsc_hbm_read_probe")
+        return float(out.value)
+
     def info(self):
         buf = (ctypes.c_int64 * 8)()
         _ffi.check(self.lib.bsc_device_info(self.handle, buf), "bsc_device_info")

@@ -123,6 +123,8 @@ def main():
     elapsed = time.perf_counter() - t0
     pass_ms, launches = ctx.profile_read() if not args.no_kernel_timing else (0.0, 0)
     ctx.profile(0)
+    # what a kernel that only reads X achieves on THIS box (boxes differ by up to 20 %)
+    read_ceiling = ctx.read_probe(X) if rank == 0 else None
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -140,18 +142,23 @@ def main():
             avg_s = pass_ms / launches * 1e-3
             achieved = algo_bytes / avg_s / 1e9
             traffic = None
+            # D == 256: the variant with the forward pass on the MFMA pipe (csrc/bsc_blr.hip)
+            kernel_name = "blr_pass_mfma_kernel" if args.dim == 256 and \
+                os.environ.get("BSC_BLR_TILE_ROWS", "16") == "16" else "blr_pass_kernel"
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get("blr_pass_kernel", {}).get("hbm_bytes_per_launch")
+                    traffic = json.load(open(pmc)).get(kernel_name, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roofline = {"bound": "hbm", "kernel": "blr_pass_kernel", "achieved": achieved,
+            roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
                         "avg_launch_us": avg_s * 1e6, "launches": launches,
                         "timed_every": args.time_every,
-                        "launches_per_step": launches_per_step}
+                        "launches_per_step": launches_per_step,
+                        "read_ceiling_this_box": read_ceiling,
+                        "frac_of_read_ceiling": achieved / read_ceiling if read_ceiling else None}
         out = {
             "metric": "ELBO-grad updates/sec (1M-row mini-batch)",
             "value": value,

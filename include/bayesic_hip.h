@@ -73,6 +73,12 @@ int bsc_ctx_profile(bsc_ctx* ctx, int enable);
 int bsc_ctx_profile_read(bsc_ctx* ctx, double* host_total_ms, int64_t* host_launches);
 
 /* hipEvent wrappers so a ctypes caller can time the ctx stream. */
+/* Measurement aid: best pure streaming-read rate (GB/s) over `buf` on this device, from
+ * a kernel that does nothing but 16-byte loads (two launch shapes, best of `reps` timed
+ * launches each).  Synchronises.  bench.py quotes the data pass against this as well as
+ * against the spec-sheet peak. */
+int bsc_hbm_read_probe(bsc_ctx* ctx, const void* buf, size_t bytes, int reps, double* host_gbps);
+
 /* ---- mini-batch streaming: host memory -> HBM slots on a copy stream --------------
  * (README.md:69-79 "stochastic updates applied via subsampled minibatches"; the
  * reference has no loader -- SURVEY.md 8(f) rank 4.)  While the update of batch t

@@ -26,7 +26,7 @@ def main():
     y = torch.randn(B, generator=g, device=dev)
     W = torch.randn((S, D), generator=g, device=dev) / 16
     ctxs = {}
-    variants = [(8, 0, 0), (8, 1, 0), (8, 0, 1), (8, 1, 1), (4, 0, 0), (4, 2, 0), (4, 0, 1)]
+    variants = [(8, 0, 1), (16, 0, 1), (16, 0, 0), (16, 1, 1)]
     for rows, wps, nt in variants:
         os.environ["BSC_BLR_TILE_ROWS"] = str(rows)
         os.environ["BSC_BLR_WAVES_PER_SIMD"] = str(wps)
@@ -47,6 +47,7 @@ def main():
             c.profile(False)
             res[rows].append(ms / n * 1e3)
     bytes_ = 4.0 * B * D + 4.0 * B
+    print("pure-read probe on this box: %.0f GB/s" % next(iter(ctxs.values())).read_probe(X))
     for key in ctxs:
         a = np.array(res[key])
         print("rows=%d waves/SIMD cap=%d nt=%d  per-launch us: median %.1f  min %.1f  max %.1f  -> %.0f GB/s (median)"
