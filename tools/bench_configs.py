@@ -21,12 +21,21 @@ from bayesic_amd.device import Context
 HBM, F32 = 8.0e12, 157.3e12
 
 
-def timed(ctx, fn, reps, warm=3):
-    for _ in range(warm):
-        fn()
-    ctx.sync()
-    ctx.profile(True)
+def timed(ctx, fn, reps, warm=3, warm_ms=60.0):
+    """Mean wall / kernel time of `reps` calls after at least `warm` calls AND `warm_ms` of
+    uninterrupted GPU time of the same call: a kernel reaches its steady rate only after
+    ~35 ms of continuous running (tools/ramp_probe.py: 228 -> 164 us for the data pass), and
+    other kernels or idle gaps in between do not count."""
     e0, e1 = ctx.event(), ctx.event()
+    done, elapsed = 0, 0.0
+    while done < warm or elapsed < warm_ms:
+        e0.record()
+        for _ in range(max(warm, 1)):
+            fn()
+        e1.record()
+        elapsed += e0.elapsed_ms(e1)
+        done += max(warm, 1)
+    ctx.profile(True)
     e0.record()
     for _ in range(reps):
         fn()
