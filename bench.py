@@ -98,11 +98,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # rehearsal on a one-GPU box: BSC_BENCH_REHEARSAL=1 puts every rank on GPU 0 and uses gloo
+    # for the collective (RCCL needs one device per rank); numbers from it mean nothing
+    rehearsal = os.environ.get("BSC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     from bayesic_amd.device import Context
     from bayesic_amd.svi.blr import BLRReparamSVI
@@ -161,7 +169,8 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get(kernel_name, {}).get("hbm_bytes_per_launch")
+                    if args.rows == 1_000_000 and args.dim == 256:   # the size the counters were taken at
+                        traffic = json.load(open(pmc)).get(kernel_name, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
             roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
