@@ -21,6 +21,7 @@ struct bsc_ctx {
     int blr_waves_per_simd = 0;  // tuning: cap resident waves per SIMD (0 = kernel's own limit)
     int fused_map_blocks_per_cu = 8;  // bsc_map_reduce, pure map: grid cap (256-thread blocks)
     int fused_map_unroll = 2;         // float4 per operand in flight per lane (1 | 2); 2 is +18% measured
+    int gemm_pipe = 1;                // GEMM: LDS operand reads one k-pair ahead of the MFMAs
     int fused_nt_store = 1;           // dense map: non-temporal stores of the result
     int fused_waves_per_cu = 16; // bsc_map_reduce: reduce splits target this many waves per CU
     int blr_nt_loads = 1;        // non-temporal loads of X (read once per pass): +9% measured

@@ -97,7 +97,7 @@ __device__ __forceinline__ void stage_store(const Staged& st, float* lds, int ti
     }
 }
 
-template <bool A_M_CONTIG, bool B_N_CONTIG>
+template <bool A_M_CONTIG, bool B_N_CONTIG, bool PIPE>
 __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_mfma_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE];   // As[2], Bs[2]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -129,33 +129,71 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_mfma_kernel(GemmArgs g
     stage_store<B_N_CONTIG>(sb, lds + 2 * TILE, tid);
     __syncthreads();
     int cur = 0;
-    for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
-        const bool more = k0 + BK < k_end;
-        if (more) {   // next tile's global loads fly during this tile's MFMAs
-            stage_load<A_M_CONTIG>(sa, A, g.sa_m, g.sa_k, m0, g.M, k0 + BK, k_end, g.vec_a, tid);
-            stage_load<B_N_CONTIG>(sb, B, g.sb_n, g.sb_k, n0, g.N, k0 + BK, k_end, g.vec_b, tid);
+    // the MFMAs of one K step on LDS buffer `buf`
+    auto compute = [&](int buf) {
+        const float* As = lds + buf * TILE;
+        const float* Bs = lds + 2 * TILE + buf * TILE;
+        if (PIPE) {
+            // operands one k-pair ahead in registers: the 4 MFMAs of pair kk (256 cycles)
+            // cover the LDS latency of pair kk+2 (sched_group_barrier pins that order --
+            // left alone the compiler reads, waits, then issues the MFMAs)
+            const float* ap = As + fk * LDA + wm * 64 + fr;
+            const float* bp = Bs + fk * LDA + wn * 64 + fr;
+            float a_n[2] = {ap[0], ap[32]}, b_n[2] = {bp[0], bp[32]};
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const float a[2] = {a_n[0], a_n[1]}, bq[2] = {b_n[0], b_n[1]};
+                if (kk + 2 < BK) {
+                    a_n[0] = ap[(kk + 2) * LDA];
+                    a_n[1] = ap[(kk + 2) * LDA + 32];
+                    b_n[0] = bp[(kk + 2) * LDA];
+                    b_n[1] = bp[(kk + 2) * LDA + 32];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                float a[2], bq[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = As[(kk + fk) * LDA + wm * 64 + i * 32 + fr];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bq[j] = Bs[(kk + fk) * LDA + wn * 64 + j * 32 + fr];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
+            }
         }
-        const float* As = lds + cur * TILE;
-        const float* Bs = lds + 2 * TILE + cur * TILE;
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[2], bq[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[(kk + fk) * LDA + wm * 64 + i * 32 + fr];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bq[j] = Bs[(kk + fk) * LDA + wn * 64 + j * 32 + fr];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
+    };
+
+    // NOTE (measured, in-process A/B at steady state): the "if (more)" blocks below are kept on
+    // purpose.  A bounds-free staging path for tile-aligned problems -- with the loads
+    // unconditional, pinned ahead of the MFMAs or spread between them, last step peeled -- was
+    // 2-30 % SLOWER than this branchy form (profiles/r01_ubench_clock_mfma_peak.txt).
+    {
+        for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
+            const bool more = k0 + BK < k_end;
+            if (more) {   // next tile's global loads fly during this tile's MFMAs
+                stage_load<A_M_CONTIG>(sa, A, g.sa_m, g.sa_k, m0, g.M, k0 + BK, k_end, g.vec_a, tid);
+                stage_load<B_N_CONTIG>(sb, B, g.sb_n, g.sb_k, n0, g.N, k0 + BK, k_end, g.vec_b, tid);
+            }
+            compute(cur);
+            if (more) {   // the other buffer was last read one step ago, behind a barrier
+                stage_store<A_M_CONTIG>(sa, lds + (cur ^ 1) * TILE, tid);
+                stage_store<B_N_CONTIG>(sb, lds + 2 * TILE + (cur ^ 1) * TILE, tid);
+            }
+            __syncthreads();
+            cur ^= 1;
         }
-        if (more) {   // the other buffer was last read one step ago, behind a barrier
-            stage_store<A_M_CONTIG>(sa, lds + (cur ^ 1) * TILE, tid);
-            stage_store<B_N_CONTIG>(sb, lds + 2 * TILE + (cur ^ 1) * TILE, tid);
-        }
-        __syncthreads();
-        cur ^= 1;
     }
 
     // C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -423,14 +461,21 @@ int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, 
     g.vec_b = vec_ok(B, b_n, sb_n, sb_k, sb_b);
     {
         bsc_prof_scope prof(ctx);
-        if (a_m && b_n)
-            hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, true>), grid, dim3(GEMM_BLOCK), 0, ctx->stream, g);
-        else if (a_m)
-            hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, false>), grid, dim3(GEMM_BLOCK), 0, ctx->stream, g);
-        else if (b_n)
-            hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, true>), grid, dim3(GEMM_BLOCK), 0, ctx->stream, g);
-        else
-            hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, false>), grid, dim3(GEMM_BLOCK), 0, ctx->stream, g);
+#define BSC_GEMM(AM, BN_)                                                                       \
+    do {                                                                                        \
+        if (ctx->gemm_pipe)                                                                     \
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<AM, BN_, true>), grid, dim3(GEMM_BLOCK), 0, \
+                               ctx->stream, g);                                                 \
+        else                                                                                    \
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<AM, BN_, false>), grid, dim3(GEMM_BLOCK), 0, \
+                               ctx->stream, g);                                                 \
+    } while (0)
+        if (a_m && b_n) BSC_GEMM(true, true);
+        else if (a_m) BSC_GEMM(true, false);
+        else if (b_n) BSC_GEMM(false, true);
+        else BSC_GEMM(false, false);
+#undef BSC_GEMM
+#undef BSC_GEMM
     }
     BSC_LAUNCH_CHECK();
     if (splits > 1) {
