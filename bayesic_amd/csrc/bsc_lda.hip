@@ -172,33 +172,50 @@ __global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_kernel(LdaArgs a) {
             P = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bt[4 * t4 + 3], P, 0, 0, 0);
         }
 
-        // ---- ratio in the result layout; padded rows / columns contribute nothing ----
+        // ---- ratio in the result layout, then phase 2: S += Th^T . R -------------------
+        // Four result registers at a time: their counts come with one LDS round trip, the
+        // division is v_rcp_f32 (1 ulp; the statistic's tolerance is 3e-5), and their 4 x KT
+        // MFMAs run while the next four are fetched and divided -- the MFMA pipe would
+        // otherwise idle through the whole ratio stretch.  Padded rows / columns give R = 0.
+        float c_n[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float c = ct[row * C_LD + 32 * wave + j];
-            P[r] = (v_ok && d0 + row < d_end) ? c / P[r] : 0.f;
-        }
-
-        // ---- phase 2: S += Th^T . R ----------------------------------------------
+        for (int i = 0; i < 4; ++i) c_n[i] = ct[(i + 4 * h) * C_LD + 32 * wave + j];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float* src = th + row * TH_LD + KT * j;
-            float av[KT];
-            if constexpr (KT == 4) {
-                const float4 t = *reinterpret_cast<const float4*>(src);
-                av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
-            } else if constexpr (KT == 2) {
-                const float2 t = *reinterpret_cast<const float2*>(src);
-                av[0] = t.x; av[1] = t.y;
-            } else {
+        for (int q = 0; q < 4; ++q) {
+            float c[4];
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) av[kt] = src[kt];
+            for (int i = 0; i < 4; ++i) c[i] = c_n[i];
+            if (q + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    c_n[i] = ct[(i + 8 * (q + 1) + 4 * h) * C_LD + 32 * wave + j];
             }
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-                S[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kt], P[r], S[kt], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * q + i;
+                const int row = i + 8 * q + 4 * h;
+                P[r] = (v_ok && d0 + row < d_end) ? c[i] * __builtin_amdgcn_rcpf(P[r]) : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * q + i;
+                const int row = i + 8 * q + 4 * h;
+                const float* src = th + row * TH_LD + KT * j;
+                float av[KT];
+                if constexpr (KT == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(src);
+                    av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+                } else if constexpr (KT == 2) {
+                    const float2 t = *reinterpret_cast<const float2*>(src);
+                    av[0] = t.x; av[1] = t.y;
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) av[kt] = src[kt];
+                }
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+                    S[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kt], P[r], S[kt], 0, 0, 0);
+            }
         }
 
         if (more) stage_store<KT>(st, th_s[cur ^ 1], c_s[cur ^ 1], tid);
