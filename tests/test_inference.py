@@ -161,3 +161,57 @@ def test_mean_field_normal_gamma_on_device(ctx):
         vmp.sweep()
     m, v, a, b = reference_mean_field(xs.astype(np.float64), 0.0, 100.0, 1.0, 1.0, 10)
     npt.assert_allclose([q_mu.mean, q_mu.variance, q_tau.shape, q_tau.rate], [m, v, a, b], rtol=2e-5)
+
+
+@pytest.mark.gpu
+def test_generic_score_function_vi_matches_the_fused_config5_path(ctx):
+    """The general BBVI engine (model = algebra expression, evaluated by the executor) and the
+    hand-fused config-5 kernels see the same Philox draws for the same seed, so one update
+    from the same lam must agree: f_s to float32 evaluation error, and the engine's gradient
+    must be the oracle's estimator applied to its own f."""
+    import math
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from bayesic_amd.inference import ScoreFunctionVI
+    from bayesic_amd.svi.bbvi import LogRegBBVI
+    from oracle import svi
+    N, D, G, S = 3000, 8, 5, 64
+    X_, y_, g_, _, _ = svi.make_cfg5(N, D, G)
+    n_total, a0, b0 = 10.0 * N, 1.0, 1.0
+    scale = n_total / N
+    onehot = np.eye(G, dtype=np.float32)[g_]
+
+    Xv, yv, Gm = A.var("X", 2), A.var("y", 1), A.var("Gm", 2)
+    W, Bg, Z = A.var("W", 2), A.var("Bg", 2), A.var("Z", 2)          # [S,D], [S,G], [S,1]
+    L = A.dot(Xv, W.T) + A.dot(Gm, Bg.T)                              # logits [N, S]
+    loglik = A.sum(A.dimshuffle(yv, 0, "x") * L - A.log(1 + A.exp(L)), axis=0)
+    zeta = A.sum(Z, axis=1)                                            # [S]
+    lp_w = A.sum(-0.5 * (W * W), axis=1) - 0.5 * D * math.log(2 * math.pi)
+    lp_b = (-0.5 * G * math.log(2 * math.pi)) + (0.5 * G) * zeta \
+        - 0.5 * (A.exp(zeta) * A.sum(Bg * Bg, axis=1))
+    lp_z = (a0 * math.log(b0) - math.lgamma(a0)) + a0 * zeta - b0 * A.exp(zeta)
+    log_joint = scale * loglik + lp_w + lp_b + lp_z
+
+    eng = ScoreFunctionVI(log_joint, [(W, D), (Bg, G), (Z, 1)],
+                          {"X": X_, "y": y_, "Gm": onehot}, n_samples=S, seed=5, lr=0.05,
+                          backend=DeviceBackend(ctx))
+    fused = LogRegBBVI(X_, y_, g_, G, n_total=n_total, n_samples=S, seed=5, lr=0.05, a0=a0, b0=b0,
+                       ctx=ctx)
+    lam0 = eng.lam.copy()
+    npt.assert_array_equal(lam0, fused.lam.cpu().numpy())
+    eng.step()
+    fused.step()
+    ctx.sync()
+    f_fused = fused.f.cpu().numpy()
+    npt.assert_allclose(eng.f, f_fused, rtol=2e-5, atol=2e-2)          # |f| ~ 1e4, float32 sums
+    P = D + G + 1
+    eps, _ = svi.bbvi_sample(lam0, P, S, 5, step=0)
+    elbo_ref, grad_ref, _, _ = svi.bbvi_elbo_and_grad(
+        lam0, eps, (eng.f - (svi.bbvi_log_prior(lam0[:P][None, :] + np.exp(lam0[P:])[None, :] * eps,
+                                                D, G, a0, b0)
+                             - (-0.5 * math.log(2 * math.pi) - lam0[P:][None, :]
+                                - 0.5 * eps * eps).sum(1))) / scale, D, G, scale, a0, b0)
+    npt.assert_allclose(eng.elbo, elbo_ref, rtol=1e-9)
+    npt.assert_allclose(eng.grad, grad_ref, rtol=1e-6, atol=1e-8 * np.abs(grad_ref).max())
+    # both paths move lam the same way (same draws, same estimator)
+    d_eng, d_fused = eng.lam - lam0, fused.lam.cpu().numpy() - lam0
+    assert np.mean(np.sign(d_eng) == np.sign(d_fused)) > 0.95
