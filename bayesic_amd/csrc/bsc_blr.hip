@@ -725,7 +725,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
         // every small operand of wave 0 is requested before the slab so that the whole
         // workgroup pays one memory round trip, not one per dependent stage
         double p_m = 0.0, p_rho = 0.0, p_m1 = 0.0, p_m2 = 0.0, p_r1 = 0.0, p_r2 = 0.0;
-        double e_next = 0.0;
+        double e_next = 0.0, e_rho = 0.0;   // e_rho = exp(rho), set before it is used on either path
         const bool pre_noise = a.eps_next && a.eps_next_ready;
         if (wave == 0) {
             if (sl == 0 && d < D) {
@@ -743,20 +743,65 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
                 xs = a.xi[sl];
                 ev = a.eps[(int64_t)sl * (D + 1) + d];
             }
-            red[wave][lane] = slab_column_sum<32>(a.slab + 64 * blockIdx.x + lane, wave,
-                                                  FUSED_WAVES, a.n_slab);
+            // This wave's share of the slab: rows wave + 16 k, the workgroup's 64-float run of
+            // each, as 16-byte buffer loads that cover four rows apiece (lane = (row group q,
+            // column chunk c)).  Rows past n_slab read as zero through the descriptor.  Kept
+            // deliberately compact: the kernel starts instruction-cache cold behind the
+            // 165-us data pass, and straight-line code is fetched at ~0.5 us per 64 bytes --
+            // 32 guarded scalar loads (1.5 KB of code) cost 10 us before the first load issued
+            // (cycle counters, round 1).
+            const uint64_t slab_bytes = (uint64_t)a.n_slab * SLAB_STRIDE * 4u;
+            auto rs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)a.slab, 0, slab_bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)slab_bytes,
+                0x00020000);
+            const int q4 = lane >> 4, c16 = lane & 15;
+            const int voff = ((wave + FUSED_WAVES * q4) * SLAB_STRIDE + 64 * (int)blockIdx.x + 4 * c16) * 4;
+            constexpr int BATCH_BYTES = 4 * FUSED_WAVES * SLAB_STRIDE * 4;   // 64 rows per load
+            double s4[4] = {0.0, 0.0, 0.0, 0.0};
+            double e_mxs = 0.0;
+            for (int base = 0; base < a.n_slab; base += 32 * FUSED_WAVES) {   // one trip up to 512 partials
+                float4 v8[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    auto v = __builtin_amdgcn_raw_buffer_load_b128(
+                        rs, voff, base * (SLAB_STRIDE * 4) + jj * BATCH_BYTES, 0);
+                    v8[jj] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]),
+                                         __uint_as_float(v[2]), __uint_as_float(v[3]));
+                }
+                if (base == 0 && wave == 0) {
+                    // float64 exponentials that do not depend on the slab, while it is in flight
+                    e_mxs = exp(-xs);
+                    e_rho = exp(p_rho);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    s4[0] += (double)v8[jj].x; s4[1] += (double)v8[jj].y;
+                    s4[2] += (double)v8[jj].z; s4[3] += (double)v8[jj].w;
+                }
+            }
+            // fold the four row groups (lane bits 4, 5); lanes 0-15 then hold 4 columns each
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s4[i] += __shfl_xor(s4[i], 16);
+                s4[i] += __shfl_xor(s4[i], 32);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) red[wave][4 * lane + i] = s4[i];
+            }
             __syncthreads();
             if (wave != 0) return;
             double g = red[0][lane];
 #pragma unroll
             for (int k = 1; k < FUSED_WAVES; ++k) g += red[k][lane];
             if (live) {
-                const double dw = exp(-xs) * (a.scale * g - wv);
+                const double dw = e_mxs * (a.scale * g - wv);
                 gm = dw;
                 gr = dw * ev;
             }
         } else {
             if (wave != 0) return;
+            e_rho = exp(p_rho);
             for (int s = sl; s < S; s += 8) {
                 if (d < D) {
                     const double g = a.stats[S + (int64_t)s * D + d];
@@ -778,7 +823,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
         if (sl == 0 && d < D) {
             const double rho = p_rho;
             const double g_m = gm * inv_S;
-            const double g_r = gr * inv_S * exp(rho) + 1.0;
+            const double g_r = gr * inv_S * e_rho + 1.0;
             a.grad[d] = g_m;
             a.grad[D + d] = g_r;
             double m1 = p_m1, m2 = p_m2;

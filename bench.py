@@ -38,6 +38,9 @@ def parse_args():
     ap.add_argument("--dim", type=int, default=256)
     ap.add_argument("--samples", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true",
+                    help="N=1 through the multi-GPU code path (float64 statistics between the pass "
+                         "and the finish, no collective): what the N>1 step costs besides RCCL")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the hipEvent pair around the pass kernel")
     ap.add_argument("--spin-up-ms", type=float, default=60.0,
@@ -119,7 +122,7 @@ def main():
     X, y = make_data(torch, device, rank, args.rows, args.dim)
     n_total = float(args.rows * world)  # the resident global batch is the data set
     model = BLRReparamSVI(X, y, n_total=n_total, n_samples=args.samples, seed=1234, lr=1e-3,
-                          ctx=ctx)
+                          ctx=ctx, fused=not args.unfused)
 
     def barrier():
         if world > 1:
