@@ -437,6 +437,50 @@ __device__ __forceinline__ double slab_column_sum(const float* __restrict__ p, i
     return sum;
 }
 
+// Float64 sums of a 64-column run of the slab (columns col0 .. col0+63) over the rows
+// wave + n_waves * k that this wave owns: 16-byte buffer loads covering four rows apiece
+// (lane = (row group lane>>4, column chunk lane&15)); rows past n_slab read as zero through
+// the descriptor.  On return lanes 0-15 hold, in s4[0..3], the sums of columns
+// col0 + 4*lane .. +3.  `between` runs after the first batch of loads has been issued and
+// before it is consumed (work that does not depend on the slab).
+// Kept deliberately compact: these finishing kernels start instruction-cache cold behind the
+// 165-us data pass, and straight-line code is fetched at ~0.5 us per 64 bytes -- the 32
+// guarded scalar loads this replaces (1.5 KB of code) cost 10 us before the first load had
+// even been issued (cycle counters, round 1).
+template <int N_WAVES, typename F>
+__device__ __forceinline__ void slab_run_sum(const float* __restrict__ slab, int n_slab, int col0,
+                                             int wave, int lane, double (&s4)[4], F between) {
+    const uint64_t slab_bytes = (uint64_t)n_slab * SLAB_STRIDE * 4u;
+    auto rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)slab, 0, slab_bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)slab_bytes, 0x00020000);
+    const int q4 = lane >> 4, c16 = lane & 15;
+    const int voff = ((wave + N_WAVES * q4) * SLAB_STRIDE + col0 + 4 * c16) * 4;
+    constexpr int BATCH_BYTES = 4 * N_WAVES * SLAB_STRIDE * 4;      // 4 * N_WAVES rows per load
+    s4[0] = s4[1] = s4[2] = s4[3] = 0.0;
+    for (int base = 0; base < n_slab; base += 32 * N_WAVES) {       // one trip up to 32 * N_WAVES partials
+        float4 v8[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            auto v = __builtin_amdgcn_raw_buffer_load_b128(
+                rs, voff, base * (SLAB_STRIDE * 4) + jj * BATCH_BYTES, 0);
+            v8[jj] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
+                                 __uint_as_float(v[3]));
+        }
+        if (base == 0) between();
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            s4[0] += (double)v8[jj].x; s4[1] += (double)v8[jj].y;
+            s4[2] += (double)v8[jj].z; s4[3] += (double)v8[jj].w;
+        }
+    }
+    // fold the four row groups (lane bits 4, 5)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s4[i] += __shfl_xor(s4[i], 16);
+        s4[i] += __shfl_xor(s4[i], 32);
+    }
+}
+
 // Sum block partials in float64, fixed order.  One output per lane; the 16
 // waves of a block split the slab rows, then combine through LDS in wave order.
 constexpr int RED_BLOCK = 1024;
@@ -449,9 +493,12 @@ __global__ __launch_bounds__(RED_BLOCK) void blr_slab_reduce_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int i = blockIdx.x * BSC_WAVE + lane;
-    double sum = 0.0;
-    if (i < SLAB_STRIDE) sum = slab_column_sum<32>(slab + i, wave, RED_WAVES, n_blocks);
-    part[wave][lane] = sum;
+    double s4[4];
+    slab_run_sum<RED_WAVES>(slab, n_blocks, (int)blockIdx.x * BSC_WAVE, wave, lane, s4, [] {});
+    if (lane < 16) {   // (columns past SLAB_STRIDE in the last workgroup are read but never written out)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part[wave][4 * lane + k] = s4[k];
+    }
     __syncthreads();
     if (wave == 0 && i < SLAB_STRIDE) {
         double tot = part[0][lane];
@@ -743,48 +790,16 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
                 xs = a.xi[sl];
                 ev = a.eps[(int64_t)sl * (D + 1) + d];
             }
-            // This wave's share of the slab: rows wave + 16 k, the workgroup's 64-float run of
-            // each, as 16-byte buffer loads that cover four rows apiece (lane = (row group q,
-            // column chunk c)).  Rows past n_slab read as zero through the descriptor.  Kept
-            // deliberately compact: the kernel starts instruction-cache cold behind the
-            // 165-us data pass, and straight-line code is fetched at ~0.5 us per 64 bytes --
-            // 32 guarded scalar loads (1.5 KB of code) cost 10 us before the first load issued
-            // (cycle counters, round 1).
-            const uint64_t slab_bytes = (uint64_t)a.n_slab * SLAB_STRIDE * 4u;
-            auto rs = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)a.slab, 0, slab_bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)slab_bytes,
-                0x00020000);
-            const int q4 = lane >> 4, c16 = lane & 15;
-            const int voff = ((wave + FUSED_WAVES * q4) * SLAB_STRIDE + 64 * (int)blockIdx.x + 4 * c16) * 4;
-            constexpr int BATCH_BYTES = 4 * FUSED_WAVES * SLAB_STRIDE * 4;   // 64 rows per load
-            double s4[4] = {0.0, 0.0, 0.0, 0.0};
+            // this wave's share of the slab (rows wave + 16 k, the workgroup's 64-float run); the
+            // float64 exponentials that do not depend on it run while it is in flight
+            double s4[4];
             double e_mxs = 0.0;
-            for (int base = 0; base < a.n_slab; base += 32 * FUSED_WAVES) {   // one trip up to 512 partials
-                float4 v8[8];
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    auto v = __builtin_amdgcn_raw_buffer_load_b128(
-                        rs, voff, base * (SLAB_STRIDE * 4) + jj * BATCH_BYTES, 0);
-                    v8[jj] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]),
-                                         __uint_as_float(v[2]), __uint_as_float(v[3]));
-                }
-                if (base == 0 && wave == 0) {
-                    // float64 exponentials that do not depend on the slab, while it is in flight
+            slab_run_sum<FUSED_WAVES>(a.slab, a.n_slab, 64 * (int)blockIdx.x, wave, lane, s4, [&] {
+                if (wave == 0) {
                     e_mxs = exp(-xs);
                     e_rho = exp(p_rho);
                 }
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    s4[0] += (double)v8[jj].x; s4[1] += (double)v8[jj].y;
-                    s4[2] += (double)v8[jj].z; s4[3] += (double)v8[jj].w;
-                }
-            }
-            // fold the four row groups (lane bits 4, 5); lanes 0-15 then hold 4 columns each
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                s4[i] += __shfl_xor(s4[i], 16);
-                s4[i] += __shfl_xor(s4[i], 32);
-            }
+            });
             if (lane < 16) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) red[wave][4 * lane + i] = s4[i];
