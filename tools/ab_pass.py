@@ -26,7 +26,7 @@ def main():
     y = torch.randn(B, generator=g, device=dev)
     W = torch.randn((S, D), generator=g, device=dev) / 16
     ctxs = {}
-    variants = [(8, 0, 1), (16, 0, 1), (16, 0, 0), (16, 1, 1)]
+    variants = [(8, 0, 1), (16, 0, 1)]
     for rows, wps, nt in variants:
         os.environ["BSC_BLR_TILE_ROWS"] = str(rows)
         os.environ["BSC_BLR_WAVES_PER_SIMD"] = str(wps)
