@@ -105,7 +105,7 @@ __global__ __launch_bounds__(LR_BLOCK, 2) void logreg_loglik_kernel(
         const int col = 16 * (s >> 2) + 4 * kq + (s & 3);
         wreg[s] = col < D ? Wz[(int64_t)(16 * wave + i16) * D + col] : 0.f;
     }
-    float acc_ll = 0.f;
+    double acc_ll = 0.0;   // per-tile float32 sums enter a float64 accumulator: no drift over the 60 tiles
 
     int64_t tile = blockIdx.x;
     const int64_t stride = gridDim.x;
@@ -163,6 +163,7 @@ __global__ __launch_bounds__(LR_BLOCK, 2) void logreg_loglik_kernel(
         load_groups(gi, g, (tile + 2 * stride) * LT, N, kq, n_groups);
         // C/D map of 16x16x4: col = lane & 15 (sample), row = 4 * (lane >> 4) + reg
         const int64_t row0 = tile * LT;
+        float tile_ll = 0.f;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -175,9 +176,10 @@ __global__ __launch_bounds__(LR_BLOCK, 2) void logreg_loglik_kernel(
                     // hardware exp/log pair is accurate to ~1e-7 ABSOLUTE here (argument of
                     // the log is in (1, 2]), far inside the stated tolerance; log1pf would
                     // cost ~5x the instructions for relative accuracy nobody can observe.
-                    acc_ll += yv * l - (fmaxf(l, 0.f) + __logf(1.0f + __expf(-fabsf(l))));
+                    tile_ll += yv * l - (fmaxf(l, 0.f) + __logf(1.0f + __expf(-fabsf(l))));
                 }
             }
+        acc_ll += (double)tile_ll;
         stage_store(st, lds + (cur ^ 1) * TILE_FLOATS, wave, lane);
         __syncthreads();
         cur ^= 1;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(LR_BLOCK, 2) void logreg_loglik_kernel(
     // lanes with the same sample (lane & 15) hold different rows: fold bits 4,5
     acc_ll += __shfl_xor(acc_ll, 16);
     acc_ll += __shfl_xor(acc_ll, 32);
-    if (lane < 16) slab[(int64_t)blockIdx.x * LS + 16 * wave + lane] = acc_ll;
+    if (lane < 16) slab[(int64_t)blockIdx.x * LS + 16 * wave + lane] = (float)acc_ll;
 }
 
 __global__ __launch_bounds__(1024) void loglik_reduce_kernel(const float* __restrict__ slab,

@@ -88,9 +88,9 @@ def test_cfg4_full_size_counts_are_conserved(ctx):
 def test_cfg5_full_size_log_likelihood(ctx):
     """1M x 256, G = 1000, S = 64: with w = 0 and b = 0 every logit is 0 and
     ell_s = -N log 2; with w = 0 and a constant intercept c the value is
-    sum_n [y_n c - softplus(c)]; two row shards add up to the whole.  Tolerance: the kernel's
-    stated one, 2e-5 * sum_n (|l_ns| + 1) (per-lane float32 partial sums; with IDENTICAL terms,
-    as in the first two checks, their rounding is systematic: 1.8e-6 relative observed)."""
+    sum_n [y_n c - softplus(c)]; two row shards add up to the whole.  Per-tile float32 sums
+    enter float64 accumulators, so even these sums of IDENTICAL terms (systematic rounding, 1.8e-6
+    relative with a float32 accumulator) come out to a few 1e-7."""
     N, D, G, S = 1_000_000, 256, 1000, 64
     g = torch.Generator(device=ctx.device).manual_seed(6)
     X = torch.randn((N, D), generator=g, device=ctx.device)
@@ -105,13 +105,13 @@ def test_cfg5_full_size_log_likelihood(ctx):
 
     zeroW = torch.zeros((S, D), device=ctx.device)
     npt.assert_allclose(loglik(X, y, grp, zeroW, torch.zeros((G, S), device=ctx.device)),
-                        -N * math.log(2.0), rtol=0, atol=2e-5 * N)
+                        -N * math.log(2.0), rtol=5e-7)
     cs = torch.linspace(-3.0, 3.0, S, device=ctx.device)
     Bz = cs[None, :].repeat(G, 1).contiguous()
     n1 = y.double().sum().item()
     want = n1 * cs.double().cpu().numpy() - N * np.logaddexp(0.0, cs.double().cpu().numpy())
     bound = N * (np.abs(cs.double().cpu().numpy()) + 1.0)
-    assert (np.abs(loglik(X, y, grp, zeroW, Bz) - want) <= 2e-5 * bound).all()
+    assert (np.abs(loglik(X, y, grp, zeroW, Bz) - want) <= 5e-7 * bound).all()
     Wz = torch.randn((S, D), generator=g, device=ctx.device) / 16
     Bz = torch.randn((G, S), generator=g, device=ctx.device)
     whole = loglik(X, y, grp, Wz, Bz)
