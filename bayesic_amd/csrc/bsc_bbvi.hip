@@ -269,88 +269,120 @@ __global__ void bbvi_sample_kernel(const double* __restrict__ lam, int D, int G,
     }
 }
 
-// One workgroup.  f_s, the scalar control variate and the score-function gradient.
-constexpr int BB_BLOCK = 1024;
+// f_s, the scalar control variate and the score-function gradient, as three small
+// launches (a single workgroup did all of it in ~70 us, a quarter of the whole update):
+//   bbvi_f_kernel        one workgroup per sample:  f_s = scale*ell_s + log p(z_s) - log q(z_s)
+//   bbvi_moments_kernel  one thread per score component i: its covariance / variance terms,
+//                        summed per workgroup (fixed order)
+//   bbvi_finish_kernel   a = sum cov / sum var;  grad_i = mean_s (f_s - a) h_si;  elbo
+constexpr int BB_BLOCK = 256;
+constexpr int BB_WAVES = BB_BLOCK / 64;
 constexpr int BB_MAX_S = 64;
 
-__global__ __launch_bounds__(BB_BLOCK) void bbvi_grad_kernel(
+__global__ __launch_bounds__(BB_BLOCK) void bbvi_f_kernel(
     const double* __restrict__ lam, const double* __restrict__ eps, const double* __restrict__ ell,
-    int D, int G, int S, double scale, double a0, double b0, double log_prior_const,
-    double* __restrict__ elbo, double* __restrict__ grad, double* __restrict__ f_out) {
-    __shared__ double f[BB_MAX_S];
-    __shared__ double red[16][4];
-    __shared__ double cv;
+    int D, int G, double scale, double a0, double b0, double log_prior_const,
+    double* __restrict__ f, double* __restrict__ f_out) {
+    __shared__ double red[BB_WAVES];
     const int P = D + G + 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double LOG_2PI = 1.8378770664093454835606594728112;
-    // f_s: wave per sample (strided), lanes over parameters, fixed order
-    for (int s = wave; s < S; s += 16) {
-        const double zeta = lam[P - 1] + exp(lam[2 * P - 1]) * eps[(int64_t)s * P + P - 1];
-        const double tau = exp(zeta);
-        double part = 0.0;
-        for (int i = lane; i < P; i += 64) {
-            const double e = eps[(int64_t)s * P + i], rho = lam[P + i];
-            const double z = lam[i] + exp(rho) * e;
-            double lp;
-            if (i < D) lp = -0.5 * LOG_2PI - 0.5 * z * z;
-            else if (i < D + G) lp = -0.5 * LOG_2PI + 0.5 * zeta - 0.5 * tau * z * z;
-            else lp = log_prior_const + a0 * zeta - b0 * tau;
-            const double lq = -0.5 * LOG_2PI - rho - 0.5 * e * e;
-            part += lp - lq;
-        }
-        part = wave_allsum_f64(part);
-        if (lane == 0) f[s] = scale * ell[s] + part;
+    const double zeta = lam[P - 1] + exp(lam[2 * P - 1]) * eps[(int64_t)s * P + P - 1];
+    const double tau = exp(zeta);
+    double part = 0.0;
+    for (int i = tid; i < P; i += BB_BLOCK) {
+        const double e = eps[(int64_t)s * P + i], rho = lam[P + i];
+        const double z = lam[i] + exp(rho) * e;
+        double lp;
+        if (i < D) lp = -0.5 * LOG_2PI - 0.5 * z * z;
+        else if (i < D + G) lp = -0.5 * LOG_2PI + 0.5 * zeta - 0.5 * tau * z * z;
+        else lp = log_prior_const + a0 * zeta - b0 * tau;
+        const double lq = -0.5 * LOG_2PI - rho - 0.5 * e * e;
+        part += lp - lq;
     }
+    part = wave_allsum_f64(part);
+    if (lane == 0) red[wave] = part;
     __syncthreads();
-    // control variate a = sum_i Cov(f h_i, h_i) / sum_i Var(h_i) over the 2P score components
+    if (tid == 0) {
+        double tot = red[0];
+        for (int k = 1; k < BB_WAVES; ++k) tot += red[k];
+        const double v = scale * ell[s] + tot;
+        f[s] = v;
+        if (f_out) f_out[s] = v;
+    }
+}
+
+__device__ __forceinline__ double score_component(const double* __restrict__ eps, int64_t s, int P,
+                                                  int i, int p, double inv_sd) {
+    const double e = eps[s * P + p];
+    return i < P ? e * inv_sd : e * e - 1.0;
+}
+
+__global__ __launch_bounds__(BB_BLOCK) void bbvi_moments_kernel(
+    const double* __restrict__ lam, const double* __restrict__ eps, const double* __restrict__ f,
+    int P, int S, double* __restrict__ cov_part, double* __restrict__ var_part) {
+    __shared__ double fs[BB_MAX_S];
+    __shared__ double red[BB_WAVES][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < S) fs[tid] = f[tid];
+    __syncthreads();
+    const int i = blockIdx.x * BB_BLOCK + tid;
     double cov = 0.0, var = 0.0;
-    for (int i = tid; i < 2 * P; i += BB_BLOCK) {
+    if (i < 2 * P) {
         const int p = i < P ? i : i - P;
         const double inv_sd = exp(-lam[P + p]);
         double mh = 0.0, mfh = 0.0;
         for (int s = 0; s < S; ++s) {
-            const double e = eps[(int64_t)s * P + p];
-            const double h = i < P ? e * inv_sd : e * e - 1.0;
+            const double h = score_component(eps, s, P, i, p, inv_sd);
             mh += h;
-            mfh += f[s] * h;
+            mfh += fs[s] * h;
         }
         mh /= S;
         mfh /= S;
         double c = 0.0, v = 0.0;
         for (int s = 0; s < S; ++s) {
-            const double e = eps[(int64_t)s * P + p];
-            const double h = i < P ? e * inv_sd : e * e - 1.0;
-            c += (f[s] * h - mfh) * (h - mh);
+            const double h = score_component(eps, s, P, i, p, inv_sd);
+            c += (fs[s] * h - mfh) * (h - mh);
             v += (h - mh) * (h - mh);
         }
-        cov += c / (S - 1);
-        var += v / (S - 1);
+        cov = c / (S - 1);
+        var = v / (S - 1);
     }
     cov = wave_allsum_f64(cov);
     var = wave_allsum_f64(var);
     if (lane == 0) { red[wave][0] = cov; red[wave][1] = var; }
     __syncthreads();
     if (tid == 0) {
-        double c = 0.0, v = 0.0, fm = 0.0;
-        for (int k = 0; k < 16; ++k) { c += red[k][0]; v += red[k][1]; }
-        cv = c / v;
-        for (int s = 0; s < S; ++s) fm += f[s];
-        elbo[0] = fm / S;
-        if (f_out) for (int s = 0; s < S; ++s) f_out[s] = f[s];
+        double c = 0.0, v = 0.0;
+        for (int k = 0; k < BB_WAVES; ++k) { c += red[k][0]; v += red[k][1]; }
+        cov_part[blockIdx.x] = c;
+        var_part[blockIdx.x] = v;
     }
+}
+
+__global__ __launch_bounds__(BB_BLOCK) void bbvi_finish_kernel(
+    const double* __restrict__ lam, const double* __restrict__ eps, const double* __restrict__ f,
+    int P, int S, const double* __restrict__ cov_part, const double* __restrict__ var_part,
+    int n_parts, double* __restrict__ elbo, double* __restrict__ grad) {
+    __shared__ double fs[BB_MAX_S];
+    const int tid = threadIdx.x;
+    if (tid < S) fs[tid] = f[tid];
     __syncthreads();
-    const double a = cv;
-    for (int i = tid; i < 2 * P; i += BB_BLOCK) {
-        const int p = i < P ? i : i - P;
-        const double inv_sd = exp(-lam[P + p]);
-        double gsum = 0.0;
-        for (int s = 0; s < S; ++s) {
-            const double e = eps[(int64_t)s * P + p];
-            const double h = i < P ? e * inv_sd : e * e - 1.0;
-            gsum += (f[s] - a) * h;
-        }
-        grad[i] = gsum / S;
+    double c = 0.0, v = 0.0;                       // every thread: the same fixed-order sums
+    for (int k = 0; k < n_parts; ++k) { c += cov_part[k]; v += var_part[k]; }
+    const double a = c / v;
+    if (blockIdx.x == 0 && tid == 0) {
+        double fm = 0.0;
+        for (int s = 0; s < S; ++s) fm += fs[s];
+        elbo[0] = fm / S;
     }
+    const int i = blockIdx.x * BB_BLOCK + tid;
+    if (i >= 2 * P) return;
+    const int p = i < P ? i : i - P;
+    const double inv_sd = exp(-lam[P + p]);
+    double gsum = 0.0;
+    for (int s = 0; s < S; ++s) gsum += (fs[s] - a) * score_component(eps, s, P, i, p, inv_sd);
+    grad[i] = gsum / S;
 }
 
 }  // namespace
@@ -422,8 +454,23 @@ int bsc_bbvi_grad(bsc_ctx* ctx, const double* lam, const double* eps, const doub
                 D, G, S, BB_MAX_S);
     BSC_REQUIRE(a0 > 0 && b0 > 0, "bsc_bbvi_grad: a0, b0 must be positive");
     const double log_prior_const = a0 * log(b0) - lgamma(a0);
-    hipLaunchKernelGGL(bbvi_grad_kernel, dim3(1), dim3(BB_BLOCK), 0, ctx->stream, lam, eps, ell,
-                       (int)D, (int)G, (int)S, scale, a0, b0, log_prior_const, elbo, grad, f_out);
+    const int P = D + G + 1;
+    const int n_parts = (2 * P + BB_BLOCK - 1) / BB_BLOCK;
+    void* ws = nullptr;
+    int rc = bsc_workspace(ctx, (size_t)(BB_MAX_S + 2 * n_parts) * sizeof(double), &ws);
+    if (rc != BSC_OK) return rc;
+    ctx->slab_rows = 0;
+    double* f = (double*)ws;
+    double* cov_part = f + BB_MAX_S;
+    double* var_part = cov_part + n_parts;
+    hipLaunchKernelGGL(bbvi_f_kernel, dim3((unsigned)S), dim3(BB_BLOCK), 0, ctx->stream, lam, eps, ell,
+                       (int)D, (int)G, scale, a0, b0, log_prior_const, f, f_out);
+    BSC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bbvi_moments_kernel, dim3((unsigned)n_parts), dim3(BB_BLOCK), 0, ctx->stream,
+                       lam, eps, f, P, (int)S, cov_part, var_part);
+    BSC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bbvi_finish_kernel, dim3((unsigned)n_parts), dim3(BB_BLOCK), 0, ctx->stream,
+                       lam, eps, f, P, (int)S, cov_part, var_part, n_parts, elbo, grad);
     BSC_LAUNCH_CHECK();
     return BSC_OK;
 }

@@ -76,14 +76,19 @@ __device__ __forceinline__ int64_t dot_strides(const int64_t (&idx)[MAXR], const
     return off;
 }
 
-template <typename T>
+// SP: with the special functions (lgamma, digamma).  They are compiled only into the
+// generic kernels' SP instantiations: inlined into every kernel they cost 100+ VGPRs and
+// scratch, which made the plain streaming kernels 3x slower (measured).
+template <typename T, bool SP = false>
 __device__ __forceinline__ T apply_unary(int op, T x, double arg) {
+    if (SP) {
+        if (op == BSC_OP_LGAMMA) return (T)lgamma((double)x);
+        if (op == BSC_OP_DIGAMMA) return (T)bsc_digamma_f64((double)x);
+    }
     switch (op) {
         case BSC_OP_LOG: return log(x);
         case BSC_OP_EXP: return exp(x);
         case BSC_OP_ABS: return fabs(x);
-        case BSC_OP_LGAMMA: return (T)lgamma((double)x);
-        case BSC_OP_DIGAMMA: return (T)bsc_digamma_f64((double)x);
         case BSC_OP_POW:
             if (arg == -1.0) return (T)1 / x;
             if (arg == 2.0) return x * x;
@@ -94,15 +99,15 @@ __device__ __forceinline__ T apply_unary(int op, T x, double arg) {
     }
 }
 
-template <typename T>
+template <typename T, bool SP = false>
 __device__ __forceinline__ T finish_value(const MapArgs& a, T v) {
     if (a.scale != 1.0) v *= (T)a.scale;
     if (a.shift != 0.0) v += (T)a.shift;
-    return apply_unary<T>(a.post_op, v, a.post_arg);
+    return apply_unary<T, SP>(a.post_op, v, a.post_arg);
 }
 
 // value at (kept offsets koff[i], reduce index ridx)
-template <typename T>
+template <typename T, bool SP>
 __device__ __forceinline__ T map_value(const MapArgs& a, const int64_t (&koff)[MAXIN],
                                        const int64_t (&ridx)[MAXR]) {
     T v = a.combine == BSC_OP_MUL ? (T)1 : (T)0;
@@ -110,16 +115,16 @@ __device__ __forceinline__ T map_value(const MapArgs& a, const int64_t (&koff)[M
     for (int k = 0; k < MAXIN; ++k) {
         if (k < a.n_in) {
             const int64_t off = koff[k] + dot_strides(ridx, a.red_strides[k], a.red.rank);
-            const T x = apply_unary<T>(a.pre_op[k], static_cast<const T*>(a.in[k])[off], a.pre_arg[k]);
+            const T x = apply_unary<T, SP>(a.pre_op[k], static_cast<const T*>(a.in[k])[off], a.pre_arg[k]);
             v = a.combine == BSC_OP_MUL ? v * x : v + x;
         }
     }
-    return finish_value<T>(a, v);
+    return finish_value<T, SP>(a, v);
 }
 
 // ---- pure map ------------------------------------------------------------------
 
-template <typename T>
+template <typename T, bool SP>
 __global__ __launch_bounds__(256) void map_strided_kernel(MapArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int64_t zero[MAXR] = {0, 0, 0, 0, 0, 0};
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256) void map_strided_kernel(MapArgs a) {
         for (int k = 0; k < MAXIN; ++k)
             koff[k] = k < a.n_in ? dot_strides(idx, a.keep_strides[k], a.keep.rank) : 0;
         static_cast<T*>(a.out)[dot_strides(idx, a.out_strides, a.keep.rank)] =
-            map_value<T>(a, koff, zero);
+            map_value<T, SP>(a, koff, zero);
     }
 }
 
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(256) void map_dense_f32_kernel(MapArgs a, int64_t n
 // Variant A: the fastest-varying operand axis is a REDUCED one.  One wave per
 // (output, split); lanes stride over the flattened reduce index, 4 elements in
 // flight per lane.
-template <typename T>
+template <typename T, bool SP>
 __global__ __launch_bounds__(256) void map_reduce_wave_kernel(MapArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t job = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256) void map_reduce_wave_kernel(MapArgs a) {
         for (int j = 0; j < 4; ++j) {
             int64_t ridx[MAXR];
             unravel(r + 64 * j, a.red, ridx);
-            v[j] = map_value<T>(a, koff, ridx);
+            v[j] = map_value<T, SP>(a, koff, ridx);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc += (double)v[j];
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(256) void map_reduce_wave_kernel(MapArgs a) {
     for (; r < r1; r += 64) {
         int64_t ridx[MAXR];
         unravel(r, a.red, ridx);
-        acc += (double)map_value<T>(a, koff, ridx);
+        acc += (double)map_value<T, SP>(a, koff, ridx);
     }
     acc = wave_allsum_f64(acc);
     if (lane == 0) {
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(256) void map_reduce_lane_dense_f32_kernel(MapArgs 
 // Variant B: the fastest-varying operand axis is a KEPT one.  Lane <-> output, so a
 // wave reads 64 consecutive elements per reduce step; the four waves of a block
 // and `splits` blocks divide the reduce range.
-template <typename T>
+template <typename T, bool SP>
 __global__ __launch_bounds__(256) void map_reduce_lane_kernel(MapArgs a) {
     __shared__ double red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(256) void map_reduce_lane_kernel(MapArgs a) {
             for (int j = 0; j < 4; ++j) {
                 int64_t ridx[MAXR];
                 unravel(r + 4 * j, a.red, ridx);
-                v[j] = map_value<T>(a, koff, ridx);
+                v[j] = map_value<T, SP>(a, koff, ridx);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc += (double)v[j];
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(256) void map_reduce_lane_kernel(MapArgs a) {
         for (; r < r1; r += 4) {
             int64_t ridx[MAXR];
             unravel(r, a.red, ridx);
-            acc += (double)map_value<T>(a, koff, ridx);
+            acc += (double)map_value<T, SP>(a, koff, ridx);
         }
     }
     red[wave][lane] = acc;
@@ -524,6 +529,9 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
         for (int a = 0; a < rank_red; ++a) red.strides[k][a] = host_in_red_strides[k * rank_red + a];
     }
     if (n_out == 0) return BSC_OK;
+    bool special = post_op == BSC_OP_LGAMMA || post_op == BSC_OP_DIGAMMA;
+    for (int k = 0; k < n_in; ++k)
+        special = special || host_pre_op[k] == BSC_OP_LGAMMA || host_pre_op[k] == BSC_OP_DIGAMMA;
     coalesce(keep, n_in + 1);
     coalesce(red, n_in);
     m.keep.rank = keep.rank;
@@ -552,7 +560,7 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
 
     if (rank_red == 0) {
         // ---- pure map ----
-        bool dense = dtype == BSC_F32 && keep.rank <= 1 && (n_out % 4) == 0 &&
+        bool dense = !special && dtype == BSC_F32 && keep.rank <= 1 && (n_out % 4) == 0 &&
                      (((uintptr_t)out) & 15) == 0 && (keep.rank == 0 || m.out_strides[0] == 1);
         int scalar_mask = 0;
         for (int k = 0; k < n_in && dense; ++k) {
@@ -575,12 +583,18 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
             int64_t blocks = (n_out + 255) / 256;
             const int64_t cap = (int64_t)ctx->cu_count * 8;
             if (blocks > cap) blocks = cap;
-            if (dtype == BSC_F32)
-                hipLaunchKernelGGL(map_strided_kernel<float>, dim3((unsigned)blocks), dim3(256), 0,
-                                   ctx->stream, m);
-            else
-                hipLaunchKernelGGL(map_strided_kernel<double>, dim3((unsigned)blocks), dim3(256), 0,
-                                   ctx->stream, m);
+#define BSC_GENERIC(KERNEL, GRID)                                                              \
+    do {                                                                                       \
+        if (dtype == BSC_F32 && special)                                                       \
+            hipLaunchKernelGGL((KERNEL<float, true>), dim3((unsigned)(GRID)), dim3(256), 0, ctx->stream, m);  \
+        else if (dtype == BSC_F32)                                                             \
+            hipLaunchKernelGGL((KERNEL<float, false>), dim3((unsigned)(GRID)), dim3(256), 0, ctx->stream, m); \
+        else if (special)                                                                      \
+            hipLaunchKernelGGL((KERNEL<double, true>), dim3((unsigned)(GRID)), dim3(256), 0, ctx->stream, m); \
+        else                                                                                   \
+            hipLaunchKernelGGL((KERNEL<double, false>), dim3((unsigned)(GRID)), dim3(256), 0, ctx->stream, m); \
+    } while (0)
+            BSC_GENERIC(map_strided_kernel, blocks);
         }
         BSC_LAUNCH_CHECK();
         return BSC_OK;
@@ -600,9 +614,9 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
     }
     const bool lanes_over_outputs = min_keep < min_red && n_out >= 16;
     // dense variants (16 B per lane): one reduce axis, and for the lane variant one kept axis
-    bool dense_lane = lanes_over_outputs && dtype == BSC_F32 && n_in <= 3 && keep.rank == 1 && red.rank == 1 &&
+    bool dense_lane = !special && lanes_over_outputs && dtype == BSC_F32 && n_in <= 3 && keep.rank == 1 && red.rank == 1 &&
                       (n_out % 4) == 0 && m.out_strides[0] == 1;
-    bool dense_wave = !lanes_over_outputs && dtype == BSC_F32 && n_in <= 3 && red.rank == 1 &&
+    bool dense_wave = !special && !lanes_over_outputs && dtype == BSC_F32 && n_in <= 3 && red.rank == 1 &&
                       (n_red % 4) == 0;
     for (int k = 0; k < n_in; ++k) {
         if (dense_lane && (m.keep_strides[k][0] != 1 || (((uintptr_t)m.in[k]) & 15) != 0 ||
@@ -646,12 +660,9 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
         break;
             switch (n_in) { BSC_LANE(1) BSC_LANE(2) BSC_LANE(3) }
 #undef BSC_LANE
-        } else if (dtype == BSC_F32)
-            hipLaunchKernelGGL(map_reduce_lane_kernel<float>, dim3((unsigned)blocks), dim3(256), 0,
-                               ctx->stream, m);
-        else
-            hipLaunchKernelGGL(map_reduce_lane_kernel<double>, dim3((unsigned)blocks), dim3(256), 0,
-                               ctx->stream, m);
+        } else {
+            BSC_GENERIC(map_reduce_lane_kernel, blocks);
+        }
     } else {
         // the wave kernels run four (output, split) jobs per block
         const int64_t blocks = (n_out * splits + 3) / 4;
@@ -667,12 +678,9 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
         break;
             switch (n_in) { BSC_WAVE_CASE(1) BSC_WAVE_CASE(2) BSC_WAVE_CASE(3) }
 #undef BSC_WAVE_CASE
-        } else if (dtype == BSC_F32)
-            hipLaunchKernelGGL(map_reduce_wave_kernel<float>, dim3((unsigned)blocks), dim3(256), 0,
-                               ctx->stream, m);
-        else
-            hipLaunchKernelGGL(map_reduce_wave_kernel<double>, dim3((unsigned)blocks), dim3(256), 0,
-                               ctx->stream, m);
+        } else {
+            BSC_GENERIC(map_reduce_wave_kernel, blocks);
+        }
     }
     BSC_LAUNCH_CHECK();
     if (splits > 1) {

@@ -113,7 +113,15 @@ def main():
         w, k = timed(ctx, lambda: ctx.call("bsc_mog_estep", X3, D3, N3, D3, K3, Wm, c, stats, lse), 20, warm=10)
         row("cfg3 mog_estep %dMx16 K=64" % (N3 // 1_000_000), w, k, 4.0 * N3 * D3,
             8.0 * K3 * D3 * N3, "f32-mfma")
-        del X3
+        from bayesic_amd.svi.mog import MoGNatGradSVI
+        from oracle import svi as _osvi          # priors / initial natural parameters only
+        eta0 = _osvi.mog_prior_eta(K3, D3)
+        eta_init = _osvi.mog_init_eta(X3[:2000].cpu().numpy(), K3, D3, seed=2)
+        mog = MoGNatGradSVI(X3, K3, eta0, eta_init, n_total=float(N3), ctx=ctx)
+        w, _ = timed(ctx, mog.step, 20, warm=10)
+        row("cfg3 whole MoG update (expected params + E-step + natural-gradient step)", w,
+            float("nan"), 4.0 * N3 * D3, 8.0 * K3 * D3 * N3, "f32-mfma")
+        del X3, mog
 
     if want("cfg5"):
         # ---- config 5: BBVI log-likelihood pass ------------------------------------------
@@ -128,7 +136,12 @@ def main():
                                            Bz, S5, ell), 20, warm=10)
         row("cfg5 logreg_loglik 1Mx256 S=64", w, k, 4.0 * N5 * D5 + 8.0 * N5, 2.0 * N5 * D5 * S5,
             "hbm/f32-mfma")
-        del X5
+        from bayesic_amd.svi.bbvi import LogRegBBVI
+        bb = LogRegBBVI(X5, y5, g5, G5, n_samples=S5, ctx=ctx)
+        w, _ = timed(ctx, bb.step, 20, warm=10)
+        row("cfg5 whole BBVI update (sample + pass + control variate + Adam)", w, float("nan"),
+            4.0 * N5 * D5 + 8.0 * N5, 2.0 * N5 * D5 * S5, "hbm/f32-mfma")
+        del X5, bb
 
     if want("cfg4"):
         # ---- config 4: LDA local step on one GPU's shard -----------------------------------

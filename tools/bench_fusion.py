@@ -19,11 +19,17 @@ dev = ctx.device
 g = torch.Generator(device=dev).manual_seed(3)
 
 
-def timeit(fn, n):
-    for _ in range(2):
-        fn()
-    ctx.sync()
+def timeit(fn, n, warm_ms=60.0):
+    """Mean time of n calls after at least warm_ms of the same call back to back (a kernel
+    reaches its steady rate only after ~35 ms of continuous running, tools/ramp_probe.py)."""
     e0, e1 = ctx.event(), ctx.event()
+    elapsed = 0.0
+    while elapsed < warm_ms:
+        e0.record()
+        fn()
+        fn()
+        e1.record()
+        elapsed += e0.elapsed_ms(e1)
     e0.record()
     for _ in range(n):
         fn()
