@@ -1,0 +1,66 @@
+"""Compile-time resource guard for the hot kernels (no GPU needed: hipcc cross-compiles).
+
+A streaming kernel that silently picks up scratch or doubles its VGPR count still passes
+every parity test and only shows up as a slower benchmark -- this happened once in round 1
+(lgamma inlined into every fused map kernel: 62 -> 200 VGPRs + scratch, 3x slower).  The
+limits below are what the current code needs plus headroom, and the occupancy each kernel
+was tuned for."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+# kernel-name substring -> (max VGPRs, max scratch bytes per lane)
+LIMITS = {
+    "bsc_blr.hip": {
+        "blr_pass_mfma_kernelILb1E": (232, 0),          # 2 waves/SIMD needs <= 256
+        "blr_pass_kernelILb1ELi8ELb1E": (256, 0),
+        "blr_fused_update_kernel": (128, 0),
+    },
+    "bsc_fused.hip": {
+        "map_dense_f32_kernelILi2E": (128, 0),
+        "map_reduce_wave_dense_f32_kernelILi2ELi4E": (128, 0),
+        "map_reduce_lane_dense_f32_kernelILi2E": (128, 0),
+        "map_reduce_wave_kernelIfLb0E": (128, 0),
+        "map_strided_kernelIfLb0E": (96, 0),
+    },
+    "bsc_lda.hip": {
+        "lda_sstats_kernelILi4E": (256, 0),
+    },
+}
+
+
+def resources(source):
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize",
+           "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-c",
+           os.path.join(ROOT, "bayesic_amd", "csrc", source), "-o", os.devnull,
+           "-Rpass-analysis=kernel-resource-usage"]
+    err = subprocess.run(cmd, capture_output=True, text=True, timeout=600).stderr
+    out, name = {}, None
+    for line in err.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            out[name] = {}
+        m = re.search(r"\s(VGPRs|ScratchSize \[bytes/lane\]): (\d+)", line)
+        if m and name:
+            out[name][m.group(1).split()[0]] = int(m.group(2))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("source", sorted(LIMITS))
+def test_hot_kernels_stay_within_their_register_budget(source):
+    got = resources(source)
+    assert got, "no resource remarks from hipcc for %s" % source
+    for needle, (max_vgpr, max_scratch) in LIMITS[source].items():
+        matches = {k: v for k, v in got.items() if needle in k}
+        assert matches, "kernel %s not found in %s (renamed?)" % (needle, source)
+        for name, r in matches.items():
+            assert r["VGPRs"] <= max_vgpr, "%s: %d VGPRs > %d" % (name, r["VGPRs"], max_vgpr)
+            assert r["ScratchSize"] <= max_scratch, "%s: %d bytes of scratch" % (name, r["ScratchSize"])
