@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void lda_reduce_kernel(const float* __restrict
 //
 // Real bag-of-words data is ~1 % dense; the dense kernel above spends its MFMAs on
 // zeros.  Here a workgroup owns 64 consecutive words (16 per wave); a word's
-// nonzeros (document id, count) are walked four at a time, one per 16-lane group,
+// nonzeros (document id, count) are walked a dozen at a time, three or four per 16-lane group,
 // each lane holding K/16 consecutive topics of that document's Th row:
 //   p = <Th[d,:], Bt[:,v]>  (in-lane partial + 4 DPP adds inside the 16-lane row)
 //   acc[k] += Th[d,k] * c / p
@@ -304,11 +304,11 @@ __global__ __launch_bounds__(LDA_BLOCK) void lda_sstats_csc_kernel(LdaCscArgs a)
             acc[i] = 0.f;
         }
         const int64_t begin = a.colptr[v], end = a.colptr[v + 1];
-        for (int64_t j0 = begin; j0 < end; j0 += 8) {
-            // two nonzeros per 16-lane group in flight
-            float th[2][KPL], cnt[2];
+        constexpr int U = KPL <= 4 ? 4 : 3;   // nonzeros per 16-lane group in flight (register budget)
+        for (int64_t j0 = begin; j0 < end; j0 += 4 * U) {
+            float th[U][KPL], cnt[U];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int64_t j = j0 + 4 * u + g;
                 const bool ok = j < end;
                 const int64_t jj = ok ? j : begin;            // a valid address either way
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(LDA_BLOCK) void lda_sstats_csc_kernel(LdaCscArgs a)
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
                 float p = 0.f;
 #pragma unroll
                 for (int i = 0; i < KPL; ++i) p += th[u][i] * bt[i];
