@@ -305,6 +305,75 @@ __global__ __launch_bounds__(256) void gemv_mcontig_kernel(GemvArgs g) {
     }
 }
 
+// m contiguous, 16-byte loads: lane <-> 4 consecutive outputs (a wave covers 256 of them per
+// matrix row), the four waves of a block and the splits interleave over the rows so that the
+// whole grid reads one moving window of memory; x[k] is one broadcast load per row.
+typedef float gemv_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void gemv_mcontig4_kernel(GemvArgs g) {
+    __shared__ double red[4][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t groups = (g.M + 255) / 256;
+    const int64_t grp = blockIdx.x % groups;
+    const int split = (int)(blockIdx.x / groups);
+    const int64_t m = grp * 256 + 4 * lane;           // M % 4 == 0 (host)
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (m < g.M) {
+        constexpr int U = 4;                           // rows in flight per lane
+        const float* base = g.A + m;
+        for (int64_t kb = (int64_t)split * 4 * U + wave; kb < g.K; kb += (int64_t)g.splits * 4 * U) {
+            gemv_f32x4 a[U];
+            float xk[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t k = kb + 4 * u < g.K ? kb + 4 * u : g.K - 1;   // clamped, dropped below
+                a[u] = __builtin_nontemporal_load(reinterpret_cast<const gemv_f32x4*>(base + k * g.sa_k));
+                xk[u] = g.x[k * g.sx];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (kb + 4 * u < g.K) {
+                    const double xv = (double)xk[u];
+                    acc[0] += (double)a[u].x * xv; acc[1] += (double)a[u].y * xv;
+                    acc[2] += (double)a[u].z * xv; acc[3] += (double)a[u].w * xv;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[wave][lane][c] = acc[c];
+    __syncthreads();
+    if (wave == 0 && m < g.M) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double tot = ((red[0][lane][c] + red[1][lane][c]) + red[2][lane][c]) + red[3][lane][c];
+            if (g.splits > 1) g.partial[(int64_t)split * g.M + m + c] = tot;
+            else g.y[(m + c) * g.sy] = (float)tot;
+        }
+    }
+}
+
+// one wave per output: lanes stride over the split partials (a serial loop per output took
+// longer than the streaming kernel itself when there are hundreds of splits)
+__global__ __launch_bounds__(256) void gemv_finish_wave_kernel(const double* partial, int splits,
+                                                               int64_t M, float* y, int64_t sy) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    double tot = 0.0;
+    int s = lane;
+    for (; s + 192 < splits; s += 256) {
+        double v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = partial[(int64_t)(s + 64 * j) * M + m];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tot += v[j];
+    }
+    for (; s < splits; s += 64) tot += partial[(int64_t)s * M + m];
+    tot = wave_allsum_f64(tot);
+    if (lane == 0) y[m * sy] = (float)tot;
+}
+
 __global__ void gemv_finish_kernel(const double* partial, int splits, int64_t M, float* y,
                                    int64_t sy) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -391,7 +460,8 @@ int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, 
             BSC_LAUNCH_CHECK();
             return BSC_OK;
         }
-        const int64_t groups = (v.M + 63) / 64;
+        const bool vec4 = v.sa_m == 1 && v.M % 4 == 0 && v.sa_k % 4 == 0 && (((uintptr_t)v.A) & 15) == 0;
+        const int64_t groups = vec4 ? (v.M + 255) / 256 : (v.M + 63) / 64;
         int64_t splits = (4 * (int64_t)ctx->cu_count) / groups;
         if (splits > K / 256) splits = K / 256;
         if (splits < 1) splits = 1;
@@ -404,12 +474,20 @@ int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, 
             v.partial = (double*)ws;
             ctx->slab_rows = 0;
         }
-        hipLaunchKernelGGL(gemv_mcontig_kernel, dim3((unsigned)(groups * splits)), dim3(256), 0,
-                           ctx->stream, v);
+        if (vec4)
+            hipLaunchKernelGGL(gemv_mcontig4_kernel, dim3((unsigned)(groups * splits)), dim3(256), 0,
+                               ctx->stream, v);
+        else
+            hipLaunchKernelGGL(gemv_mcontig_kernel, dim3((unsigned)(groups * splits)), dim3(256), 0,
+                               ctx->stream, v);
         BSC_LAUNCH_CHECK();
         if (splits > 1) {
-            hipLaunchKernelGGL(gemv_finish_kernel, dim3((unsigned)((v.M + 255) / 256)), dim3(256), 0,
-                               ctx->stream, (const double*)v.partial, v.splits, v.M, v.y, v.sy);
+            if (v.M < 4096)
+                hipLaunchKernelGGL(gemv_finish_wave_kernel, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0,
+                                   ctx->stream, (const double*)v.partial, v.splits, v.M, v.y, v.sy);
+            else
+                hipLaunchKernelGGL(gemv_finish_kernel, dim3((unsigned)((v.M + 255) / 256)), dim3(256), 0,
+                                   ctx->stream, (const double*)v.partial, v.splits, v.M, v.y, v.sy);
             BSC_LAUNCH_CHECK();
         }
         return BSC_OK;
