@@ -267,7 +267,22 @@ class DeviceBackend(Backend):
         keep = [a for a in range(rank) if a not in red]
         shape = lazy.shape
         terms = lazy.terms
-        out = self._empty([shape[a] for a in keep], lazy.dtype)
+        out = None
+        if not red and rank > 1:
+            # Pure map: lay the result out the way its biggest operand lies in memory (a
+            # transposed view stays a transposed view) so that reads and writes both stream;
+            # a row-major result of a column-major operand is an uncoalesced transpose.
+            ref = max((t for t, _, _ in terms), key=lambda t: t.numel())
+            order = sorted(range(rank), key=lambda ax: (-abs(ref.stride(ax)) if ref.shape[ax] != 1 else 0,
+                                                        ax))
+            order = [ax for ax in order if ref.shape[ax] != 1] + [ax for ax in range(rank)
+                                                                   if ref.shape[ax] == 1]
+            if order != list(range(rank)) and ref.numel() == math.prod(shape):
+                base = self._empty([shape[ax] for ax in order], lazy.dtype)
+                inverse = [order.index(ax) for ax in range(rank)]
+                out = base.permute(inverse)
+        if out is None:
+            out = self._empty([shape[a] for a in keep], lazy.dtype)
 
         def strides(t, axes):
             return [0 if (t.shape[ax] == 1 and shape[ax] != 1) else t.stride(ax) for ax in axes]
@@ -437,28 +452,37 @@ class DeviceBackend(Backend):
         return extent, stride
 
     def _dot_products(self, x, y, x_dot, y_dot, x_batch, y_batch):
-        """_tensordot with no free axes: out[batch] = sum_dot x * y in one fused pass
-        (operands may be deferred element-wise values; nothing is materialised)."""
+        """_tensordot in which y has no free axes: out[batch, x free] = sum_dot x * y in one
+        fused pass -- y is broadcast over x's free axes (operands may be deferred
+        element-wise values; nothing is materialised)."""
         # line y's axes up with x's, then it is sum(x * y) over x's dot axes
-        order = [None] * x.dim()
+        order = ["x"] * x.dim()
         for ax, ay in zip(list(x_batch) + list(x_dot), list(y_batch) + list(y_dot)):
             order[ax] = ay
         y = self.dimshuffle(y, order)
-        for ax in range(x.dim()):
+        for ax in list(x_batch) + list(x_dot):
             if x.shape[ax] != y.shape[ax]:
                 raise ValueError("tensordot: contracted / batch extents differ (%d vs %d)"
                                  % (x.shape[ax], y.shape[ax]))
         prod = self._combine("mul", [x, y])
         out = self._launch(prod, x_dot)               # kept axes in x's axis order
         kept = [a for a in range(x.dim()) if a not in x_dot]
-        perm = [kept.index(a) for a in x_batch]
+        x_other = [a for a in kept if a not in x_batch]
+        perm = [kept.index(a) for a in list(x_batch) + x_other]
         return out.permute(perm) if perm != sorted(perm) else out
 
     def tensordot(self, x, y, x_dot, y_dot, x_batch, y_batch):
         free_x = x.dim() - len(x_dot) - len(x_batch)
         free_y = y.dim() - len(y_dot) - len(y_batch)
-        if free_x == 0 and free_y == 0 and self.fuse:      # (batched) dot products
-            return self._dot_products(x, y, x_dot, y_dot, x_batch, y_batch)
+        if self.fuse:
+            if free_x == 0 and free_y == 0:                # (batched) dot products
+                return self._dot_products(x, y, x_dot, y_dot, x_batch, y_batch)
+            # matrix-vector shapes with a deferred element-wise operand: one fused pass instead
+            # of materialising it for the GEMV (sum_n exp(X)_nd u_n and the like)
+            if free_y == 0 and isinstance(x, Lazy):
+                return self._dot_products(x, y, x_dot, y_dot, x_batch, y_batch)
+            if free_x == 0 and isinstance(y, Lazy):
+                return self._dot_products(y, x, y_dot, x_dot, y_batch, x_batch)
         x, y = self._force(x), self._force(y)
         (x, y), dtype, _ = self._common([x, y]) if x.dtype != y.dtype else ((x, y), x.dtype, 0)
         x_other = [a for a in range(x.dim()) if a not in x_dot and a not in x_batch]

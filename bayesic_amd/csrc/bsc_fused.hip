@@ -45,6 +45,8 @@ struct MapArgs {
     double* partial;  // [splits][n_out] when splits > 1
     int splits;
     int nt_store;     // dense map: streaming stores
+    int bcast;        // dense kernels: bit k = operand k is constant along the fast axis (one
+                      // scalar load, splat) instead of a 16-byte load
 };
 
 __device__ __forceinline__ void unravel(int64_t flat, const Dims& d, int64_t (&idx)[MAXR]) {
@@ -190,6 +192,62 @@ __global__ __launch_bounds__(256) void map_dense_f32_kernel(MapArgs a, int64_t n
     }
 }
 
+// Two kept axes [R, C], every operand either dense along C (16-byte loads) or constant
+// along it (one scalar per row, splat) -- column scalings, row weights, biases: the
+// broadcasts of dimshuffle('x', ...).  A wave takes rows (interleaved over the grid: one
+// moving window of memory), lanes take 16-byte column chunks; U rows in flight.
+template <int N>
+__global__ __launch_bounds__(256) void map_rows_f32_kernel(MapArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gwave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int64_t R = a.keep.shape[0], C = a.keep.shape[1];
+    const float id = a.combine == BSC_OP_MUL ? 1.f : 0.f;
+    constexpr int U = 2;
+    for (int64_t rb = gwave; rb < R; rb += n_waves * U) {
+        for (int64_t c = 4 * lane; c < C; c += 256) {
+            float4 u[N][U];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int64_t r = rb + n_waves * j < R ? rb + n_waves * j : R - 1;
+                    const float* p = static_cast<const float*>(a.in[k]) + r * a.keep_strides[k][0];
+                    if ((a.bcast >> k) & 1) {
+                        const float sv = p[0];
+                        u[k][j] = make_float4(sv, sv, sv, sv);
+                    } else {
+                        u[k][j] = load4_nt(p + c);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                float4 v = make_float4(id, id, id, id);
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    const int op = a.pre_op[k];
+                    const double arg = a.pre_arg[k];
+                    const float x0 = apply_unary<float>(op, u[k][j].x, arg);
+                    const float x1 = apply_unary<float>(op, u[k][j].y, arg);
+                    const float x2 = apply_unary<float>(op, u[k][j].z, arg);
+                    const float x3 = apply_unary<float>(op, u[k][j].w, arg);
+                    if (a.combine == BSC_OP_MUL) { v.x *= x0; v.y *= x1; v.z *= x2; v.w *= x3; }
+                    else { v.x += x0; v.y += x1; v.z += x2; v.w += x3; }
+                }
+                const int64_t r = rb + n_waves * j;
+                if (r < R) {
+                    const f32x4 w = {finish_value<float>(a, v.x), finish_value<float>(a, v.y),
+                                     finish_value<float>(a, v.z), finish_value<float>(a, v.w)};
+                    f32x4* dst = reinterpret_cast<f32x4*>(static_cast<float*>(a.out) + r * a.out_strides[0] + c);
+                    if (a.nt_store) __builtin_nontemporal_store(w, dst);
+                    else *dst = w;
+                }
+            }
+        }
+    }
+}
+
 // ---- map + reduce ----------------------------------------------------------------
 
 // Variant A: the fastest-varying operand axis is a REDUCED one.  One wave per
@@ -259,14 +317,22 @@ __global__ __launch_bounds__(256) void map_reduce_wave_dense_f32_kernel(MapArgs 
     // bandwidth.  Pieces past the end are clamped to a valid address and dropped.
     // (U = 1 for rows of up to 64 float4, where deeper unrolling would only re-read.)
     const int64_t r1 = n4;
+    float fixed[N];                                   // operands constant along the reduce axis
+#pragma unroll
+    for (int k = 0; k < N; ++k) fixed[k] = (a.bcast >> k) & 1 ? base[k][0] : 0.f;
     for (int64_t rb = (int64_t)split * 64 * U + lane; rb < r1; rb += (int64_t)a.splits * 64 * U) {
         float4 u[N][U];
 #pragma unroll
         for (int k = 0; k < N; ++k) {
+            if ((a.bcast >> k) & 1) {
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const int64_t r = rb + 64 * j;
-                u[k][j] = load4_nt(base[k] + 4 * (r < r1 ? r : r1 - 1));
+                for (int j = 0; j < U; ++j) u[k][j] = make_float4(fixed[k], fixed[k], fixed[k], fixed[k]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int64_t r = rb + 64 * j;
+                    u[k][j] = load4_nt(base[k] + 4 * (r < r1 ? r : r1 - 1));
+                }
             }
         }
 #pragma unroll
@@ -305,7 +371,8 @@ __global__ __launch_bounds__(256) void map_reduce_wave_dense_f32_kernel(MapArgs 
 template <int N>
 __global__ __launch_bounds__(256) void map_reduce_lane_dense_f32_kernel(MapArgs a) {
     __shared__ double red[4][64][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // rows are wave-uniform
     const int64_t n_groups = (a.n_out + 255) / 256;
     const int64_t group = blockIdx.x % n_groups;
     const int split = (int)(blockIdx.x / n_groups);
@@ -325,7 +392,13 @@ __global__ __launch_bounds__(256) void map_reduce_lane_dense_f32_kernel(MapArgs 
 #pragma unroll
                 for (int j = 0; j < U; ++j) {
                     const int64_t r = rb + 4 * j < r1 ? rb + 4 * j : r1 - 1;
-                    u[k][j] = load4_nt(base + r * a.red_strides[k][0]);
+                    if ((a.bcast >> k) & 1) {       // one value per row, the same for every column:
+                        // a wave-uniform address, so this is a scalar (SMEM) load
+                        const float sv = static_cast<const float*>(a.in[k])[r * a.red_strides[k][0]];
+                        u[k][j] = make_float4(sv, sv, sv, sv);
+                    } else {
+                        u[k][j] = load4_nt(base + r * a.red_strides[k][0]);
+                    }
                 }
             }
 #pragma unroll
@@ -480,6 +553,19 @@ void coalesce(AxisGroup& g, int n_rows) {
 
 int64_t iabs(int64_t v) { return v < 0 ? -v : v; }
 
+// Order the axes of a group by decreasing |stride| of row `key` (an element-wise map does not
+// care in which order its index space is walked; a sum only changes its -- still fixed --
+// summation order).  A transposed view then coalesces like its row-major original.
+void sort_axes(AxisGroup& g, int n_rows, int key) {
+    for (int a = 1; a < g.rank; ++a)          // insertion sort, stable
+        for (int b = a; b > 0 && iabs(g.strides[key][b - 1]) < iabs(g.strides[key][b]); --b) {
+            int64_t t = g.shape[b]; g.shape[b] = g.shape[b - 1]; g.shape[b - 1] = t;
+            for (int k = 0; k < n_rows; ++k) {
+                t = g.strides[k][b]; g.strides[k][b] = g.strides[k][b - 1]; g.strides[k][b - 1] = t;
+            }
+        }
+}
+
 }  // namespace
 
 extern "C" {
@@ -532,6 +618,17 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
     bool special = post_op == BSC_OP_LGAMMA || post_op == BSC_OP_DIGAMMA;
     for (int k = 0; k < n_in; ++k)
         special = special || host_pre_op[k] == BSC_OP_LGAMMA || host_pre_op[k] == BSC_OP_DIGAMMA;
+    sort_axes(keep, n_in + 1, n_in);                  // by the output's strides
+    if (red.rank > 1) {                               // by the strides of the biggest operand
+        int key = 0;
+        int64_t best = -1;
+        for (int k = 0; k < n_in; ++k) {
+            int64_t span = 0;
+            for (int a = 0; a < red.rank; ++a) span += iabs(red.strides[k][a]) * (red.shape[a] - 1);
+            if (span > best) { best = span; key = k; }
+        }
+        sort_axes(red, n_in, key);
+    }
     coalesce(keep, n_in + 1);
     coalesce(red, n_in);
     m.keep.rank = keep.rank;
@@ -568,6 +665,31 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
             if (s == 0) scalar_mask |= 1 << k;
             else if (s != 1 || (((uintptr_t)m.in[k]) & 15) != 0) dense = false;
         }
+        // two kept axes with row / column broadcasts
+        bool rows2d = !dense && !special && dtype == BSC_F32 && keep.rank == 2 && n_in <= 3 &&
+                      keep.shape[1] % 4 == 0 && keep.shape[1] >= 64 && m.out_strides[1] == 1 &&
+                      m.out_strides[0] % 4 == 0 && (((uintptr_t)out) & 15) == 0;
+        int bmask = 0;
+        for (int k = 0; k < n_in && rows2d; ++k) {
+            const int64_t sc = m.keep_strides[k][1];
+            if (sc == 0) bmask |= 1 << k;
+            else if (sc != 1 || m.keep_strides[k][0] % 4 != 0 || (((uintptr_t)m.in[k]) & 15) != 0)
+                rows2d = false;
+        }
+        if (rows2d) {
+            m.bcast = bmask;
+            int64_t blocks = (keep.shape[0] + 7) / 8;          // 4 waves x 2 rows per step
+            const int64_t cap = (int64_t)ctx->cu_count * ctx->fused_map_blocks_per_cu;
+            if (blocks > cap) blocks = cap;
+            if (blocks < 1) blocks = 1;
+            switch (n_in) {
+                case 1: hipLaunchKernelGGL(map_rows_f32_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, m); break;
+                case 2: hipLaunchKernelGGL(map_rows_f32_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, m); break;
+                default: hipLaunchKernelGGL(map_rows_f32_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, m); break;
+            }
+            BSC_LAUNCH_CHECK();
+            return BSC_OK;
+        }
         if (dense && n_out >= 4) {
             const int64_t n4 = n_out / 4;
             int64_t blocks = (n4 + 255) / 256;
@@ -600,17 +722,25 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
         return BSC_OK;
     }
 
-    // ---- map + reduce: which operand axis varies fastest? ----
-    int64_t min_keep = INT64_MAX, min_red = INT64_MAX;
+    // ---- map + reduce: which axis of the BIGGEST operand varies fastest? ----
+    // (a broadcast vector riding along -- sum_n f(X)_nd u_n -- must not decide the access
+    // pattern of the matrix it multiplies)
+    int big = 0;
+    double big_elems = -1.0;
     for (int k = 0; k < n_in; ++k) {
-        for (int a = 0; a < keep.rank; ++a) {
-            const int64_t s = iabs(m.keep_strides[k][a]);
-            if (s != 0 && s < min_keep) min_keep = s;
-        }
-        for (int a = 0; a < red.rank; ++a) {
-            const int64_t s = iabs(m.red_strides[k][a]);
-            if (s != 0 && s < min_red) min_red = s;
-        }
+        double elems = 1.0;
+        for (int a = 0; a < keep.rank; ++a) if (m.keep_strides[k][a] != 0) elems *= (double)m.keep.shape[a];
+        for (int a = 0; a < red.rank; ++a) if (m.red_strides[k][a] != 0) elems *= (double)m.red.shape[a];
+        if (elems > big_elems) { big_elems = elems; big = k; }
+    }
+    int64_t min_keep = INT64_MAX, min_red = INT64_MAX;
+    for (int a = 0; a < keep.rank; ++a) {
+        const int64_t st = iabs(m.keep_strides[big][a]);
+        if (st != 0 && st < min_keep) min_keep = st;
+    }
+    for (int a = 0; a < red.rank; ++a) {
+        const int64_t st = iabs(m.red_strides[big][a]);
+        if (st != 0 && st < min_red) min_red = st;
     }
     const bool lanes_over_outputs = min_keep < min_red && n_out >= 16;
     // dense variants (16 B per lane): one reduce axis, and for the lane variant one kept axis
@@ -618,16 +748,26 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
                       (n_out % 4) == 0 && m.out_strides[0] == 1;
     bool dense_wave = !special && !lanes_over_outputs && dtype == BSC_F32 && n_in <= 3 && red.rank == 1 &&
                       (n_red % 4) == 0;
+    int bmask = 0;
     for (int k = 0; k < n_in; ++k) {
-        if (dense_lane && (m.keep_strides[k][0] != 1 || (((uintptr_t)m.in[k]) & 15) != 0 ||
-                           m.red_strides[k][0] % 4 != 0))
-            dense_lane = false;
+        if (dense_lane) {
+            const int64_t sk = m.keep_strides[k][0];
+            if (sk == 0) bmask |= 1 << k;                         // one value per reduced row
+            else if (sk != 1 || (((uintptr_t)m.in[k]) & 15) != 0 || m.red_strides[k][0] % 4 != 0)
+                dense_lane = false;
+        }
         if (dense_wave) {
-            if (m.red_strides[k][0] != 1 || (((uintptr_t)m.in[k]) & 15) != 0) dense_wave = false;
-            for (int a = 0; a < keep.rank; ++a)
-                if (m.keep_strides[k][a] % 4 != 0) dense_wave = false;
+            const int64_t sr = m.red_strides[k][0];
+            if (sr == 0) bmask |= 1 << k;                         // one value per output
+            else {
+                if (sr != 1 || (((uintptr_t)m.in[k]) & 15) != 0) dense_wave = false;
+                for (int a = 0; a < keep.rank; ++a)
+                    if (m.keep_strides[k][a] % 4 != 0) dense_wave = false;
+            }
         }
     }
+    if (bmask == (1 << n_in) - 1) dense_lane = dense_wave = false;   // nothing streams
+    m.bcast = (dense_lane || dense_wave) ? bmask : 0;
     // split the reduce range until about fused_waves_per_cu waves per CU are in flight
     // (a block is 4 waves: 4 (output, split) jobs in the wave kernels, one output group
     // in the lane kernels)

@@ -273,3 +273,29 @@ def test_memory_plan_reuses_intermediates_but_never_the_result(dev):
     X_ = rs.standard_normal((40, 30)).astype(np.float32)
     f(X=dev.from_host(X_, "float32", 2), Y=dev.from_host(X_, "float32", 2))
     assert [b.data_ptr() for b in dev._plans[id(e)][1] if b is not None][:len(before)] == before
+
+
+@pytest.mark.parametrize("R,C", [(1000, 256), (37, 64), (5, 4096), (4097, 128)])
+def test_row_and_column_broadcasts_take_the_vector_paths(dev, R, C):
+    """dimshuffle('x', ...) broadcasts -- column scalings, row weights, biases -- with and
+    without a trailing sum, against numpy (these shapes run on the 16-byte kernels with one
+    operand constant along the fast axis)."""
+    X, v, u = var("X", ndim=2), var("v", ndim=1), var("u", ndim=1)
+    X_ = RNG.standard_normal((R, C)).astype(np.float32)
+    v_ = (RNG.rand(C) + 0.5).astype(np.float32)
+    u_ = (RNG.rand(R) + 0.5).astype(np.float32)
+    vals = {"X": X_, "v": v_, "u": u_}
+    X64 = X_.astype(np.float64)
+    cases = [
+        (X * dimshuffle(v, "x", 0), X64 * v_[None, :]),
+        (X + dimshuffle(u, 0, "x"), X64 + u_[:, None]),
+        (exp(X) * dimshuffle(u, 0, "x") * dimshuffle(log(v), "x", 0), np.exp(X64) * u_[:, None] * np.log(v_)[None, :]),
+        (sum(exp(X) * dimshuffle(u, 0, "x"), axis=0), (np.exp(X64) * u_[:, None]).sum(0)),
+        (sum(X * dimshuffle(v, "x", 0), axis=0), (X64 * v_[None, :]).sum(0)),
+        (sum(abs(X) * dimshuffle(u, 0, "x"), axis=1), (np.abs(X64) * u_[:, None]).sum(1)),
+        (sum(X * X * dimshuffle(v, "x", 0), axis=1), (X64 * X64 * v_[None, :]).sum(1)),
+    ]
+    for expr, want in cases:
+        got = expr.compile(dev)(**{n: vals[n] for n in expr.input_types})
+        assert got.shape == want.shape, repr(expr)
+        npt.assert_allclose(got, want, rtol=2e-5, atol=1e-4, err_msg=repr(expr))

@@ -77,6 +77,17 @@ case("sum(exp(X)*Y) %dx256" % rows, asum(exp(X) * Y), dict(X=Xd, Y=Yd), 8 * n, 2
 case("sum(exp(X)*Y, axis=0) %dx256" % rows, asum(exp(X) * Y, axis=0), dict(X=Xd, Y=Yd), 8 * n, 20)
 case("X / Y %dx256" % rows, X / Y, dict(X=Xd, Y=Yd), 12 * n, 20)
 case("log(exp(X) + exp(Y)) %dx256" % rows, log(exp(X) + exp(Y)), dict(X=Xd, Y=Yd), 12 * n, 20)
+vrow = var("v", ndim=1)
+ucol = var("u", ndim=1)
+vd = torch.randn(256, generator=g, device=dev)
+ud = torch.randn(rows, generator=g, device=dev)
+from bayesic_amd.algebra import dimshuffle
+case("X * v[None,:] %dx256" % rows, X * dimshuffle(vrow, "x", 0), dict(X=Xd, v=vd), 8 * n, 20)
+case("X + u[:,None] %dx256" % rows, X + dimshuffle(ucol, 0, "x"), dict(X=Xd, u=ud), 8 * n, 20)
+case("sum(X * v[None,:], axis=1) %dx256" % rows, asum(X * dimshuffle(vrow, "x", 0), axis=1),
+     dict(X=Xd, v=vd), 4 * n, 20)
+case("sum(exp(X) * u[:,None], axis=0) %dx256" % rows, asum(exp(X) * dimshuffle(ucol, 0, "x"), axis=0),
+     dict(X=Xd, u=ud), 4 * n, 20)
 del Xd, Yd
 
 if no_lda:
