@@ -7,9 +7,51 @@ mini-batching) + README.md:36,75-77 (VMP == unit-step natural gradient; SVI, ref
 (fp32 MFMA) -> float64 reduction -> (all-reduce of the K(1+2D) statistics + the
 bound term when data-parallel) -> natural-gradient step.  All on the device.
 """
+import numpy as np
 import torch
 
 from ..device import default_context
+
+
+# -- natural-parameter layout (host side, parameter-sized) ------------------------------------
+# eta = [alpha-1 (K) | kappa*m (K*D) | kappa (K*D) | 2a-1 (K*D) | 2b + kappa*m^2 (K*D)]:
+# Dirichlet(alpha) over the weights, Normal-Gamma(m, kappa, a, b) per component and dimension
+# (the layout csrc/bsc_mog.hip reads).
+
+def prior_eta(K, D, alpha0=1.0, m0=0.0, kappa0=0.01, a0=1.0, b0=1.0):
+    """Natural parameters of the prior."""
+    return np.concatenate([np.full(K, alpha0 - 1.0), np.full(K * D, kappa0 * m0),
+                           np.full(K * D, kappa0), np.full(K * D, 2.0 * a0 - 1.0),
+                           np.full(K * D, 2.0 * b0 + kappa0 * m0 * m0)])
+
+
+def message(stats, K, D):
+    """Summed statistics [K, 1+2D] = (sum r, sum r x, sum r x^2) -> natural-parameter increment."""
+    stats = np.asarray(stats, np.float64).reshape(K, 1 + 2 * D)
+    Rk, Sx, Sxx = stats[:, 0], stats[:, 1:1 + D], stats[:, 1 + D:]
+    Rkd = np.repeat(Rk[:, None], D, axis=1)
+    return np.concatenate([Rk, Sx.ravel(), Rkd.ravel(), Rkd.ravel(), Sxx.ravel()])
+
+
+def init_eta(X_sample, K, D, seed=0, **prior):
+    """Prior plus one pseudo-observation per component at K randomly chosen rows of
+    X_sample (breaks the symmetry between components)."""
+    X_sample = np.asarray(X_sample, np.float64)
+    picks = X_sample[np.random.RandomState(seed).choice(len(X_sample), K, replace=False)]
+    stats = np.zeros((K, 1 + 2 * D))
+    stats[:, 0] = 1.0
+    stats[:, 1:1 + D] = picks
+    stats[:, 1 + D:] = picks * picks + 1.0
+    return prior_eta(K, D, **prior) + message(stats, K, D)
+
+
+def unpack(eta, K, D):
+    """(alpha [K], m, kappa, a, b [K, D]) from natural parameters."""
+    eta = np.asarray(eta, np.float64)
+    alpha = eta[:K] + 1.0
+    e1, e2, e3, e4 = (eta[K + i * K * D: K + (i + 1) * K * D].reshape(K, D) for i in range(4))
+    m = e1 / e2
+    return alpha, m, e2, 0.5 * (e3 + 1.0), 0.5 * (e4 - e2 * m * m)
 
 
 class MoGNatGradSVI:

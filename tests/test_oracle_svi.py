@@ -124,3 +124,20 @@ def test_chunked_pass_equals_plain_pass():
     Q2, G2 = svi.blr_data_pass_chunked(X, y, W, chunk=128)
     np.testing.assert_allclose(Q1, Q2, rtol=1e-12)
     np.testing.assert_allclose(G1, G2, rtol=1e-10, atol=1e-9)
+
+
+def test_product_side_mog_helpers_match_the_oracle():
+    """bayesic_amd.svi.mog.prior_eta / init_eta / message / unpack (what a user builds the
+    driver's inputs with) against the oracle's layout."""
+    from bayesic_amd.svi import mog
+    rs = np.random.RandomState(0)
+    K, D = 5, 3
+    np.testing.assert_array_equal(mog.prior_eta(K, D, alpha0=1.5, kappa0=0.1),
+                                  svi.mog_prior_eta(K, D, alpha0=1.5, kappa0=0.1))
+    X = rs.standard_normal((50, D))
+    np.testing.assert_allclose(mog.init_eta(X, K, D, seed=4), svi.mog_init_eta(X, K, D, seed=4))
+    stats = rs.rand(K, 1 + 2 * D)
+    np.testing.assert_array_equal(mog.message(stats, K, D), svi.mog_message(stats, K, D))
+    eta = mog.init_eta(X, K, D, seed=1)
+    for a, b in zip(mog.unpack(eta, K, D), svi.mog_unpack(eta, K, D)):
+        np.testing.assert_allclose(a, b)

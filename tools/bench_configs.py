@@ -113,10 +113,10 @@ def main():
         w, k = timed(ctx, lambda: ctx.call("bsc_mog_estep", X3, D3, N3, D3, K3, Wm, c, stats, lse), 20, warm=10)
         row("cfg3 mog_estep %dMx16 K=64" % (N3 // 1_000_000), w, k, 4.0 * N3 * D3,
             8.0 * K3 * D3 * N3, "f32-mfma")
+        from bayesic_amd.svi import mog as mog_mod
         from bayesic_amd.svi.mog import MoGNatGradSVI
-        from oracle import svi as _osvi          # priors / initial natural parameters only
-        eta0 = _osvi.mog_prior_eta(K3, D3)
-        eta_init = _osvi.mog_init_eta(X3[:2000].cpu().numpy(), K3, D3, seed=2)
+        eta0 = mog_mod.prior_eta(K3, D3)
+        eta_init = mog_mod.init_eta(X3[:2000].cpu().numpy(), K3, D3, seed=2)
         mog = MoGNatGradSVI(X3, K3, eta0, eta_init, n_total=float(N3), ctx=ctx)
         w, _ = timed(ctx, mog.step, 20, warm=10)
         row("cfg3 whole MoG update (expected params + E-step + natural-gradient step)", w,
