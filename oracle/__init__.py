@@ -12,7 +12,9 @@ Pinning status (see DESIGN.md "Oracle"):
   oracle (``bayesic/tests/test_algebra.py:44-191``), and by the symbolic golden
   fixtures in ``tests/golden/`` generated from the reference's pure-Python
   front end.
-* exponential-family nodes (``oracle.expfam``): the reference's formulas
+* exponential-family nodes: the node classes (``bayesic_amd.distribution``) build
+  algebra expressions, which the tests evaluate in float64 with
+  ``oracle.einsum_eval.NumpyBackend`` -- the reference's formulas
   (``bayesic/distribution/core.py:16-20,41-47``) with corrected log-normalisers,
   pinned by ``scipy.stats`` known answers (the reference files do not import).
 * ELBO / reparameterisation sampler / natural-gradient update / BBVI
