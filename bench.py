@@ -66,29 +66,36 @@ def make_data(torch, device, rank, rows, dim):
     return X, y
 
 
-def cpu_baseline(X_host, y_host, samples, n_total, budget_s=12.0, max_updates=6):
-    """The oracle (numpy restatement, float64 accumulate) timed on this host.
-    Bounded sample: full 1M-row updates until ~budget_s of CPU work."""
+def cpu_baseline(X_host, y_host, samples, n_total, budget_s=12.0, max_updates=100):
+    """The oracle timed on this host: the data pass in plain C + OpenMP (oracle/c, float64
+    accumulate) when gcc built it, else the numpy restatement.  Bounded sample: full 1M-row
+    updates until ~budget_s of CPU work."""
     import numpy as np
     from oracle import svi
+    data_pass, how = None, "numpy float64 restatement (oracle.svi.blr_step)"
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        from oracle import cbuild
+        threads = cbuild.load().oracle_threads()
+        data_pass, how = cbuild.blr_data_pass, "C + OpenMP data pass (oracle/c), numpy finish"
     except Exception:
-        threads = os.cpu_count() or 1
+        try:
+            from threadpoolctl import threadpool_info
+            threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        except Exception:
+            threads = os.cpu_count() or 1
     D = X_host.shape[1]
     lam = svi.blr_init_lam(D)
     m1, m2 = np.zeros_like(lam), np.zeros_like(lam)
     done, t0 = 0, time.perf_counter()
     while done < max_updates and (time.perf_counter() - t0 < budget_s or done == 0):
         lam, m1, m2, _, _ = svi.blr_step(lam, m1, m2, done + 1, X_host, y_host, samples, 1234,
-                                         n_total, 0.01, chunked=True)
+                                         n_total, 0.01, chunked=True, data_pass=data_pass)
         done += 1
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "updates/s (1M-row mini-batch)", "cores": int(threads),
             "kind": "port",
-            "sample": "%d full updates on the same %dx%d mini-batch, numpy float64 restatement "
-                      "(oracle.svi.blr_step), %.1f s" % (done, X_host.shape[0], D, dt)}
+            "sample": "%d full updates on the same %dx%d mini-batch, %s, %.1f s"
+                      % (done, X_host.shape[0], D, how, dt)}
 
 
 def main():

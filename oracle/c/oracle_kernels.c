@@ -1,0 +1,152 @@
+/* Plain-C restatement of the data-sized statistics of the Bayesic SVI hot path.
+ * TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): an independent second oracle beside the
+ * numpy one, fast enough (OpenMP) to check the HIP kernels at BASELINE's full sizes and to
+ * serve as a compiled CPU baseline.  float32 operands, float64 arithmetic, fixed reduction
+ * order (static row blocks, partials combined in thread order).
+ *
+ * PARITY UNPINNED, like oracle/svi.py: the reference has no code for this path
+ * (README.md:24-80 is prose); every function restates the formula cited at its head and is
+ * itself checked against the numpy oracle in tests/test_oracle_c.py.
+ *
+ *   gcc -O2 -fopenmp -shared -fPIC oracle/c/oracle_kernels.c -o oracle/_build/liboracle.so -lm
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#else
+static int omp_get_max_threads(void) { return 1; }
+static int omp_get_thread_num(void) { return 0; }
+#endif
+
+static void row_block(long n, int t, int nt, long* lo, long* hi) {
+    const long per = (n + nt - 1) / nt;
+    *lo = (long)t * per;
+    *hi = *lo + per < n ? *lo + per : n;
+    if (*lo > n) *lo = n;
+}
+
+/* Config 2 (README.md:51, reparameterised ELBO of Bayesian linear regression):
+ *   r_ns = y_n - x_n . w_s,   Q[s] = sum_n r_ns^2,   G[s,d] = sum_n r_ns x_nd. */
+void oracle_blr_data_pass(const float* X, long ldx, const float* y, long B, int D, const float* W,
+                          int S, double* Q, double* G) {
+    const int nt = omp_get_max_threads();
+    double* part = (double*)calloc((size_t)nt * (S + (size_t)S * D), sizeof(double));
+#pragma omp parallel num_threads(nt)
+    {
+        const int t = omp_get_thread_num();
+        double* q = part + (size_t)t * (S + (size_t)S * D);
+        double* g = q + S;
+        long lo, hi;
+        row_block(B, t, nt, &lo, &hi);
+        for (long n = lo; n < hi; ++n) {
+            const float* x = X + n * ldx;
+            for (int s = 0; s < S; ++s) {
+                const float* w = W + (long)s * D;
+                double dot = 0.0;
+                for (int d = 0; d < D; ++d) dot += (double)x[d] * (double)w[d];
+                const double r = (double)y[n] - dot;
+                q[s] += r * r;
+                double* gs = g + (long)s * D;
+                for (int d = 0; d < D; ++d) gs[d] += r * (double)x[d];
+            }
+        }
+    }
+    memset(Q, 0, sizeof(double) * S);
+    memset(G, 0, sizeof(double) * (size_t)S * D);
+    for (int t = 0; t < nt; ++t) {
+        const double* q = part + (size_t)t * (S + (size_t)S * D);
+        for (int s = 0; s < S; ++s) Q[s] += q[s];
+        for (long i = 0; i < (long)S * D; ++i) G[i] += q[S + i];
+    }
+    free(part);
+}
+
+/* Config 5 (README.md:52, BBVI): ell[s] = sum_n [ y_n l_ns - softplus(l_ns) ],
+ *   l_ns = x_n . Wz[s] + Bz[g_n, s]   (Bz is [G, S]). */
+void oracle_logreg_loglik(const float* X, long ldx, const float* y, const int* g, long N, int D,
+                          int G, const float* Wz, const float* Bz, int S, double* ell) {
+    const int nt = omp_get_max_threads();
+    double* part = (double*)calloc((size_t)nt * S, sizeof(double));
+    (void)G;
+#pragma omp parallel num_threads(nt)
+    {
+        const int t = omp_get_thread_num();
+        double* e = part + (size_t)t * S;
+        long lo, hi;
+        row_block(N, t, nt, &lo, &hi);
+        for (long n = lo; n < hi; ++n) {
+            const float* x = X + n * ldx;
+            const float* b = Bz + (long)g[n] * S;
+            for (int s = 0; s < S; ++s) {
+                const float* w = Wz + (long)s * D;
+                double l = (double)b[s];
+                for (int d = 0; d < D; ++d) l += (double)x[d] * (double)w[d];
+                const double sp = (l > 0.0 ? l : 0.0) + log1p(exp(-fabs(l)));
+                e[s] += (double)y[n] * l - sp;
+            }
+        }
+    }
+    for (int s = 0; s < S; ++s) {
+        ell[s] = 0.0;
+        for (int t = 0; t < nt; ++t) ell[s] += part[(size_t)t * S + s];
+    }
+    free(part);
+}
+
+/* Config 3 (README.md:43,72: discrete latent marginalised by summation):
+ *   logit_nk = c_k + sum_d (Wmat[k,d] x_nd + Wmat[k,D+d] x_nd^2),  r_nk = softmax_k,
+ *   stats[k] = (sum_n r_nk, sum_n r_nk x_n, sum_n r_nk x_n^2),  lse = sum_n logsumexp_k. */
+void oracle_mog_estep(const float* X, long ldx, long N, int D, int K, const float* Wmat,
+                      const float* c, double* stats, double* lse) {
+    const int nt = omp_get_max_threads();
+    const size_t per = (size_t)K * (1 + 2 * D) + 1;
+    double* part = (double*)calloc((size_t)nt * per, sizeof(double));
+#pragma omp parallel num_threads(nt)
+    {
+        const int t = omp_get_thread_num();
+        double* st = part + (size_t)t * per;
+        double* logit = (double*)malloc(sizeof(double) * K);
+        long lo, hi;
+        row_block(N, t, nt, &lo, &hi);
+        for (long n = lo; n < hi; ++n) {
+            const float* x = X + n * ldx;
+            double m = -1e300;
+            for (int k = 0; k < K; ++k) {
+                const float* w = Wmat + (long)k * 2 * D;
+                double l = (double)c[k];
+                for (int d = 0; d < D; ++d) {
+                    const double xd = (double)x[d];
+                    l += (double)w[d] * xd + (double)w[D + d] * xd * xd;
+                }
+                logit[k] = l;
+                if (l > m) m = l;
+            }
+            double z = 0.0;
+            for (int k = 0; k < K; ++k) { logit[k] = exp(logit[k] - m); z += logit[k]; }
+            st[per - 1] += m + log(z);
+            for (int k = 0; k < K; ++k) {
+                const double r = logit[k] / z;
+                double* sk = st + (size_t)k * (1 + 2 * D);
+                sk[0] += r;
+                for (int d = 0; d < D; ++d) {
+                    const double xd = (double)x[d];
+                    sk[1 + d] += r * xd;
+                    sk[1 + D + d] += r * xd * xd;
+                }
+            }
+        }
+        free(logit);
+    }
+    memset(stats, 0, sizeof(double) * (per - 1));
+    *lse = 0.0;
+    for (int t = 0; t < nt; ++t) {
+        const double* st = part + (size_t)t * per;
+        for (size_t i = 0; i + 1 < per; ++i) stats[i] += st[i];
+        *lse += st[per - 1];
+    }
+    free(part);
+}
+
+int oracle_threads(void) { return omp_get_max_threads(); }

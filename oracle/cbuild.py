@@ -1,0 +1,74 @@
+"""Builds and loads the plain-C second oracle (oracle/c/oracle_kernels.c).  TEST
+INFRASTRUCTURE ONLY -- see oracle/__init__.py.  Output goes to oracle/_build/ (git-ignored;
+it travels to the GPU box with the snapshot, and is rebuilt there if gcc is present)."""
+import ctypes
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "c", "oracle_kernels.c")
+OUT = os.path.join(HERE, "_build", "liboracle.so")
+
+
+def build(force=False):
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        if os.path.exists(OUT):
+            return OUT
+        raise RuntimeError("gcc not found and no prebuilt oracle/_build/liboracle.so")
+    if force or not os.path.exists(OUT) or os.path.getmtime(OUT) < os.path.getmtime(SRC):
+        os.makedirs(os.path.dirname(OUT), exist_ok=True)
+        subprocess.check_call([gcc, "-O2", "-fopenmp", "-shared", "-fPIC", SRC, "-o", OUT, "-lm"])
+    return OUT
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        lib = ctypes.CDLL(build())
+        vp, c_long, c_int = ctypes.c_void_p, ctypes.c_long, ctypes.c_int
+        lib.oracle_blr_data_pass.argtypes = [vp, c_long, vp, c_long, c_int, vp, c_int, vp, vp]
+        lib.oracle_logreg_loglik.argtypes = [vp, c_long, vp, vp, c_long, c_int, c_int, vp, vp, c_int, vp]
+        lib.oracle_mog_estep.argtypes = [vp, c_long, c_long, c_int, c_int, vp, vp, vp, vp]
+        lib.oracle_threads.restype = c_int
+        for f in (lib.oracle_blr_data_pass, lib.oracle_logreg_loglik, lib.oracle_mog_estep):
+            f.restype = None
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def blr_data_pass(X, y, W):
+    import numpy as np
+    X, y, W = (np.ascontiguousarray(a, np.float32) for a in (X, y, W))
+    S, D = W.shape
+    Q, G = np.zeros(S), np.zeros((S, D))
+    load().oracle_blr_data_pass(_p(X), X.shape[1], _p(y), X.shape[0], D, _p(W), S, _p(Q), _p(G))
+    return Q, G
+
+
+def logreg_loglik(X, y, g, Wz, Bz):
+    import numpy as np
+    X, y, Wz, Bz = (np.ascontiguousarray(a, np.float32) for a in (X, y, Wz, Bz))
+    g = np.ascontiguousarray(g, np.int32)
+    S, D = Wz.shape
+    ell = np.zeros(S)
+    load().oracle_logreg_loglik(_p(X), X.shape[1], _p(y), _p(g), X.shape[0], D, Bz.shape[0], _p(Wz),
+                                _p(Bz), S, _p(ell))
+    return ell
+
+
+def mog_estep(X, Wmat, c):
+    import numpy as np
+    X, Wmat, c = (np.ascontiguousarray(a, np.float32) for a in (X, Wmat, c))
+    K, D = Wmat.shape[0], X.shape[1]
+    stats, lse = np.zeros((K, 1 + 2 * D)), np.zeros(1)
+    load().oracle_mog_estep(_p(X), X.shape[1], X.shape[0], D, K, _p(Wmat), _p(c), _p(stats), _p(lse))
+    return stats, float(lse[0])

@@ -196,13 +196,16 @@ def adam_ascent(lam, grad, m1, m2, t, lr, beta1=0.9, beta2=0.999, eps=1e-8):
 
 
 def blr_step(lam, m1, m2, t, X, y, S, seed, n_total, lr, alpha0=1.0, beta0=1.0,
-             chunked=False):
+             chunked=False, data_pass=None):
     """One full ELBO-gradient update on one mini-batch (sample -> pass ->
     gradient -> Adam).  ``t`` is the 1-based step index and also the Philox
-    step counter (t - 1).  Returns (lam, m1, m2, elbo, grad)."""
+    step counter (t - 1).  ``data_pass`` swaps in another restatement of the pass
+    (oracle.cbuild.blr_data_pass).  Returns (lam, m1, m2, elbo, grad)."""
     B, D = X.shape
     eps, W, xi = blr_sample(lam, D, S, seed, step=t - 1)
-    Q, G = (blr_data_pass_chunked if chunked else blr_data_pass)(X, y, W)
+    if data_pass is None:
+        data_pass = blr_data_pass_chunked if chunked else blr_data_pass
+    Q, G = data_pass(X, y, W)
     elbo, grad = blr_elbo_and_grad(lam, eps, W, xi, Q, G, B, n_total / B, alpha0, beta0)
     lam, m1, m2 = adam_ascent(lam, grad, m1, m2, t, lr)
     return lam, m1, m2, elbo, grad

@@ -1,0 +1,112 @@
+"""The plain-C second oracle (oracle/c/oracle_kernels.c) against the numpy oracle on small
+inputs (CPU), and the HIP kernels against the C oracle at BASELINE's FULL sizes (GPU) -- the
+numpy oracle takes minutes there, the OpenMP C one seconds."""
+import math
+import shutil
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from oracle import svi
+
+needs_gcc = pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not available")
+rs = np.random.RandomState(8)
+
+
+@needs_gcc
+def test_c_oracle_matches_numpy_oracle():
+    from oracle import cbuild
+    X = rs.standard_normal((777, 24)).astype(np.float32)
+    y = rs.standard_normal(777).astype(np.float32)
+    W = (rs.standard_normal((5, 24)) / 4).astype(np.float32)
+    Q, G = cbuild.blr_data_pass(X, y, W)
+    q_ref, g_ref = svi.blr_data_pass(X, y, W)
+    npt.assert_allclose(Q, q_ref, rtol=1e-12)
+    npt.assert_allclose(G, g_ref, rtol=1e-11, atol=1e-11)
+
+    g = rs.randint(7, size=777).astype(np.int32)
+    yb = (rs.uniform(size=777) < 0.4).astype(np.float32)
+    Wz = (rs.standard_normal((16, 24)) / 4).astype(np.float32)
+    Bz = rs.standard_normal((7, 16)).astype(np.float32)
+    npt.assert_allclose(cbuild.logreg_loglik(X, yb, g, Wz, Bz), svi.logreg_loglik(X, yb, g, Wz, Bz),
+                        rtol=1e-12)
+
+    K, D = 6, 24
+    T = rs.uniform(0.5, 2.0, (K, D))
+    cen = rs.standard_normal((K, D))
+    Wmat = np.concatenate([T * cen, -0.5 * T], axis=1).astype(np.float32)
+    c = rs.standard_normal(K).astype(np.float32)
+    stats, lse = cbuild.mog_estep(X, Wmat, c)
+    s_ref, l_ref = svi.mog_local_step(X, Wmat, c)
+    npt.assert_allclose(stats, s_ref, rtol=1e-10, atol=1e-10)
+    npt.assert_allclose(lse, l_ref, rtol=1e-12)
+
+
+@needs_gcc
+@pytest.mark.gpu
+def test_cfg2_full_size_against_c_oracle(ctx):
+    """1M x 256, S = 8: the data pass against the C oracle on the very same data."""
+    import torch
+    from oracle import cbuild
+    g = torch.Generator(device=ctx.device).manual_seed(21)
+    B, D, S = 1_000_000, 256, 8
+    X = torch.randn((B, D), generator=g, device=ctx.device)
+    y = torch.randn(B, generator=g, device=ctx.device)
+    W = torch.randn((S, D), generator=g, device=ctx.device) / 16
+    Q, G = ctx.zeros(S, torch.float64), ctx.zeros((S, D), torch.float64)
+    ctx.call("bsc_blr_data_pass", X, D, y, B, D, W, S, Q, G)
+    ctx.sync()
+    Xh, yh, Wh = X.cpu().numpy(), y.cpu().numpy(), W.cpu().numpy()
+    q_ref, g_ref = cbuild.blr_data_pass(Xh, yh, Wh)
+    npt.assert_allclose(Q.cpu().numpy(), q_ref, rtol=2e-6)
+    # each G[s, d] is a sum of 1e6 terms of either sign: bound by the scale of the sum
+    scale = np.sqrt(q_ref)[:, None] * np.sqrt((Xh.astype(np.float64) ** 2).sum(0))[None, :]
+    assert (np.abs(G.cpu().numpy() - g_ref) <= 2e-5 * scale).all()
+
+
+@needs_gcc
+@pytest.mark.gpu
+def test_cfg5_full_size_against_c_oracle(ctx):
+    """1M x 256, G = 1000, S = 64."""
+    import torch
+    from oracle import cbuild
+    g = torch.Generator(device=ctx.device).manual_seed(22)
+    N, D, G, S = 1_000_000, 256, 1000, 64
+    X = torch.randn((N, D), generator=g, device=ctx.device)
+    y = (torch.rand(N, generator=g, device=ctx.device) < 0.4).float()
+    grp = torch.randint(G, (N,), generator=g, device=ctx.device).to(torch.int32)
+    Wz = torch.randn((S, D), generator=g, device=ctx.device) / 16
+    Bz = torch.randn((G, S), generator=g, device=ctx.device)
+    ell = ctx.zeros(S, torch.float64)
+    ctx.call("bsc_logreg_bbvi_loglik", X, D, y, grp, N, D, G, Wz, Bz, S, ell)
+    ctx.sync()
+    want = cbuild.logreg_loglik(X.cpu().numpy(), y.cpu().numpy(), grp.cpu().numpy(),
+                                Wz.cpu().numpy(), Bz.cpu().numpy())
+    npt.assert_allclose(ell.cpu().numpy(), want, rtol=2e-6)
+
+
+@needs_gcc
+@pytest.mark.gpu
+def test_cfg3_full_size_against_c_oracle(ctx):
+    """10M x 16, K = 64."""
+    import torch
+    from oracle import cbuild
+    g = torch.Generator(device=ctx.device).manual_seed(23)
+    N, D, K = 10_000_000, 16, 64
+    cen = torch.randn((K, D), generator=g, device=ctx.device) * 2
+    X = cen[torch.randint(K, (N,), generator=g, device=ctx.device)] + \
+        torch.randn((N, D), generator=g, device=ctx.device)
+    T = torch.rand((K, D), generator=g, device=ctx.device) + 0.5
+    Wmat = torch.cat([T * cen, -0.5 * T], dim=1).contiguous()
+    c = (-0.5 * (T * cen ** 2).sum(1)).contiguous()
+    stats = ctx.zeros((K, 1 + 2 * D), torch.float64)
+    lse = ctx.zeros(1, torch.float64)
+    ctx.call("bsc_mog_estep", X, D, N, D, K, Wmat, c, stats, lse)
+    ctx.sync()
+    Xh = X.cpu().numpy()
+    s_ref, l_ref = cbuild.mog_estep(Xh, Wmat.cpu().numpy(), c.cpu().numpy())
+    X64 = np.abs(Xh.astype(np.float64))
+    scale = np.concatenate([[float(N)], X64.sum(0), (X64 ** 2).sum(0)])
+    assert (np.abs(stats.cpu().numpy() - s_ref) <= 2e-5 * scale[None, :] / math.sqrt(K)).all()
+    npt.assert_allclose(lse.item(), l_ref, rtol=2e-6)
