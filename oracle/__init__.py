@@ -24,7 +24,7 @@ Pinning status (see DESIGN.md "Oracle"):
   conjugate posteriors, finite differences and the Random123 Philox4x32-10
   known-answer vectors.
 * ``oracle/c/oracle_kernels.c`` (loaded by ``oracle.cbuild``): the data-sized sums
-  of configs 2, 3 and 5 once more in plain C + OpenMP, written independently of
+  of configs 2, 3, 4 and 5 once more in plain C + OpenMP, written independently of
   ``oracle.svi`` and checked against it; **PARITY UNPINNED** for the same reason.
   It exists so the HIP kernels can be compared on identical data at full size.
 """

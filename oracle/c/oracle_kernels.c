@@ -149,4 +149,32 @@ void oracle_mog_estep(const float* X, long ldx, long N, int D, int K, const floa
     free(part);
 }
 
+/* Config 4 (README.md:36,75-77; fixed-gamma local step):
+ *   sstats[k,v] = Bt[k,v] * sum_d Th[d,k] C[d,v] / (sum_k' Th[d,k'] Bt[k',v]).
+ * Zero counts contribute nothing and are skipped.  Threads own column blocks, so every
+ * output has one writer and the document order of each sum is fixed. */
+void oracle_lda_sstats(const float* C, long ldc, long docs, long V, int K, const float* Th,
+                       const float* Bt, double* out) {
+    const int nt = omp_get_max_threads();
+    memset(out, 0, sizeof(double) * (size_t)K * V);
+#pragma omp parallel num_threads(nt)
+    {
+        long lo, hi;
+        row_block(V, omp_get_thread_num(), nt, &lo, &hi);
+        for (long d = 0; d < docs; ++d) {
+            const float* th = Th + d * K;
+            for (long v = lo; v < hi; ++v) {
+                const double cnt = (double)C[d * ldc + v];
+                if (cnt == 0.0) continue;
+                double p = 0.0;
+                for (int k = 0; k < K; ++k) p += (double)th[k] * (double)Bt[(long)k * V + v];
+                const double ratio = cnt / p;
+                for (int k = 0; k < K; ++k) out[(long)k * V + v] += (double)th[k] * ratio;
+            }
+        }
+        for (int k = 0; k < K; ++k)
+            for (long v = lo; v < hi; ++v) out[(long)k * V + v] *= (double)Bt[(long)k * V + v];
+    }
+}
+
 int oracle_threads(void) { return omp_get_max_threads(); }

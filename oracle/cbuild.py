@@ -34,8 +34,10 @@ def load():
         lib.oracle_blr_data_pass.argtypes = [vp, c_long, vp, c_long, c_int, vp, c_int, vp, vp]
         lib.oracle_logreg_loglik.argtypes = [vp, c_long, vp, vp, c_long, c_int, c_int, vp, vp, c_int, vp]
         lib.oracle_mog_estep.argtypes = [vp, c_long, c_long, c_int, c_int, vp, vp, vp, vp]
+        lib.oracle_lda_sstats.argtypes = [vp, c_long, c_long, c_long, c_int, vp, vp, vp]
         lib.oracle_threads.restype = c_int
-        for f in (lib.oracle_blr_data_pass, lib.oracle_logreg_loglik, lib.oracle_mog_estep):
+        for f in (lib.oracle_blr_data_pass, lib.oracle_logreg_loglik, lib.oracle_mog_estep,
+                  lib.oracle_lda_sstats):
             f.restype = None
         _lib = lib
     return _lib
@@ -72,3 +74,12 @@ def mog_estep(X, Wmat, c):
     stats, lse = np.zeros((K, 1 + 2 * D)), np.zeros(1)
     load().oracle_mog_estep(_p(X), X.shape[1], X.shape[0], D, K, _p(Wmat), _p(c), _p(stats), _p(lse))
     return stats, float(lse[0])
+
+
+def lda_sstats(C, Th, Bt):
+    import numpy as np
+    C, Th, Bt = (np.ascontiguousarray(a, np.float32) for a in (C, Th, Bt))
+    K, V = Bt.shape
+    out = np.zeros((K, V))
+    load().oracle_lda_sstats(_p(C), C.shape[1], C.shape[0], V, K, _p(Th), _p(Bt), _p(out))
+    return out

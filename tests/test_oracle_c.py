@@ -42,6 +42,11 @@ def test_c_oracle_matches_numpy_oracle():
     npt.assert_allclose(stats, s_ref, rtol=1e-10, atol=1e-10)
     npt.assert_allclose(lse, l_ref, rtol=1e-12)
 
+    C = rs.poisson(0.3, (90, 40)).astype(np.float32)
+    Th = rs.uniform(0.1, 1.0, (90, 32)).astype(np.float32)
+    Bt = rs.uniform(0.1, 1.0, (32, 40)).astype(np.float32)
+    npt.assert_allclose(cbuild.lda_sstats(C, Th, Bt), svi.lda_sstats(C, Th, Bt), rtol=1e-12)
+
 
 @needs_gcc
 @pytest.mark.gpu
@@ -110,3 +115,33 @@ def test_cfg3_full_size_against_c_oracle(ctx):
     scale = np.concatenate([[float(N)], X64.sum(0), (X64 ** 2).sum(0)])
     assert (np.abs(stats.cpu().numpy() - s_ref) <= 2e-5 * scale[None, :] / math.sqrt(K)).all()
     npt.assert_allclose(lse.item(), l_ref, rtol=2e-6)
+
+
+@needs_gcc
+@pytest.mark.gpu
+def test_cfg4_full_size_against_c_oracle(ctx):
+    """6250 x 100 000 counts (one GPU's shard of config 4), K = 128: the dense MFMA kernel and
+    the sparse (CSC) kernel against the C oracle."""
+    import scipy.sparse as sp
+    import torch
+    from oracle import cbuild
+    docs, V, K = 6250, 100_000, 128
+    g = torch.Generator(device=ctx.device).manual_seed(24)
+    C = torch.poisson(torch.full((docs, V), 0.05, device=ctx.device), generator=g)
+    Th = torch.rand((docs, K), generator=g, device=ctx.device) + 0.1
+    Bt = torch.rand((K, V), generator=g, device=ctx.device) + 0.1
+    dense = ctx.zeros((K, V), torch.float32)
+    ctx.call("bsc_lda_sstats", C, V, docs, V, K, Th, K, Bt, V, dense, V)
+    ctx.sync()
+    Ch = C.cpu().numpy()
+    want = cbuild.lda_sstats(Ch, Th.cpu().numpy(), Bt.cpu().numpy())
+    # a sum of ~300 positive float32 terms per output
+    npt.assert_allclose(dense.cpu().numpy(), want, rtol=2e-5)
+    csc = sp.csc_matrix(Ch)
+    colptr = torch.from_numpy(csc.indptr.astype(np.int64)).to(ctx.device)
+    rowidx = torch.from_numpy(csc.indices.astype(np.int32)).to(ctx.device)
+    vals = torch.from_numpy(csc.data.astype(np.float32)).to(ctx.device)
+    sparse = ctx.zeros((K, V), torch.float32)
+    ctx.call("bsc_lda_sstats_csc", colptr, rowidx, vals, docs, V, K, Th, K, Bt, V, sparse, V)
+    ctx.sync()
+    npt.assert_allclose(sparse.cpu().numpy(), want, rtol=2e-5)
