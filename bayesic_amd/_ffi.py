@@ -85,6 +85,8 @@ SIGNATURES = {
                                c_int64, c_void_p, c_int64, c_void_p, c_int64]),
     "bsc_lda_sstats_csc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32,
                                    c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
+    "bsc_weighted_outer": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                   c_int64, c_int32, c_int32, c_int32, c_double, c_void_p]),
     "bsc_hbm_read_probe": (c_int, [c_void_p, c_void_p, c_size_t, c_int, POINTER(c_double)]),
     "bsc_host_register": (c_int, [c_void_p, c_size_t]),
     "bsc_host_unregister": (c_int, [c_void_p]),

@@ -471,6 +471,60 @@ class DeviceBackend(Backend):
         perm = [kept.index(a) for a in list(x_batch) + x_other]
         return out.permute(perm) if perm != sorted(perm) else out
 
+    def _weighted_outer(self, x, y, x_dot, y_dot):
+        """sum_n A[k,n] B[d,n] Y[n,e] -- what the front end makes of
+        einsum(out_kde = sum_n R_nk X_nd Y_ne): _tensordot(_mul(_dimshuffle(R,1,'x',0),
+        _dimshuffle(X,'x',1,0)), Y, [2], [0]) (bayesic/algebra.py:632-636).  Run as one pass of
+        bsc_weighted_outer instead of materialising the K x D x N product; None when the
+        shapes are not that pattern or outside the kernel's limits."""
+        if not (x.combine == "mul" and x.post is None and x.shift == 0.0 and len(x.terms) == 2
+                and x.dim() == 3 and len(x_dot) == 1 and len(y_dot) == 1
+                and isinstance(y, torch.Tensor) and y.dim() == 2
+                and x.dtype == torch.float32 and y.dtype == torch.float32
+                and all(op is None and isinstance(t, torch.Tensor) for t, op, _ in x.terms)):
+            return None
+        n_ax, yd = x_dot[0], y_dot[0]
+        ye = 1 - yd
+        f0, f1 = [a for a in range(3) if a != n_ax]
+        n = x.shape[n_ax]
+        if y.shape[yd] != n:
+            raise ValueError("tensordot: contracted / batch extents differ (%d vs %d)"
+                             % (n, y.shape[yd]))
+
+        def role(t):    # the free axis this factor varies along (it must not vary along the other)
+            if t.shape[n_ax] != n:
+                return None
+            if t.shape[f1] == 1 and t.shape[f0] == x.shape[f0]:
+                return f0
+            if t.shape[f0] == 1 and t.shape[f1] == x.shape[f1]:
+                return f1
+            return None
+
+        (ta, _, _), (tb, _, _) = x.terms
+        ra, rb = role(ta), role(tb)
+        if ra is None or rb is None or ra == rb:
+            return None
+        if ra != f0:
+            ta, tb = tb, ta                         # ta varies along f0, tb along f1
+        # the kernel takes K <= 64 on its first factor and D <= 32 on its second
+        if x.shape[f0] <= 64 and x.shape[f1] <= 32:
+            r, ax_r, xx, ax_x, swap = ta, f0, tb, f1, False
+        elif x.shape[f1] <= 64 and x.shape[f0] <= 32:
+            r, ax_r, xx, ax_x, swap = tb, f1, ta, f0, True
+        else:
+            return None
+        K, D, E = r.shape[ax_r], xx.shape[ax_x], y.shape[ye]
+        ldr, ldx, ldy = r.stride(n_ax), xx.stride(n_ax), y.stride(yd)
+        if K % 4 or D % 4 or E % 4 or E > 32 or n == 0 or \
+                r.stride(ax_r) != 1 or xx.stride(ax_x) != 1 or y.stride(ye) != 1 or \
+                ldr % 4 or ldx % 4 or ldy % 4 or ldr < K or ldx < D or ldy < E or \
+                (r.data_ptr() | xx.data_ptr() | y.data_ptr()) % 16:
+            return None
+        out = self._empty((K, D, E), torch.float32)
+        self.ctx.call("bsc_weighted_outer", _ffi.ptr(r), ldr, _ffi.ptr(xx), ldx, _ffi.ptr(y), ldy,
+                      n, K, D, E, float(x.scale), _ffi.ptr(out))
+        return out.permute(1, 0, 2) if swap else out
+
     def tensordot(self, x, y, x_dot, y_dot, x_batch, y_batch):
         free_x = x.dim() - len(x_dot) - len(x_batch)
         free_y = y.dim() - len(y_dot) - len(y_batch)
@@ -483,6 +537,10 @@ class DeviceBackend(Backend):
                 return self._dot_products(x, y, x_dot, y_dot, x_batch, y_batch)
             if free_x == 0 and isinstance(y, Lazy):
                 return self._dot_products(y, x, y_dot, x_dot, y_batch, x_batch)
+            if isinstance(x, Lazy) and not x_batch and not y_batch:
+                out = self._weighted_outer(x, y, x_dot, y_dot)
+                if out is not None:
+                    return out
         x, y = self._force(x), self._force(y)
         (x, y), dtype, _ = self._common([x, y]) if x.dtype != y.dtype else ((x, y), x.dtype, 0)
         x_other = [a for a in range(x.dim()) if a not in x_dot and a not in x_batch]

@@ -235,6 +235,20 @@ int bsc_suffstats_normal(bsc_ctx* ctx, const float* x, int64_t n, double* stats)
 int bsc_mog_estep(bsc_ctx* ctx, const float* X, int64_t ldx, int64_t N, int32_t D, int32_t K,
                   const float* Wmat, const float* c, double* stats, double* lse);
 
+/* Responsibility-weighted second moments (full-covariance mixture statistic
+ * sum_n r_nk x_n x_n^T; t(x) = (x, x x^T) of bayesic/distribution/core.py:41-44 summed over
+ * the iid axis, bayesic/distribution/base.py:329-332):
+ *     out[k,d,e] = scale * sum_n R[n,k] X[n,d] Y[n,e]          (float32 [K, D, E], contiguous)
+ * in ONE pass over R[N,K], X[N,D], Y[N,E] (row-major, leading dimensions in floats).  The
+ * reference lowers this einsum to a _tensordot over a materialised K x D x N product
+ * (bayesic/algebra.py:632-636).  Y == X (same pointer, ld and extent) computes only d <= e and
+ * mirrors.  fp32 MFMA, float64 fixed-order finish.  Limits: K <= 64, D, E <= 32, all
+ * multiples of 4, 16-byte aligned operands, ld % 4 == 0 (else BSC_ERR_UNSUPPORTED -- the
+ * executor then takes the general route). */
+int bsc_weighted_outer(bsc_ctx* ctx, const float* R, int64_t ldr, const float* X, int64_t ldx,
+                       const float* Y, int64_t ldy, int64_t N, int32_t K, int32_t D, int32_t E,
+                       double scale, float* out);
+
 /* Mean-field global parameters of the mixture: Dirichlet over weights and a
  * Normal-Gamma per (component, column), as one natural-parameter vector
  *   eta = [alpha-1 (K) | kappa*m (K*D) | kappa (K*D) | 2a-1 (K*D) | 2b+kappa*m^2 (K*D)].

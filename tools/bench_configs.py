@@ -121,7 +121,15 @@ def main():
         w, _ = timed(ctx, mog.step, 20, warm=10)
         row("cfg3 whole MoG update (expected params + E-step + natural-gradient step)", w,
             float("nan"), 4.0 * N3 * D3, 8.0 * K3 * D3 * N3, "f32-mfma")
-        del X3, mog
+        # full-covariance statistic sum_n r_nk x_n x_n^T: one pass instead of the K x D x N product
+        Rm = torch.softmax(torch.randn((N3, K3), generator=g, device=dev), dim=1)
+        cov = torch.empty((K3, D3, D3), device=dev)
+        w, k = timed(ctx, lambda: ctx.call("bsc_weighted_outer", Rm, K3, X3, D3, X3, D3, N3, K3, D3,
+                                           D3, 1.0, cov), 10, warm=5)
+        pairs = D3 * (D3 + 1) // 2
+        row("cfg3' weighted second moment %dMx16 K=64 (bsc_weighted_outer, d<=e pairs)"
+            % (N3 // 1_000_000), w, k, 4.0 * N3 * (K3 + D3), 2.0 * N3 * K3 * pairs, "f32-mfma")
+        del X3, mog, Rm
 
     if want("cfg5"):
         # ---- config 5: BBVI log-likelihood pass ------------------------------------------
