@@ -14,9 +14,9 @@
 //
 // on v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulate).  When Y is X only the
 // D(D+1)/2 pairs d <= e are computed and mirrored on output.  A workgroup stages 64 rows of
-// R, X (and Y) in LDS; each of its waves owns one 32-pair tile for both component tiles, so a
-// k-step of a wave is three LDS reads and one multiply against two MFMAs.  Bound: fp32 MFMA.
-// Workgroups are summed by a fixed-order float64 finish.
+// R, X (and Y) in LDS; a wave takes one component tile and a part of the rows for all pair
+// tiles of the workgroup, so its k-step is 1 + 2 CT LDS reads and CT multiplies against CT
+// MFMAs.  Bound: fp32 MFMA.  Partial sums are added by a fixed-order float64 finish.
 #include "bsc_common.h"
 
 namespace {
@@ -25,7 +25,7 @@ constexpr int WO_TR = 64;       // rows per stage
 constexpr int WO_BLOCK = 256;
 constexpr int WO_MAXK = 64;
 constexpr int WO_MAXD = 32;
-constexpr int WO_MAXCT = 8;     // pair tiles (= waves) per workgroup
+constexpr int WO_MAXCT = 8;     // pair tiles per workgroup
 constexpr int WO_TILE = 1024;   // floats of one 32 x 32 accumulator tile
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -57,80 +57,145 @@ __device__ __forceinline__ void wo_pair(int p, int D, int E, int sym, int& d, in
     e = d + p;
 }
 
-// blockDim.x = 64 * CT: wave w owns pair tile blockIdx.y * CT + w for every component tile
-// and walks all rows of the stage; no wave shares an accumulator, so nothing is combined
-// inside the workgroup.  ~60 VGPRs: several workgroups per CU overlap one's loads with the
-// others' MFMAs, which is all the latency hiding there is (no register prefetch).
-template <int KT, bool SYM>
-__global__ __launch_bounds__(512) void weighted_outer_kernel(WOArgs a) {
+// Four waves per workgroup, one per SIMD: wave = (component tile kt, row part rp) with
+// KT * RP = 4.  A wave walks its part of the stage's rows for all CT pair tiles of the
+// workgroup (CT accumulators, 16 registers each); row parts are added through LDS at the end.  (A wave per pair tile -- five waves at D = 16 -- leaves one SIMD with twice the
+// work of the others: 1.90 ms against 1.3 ms of MFMA time.)
+__device__ __forceinline__ float4 wo_load4(const float* p, bool ok) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) v = *(const float4*)p;
+    return v;
+}
+
+template <int KT, int CT>
+__global__ __launch_bounds__(WO_BLOCK) void weighted_outer_kernel(WOArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[WO_TR * (WO_MAXK + 2 * WO_MAXD)];
     constexpr int RS = KT * 32;
+    constexpr int RP = 4 / KT;                 // row parts
+    constexpr int ROWS = WO_TR / RP;           // rows of a stage per wave
     float* Rs = lds;
     float* Xs = lds + WO_TR * WO_MAXK;
-    float* Ys = SYM ? Xs : Xs + WO_TR * WO_MAXD;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_thr = blockDim.x;
-    const int CT = n_thr >> 6;
+    float* Ys = a.sym ? Xs : Xs + WO_TR * WO_MAXD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kt = wave % KT, rp = wave / KT;
     const int col = lane & 31, half = lane >> 5;
 
-    int xo = 0, yo = 0;
-    {
-        const int p = ((int)blockIdx.y * CT + wave) * 32 + col;
-        if (p < a.P) wo_pair(p, a.D, a.E, SYM, xo, yo);
+    int xo[CT], yo[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int p = ((int)blockIdx.y * CT + ct) * 32 + col;
+        int d = 0, e = 0;
+        if (p < a.P) wo_pair(p, a.D, a.E, a.sym, d, e);
+        xo[ct] = d;
+        yo[ct] = e;
     }
-    f32x16 acc[KT];
+    f32x16 acc[CT];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[kt][q] = 0.f;
+        for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
 
     const int k4 = a.K >> 2, d4 = a.D >> 2, e4 = a.E >> 2;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* rrow = Rs + (rp * ROWS + half) * RS + kt * 32 + col;
+    const float* xrow = Xs + (rp * ROWS + half) * WO_MAXD;
+    const float* yrow = Ys + (rp * ROWS + half) * WO_MAXD;
+    constexpr int NR = WO_TR * 16 / WO_BLOCK, NX = WO_TR * 8 / WO_BLOCK;
+    // a stage: R has 16 float4 slots per row (zero beyond K), X / Y have 8
+    const int rr = tid >> 4, rc = tid & 15, xr = tid >> 3, xc = tid & 7;
+    const bool r_ok = rc < k4, x_ok = xc < d4, y_ok = !a.sym && xc < e4;
+    const float* rsrc = a.R + rc * 4;
+    const float* xsrc = a.X + xc * 4;
+    const float* ysrc = a.Y + xc * 4;
+    float4 pr[NR], px[NX], py[NX];
+#define WO_FETCH(IT)                                                                          \
+    {                                                                                         \
+        const int64_t row0_ = ((int64_t)blockIdx.x + (int64_t)(IT) * gridDim.x) * WO_TR;       \
+        _Pragma("unroll") for (int i = 0; i < NR; ++i) {                                      \
+            const int64_t row = row0_ + rr + i * (WO_BLOCK / 16);                             \
+            pr[i] = wo_load4(rsrc + row * a.ldr, r_ok && row < a.N);                          \
+        }                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                      \
+            const int64_t row = row0_ + xr + i * (WO_BLOCK / 8);                              \
+            px[i] = wo_load4(xsrc + row * a.ldx, x_ok && row < a.N);                          \
+            py[i] = wo_load4(ysrc + row * a.ldy, y_ok && row < a.N);                          \
+        }                                                                                     \
+    }
+    if (a.iters > 0) WO_FETCH(0)
     for (int it = 0; it < a.iters; ++it) {
-        const int64_t row0 = ((int64_t)blockIdx.x + (int64_t)it * gridDim.x) * WO_TR;
-        // a stage: R has 16 float4 slots per row (zero beyond K), X / Y have 8
-        for (int s = tid; s < WO_TR * 16; s += n_thr) {
-            const int r = s >> 4, c = s & 15;
-            const int64_t row = row0 + r;
-            const float4 v = (c < k4 && row < a.N) ? *(const float4*)(a.R + row * a.ldr + c * 4) : zero4;
-            if (c < KT * 8) *(float4*)(Rs + r * RS + c * 4) = v;
-        }
-        for (int s = tid; s < WO_TR * 8; s += n_thr) {
-            const int r = s >> 3, c = s & 7;
-            const int64_t row = row0 + r;
-            *(float4*)(Xs + r * WO_MAXD + c * 4) =
-                (c < d4 && row < a.N) ? *(const float4*)(a.X + row * a.ldx + c * 4) : zero4;
-            if (!SYM)
-                *(float4*)(Ys + r * WO_MAXD + c * 4) =
-                    (c < e4 && row < a.N) ? *(const float4*)(a.Y + row * a.ldy + c * 4) : zero4;
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+            if (rc < KT * 8) *(float4*)(Rs + (rr + i * (WO_BLOCK / 16)) * RS + rc * 4) = pr[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            *(float4*)(Xs + (xr + i * (WO_BLOCK / 8)) * WO_MAXD + xc * 4) = px[i];
+            if (!a.sym) *(float4*)(Ys + (xr + i * (WO_BLOCK / 8)) * WO_MAXD + xc * 4) = py[i];
         }
         __syncthreads();
-#pragma unroll 8
-        for (int j = 0; j < WO_TR / 2; ++j) {
-            const int r = 2 * j + half;
-            const float z = Xs[r * WO_MAXD + xo] * Ys[r * WO_MAXD + yo];
+        // the next stage's rows travel through registers while this one is multiplied
+        if (it + 1 < a.iters) WO_FETCH(it + 1)
+#undef WO_FETCH
+#pragma unroll 4
+        for (int j = 0; j < ROWS / 2; ++j) {
+            const float av = rrow[2 * j * RS];
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Rs[r * RS + kt * 32 + col], z, acc[kt], 0, 0, 0);
+            for (int ct = 0; ct < CT; ++ct) {
+                const float z = xrow[2 * j * WO_MAXD + xo[ct]] * yrow[2 * j * WO_MAXD + yo[ct]];
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, z, acc[ct], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
 
-    float* out = a.part + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (KT * CT)) * WO_TILE;
+    // row parts of one component tile are added through LDS (fixed order), pair tile by pair tile
+    float* red = lds;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int ct = 0; ct < CT; ++ct) {
+        if (rp > 0) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) out[(kt * CT + wave) * WO_TILE + q * 64 + lane] = acc[kt][q];
+            for (int q = 0; q < 16; ++q) red[wave * WO_TILE + q * 64 + lane] = acc[ct][q];
+        }
+        __syncthreads();
+        if (rp == 0) {
+#pragma unroll
+            for (int r = 1; r < RP; ++r)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[ct][q] += red[(r * KT + kt) * WO_TILE + q * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (rp != 0) return;
+    float* out = a.part + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (KT * CT) + kt * CT) * WO_TILE;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) out[ct * WO_TILE + q * 64 + lane] = acc[ct][q];
+}
+
+template <int KT>
+void launch_wo(int CT, dim3 grid, hipStream_t stream, const WOArgs& a) {
+    const dim3 block(WO_BLOCK);
+    switch (CT) {
+        case 1: hipLaunchKernelGGL((weighted_outer_kernel<KT, 1>), grid, block, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((weighted_outer_kernel<KT, 2>), grid, block, 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((weighted_outer_kernel<KT, 3>), grid, block, 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((weighted_outer_kernel<KT, 4>), grid, block, 0, stream, a); break;
+        case 5: hipLaunchKernelGGL((weighted_outer_kernel<KT, 5>), grid, block, 0, stream, a); break;
+        case 6: hipLaunchKernelGGL((weighted_outer_kernel<KT, 6>), grid, block, 0, stream, a); break;
+        case 7: hipLaunchKernelGGL((weighted_outer_kernel<KT, 7>), grid, block, 0, stream, a); break;
+        default: hipLaunchKernelGGL((weighted_outer_kernel<KT, 8>), grid, block, 0, stream, a); break;
+    }
 }
 
 // out[k][d][e] (and [k][e][d] when symmetric) = scale * sum over workgroups, float64, fixed
-// order.  A block owns one (component, 32 pairs) line: 8 groups of 32 lanes walk the
+// order.  A block owns one (component, 32 pairs) line: 32 groups of 32 lanes walk the
 // workgroups interleaved, then combine in group order.
-__global__ __launch_bounds__(256) void weighted_outer_finish_kernel(const float* __restrict__ part,
-                                                                    int gx, int KT, int CT, int K,
-                                                                    int D, int E, int sym, int P,
-                                                                    double scale,
-                                                                    float* __restrict__ out) {
-    __shared__ double comb[8][32];
+__global__ __launch_bounds__(1024) void weighted_outer_finish_kernel(const float* __restrict__ part,
+                                                                     int gx, int KT, int CT, int K,
+                                                                     int D, int E, int sym, int P,
+                                                                     double scale,
+                                                                     float* __restrict__ out) {
+    constexpr int G = 32;
+    __shared__ double comb[G][32];
     const int n_ct = (P + 31) / 32;
     const int k = blockIdx.x / n_ct, ctg = blockIdx.x - k * n_ct;
     const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -141,13 +206,22 @@ __global__ __launch_bounds__(256) void weighted_outer_finish_kernel(const float*
     const float* src = part + (int64_t)gy * gx * wg_stride + (int64_t)(kt * CT + ct) * WO_TILE +
                        q * 64 + half * 32 + j;
     double s = 0.0;
-    for (int b = grp; b < gx; b += 8) s += (double)src[(int64_t)b * wg_stride];
+    int b = grp;
+    for (; b + 3 * G < gx; b += 4 * G) {
+        const float v0 = src[(int64_t)b * wg_stride], v1 = src[(int64_t)(b + G) * wg_stride];
+        const float v2 = src[(int64_t)(b + 2 * G) * wg_stride], v3 = src[(int64_t)(b + 3 * G) * wg_stride];
+        s += (double)v0;
+        s += (double)v1;
+        s += (double)v2;
+        s += (double)v3;
+    }
+    for (; b < gx; b += G) s += (double)src[(int64_t)b * wg_stride];
     comb[grp][j] = s;
     __syncthreads();
     if (grp != 0) return;
     double tot = comb[0][j];
 #pragma unroll
-    for (int g = 1; g < 8; ++g) tot += comb[g][j];
+    for (int g = 1; g < G; ++g) tot += comb[g][j];
     const int p = ctg * 32 + j;
     if (p >= P) return;
     int d, e;
@@ -185,8 +259,8 @@ extern "C" int bsc_weighted_outer(bsc_ctx* ctx, const float* R, int64_t ldr, con
     const int gy = (n_ct + WO_MAXCT - 1) / WO_MAXCT;
     const int CT = (n_ct + gy - 1) / gy;
     const int64_t stages = (N + WO_TR - 1) / WO_TR;
-    // about 20 waves per CU (LDS allows five workgroups), spread over the pair-tile groups
-    const int wg_per_cu = std::max(1, std::min(5, 20 / CT));
+    // every instantiation stays under 128 VGPRs: four workgroups per CU (LDS allows five)
+    const int wg_per_cu = 4;
     int64_t gx = std::max<int64_t>(1, (int64_t)wg_per_cu * ctx->cu_count / gy);
     gx = std::min(gx, std::max<int64_t>(stages, 1));
     a.iters = (int)((stages + gx - 1) / gx);
@@ -199,14 +273,11 @@ extern "C" int bsc_weighted_outer(bsc_ctx* ctx, const float* R, int64_t ldr, con
     if (stages > 0) {
         bsc_prof_scope prof(ctx);
         const dim3 grid((unsigned)gx, (unsigned)gy);
-        const dim3 block((unsigned)(64 * CT));
-        if (KT == 1 && a.sym) hipLaunchKernelGGL((weighted_outer_kernel<1, true>), grid, block, 0, ctx->stream, a);
-        else if (KT == 1) hipLaunchKernelGGL((weighted_outer_kernel<1, false>), grid, block, 0, ctx->stream, a);
-        else if (a.sym) hipLaunchKernelGGL((weighted_outer_kernel<2, true>), grid, block, 0, ctx->stream, a);
-        else hipLaunchKernelGGL((weighted_outer_kernel<2, false>), grid, block, 0, ctx->stream, a);
+        if (KT == 1) launch_wo<1>(CT, grid, ctx->stream, a);
+        else launch_wo<2>(CT, grid, ctx->stream, a);
         BSC_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(weighted_outer_finish_kernel, dim3((unsigned)(K * n_ct)), dim3(256), 0,
+    hipLaunchKernelGGL(weighted_outer_finish_kernel, dim3((unsigned)(K * n_ct)), dim3(1024), 0,
                        ctx->stream, (const float*)ws, stages > 0 ? (int)gx : 0, KT, CT, (int)K, (int)D,
                        (int)E, a.sym, a.P, scale, out);
     BSC_LAUNCH_CHECK();
