@@ -260,7 +260,7 @@ extern "C" int bsc_weighted_outer(bsc_ctx* ctx, const float* R, int64_t ldr, con
     const int CT = (n_ct + gy - 1) / gy;
     const int64_t stages = (N + WO_TR - 1) / WO_TR;
     // every instantiation stays under 128 VGPRs: four workgroups per CU (LDS allows five)
-    const int wg_per_cu = 4;
+    const int wg_per_cu = ctx->wo_wg_per_cu;
     int64_t gx = std::max<int64_t>(1, (int64_t)wg_per_cu * ctx->cu_count / gy);
     gx = std::min(gx, std::max<int64_t>(stages, 1));
     a.iters = (int)((stages + gx - 1) / gx);
