@@ -177,4 +177,34 @@ void oracle_lda_sstats(const float* C, long ldc, long docs, long V, int K, const
     }
 }
 
+/* Full-covariance mixture statistic (t(x) = (x, x x^T), core.py:41-44, summed over rows):
+ *   out[k,d,e] = sum_n R[n,k] X[n,d] Y[n,e].  Threads own row blocks; partials in thread order. */
+void oracle_weighted_outer(const float* R, const float* X, const float* Y, long N, int K, int D,
+                           int E, double* out) {
+    const int nt = omp_get_max_threads();
+    const size_t sz = (size_t)K * D * E;
+    double* part = (double*)calloc((size_t)nt * sz, sizeof(double));
+#pragma omp parallel num_threads(nt)
+    {
+        double* o = part + (size_t)omp_get_thread_num() * sz;
+        long lo, hi;
+        row_block(N, omp_get_thread_num(), nt, &lo, &hi);
+        for (long n = lo; n < hi; ++n)
+            for (int d = 0; d < D; ++d)
+                for (int e = 0; e < E; ++e) {
+                    const double z = (double)X[n * D + d] * (double)Y[n * E + e];
+                    double* oo = o + ((size_t)d * E + e) * K;      /* [d][e][k]: k contiguous */
+                    const float* r = R + n * K;
+                    for (int k = 0; k < K; ++k) oo[k] += (double)r[k] * z;
+                }
+    }
+    memset(out, 0, sizeof(double) * sz);
+    for (int t = 0; t < nt; ++t)
+        for (int d = 0; d < D; ++d)
+            for (int e = 0; e < E; ++e)
+                for (int k = 0; k < K; ++k)
+                    out[((size_t)k * D + d) * E + e] += part[(size_t)t * sz + ((size_t)d * E + e) * K + k];
+    free(part);
+}
+
 int oracle_threads(void) { return omp_get_max_threads(); }

@@ -35,6 +35,8 @@ def load():
         lib.oracle_logreg_loglik.argtypes = [vp, c_long, vp, vp, c_long, c_int, c_int, vp, vp, c_int, vp]
         lib.oracle_mog_estep.argtypes = [vp, c_long, c_long, c_int, c_int, vp, vp, vp, vp]
         lib.oracle_lda_sstats.argtypes = [vp, c_long, c_long, c_long, c_int, vp, vp, vp]
+        lib.oracle_weighted_outer.argtypes = [vp, vp, vp, c_long, c_int, c_int, c_int, vp]
+        lib.oracle_weighted_outer.restype = None
         lib.oracle_threads.restype = c_int
         for f in (lib.oracle_blr_data_pass, lib.oracle_logreg_loglik, lib.oracle_mog_estep,
                   lib.oracle_lda_sstats):
@@ -82,4 +84,13 @@ def lda_sstats(C, Th, Bt):
     K, V = Bt.shape
     out = np.zeros((K, V))
     load().oracle_lda_sstats(_p(C), C.shape[1], C.shape[0], V, K, _p(Th), _p(Bt), _p(out))
+    return out
+
+
+def weighted_outer(R, X, Y):
+    import numpy as np
+    R, X, Y = (np.ascontiguousarray(a, np.float32) for a in (R, X, Y))
+    K, D, E = R.shape[1], X.shape[1], Y.shape[1]
+    out = np.zeros((K, D, E))
+    load().oracle_weighted_outer(_p(R), _p(X), _p(Y), R.shape[0], K, D, E, _p(out))
     return out

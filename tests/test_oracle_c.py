@@ -47,6 +47,12 @@ def test_c_oracle_matches_numpy_oracle():
     Bt = rs.uniform(0.1, 1.0, (32, 40)).astype(np.float32)
     npt.assert_allclose(cbuild.lda_sstats(C, Th, Bt), svi.lda_sstats(C, Th, Bt), rtol=1e-12)
 
+    Rr = rs.dirichlet(np.ones(6), 777).astype(np.float32)
+    Yy = rs.standard_normal((777, 5)).astype(np.float32)
+    npt.assert_allclose(cbuild.weighted_outer(Rr, X[:, :7], Yy),
+                        np.einsum("nk,nd,ne->kde", Rr.astype(np.float64), X[:, :7].astype(np.float64),
+                                  Yy.astype(np.float64)), rtol=1e-11, atol=1e-11)
+
 
 @needs_gcc
 @pytest.mark.gpu
@@ -145,3 +151,23 @@ def test_cfg4_full_size_against_c_oracle(ctx):
     ctx.call("bsc_lda_sstats_csc", colptr, rowidx, vals, docs, V, K, Th, K, Bt, V, sparse, V)
     ctx.sync()
     npt.assert_allclose(sparse.cpu().numpy(), want, rtol=2e-5)
+
+
+@needs_gcc
+@pytest.mark.gpu
+def test_weighted_second_moment_full_size_against_c_oracle(ctx):
+    """10M x 16, K = 64: sum_n r_nk x_n x_n^T in one pass (bsc_weighted_outer)."""
+    import torch
+    from oracle import cbuild
+    g = torch.Generator(device=ctx.device).manual_seed(25)
+    N, D, K = 10_000_000, 16, 64
+    X = torch.randn((N, D), generator=g, device=ctx.device)
+    R = torch.softmax(2 * torch.randn((N, K), generator=g, device=ctx.device), dim=1)
+    out = ctx.zeros((K, D, D), torch.float32)
+    ctx.call("bsc_weighted_outer", R, K, X, D, X, D, N, K, D, D, 1.0, out)
+    ctx.sync()
+    Xh, Rh = X.cpu().numpy(), R.cpu().numpy()
+    want = cbuild.weighted_outer(Rh, Xh, Xh)
+    # |sum| is bounded by sum_n r |x_d||x_e|; the diagonal entries are sums of positive terms
+    bound = cbuild.weighted_outer(Rh, np.abs(Xh), np.abs(Xh))
+    assert (np.abs(out.cpu().numpy() - want) <= 2e-5 * bound).all()
