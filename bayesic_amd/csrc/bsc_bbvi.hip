@@ -23,19 +23,20 @@ namespace {
 constexpr int LS = 64;            // samples
 constexpr int LD = 256;           // column capacity
 constexpr int LT = 32;            // rows per tile
-constexpr int LSTR = LD + 4;      // LDS row stride (floats): 16 rows x 16 B reads hit 8 distinct 4-bank groups per 8 lanes
+constexpr int LSTR = LD + 4;      // LDS row stride (floats): row r starts on bank 4 r, so 16 rows x 16 B cover the 64 banks once
 constexpr int LR_BLOCK = 256;
 constexpr int TILE_FLOATS = LT * LSTR + LT;   // rows + y
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct Stage {   // one wave's share of a tile in registers: 8 rows x 16 B per lane
-    float4 x[8];
+template <int RW>
+struct Stage {   // one wave's share of a tile in registers: RW rows x 16 B per lane
+    float4 x[RW];
     float yv;
 };
 
-template <bool FULL>
-__device__ __forceinline__ void stage_load(Stage& st, const float* __restrict__ X, int64_t ldx,
+template <bool FULL, int RW>
+__device__ __forceinline__ void stage_load(Stage<RW>& st, const float* __restrict__ X, int64_t ldx,
                                            const float* __restrict__ y, const int* __restrict__ g,
                                            int64_t row0, int64_t N, int D, int wave, int lane) {
     const int64_t rem = N - row0;
@@ -51,8 +52,8 @@ __device__ __forceinline__ void stage_load(Stage& st, const float* __restrict__ 
     auto ys = __builtin_amdgcn_make_buffer_rsrc((void*)(y + safe0), 0, yrec, 0x00020000);
     const int row_bytes = (int)(ldx * 4);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        auto v = __builtin_amdgcn_raw_buffer_load_b128(xs, 16 * lane, (8 * wave + r) * row_bytes, 2);  // nt
+    for (int r = 0; r < RW; ++r) {
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(xs, 16 * lane, (RW * wave + r) * row_bytes, 2);  // nt
         float4 f = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
                                __uint_as_float(v[3]));
         if (!FULL && 4 * lane >= D) f = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -62,17 +63,18 @@ __device__ __forceinline__ void stage_load(Stage& st, const float* __restrict__ 
     st.yv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ys, 4 * (lane & 31), 0, 0));
 }
 
-// The 8 group ids of the rows whose logits this lane ends up holding (MFMA result
-// rows 16 rb + 4 kq + r), clamped to [0, n_groups); rows past N read as group 0.
-__device__ __forceinline__ void load_groups(int (&gi)[8], const int* __restrict__ g, int64_t row0,
-                                            int64_t N, int kq, int n_groups) {
+// The group ids of the rows whose logits this lane ends up holding (MFMA result
+// rows 16 (rb0 + rb) + 4 kq + r), clamped to [0, n_groups); rows past N read as group 0.
+template <int RB>
+__device__ __forceinline__ void load_groups(int (&gi)[4 * RB], const int* __restrict__ g, int64_t row0,
+                                            int64_t N, int kq, int n_groups, int rb0) {
     const int64_t rem = N - row0;
     const uint64_t gb = rem > 0 ? (uint64_t)rem * 4u : 0;
     const unsigned grec = gb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)gb;
     auto gs = __builtin_amdgcn_make_buffer_rsrc((void*)(g + (rem > 0 ? row0 : 0)), 0, grec, 0x00020000);
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        auto v = __builtin_amdgcn_raw_buffer_load_b128(gs, 4 * (16 * rb + 4 * kq), 0, 0);
+    for (int rb = 0; rb < RB; ++rb) {
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(gs, 4 * (16 * (rb0 + rb) + 4 * kq), 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int x = (int)v[r];
@@ -81,15 +83,19 @@ __device__ __forceinline__ void load_groups(int (&gi)[8], const int* __restrict_
     }
 }
 
-__device__ __forceinline__ void stage_store(const Stage& st, float* tile, int wave, int lane) {
+template <int RW>
+__device__ __forceinline__ void stage_store(const Stage<RW>& st, float* tile, int wave, int lane) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
-        *reinterpret_cast<float4*>(tile + (8 * wave + r) * LSTR + 4 * lane) = st.x[r];
+    for (int r = 0; r < RW; ++r)
+        *reinterpret_cast<float4*>(tile + (RW * wave + r) * LSTR + 4 * lane) = st.x[r];
     if (wave == 0 && lane < 32) tile[LT * LSTR + lane] = st.yv;
 }
 
-template <bool FULL>   // FULL: D == 256, no column masking
-__global__ __launch_bounds__(LR_BLOCK, 2) void logreg_loglik_kernel(
+// NW = 4: a wave owns 16 samples for both 16-row blocks of the tile (two accumulators).
+// NW = 8: a wave owns 16 samples for ONE row block -- twice the waves per SIMD to cover the
+// softplus epilogue, the LDS stores and the barrier of the others.
+template <bool FULL, int NW>   // FULL: D == 256, no column masking
+__global__ __launch_bounds__(64 * NW, 2) void logreg_loglik_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ y,
     const int* __restrict__ g, int64_t N, int D, const float* __restrict__ Wz,
     const float* __restrict__ Bz, int n_groups, float* __restrict__ slab, int n_iter) {
@@ -97,78 +103,97 @@ __global__ __launch_bounds__(LR_BLOCK, 2) void logreg_loglik_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
+    constexpr int RB = 8 / NW;          // row blocks per wave
+    constexpr int RW = LT / NW;         // rows a wave stages per tile
+    const int sb = wave & 3;            // sample block
+    const int rb0 = NW == 8 ? (wave >> 2) : 0;
 
-    // B operand: Wz[sample 16*wave + i16][column of (k-step s, lane group kq)]
+    // B operand: Wz[sample 16*sb + i16][column of (k-step s, lane group kq)]
     float wreg[LD / 4];
 #pragma unroll
     for (int s = 0; s < LD / 4; ++s) {
-        const int col = 16 * (s >> 2) + 4 * kq + (s & 3);
-        wreg[s] = col < D ? Wz[(int64_t)(16 * wave + i16) * D + col] : 0.f;
+        // lane group kq contracts columns [64 kq, 64 kq + 64): the four 16-byte A reads of a
+        // row then sit 256 B apart, on the same banks, and every ds_read_b128 lane group
+        // (each holds all 16 rows once, with two different kq) is conflict-free; with the
+        // columns interleaved (4 kq + 16 q) each lane group had one 2-way conflict
+        const int col = 64 * kq + s;
+        wreg[s] = col < D ? Wz[(int64_t)(16 * sb + i16) * D + col] : 0.f;
     }
     double acc_ll = 0.0;   // per-tile float32 sums enter a float64 accumulator: no drift over the 60 tiles
 
     int64_t tile = blockIdx.x;
     const int64_t stride = gridDim.x;
-    Stage st;
+    Stage<RW> st;
     stage_load<FULL>(st, X, ldx, y, g, tile * LT, N, D, wave, lane);
     stage_store(st, lds, wave, lane);
     // The intercept b[g_n, s] is a gather that depends on the row's group id: requested
     // when it is needed it costs a full memory round trip per tile with the MFMA pipe idle.
     // So group ids run two tiles ahead and intercepts one tile ahead, in registers.
-    const float* bz_lane = Bz + 16 * wave + i16;
-    int gi[8];
-    float bz_a[8], bz_b[8];
-    load_groups(gi, g, tile * LT, N, kq, n_groups);
+    const float* bz_lane = Bz + 16 * sb + i16;
+    int gi[4 * RB];
+    float bz_a[4 * RB], bz_b[4 * RB];
+    load_groups<RB>(gi, g, tile * LT, N, kq, n_groups, rb0);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bz_a[e] = bz_lane[(int64_t)gi[e] * LS];
-    load_groups(gi, g, (tile + stride) * LT, N, kq, n_groups);
+    for (int e = 0; e < 4 * RB; ++e) bz_a[e] = bz_lane[(int64_t)gi[e] * LS];
+    load_groups<RB>(gi, g, (tile + stride) * LT, N, kq, n_groups, rb0);
     __syncthreads();
     int cur = 0;
     // One tile.  bz_cur holds this tile's intercepts (requested a tile ago), bz_next
     // receives the next tile's; the caller alternates the two register sets so that no
     // copy (which would wait for the loads straight away) is needed.
-    auto one_tile = [&](const float (&bz_cur)[8], float (&bz_next)[8]) {
+    auto one_tile = [&](const float (&bz_cur)[4 * RB], float (&bz_next)[4 * RB]) {
         stage_load<FULL>(st, X, ldx, y, g, (tile + stride) * LT, N, D, wave, lane);   // prefetch
         const float* t = lds + cur * TILE_FLOATS;
-        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        // A operands one k-group ahead in registers: the 8 MFMAs of group q (256 cycles)
-        // cover the LDS latency of group q+1.  The two row blocks alternate so that no
-        // MFMA waits on its predecessor (16x16x4: 32-cycle issue, 40-cycle dependent latency).
-        const float* ta = t + i16 * LSTR + 4 * kq;
-        float4 a0n = *reinterpret_cast<const float4*>(ta);
-        float4 a1n = *reinterpret_cast<const float4*>(ta + 16 * LSTR);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // the reads of group 0
+        f32x4 acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // A operands one k-group ahead in registers: the MFMAs of group q cover the LDS
+        // latency of group q+1.  With two row blocks they alternate so that no MFMA waits on
+        // its predecessor (16x16x4: 32-cycle issue, 40-cycle dependent latency); with one,
+        // the other waves of the SIMD fill the 8-cycle gaps.
+        const float* ta = t + (16 * rb0 + i16) * LSTR + 64 * kq;
+        float4 an[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) an[rb] = *reinterpret_cast<const float4*>(ta + 16 * rb * LSTR);
+        __builtin_amdgcn_sched_group_barrier(0x100, RB, 0);       // the reads of group 0
 #pragma unroll
         for (int q = 0; q < LD / 16; ++q) {
-            const float4 a0 = a0n, a1 = a1n;
+            float4 a[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) a[rb] = an[rb];
             if (q + 1 < LD / 16) {
-                a0n = *reinterpret_cast<const float4*>(ta + 16 * (q + 1));
-                a1n = *reinterpret_cast<const float4*>(ta + 16 * LSTR + 16 * (q + 1));
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    an[rb] = *reinterpret_cast<const float4*>(ta + 16 * rb * LSTR + 4 * (q + 1));
             }
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wreg[4 * q + 0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wreg[4 * q + 0], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wreg[4 * q + 1], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wreg[4 * q + 1], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wreg[4 * q + 2], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wreg[4 * q + 2], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wreg[4 * q + 3], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wreg[4 * q + 3], acc[1], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 LDS reads (group q+1) ...
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // ... then the 8 MFMAs of group q
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb].x, wreg[4 * q + 0], acc[rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb].y, wreg[4 * q + 1], acc[rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb].z, wreg[4 * q + 2], acc[rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb].w, wreg[4 * q + 3], acc[rb], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, RB, 0);       // LDS reads of group q+1 ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * RB, 0);   // ... then the MFMAs of group q
         }
         // next tile's intercepts (its group ids arrived during the MFMAs), then the ids
         // of the tile after
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bz_next[e] = bz_lane[(int64_t)gi[e] * LS];
-        load_groups(gi, g, (tile + 2 * stride) * LT, N, kq, n_groups);
+        for (int e = 0; e < 4 * RB; ++e) bz_next[e] = bz_lane[(int64_t)gi[e] * LS];
+        load_groups<RB>(gi, g, (tile + 2 * stride) * LT, N, kq, n_groups, rb0);
         // C/D map of 16x16x4: col = lane & 15 (sample), row = 4 * (lane >> 4) + reg
         const int64_t row0 = tile * LT;
         float tile_ll = 0.f;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 16 * rb + 4 * kq + r;
+                const int row = 16 * (rb0 + rb) + 4 * kq + r;
                 if (row0 + row < N) {
                     const float yv = t[LT * LSTR + row];
                     const float l = acc[rb][r] + bz_cur[4 * rb + r];
@@ -192,7 +217,8 @@ __global__ __launch_bounds__(LR_BLOCK, 2) void logreg_loglik_kernel(
     // lanes with the same sample (lane & 15) hold different rows: fold bits 4,5
     acc_ll += __shfl_xor(acc_ll, 16);
     acc_ll += __shfl_xor(acc_ll, 32);
-    if (lane < 16) slab[(int64_t)blockIdx.x * LS + 16 * wave + lane] = (float)acc_ll;
+    if (lane < 16)
+        slab[((int64_t)blockIdx.x * (NW / 4) + (wave >> 2)) * LS + 16 * sb + lane] = (float)acc_ll;
 }
 
 __global__ __launch_bounds__(1024) void loglik_reduce_kernel(const float* __restrict__ slab,
@@ -412,23 +438,25 @@ int bsc_logreg_bbvi_loglik(bsc_ctx* ctx, const float* X, int64_t ldx, const floa
         n_blocks = (int)((n_tiles + it - 1) / it);
     }
     void* ws = nullptr;
-    int rc = bsc_workspace(ctx, (size_t)n_blocks * LS * sizeof(float), &ws);
+    const int nw = ctx->bbvi_waves == 4 ? 4 : 8;
+    int rc = bsc_workspace(ctx, (size_t)n_blocks * (nw / 4) * LS * sizeof(float), &ws);
     if (rc != BSC_OK) return rc;
     ctx->slab_rows = 0;
     {
         bsc_prof_scope prof(ctx);
-        if (D == LD)
-            hipLaunchKernelGGL(logreg_loglik_kernel<true>, dim3(n_blocks), dim3(LR_BLOCK), 0,
-                               ctx->stream, X, ldx, y, (const int*)g, N, (int)D, Wz, Bz,
-                               (int)n_groups, (float*)ws, n_iter);
-        else
-            hipLaunchKernelGGL(logreg_loglik_kernel<false>, dim3(n_blocks), dim3(LR_BLOCK), 0,
-                               ctx->stream, X, ldx, y, (const int*)g, N, (int)D, Wz, Bz,
-                               (int)n_groups, (float*)ws, n_iter);
+#define BSC_LL(FULL, NW)                                                                         \
+    hipLaunchKernelGGL((logreg_loglik_kernel<FULL, NW>), dim3(n_blocks), dim3(64 * NW), 0,        \
+                       ctx->stream, X, ldx, y, (const int*)g, N, (int)D, Wz, Bz, (int)n_groups,  \
+                       (float*)ws, n_iter)
+        if (D == LD && nw == 8) BSC_LL(true, 8);
+        else if (D == LD) BSC_LL(true, 4);
+        else if (nw == 8) BSC_LL(false, 8);
+        else BSC_LL(false, 4);
+#undef BSC_LL
     }
     BSC_LAUNCH_CHECK();
     hipLaunchKernelGGL(loglik_reduce_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const float*)ws,
-                       n_blocks, ell);
+                       n_blocks * (nw / 4), ell);
     BSC_LAUNCH_CHECK();
     return BSC_OK;
 }
