@@ -438,7 +438,7 @@ int bsc_logreg_bbvi_loglik(bsc_ctx* ctx, const float* X, int64_t ldx, const floa
         n_blocks = (int)((n_tiles + it - 1) / it);
     }
     void* ws = nullptr;
-    const int nw = ctx->bbvi_waves == 4 ? 4 : 8;
+    const int nw = ctx->bbvi_waves == 8 ? 8 : 4;   // 8 measured 1 % slower (346 vs 342 us): kept as a knob
     int rc = bsc_workspace(ctx, (size_t)n_blocks * (nw / 4) * LS * sizeof(float), &ws);
     if (rc != BSC_OK) return rc;
     ctx->slab_rows = 0;

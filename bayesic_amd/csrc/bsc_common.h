@@ -23,8 +23,8 @@ struct bsc_ctx {
     int fused_map_unroll = 2;         // float4 per operand in flight per lane (1 | 2); 2 is +18% measured
     int gemm_pipe = 1;                // GEMM: LDS operand reads one k-pair ahead of the MFMAs
     int fused_nt_store = 1;           // dense map: non-temporal stores of the result
-    int bbvi_waves = 8;          // bsc_logreg_bbvi_loglik: waves per workgroup (4: one wave per 16 samples, 8: per (16 samples, 16 rows))
-    int wo_wg_per_cu = 4;        // bsc_weighted_outer: resident workgroups per CU the grid is sized for
+    int bbvi_waves = 4;          // bsc_logreg_bbvi_loglik: waves per workgroup (4: one wave per 16 samples, 8: per (16 samples, 16 rows))
+    int wo_wg_per_cu = 2;        // bsc_weighted_outer: resident workgroups per CU the grid is sized for
     int fused_waves_per_cu = 16; // bsc_map_reduce: reduce splits target this many waves per CU
     int blr_nt_loads = 1;        // non-temporal loads of X (read once per pass): +9% measured
     int slab_rows = 0;  // block partials left in `workspace` by bsc_blr_data_pass_partial

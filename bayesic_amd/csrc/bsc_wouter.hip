@@ -57,27 +57,47 @@ __device__ __forceinline__ void wo_pair(int p, int D, int E, int sym, int& d, in
     e = d + p;
 }
 
-// Four waves per workgroup, one per SIMD: wave = (component tile kt, row part rp) with
-// KT * RP = 4.  A wave walks its part of the stage's rows for all CT pair tiles of the
-// workgroup (CT accumulators, 16 registers each); row parts are added through LDS at the end.  (A wave per pair tile -- five waves at D = 16 -- leaves one SIMD with twice the
-// work of the others: 1.90 ms against 1.3 ms of MFMA time.)
-__device__ __forceinline__ float4 wo_load4(const float* p, bool ok) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok) v = *(const float4*)p;
-    return v;
+// Four waves per workgroup, one per SIMD; each takes a quarter of the stage's rows for EVERY
+// (component tile, pair tile) of the workgroup -- KT * CT accumulators of 16 registers, which
+// the compiler keeps in AGPRs.  On this part VALU instructions between MFMAs cost the MFMA
+// pipe their full issue time (profiles/r01_ubench_mfma_valu_mix.txt), so the kernel is built
+// to issue as few as possible: one multiply per pair tile and k-step, shared by both
+// component tiles; rows arrive through buffer loads whose per-stage offsets are scalar
+// (rows past N read as zero, no per-lane address arithmetic or compares).
+// Measured on the way here (10M x 16, K = 64): a wave per pair tile (5 waves) 1.90 ms -- one
+// SIMD carries two of them; wave = (component tile, row half) with a multiply per MFMA 1.77 ms.
+struct WoRows {   // buffer descriptor over the rows of one stage
+    __amdgpu_buffer_rsrc_t rsrc;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wo_rsrc(const float* base, int64_t ld, int cols,
+                                                          int64_t row0, int64_t N) {
+    const int64_t rem = N - row0;
+    uint64_t bytes = 0;
+    if (rem > 0) bytes = ((uint64_t)(rem - 1) * (uint64_t)ld + (uint64_t)cols) * 4u;
+    const unsigned rec = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (rem > 0 ? row0 : 0) * ld), 0, rec, 0x00020000);
+}
+
+// lanes that are not `ok` keep what they hold (zero, set once before the loop)
+__device__ __forceinline__ void wo_bload(float4& f, __amdgpu_buffer_rsrc_t r, int voff, int soff, bool ok) {
+    if (ok) {
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        f = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
+                        __uint_as_float(v[3]));
+    }
 }
 
 template <int KT, int CT>
-__global__ __launch_bounds__(WO_BLOCK) void weighted_outer_kernel(WOArgs a) {
+__global__ __launch_bounds__(WO_BLOCK, 2) void weighted_outer_kernel(WOArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[WO_TR * (WO_MAXK + 2 * WO_MAXD)];
     constexpr int RS = KT * 32;
-    constexpr int RP = 4 / KT;                 // row parts
-    constexpr int ROWS = WO_TR / RP;           // rows of a stage per wave
+    constexpr int ROWS = WO_TR / 4;            // rows of a stage per wave
     float* Rs = lds;
     float* Xs = lds + WO_TR * WO_MAXK;
     float* Ys = a.sym ? Xs : Xs + WO_TR * WO_MAXD;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kt = wave % KT, rp = wave / KT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, half = lane >> 5;
 
     int xo[CT], yo[CT];
@@ -89,37 +109,41 @@ __global__ __launch_bounds__(WO_BLOCK) void weighted_outer_kernel(WOArgs a) {
         xo[ct] = d;
         yo[ct] = e;
     }
-    f32x16 acc[CT];
+    f32x16 acc[KT][CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[kt][ct][q] = 0.f;
 
-    const int k4 = a.K >> 2, d4 = a.D >> 2, e4 = a.E >> 2;
-    const float* rrow = Rs + (rp * ROWS + half) * RS + kt * 32 + col;
-    const float* xrow = Xs + (rp * ROWS + half) * WO_MAXD;
-    const float* yrow = Ys + (rp * ROWS + half) * WO_MAXD;
-    constexpr int NR = WO_TR * 16 / WO_BLOCK, NX = WO_TR * 8 / WO_BLOCK;
     // a stage: R has 16 float4 slots per row (zero beyond K), X / Y have 8
+    constexpr int NR = WO_TR * 16 / WO_BLOCK, NX = WO_TR * 8 / WO_BLOCK;
     const int rr = tid >> 4, rc = tid & 15, xr = tid >> 3, xc = tid & 7;
-    const bool r_ok = rc < k4, x_ok = xc < d4, y_ok = !a.sym && xc < e4;
-    const float* rsrc = a.R + rc * 4;
-    const float* xsrc = a.X + xc * 4;
-    const float* ysrc = a.Y + xc * 4;
+    const bool r_ok = rc < (a.K >> 2), x_ok = xc < (a.D >> 2), y_ok = !a.sym && xc < (a.E >> 2);
+    const int r_voff = (int)(rr * a.ldr + rc * 4) * 4, r_step = (int)(a.ldr * 4) * (WO_BLOCK / 16);
+    const int x_voff = (int)(xr * a.ldx + xc * 4) * 4, x_step = (int)(a.ldx * 4) * (WO_BLOCK / 8);
+    const int y_voff = (int)(xr * a.ldy + xc * 4) * 4, y_step = (int)(a.ldy * 4) * (WO_BLOCK / 8);
     float4 pr[NR], px[NX], py[NX];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) pr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) px[i] = py[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 #define WO_FETCH(IT)                                                                          \
     {                                                                                         \
         const int64_t row0_ = ((int64_t)blockIdx.x + (int64_t)(IT) * gridDim.x) * WO_TR;       \
-        _Pragma("unroll") for (int i = 0; i < NR; ++i) {                                      \
-            const int64_t row = row0_ + rr + i * (WO_BLOCK / 16);                             \
-            pr[i] = wo_load4(rsrc + row * a.ldr, r_ok && row < a.N);                          \
-        }                                                                                     \
+        const auto rd = wo_rsrc(a.R, a.ldr, a.K, row0_, a.N);                                 \
+        const auto xd = wo_rsrc(a.X, a.ldx, a.D, row0_, a.N);                                 \
+        const auto yd = wo_rsrc(a.Y, a.ldy, a.E, row0_, a.N);                                 \
+        _Pragma("unroll") for (int i = 0; i < NR; ++i) wo_bload(pr[i], rd, r_voff, i * r_step, r_ok); \
         _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                      \
-            const int64_t row = row0_ + xr + i * (WO_BLOCK / 8);                              \
-            px[i] = wo_load4(xsrc + row * a.ldx, x_ok && row < a.N);                          \
-            py[i] = wo_load4(ysrc + row * a.ldy, y_ok && row < a.N);                          \
+            wo_bload(px[i], xd, x_voff, i * x_step, x_ok);                                    \
+            wo_bload(py[i], yd, y_voff, i * y_step, y_ok);                                    \
         }                                                                                     \
     }
+    const float* rrow = Rs + (wave * ROWS + half) * RS + col;
+    const float* xrow = Xs + (wave * ROWS + half) * WO_MAXD;
+    const float* yrow = Ys + (wave * ROWS + half) * WO_MAXD;
     if (a.iters > 0) WO_FETCH(0)
     for (int it = 0; it < a.iters; ++it) {
 #pragma unroll
@@ -134,41 +158,38 @@ __global__ __launch_bounds__(WO_BLOCK) void weighted_outer_kernel(WOArgs a) {
         // the next stage's rows travel through registers while this one is multiplied
         if (it + 1 < a.iters) WO_FETCH(it + 1)
 #undef WO_FETCH
-#pragma unroll 4
+#pragma unroll
         for (int j = 0; j < ROWS / 2; ++j) {
-            const float av = rrow[2 * j * RS];
+            float av[KT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) av[kt] = rrow[2 * j * RS + kt * 32];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const float z = xrow[2 * j * WO_MAXD + xo[ct]] * yrow[2 * j * WO_MAXD + yo[ct]];
-                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, z, acc[ct], 0, 0, 0);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+                    acc[kt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kt], z, acc[kt][ct], 0, 0, 0);
             }
         }
         __syncthreads();
     }
 
-    // row parts of one component tile are added through LDS (fixed order), pair tile by pair tile
-    float* red = lds;
+    // the four waves hold sums over disjoint rows: add them through LDS tile by tile, every
+    // thread finishing four elements of the tile
+    float* red = lds;   // 4 x 1024 floats
+    float* out = a.part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (KT * CT) * WO_TILE;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        if (rp > 0) {
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) red[wave * WO_TILE + q * 64 + lane] = acc[ct][q];
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) red[wave * WO_TILE + q * 64 + lane] = acc[kt][ct][q];
+            __syncthreads();
+            for (int i = tid; i < WO_TILE; i += WO_BLOCK)
+                out[(kt * CT + ct) * WO_TILE + i] =
+                    (red[i] + red[WO_TILE + i]) + (red[2 * WO_TILE + i] + red[3 * WO_TILE + i]);
+            __syncthreads();
         }
-        __syncthreads();
-        if (rp == 0) {
-#pragma unroll
-            for (int r = 1; r < RP; ++r)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[ct][q] += red[(r * KT + kt) * WO_TILE + q * 64 + lane];
-        }
-        __syncthreads();
-    }
-    if (rp != 0) return;
-    float* out = a.part + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (KT * CT) + kt * CT) * WO_TILE;
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) out[ct * WO_TILE + q * 64 + lane] = acc[ct][q];
 }
 
 template <int KT>
@@ -256,10 +277,11 @@ extern "C" int bsc_weighted_outer(bsc_ctx* ctx, const float* R, int64_t ldr, con
     a.P = a.sym ? D * (D + 1) / 2 : D * E;
     const int KT = (K + 31) / 32;
     const int n_ct = (a.P + 31) / 32;
-    const int gy = (n_ct + WO_MAXCT - 1) / WO_MAXCT;
+    const int max_ct = KT == 2 ? 5 : WO_MAXCT;      // KT * CT accumulators of 16 registers each
+    const int gy = (n_ct + max_ct - 1) / max_ct;
     const int CT = (n_ct + gy - 1) / gy;
     const int64_t stages = (N + WO_TR - 1) / WO_TR;
-    // every instantiation stays under 128 VGPRs: four workgroups per CU (LDS allows five)
+    // two workgroups per CU (up to 160 accumulator registers per wave)
     const int wg_per_cu = ctx->wo_wg_per_cu;
     int64_t gx = std::max<int64_t>(1, (int64_t)wg_per_cu * ctx->cu_count / gy);
     gx = std::min(gx, std::max<int64_t>(stages, 1));
