@@ -32,7 +32,7 @@ constexpr int MF = 2 * MD;    // features
 constexpr int MT = 32;        // rows per tile
 constexpr int MOG_BLOCK = 256;
 constexpr int MOG_WAVES = MOG_BLOCK / BSC_WAVE;
-constexpr int XT_STRIDE = MD + 4;                    // LDS row stride of the x tile
+constexpr int XT_STRIDE = MF + 4;                    // LDS row stride of the staged feature tile [row][x/sum | x^2/sum]
 constexpr int RT_STRIDE = MK + 4;                    // LDS row stride of the r tile [row][comp]
 constexpr int WAVE_LDS = MT * XT_STRIDE + MT * RT_STRIDE;
 constexpr int MOG_SLAB = MK * (1 + MF) + 1;          // [comp][R | S(32)] + L
@@ -65,6 +65,7 @@ struct XRow {
 };
 
 // lane l loads row (row0 + (l&31)): 16 floats; rows past the end and columns >= D read 0
+template <bool FULL>   // FULL: D == 16, no column masking
 __device__ __forceinline__ void load_rows(XRow& t, const float* __restrict__ X, int64_t ldx,
                                           int64_t row0, int64_t N, int D, int lane) {
     const int64_t rem = N - row0;
@@ -80,12 +81,19 @@ __device__ __forceinline__ void load_rows(XRow& t, const float* __restrict__ X, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float f = __uint_as_float(v[j]);
-            if (4 * c4 + j >= D) f = 0.f;   // D < 16: those bytes belong to the next row
+            if (!FULL && 4 * c4 + j >= D) f = 0.f;   // D < 16: those bytes belong to the next row
             t.x[4 * c4 + j] = f;
         }
     }
 }
 
+// VALU instructions issued between MFMAs cost the matrix pipe their full issue time on this
+// part (profiles/r01_ubench_mfma_valu_mix.txt), so the softmax is written for instruction
+// count: weights and biases are scaled by log2e once, so exp(l - m) is one subtract and one
+// v_exp_f32 (and a one-hot row stays exactly one-hot); the 1/sum of a row is folded into
+// the backward B operand when the row is staged (x/sum and x^2/sum, 32 multiplies per tile)
+// rather than into its 64 responsibilities; row buffers alternate instead of being copied.
+template <bool FULL>
 __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
     const float* __restrict__ X, int64_t ldx, int64_t N, int D, const float* __restrict__ Wmat,
     const float* __restrict__ cvec, int K, float* __restrict__ slab, int n_iter) {
@@ -98,6 +106,7 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
     float* xt = lds + wave * WAVE_LDS;
     float* rt = xt + MT * XT_STRIDE;
 
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
     // A operand of the forward product: W[comp = 32cb + l31][feature 2s + half]
     float wreg[2][MF / 2];
     f32x16 bias_q[2];   // bias of the component each accumulator register holds
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int comp = 32 * cb + drow(q, lane);
-            bias_q[cb][q] = comp < K ? cvec[comp] : -1.0e30f;
+            bias_q[cb][q] = comp < K ? cvec[comp] * LOG2E : -1.0e30f;
         }
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
             const int d = f & (MD - 1);
             float v = 0.f;
             if (comp < K && d < D) v = Wmat[(int64_t)comp * 2 * D + (f < MD ? d : D + d)];
-            wreg[cb][s] = v;
+            wreg[cb][s] = v * LOG2E;   // logits come out in log2 units: exp is v_exp_f32(l - m)
         }
     }
 
@@ -135,32 +144,21 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
 
     const int64_t stride = (int64_t)gridDim.x * MOG_WAVES;
     int64_t tile = (int64_t)blockIdx.x * MOG_WAVES + wave;
-    XRow cur, nxt;
-    load_rows(cur, X, ldx, tile * MT, N, D, lane);
-    for (int it = 0; it < n_iter; ++it) {
-        load_rows(nxt, X, ldx, (tile + stride) * MT, N, D, lane);   // unconditional prefetch
+    XRow xa, xb;
+    load_rows<FULL>(xa, X, ldx, tile * MT, N, D, lane);
+    auto one_tile = [&](const XRow& cur, XRow& nxt) {
+        load_rows<FULL>(nxt, X, ldx, (tile + stride) * MT, N, D, lane);   // unconditional prefetch
         const int64_t row0 = tile * MT;
-
-        // stage the tile for the backward B operand (lanes 0-31 own one row each)
-        if (half == 0) {
-#pragma unroll
-            for (int c4 = 0; c4 < MD / 4; ++c4)
-                *reinterpret_cast<float4*>(xt + l31 * XT_STRIDE + 4 * c4) =
-                    make_float4(cur.x[4 * c4], cur.x[4 * c4 + 1], cur.x[4 * c4 + 2], cur.x[4 * c4 + 3]);
-        }
-        // forward: logits[comp][row] -- lane (row = l31, half) gets comps 32cb + drow(q, lane)
+        // forward: logits[comp][row] -- lane (row = l31, half) gets comps 32cb + drow(q, lane);
+        // the C operand of the first k-step carries the bias
         f32x16 logit[2];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) logit[cb][q] = bias_q[cb][q];   // C operand carries the bias
 #pragma unroll
         for (int s = 0; s < MF / 2; ++s) {
             const int t = s & 7;
             float a = half ? cur.x[2 * t + 1] : cur.x[2 * t];
             if (s >= 8) a = a * a;
-            logit[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[0][s], a, logit[0], 0, 0, 0);
-            logit[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[1][s], a, logit[1], 0, 0, 0);
+            logit[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[0][s], a, s == 0 ? bias_q[0] : logit[0], 0, 0, 0);
+            logit[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[1][s], a, s == 0 ? bias_q[1] : logit[1], 0, 0, 0);
         }
         // softmax over the row's 64 components: 32 in this lane, 32 in lane ^ 32
         const bool valid = row0 + l31 < N;
@@ -175,41 +173,54 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                logit[cb][q] = __expf(logit[cb][q] - m);
+                logit[cb][q] = __builtin_amdgcn_exp2f(logit[cb][q] - m);
                 ssum += logit[cb][q];
             }
         ssum = swap32_sum(ssum);
         const float inv = valid ? 1.0f / ssum : 0.f;
-        if (valid && half == 0) lse_acc += m + __logf(ssum);
-        // r -> LDS as [row][comp]: registers 4g..4g+3 are 4 consecutive components
+        if (valid && half == 0) lse_acc += LN2 * (m + __builtin_amdgcn_logf(ssum));
+        // unnormalised e -> LDS as [row][comp] (registers 4g..4g+3 are 4 consecutive components);
+        // R_k accumulates e * inv
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                logit[cb][q] *= inv;
-                rsum[cb][q] += logit[cb][q];
-            }
+            for (int q = 0; q < 16; ++q) rsum[cb][q] = __builtin_fmaf(logit[cb][q], inv, rsum[cb][q]);
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq)
                 *reinterpret_cast<float4*>(rt + l31 * RT_STRIDE + 32 * cb + 8 * gq + 4 * half) =
                     make_float4(logit[cb][4 * gq], logit[cb][4 * gq + 1], logit[cb][4 * gq + 2],
                                 logit[cb][4 * gq + 3]);
         }
+        // the backward B operand of the row, already divided by the row's sum: lanes 0-31 write
+        // x / sum (features 0..15), lanes 32-63 x^2 / sum (features 16..31)
+#pragma unroll
+        for (int c4 = 0; c4 < MD / 4; ++c4) {
+            float f[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f[j] = cur.x[4 * c4 + j] * inv;
+                if (half) f[j] *= cur.x[4 * c4 + j];
+            }
+            *reinterpret_cast<float4*>(xt + l31 * XT_STRIDE + MD * half + 4 * c4) =
+                make_float4(f[0], f[1], f[2], f[3]);
+        }
         wave_lds_sync();
-        // backward: S[comp][feat] += r[row][comp] * f[row][feat], two rows per MFMA
+        // backward: S[comp][feat] += e[row][comp] * (f[row][feat] / sum[row]), two rows per MFMA
 #pragma unroll
         for (int t = 0; t < MT / 2; ++t) {
             const int row = 2 * t + half;
-            float b = xt[row * XT_STRIDE + (lane & (MD - 1))];
-            if (lane & MD) b = b * b;               // features 16..31 are the squares
+            const float b = xt[row * XT_STRIDE + l31];
             const float r0 = rt[row * RT_STRIDE + l31];
             const float r1 = rt[row * RT_STRIDE + 32 + l31];
             S[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0, b, S[0], 0, 0, 0);
             S[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r1, b, S[1], 0, 0, 0);
         }
-        wave_lds_sync();   // the next tile overwrites xt
-        cur = nxt;
+        wave_lds_sync();   // the next tile overwrites xt and rt
         tile += stride;
+    };
+    for (int it = 0; it < n_iter; it += 2) {   // n_iter is even (host): the row buffers alternate
+        one_tile(xa, xb);
+        one_tile(xb, xa);
     }
 
     // block reduction: per wave [comp][R | S] + L, then fixed-order sum over waves
@@ -379,7 +390,7 @@ int bsc_mog_estep(bsc_ctx* ctx, const float* X, int64_t ldx, int64_t N, int32_t 
     if (n_tiles > 0) {
         const int64_t it = (n_tiles + max_waves - 1) / max_waves;
         const int64_t waves = (n_tiles + it - 1) / it;
-        n_iter = (int)it;
+        n_iter = (int)(it + (it & 1));   // even: the kernel alternates two row buffers per tile pair
         n_blocks = (int)((waves + MOG_WAVES - 1) / MOG_WAVES);
     }
     void* ws = nullptr;
@@ -388,8 +399,12 @@ int bsc_mog_estep(bsc_ctx* ctx, const float* X, int64_t ldx, int64_t N, int32_t 
     ctx->slab_rows = 0;
     {
         bsc_prof_scope prof(ctx);
-        hipLaunchKernelGGL(mog_estep_kernel, dim3(n_blocks), dim3(MOG_BLOCK), 0, ctx->stream, X, ldx,
-                           N, (int)D, Wmat, c, (int)K, (float*)ws, n_iter);
+        if (D == MD)
+            hipLaunchKernelGGL(mog_estep_kernel<true>, dim3(n_blocks), dim3(MOG_BLOCK), 0, ctx->stream, X,
+                               ldx, N, (int)D, Wmat, c, (int)K, (float*)ws, n_iter);
+        else
+            hipLaunchKernelGGL(mog_estep_kernel<false>, dim3(n_blocks), dim3(MOG_BLOCK), 0, ctx->stream, X,
+                               ldx, N, (int)D, Wmat, c, (int)K, (float*)ws, n_iter);
     }
     BSC_LAUNCH_CHECK();
     hipLaunchKernelGGL(mog_reduce_kernel, dim3((MOG_SLAB + 63) / 64), dim3(1024), 0, ctx->stream,
