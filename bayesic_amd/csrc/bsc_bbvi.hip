@@ -63,11 +63,13 @@ __device__ __forceinline__ void stage_load(Stage<RW>& st, const float* __restric
     st.yv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ys, 4 * (lane & 31), 0, 0));
 }
 
-// The group ids of the rows whose logits this lane ends up holding (MFMA result
-// rows 16 (rb0 + rb) + 4 kq + r), clamped to [0, n_groups); rows past N read as group 0.
+// Byte offsets (group id * 256) into Bz of the rows whose logits this lane ends up holding
+// (MFMA result rows 16 (rb0 + rb) + 4 kq + r).  No clamping: the gather below is a buffer
+// load, so an id outside [0, n_groups) reads an intercept of 0 instead of faulting, and rows
+// past N read id 0 (their result is masked).
 template <int RB>
 __device__ __forceinline__ void load_groups(int (&gi)[4 * RB], const int* __restrict__ g, int64_t row0,
-                                            int64_t N, int kq, int n_groups, int rb0) {
+                                            int64_t N, int kq, int rb0) {
     const int64_t rem = N - row0;
     const uint64_t gb = rem > 0 ? (uint64_t)rem * 4u : 0;
     const unsigned grec = gb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)gb;
@@ -76,10 +78,7 @@ __device__ __forceinline__ void load_groups(int (&gi)[4 * RB], const int* __rest
     for (int rb = 0; rb < RB; ++rb) {
         auto v = __builtin_amdgcn_raw_buffer_load_b128(gs, 4 * (16 * (rb0 + rb) + 4 * kq), 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int x = (int)v[r];
-            gi[4 * rb + r] = x < 0 ? 0 : (x >= n_groups ? n_groups - 1 : x);
-        }
+        for (int r = 0; r < 4; ++r) gi[4 * rb + r] = (int)v[r] * (LS * 4);
     }
 }
 
@@ -129,13 +128,18 @@ __global__ __launch_bounds__(64 * NW, 2) void logreg_loglik_kernel(
     // The intercept b[g_n, s] is a gather that depends on the row's group id: requested
     // when it is needed it costs a full memory round trip per tile with the MFMA pipe idle.
     // So group ids run two tiles ahead and intercepts one tile ahead, in registers.
-    const float* bz_lane = Bz + 16 * sb + i16;
+    // Bz[g, s] gathered through a buffer descriptor: 32-bit offsets, out-of-range ids read 0
+    const auto bz_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Bz, 0, (unsigned)n_groups * (LS * 4u), 0x00020000);
+    const int bz_off = 4 * (16 * sb + i16);
+    auto bz_load = [&](int goff) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bz_rsrc, goff + bz_off, 0, 0));
+    };
     int gi[4 * RB];
     float bz_a[4 * RB], bz_b[4 * RB];
-    load_groups<RB>(gi, g, tile * LT, N, kq, n_groups, rb0);
+    load_groups<RB>(gi, g, tile * LT, N, kq, rb0);
 #pragma unroll
-    for (int e = 0; e < 4 * RB; ++e) bz_a[e] = bz_lane[(int64_t)gi[e] * LS];
-    load_groups<RB>(gi, g, (tile + stride) * LT, N, kq, n_groups, rb0);
+    for (int e = 0; e < 4 * RB; ++e) bz_a[e] = bz_load(gi[e]);
+    load_groups<RB>(gi, g, (tile + stride) * LT, N, kq, rb0);
     __syncthreads();
     int cur = 0;
     // One tile.  bz_cur holds this tile's intercepts (requested a tile ago), bz_next
@@ -184,25 +188,29 @@ __global__ __launch_bounds__(64 * NW, 2) void logreg_loglik_kernel(
         // next tile's intercepts (its group ids arrived during the MFMAs), then the ids
         // of the tile after
 #pragma unroll
-        for (int e = 0; e < 4 * RB; ++e) bz_next[e] = bz_lane[(int64_t)gi[e] * LS];
-        load_groups<RB>(gi, g, (tile + 2 * stride) * LT, N, kq, n_groups, rb0);
+        for (int e = 0; e < 4 * RB; ++e) bz_next[e] = bz_load(gi[e]);
+        load_groups<RB>(gi, g, (tile + 2 * stride) * LT, N, kq, rb0);
         // C/D map of 16x16x4: col = lane & 15 (sample), row = 4 * (lane >> 4) + reg
         const int64_t row0 = tile * LT;
         float tile_ll = 0.f;
+        // y l - softplus(l),  softplus(l) = max(l,0) + ln2 log2(1 + 2^(-|l| log2e)) on the raw
+        // v_exp_f32 / v_log_f32 (the log's argument is in (1, 2], the exponent's <= 0: no
+        // denormal handling needed, ~1e-7 ABSOLUTE error, far inside the stated tolerance).
+        // Instruction count matters here: VALU work delays the MFMAs of the other waves.
+        constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+        const bool whole = row0 + LT <= N;      // uniform: only the last tile masks rows
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * (rb0 + rb) + 4 * kq + r;
-                if (row0 + row < N) {
-                    const float yv = t[LT * LSTR + row];
-                    const float l = acc[rb][r] + bz_cur[4 * rb + r];
-                    // y l - softplus(l),  softplus(l) = max(l,0) + log(1 + exp(-|l|)).  The
-                    // hardware exp/log pair is accurate to ~1e-7 ABSOLUTE here (argument of
-                    // the log is in (1, 2]), far inside the stated tolerance; log1pf would
-                    // cost ~5x the instructions for relative accuracy nobody can observe.
-                    tile_ll += yv * l - (fmaxf(l, 0.f) + __logf(1.0f + __expf(-fabsf(l))));
-                }
+                const float yv = t[LT * LSTR + row];
+                const float l = acc[rb][r] + bz_cur[4 * rb + r];
+                const float g2 = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(l) * LOG2E));
+                float v = __builtin_fmaf(yv, l, -fmaxf(l, 0.f));
+                v = __builtin_fmaf(-LN2, g2, v);
+                if (!whole && row0 + row >= N) v = 0.f;
+                tile_ll += v;
             }
         acc_ll += (double)tile_ll;
         stage_store(st, lds + (cur ^ 1) * TILE_FLOATS, wave, lane);
@@ -426,6 +434,10 @@ int bsc_logreg_bbvi_loglik(bsc_ctx* ctx, const float* X, int64_t ldx, const floa
                         "bsc_logreg_bbvi_loglik: needs S == %d and D %% 4 == 0 in [4,%d] (got S=%d D=%d)",
                         LS, LD, S, D);
     BSC_REQUIRE(n_groups >= 1, "bsc_logreg_bbvi_loglik: n_groups=%d", n_groups);
+    if (n_groups > (1 << 22))
+        return bsc_fail(BSC_ERR_UNSUPPORTED,
+                        "bsc_logreg_bbvi_loglik: n_groups=%d exceeds the 32-bit gather range (4M groups)",
+                        n_groups);
     BSC_REQUIRE(ldx >= D && ldx % 4 == 0 && ldx < ((int64_t)1 << 26),
                 "bsc_logreg_bbvi_loglik: bad ldx=%lld", (long long)ldx);
     BSC_REQUIRE(((uintptr_t)X & 15) == 0, "bsc_logreg_bbvi_loglik: X must be 16-byte aligned");
