@@ -9,9 +9,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { M_ONLY, M_VALU1, M_VALU2, M_VALU4, M_VALU8, M_DEP1, M_LDS1, M_LDS2, M_LDS2_DEP, M_EXP1, M_KINDS };
+enum { M_CHAIN1, M_CHAIN2, M_ONLY, M_VALU1, M_VALU2, M_VALU4, M_VALU8, M_DEP1, M_LDS1, M_LDS2, M_LDS2_DEP, M_EXP1, M_KINDS };
 static const char* NAMES[M_KINDS] = {
-    "MFMA only", "+1 independent v_mul / MFMA", "+2 independent v_fma / MFMA", "+4 independent v_fma / MFMA",
+    "MFMA only, ONE dependent chain", "MFMA only, two dependent chains", "MFMA only", "+1 independent v_mul / MFMA", "+2 independent v_fma / MFMA", "+4 independent v_fma / MFMA",
     "+8 independent v_fma / MFMA", "+1 v_mul feeding the MFMA's B operand", "+1 ds_read_b32 / MFMA",
     "+2 ds_read_b32 / MFMA", "+2 ds_read_b32 -> v_mul -> B operand (read one MFMA ahead)", "+1 v_exp_f32 / MFMA"};
 
@@ -56,6 +56,14 @@ __global__ __launch_bounds__(256) void mix_loop(int iters, float* sink) {
     if (KIND == M_EXP1) asm volatile("v_exp_f32 %0, %0" : "+v"(v[0]));                              \
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, ACC, 0, 0, 0);
     for (int i = 0; i < iters; ++i) {
+        if (KIND == M_CHAIN1) {
+            EXTRA(a0) EXTRA(a0) EXTRA(a0) EXTRA(a0)
+            continue;
+        }
+        if (KIND == M_CHAIN2) {
+            EXTRA(a0) EXTRA(a1) EXTRA(a0) EXTRA(a1)
+            continue;
+        }
         EXTRA(a0)
         EXTRA(a1)
         EXTRA(a2)
@@ -99,6 +107,8 @@ int main() {
            p.gcnArchName, cus);
     float* sink;
     hipMalloc(&sink, 4);
+    run<M_CHAIN1>(cus, sink);
+    run<M_CHAIN2>(cus, sink);
     run<M_ONLY>(cus, sink);
     run<M_VALU1>(cus, sink);
     run<M_VALU2>(cus, sink);
