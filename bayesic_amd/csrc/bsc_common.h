@@ -21,6 +21,7 @@ struct bsc_ctx {
     int blr_waves_per_simd = 0;  // tuning: cap resident waves per SIMD (0 = kernel's own limit)
     int fused_map_blocks_per_cu = 8;  // bsc_map_reduce, pure map: grid cap (256-thread blocks)
     int fused_map_unroll = 2;         // float4 per operand in flight per lane (1 | 2); 2 is +18% measured
+    int gemm_fast = 1;                // GEMM: scalar-base loads for interior tiles (BSC_GEMM_FAST=0 turns them off)
     int gemm_pipe = 1;                // GEMM: LDS operand reads one k-pair ahead of the MFMAs
     int fused_nt_store = 1;           // dense map: non-temporal stores of the result
     int bbvi_waves = 4;          // bsc_logreg_bbvi_loglik: waves per workgroup (4: one wave per 16 samples, 8: per (16 samples, 16 rows))

@@ -36,6 +36,7 @@ struct GemmArgs {
     int tiles_m, tiles_n, splits;
     int64_t k_chunk;   // multiple of BK
     int vec_a, vec_b;  // 16-byte loads allowed along the operand's contiguous axis
+    int fast;          // interior tiles may use scalar-base + 32-bit-lane-offset loads (no per-lane address arithmetic)
 };
 
 // A [BK x 128] operand tile travels global -> registers -> LDS (k-major rows of
@@ -80,6 +81,28 @@ __device__ __forceinline__ void stage_load(Staged& st, const float* __restrict__
     }
 }
 
+// Interior tiles: the tile base is uniform (SGPRs) and the lane's offset inside the tile
+// fits 32 bits, so a load is `global_load_dwordx4 v, v_off, s[base]` with no per-lane
+// 64-bit multiplies or bounds tests (those cost the MFMA pipe ~4.6 cycles apiece:
+// profiles/r01_ubench_mfma_valu_mix.txt; the general loader spends ~290 per 64-MFMA k-tile).
+template <bool MN_CONTIG>
+__device__ __forceinline__ void stage_load_fast(Staged& st, const float* __restrict__ tile_base,
+                                                int64_t s_m, int64_t s_k, unsigned lane_off) {
+    // MN_CONTIG: part p is k + 8p;  else: part p is m + 32p
+    const int64_t pstride = (MN_CONTIG ? 8 * s_k : 32 * s_m) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const char* bp = reinterpret_cast<const char*>(tile_base) + p * pstride;
+        st.v[p] = *reinterpret_cast<const float4*>(bp + lane_off);
+    }
+}
+
+template <bool MN_CONTIG>
+__device__ __forceinline__ unsigned stage_lane_off(int64_t s_m, int64_t s_k, int tid) {
+    if (MN_CONTIG) return (unsigned)((4 * (tid & 31)) * s_m + (tid >> 5) * s_k) * 4u;
+    return (unsigned)((tid >> 3) * s_m + (4 * (tid & 7)) * s_k) * 4u;
+}
+
 template <bool MN_CONTIG>
 __device__ __forceinline__ void stage_store(const Staged& st, float* lds, int tid) {
 #pragma unroll
@@ -122,6 +145,11 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_mfma_kernel(GemmArgs g
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fr = lane & 31, fk = lane >> 5;  // operand fragment: row/col fr, k offset fk
+    const bool fast = g.fast && m0 + BM <= g.M && n0 + BN <= g.N;   // uniform
+    const unsigned a_off = stage_lane_off<A_M_CONTIG>(g.sa_m, g.sa_k, tid);
+    const unsigned b_off = stage_lane_off<B_N_CONTIG>(g.sb_n, g.sb_k, tid);
+    const float* a_tile = A + m0 * g.sa_m;
+    const float* b_tile = B + n0 * g.sb_n;
     Staged sa, sb;
     stage_load<A_M_CONTIG>(sa, A, g.sa_m, g.sa_k, m0, g.M, k_begin, k_end, g.vec_a, tid);
     stage_load<B_N_CONTIG>(sb, B, g.sb_n, g.sb_k, n0, g.N, k_begin, k_end, g.vec_b, tid);
@@ -175,16 +203,23 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_mfma_kernel(GemmArgs g
         }
     };
 
-    // NOTE (measured, in-process A/B at steady state): the "if (more)" blocks below are kept on
-    // purpose.  A bounds-free staging path for tile-aligned problems -- with the loads
-    // unconditional, pinned ahead of the MFMAs or spread between them, last step peeled -- was
-    // 2-30 % SLOWER than this branchy form (profiles/r01_ubench_clock_mfma_peak.txt).
+    // History (in-process A/B at steady state).  Earlier bounds-free staging variants that kept
+    // the per-lane 64-bit address arithmetic were 2-30 % SLOWER than the branchy general loader
+    // (profiles/r01_ubench_clock_mfma_peak.txt).  What costs is not the branches but the VALU
+    // instructions: ~290 per 64-MFMA k-tile in the general loader, each taking ~4.6 cycles
+    // from the MFMA pipe.  stage_load_fast (uniform tile base + one 32-bit lane offset) issues
+    // ~10 and is worth +21-31 % (4096^3: 101 -> 126 TF, 8192^3: 101 -> 128 TF, X^T X: 92 -> 121 TF).
     {
         for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
             const bool more = k0 + BK < k_end;
             if (more) {   // next tile's global loads fly during this tile's MFMAs
-                stage_load<A_M_CONTIG>(sa, A, g.sa_m, g.sa_k, m0, g.M, k0 + BK, k_end, g.vec_a, tid);
-                stage_load<B_N_CONTIG>(sb, B, g.sb_n, g.sb_k, n0, g.N, k0 + BK, k_end, g.vec_b, tid);
+                if (fast && k0 + 2 * BK <= k_end) {
+                    stage_load_fast<A_M_CONTIG>(sa, a_tile + (k0 + BK) * g.sa_k, g.sa_m, g.sa_k, a_off);
+                    stage_load_fast<B_N_CONTIG>(sb, b_tile + (k0 + BK) * g.sb_k, g.sb_n, g.sb_k, b_off);
+                } else {
+                    stage_load<A_M_CONTIG>(sa, A, g.sa_m, g.sa_k, m0, g.M, k0 + BK, k_end, g.vec_a, tid);
+                    stage_load<B_N_CONTIG>(sb, B, g.sb_n, g.sb_k, n0, g.N, k0 + BK, k_end, g.vec_b, tid);
+                }
             }
             compute(cur);
             if (more) {   // the other buffer was last read one step ago, behind a barrier
@@ -537,6 +572,12 @@ int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, 
     };
     g.vec_a = vec_ok(A, a_m, sa_m, sa_k, sa_b);
     g.vec_b = vec_ok(B, b_n, sb_n, sb_k, sb_b);
+    // lane offsets inside a [128 x 32] operand tile must fit 32 bits
+    auto span_ok = [](int64_t s_mn, int64_t s_k) {
+        const int64_t span = (127 * (s_mn < 0 ? -s_mn : s_mn) + 31 * (s_k < 0 ? -s_k : s_k) + 4) * 4;
+        return s_mn >= 0 && s_k >= 0 && span < ((int64_t)1 << 31);
+    };
+    g.fast = ctx->gemm_fast && g.vec_a && g.vec_b && span_ok(sa_m, sa_k) && span_ok(sb_n, sb_k);
     {
         bsc_prof_scope prof(ctx);
 #define BSC_GEMM(AM, BN_)                                                                       \
