@@ -43,6 +43,7 @@ struct LdaArgs {
     int64_t docs_per_split;   // multiple of DT
     int splits;
     int vec_c, vec_th;        // 16-byte global loads allowed
+    int fast;                 // interior steps may use uniform-base + 32-bit-lane-offset loads
 };
 
 // global -> registers for one step: Th tile [32][K] and C tile [32][128]
@@ -89,6 +90,33 @@ __device__ __forceinline__ void stage_load(Staged<KT>& st, const LdaArgs& a, int
             }
         }
         st.c[p] = f;
+    }
+}
+
+// Interior steps (all 32 documents and all 128 columns inside, 16-byte loads allowed): the tile
+// bases are uniform and a lane's offset inside the tile fits 32 bits, so the loads need no
+// per-lane 64-bit multiplies, bounds tests or zero fills -- VALU instructions that would
+// each take ~4.6 cycles from the MFMA pipe (profiles/r01_ubench_mfma_valu_mix.txt).
+template <int KT>
+__device__ __forceinline__ void stage_load_fast(Staged<KT>& st, const LdaArgs& a, int64_t d0,
+                                                int64_t v_base, int tid) {
+    static_assert(KT == 1 || KT == 2 || KT == 4, "row of part p must be row0 + (256 / (8 KT)) p");
+    // lane offsets inside the step's Th [32 x K] and C [32 x 128] tiles, recomputed per step
+    // (six VALU instructions) rather than kept in two of the kernel's last free registers
+    asm volatile("" : "+v"(tid));
+    const unsigned th_off = (unsigned)((tid / (8 * KT)) * (int)a.ldth + 4 * (tid % (8 * KT))) * 4u;
+    const unsigned c_off = (unsigned)((tid >> 5) * (int)a.ldc + 4 * (tid & 31)) * 4u;
+    const char* th_base = reinterpret_cast<const char*>(a.Th + d0 * a.ldth);
+    const char* c_base = reinterpret_cast<const char*>(a.C + d0 * a.ldc + v_base);
+    const int64_t th_part = (int64_t)(LDA_BLOCK / (8 * KT)) * a.ldth * 4, c_part = 8 * a.ldc * 4;
+#pragma unroll
+    for (int p = 0; p < KT; ++p)
+        st.th[p] = *reinterpret_cast<const float4*>(th_base + p * th_part + th_off);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c_base + p * c_part + c_off));
+        st.c[p] = make_float4(t.x, t.y, t.z, t.w);
     }
 }
 
@@ -145,6 +173,7 @@ __global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_kernel(LdaArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
 
+    const bool fast = (KT == 1 || KT == 2 || KT == 4) && a.fast && v_base + VT <= a.V;   // uniform
     Staged<KT> st;
     if (d_begin < d_end) {
         stage_load<KT>(st, a, d_begin, d_end, v_base, tid);
@@ -154,19 +183,26 @@ __global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_kernel(LdaArgs a) {
     int cur = 0;
     for (int64_t d0 = d_begin; d0 < d_end; d0 += DT) {
         const bool more = d0 + DT < d_end;
-        if (more) stage_load<KT>(st, a, d0 + DT, d_end, v_base, tid);
+        if (more) {
+            if constexpr (KT == 1 || KT == 2 || KT == 4) {
+                if (fast && d0 + 2 * DT <= d_end) stage_load_fast<KT>(st, a, d0 + DT, v_base, tid);
+                else stage_load<KT>(st, a, d0 + DT, d_end, v_base, tid);
+            } else {
+                stage_load<KT>(st, a, d0 + DT, d_end, v_base, tid);
+            }
+        }
         const float* th = th_s[cur];
         const float* ct = c_s[cur];
 
         // ---- phase 1: P = Th . Bt --------------------------------------------------
         f32x16 P;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) P[r] = 0.f;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float* arow = th + j * TH_LD + (K / 2) * h;
 #pragma unroll
         for (int t4 = 0; t4 < K / 8; ++t4) {
             const float4 av = *reinterpret_cast<const float4*>(arow + 4 * t4);
-            P = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bt[4 * t4 + 0], P, 0, 0, 0);
+            // the first MFMA takes the constant 0 as its C operand: no 16 moves to clear P
+            P = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bt[4 * t4 + 0], t4 == 0 ? zero16 : P, 0, 0, 0);
             P = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bt[4 * t4 + 1], P, 0, 0, 0);
             P = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bt[4 * t4 + 2], P, 0, 0, 0);
             P = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bt[4 * t4 + 3], P, 0, 0, 0);
@@ -176,7 +212,7 @@ __global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_kernel(LdaArgs a) {
         // Four result registers at a time: their counts come with one LDS round trip, the
         // division is v_rcp_f32 (1 ulp; the statistic's tolerance is 3e-5), and their 4 x KT
         // MFMAs run while the next four are fetched and divided -- the MFMA pipe would
-        // otherwise idle through the whole ratio stretch.  Padded rows / columns give R = 0.
+        // otherwise idle through the whole ratio stretch.  Padded rows / columns have count 0.
         float c_n[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) c_n[i] = ct[(i + 4 * h) * C_LD + 32 * wave + j];
@@ -193,8 +229,10 @@ __global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_kernel(LdaArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * q + i;
-                const int row = i + 8 * q + 4 * h;
-                P[r] = (v_ok && d0 + row < d_end) ? c[i] * __builtin_amdgcn_rcpf(P[r]) : 0.f;
+                // padded documents / columns were staged as zero counts; their P is 0 (Th or Bt
+                // is 0 there), so the clamp alone keeps 0 * rcp(0) from becoming NaN -- one
+                // v_max instead of a compare and a select per element (real P are > 0)
+                P[r] = c[i] * __builtin_amdgcn_rcpf(fmaxf(P[r], 1.0e-30f));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -384,6 +422,8 @@ int bsc_lda_sstats(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int6
     a.docs = docs; a.V = V;
     a.vec_c = (ldc % 4 == 0) && (((uintptr_t)C) & 15) == 0;
     a.vec_th = (ldth % 4 == 0) && (((uintptr_t)Th) & 15) == 0;
+    a.fast = a.vec_c && a.vec_th && (32 * ldc + VT) * 4 < ((int64_t)1 << 31) &&
+             (32 * ldth + K) * 4 < ((int64_t)1 << 31);
     const int64_t n_vt = (V + VT - 1) / VT;
     // Split the documents so that the grid fills whole rounds of the 2 x CU resident
     // workgroups (782 column tiles on 512 slots would leave a quarter of the chip idle).
