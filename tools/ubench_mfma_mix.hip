@@ -77,6 +77,46 @@ __global__ __launch_bounds__(256) void mix_loop(int iters, float* sink) {
     if (s == 12345.f) sink[0] = 1.f;
 }
 
+// v_mfma_f32_16x16x4_f32 (8 passes = 32 cycles nominal): 4 independent accumulators, or 2 / 1 chains
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int CHAINS>
+__global__ __launch_bounds__(256) void small_mfma_loop(int iters, float* sink) {
+    f32x4v a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+    const float x = threadIdx.x * 1e-9f, y = 1.0f;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a0, 0, 0, 0);
+        if (CHAINS >= 2) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a1, 0, 0, 0);
+        else a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a0, 0, 0, 0);
+        if (CHAINS >= 4) a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a2, 0, 0, 0);
+        else a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a0, 0, 0, 0);
+        if (CHAINS >= 4) a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a3, 0, 0, 0);
+        else if (CHAINS >= 2) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a1, 0, 0, 0);
+        else a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a0, 0, 0, 0);
+    }
+    if (a0[0] + a1[1] + a2[2] + a3[3] == 12345.f) sink[0] = 1.f;
+}
+
+template <int CHAINS>
+void run_small(int cus, float* sink) {
+    for (int wps = 1; wps <= 4; wps *= 2) {
+        const int blocks = cus * wps, iters = 80000 / wps;
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        float ms = 0;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(small_mfma_loop<CHAINS>, dim3(blocks), dim3(256), 0, 0, iters, sink);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+        }
+        const double cyc = ms * 1e-3 * 2.39e9 / (4.0 * iters * wps);
+        printf("16x16x4 f32 MFMA only, %d independent chain(s)                  waves/SIMD=%d  %6.2f ms  %6.1f cycles per MFMA per SIMD  (pipe %.0f %%)\n",
+               CHAINS, wps, ms, cyc, 3200.0 / cyc);
+    }
+}
+
 template <int KIND>
 void run(int cus, float* sink) {
     for (int wps = 1; wps <= 4; wps *= 2) {
@@ -107,6 +147,9 @@ int main() {
            p.gcnArchName, cus);
     float* sink;
     hipMalloc(&sink, 4);
+    run_small<4>(cus, sink);
+    run_small<2>(cus, sink);
+    run_small<1>(cus, sink);
     run<M_CHAIN1>(cus, sink);
     run<M_CHAIN2>(cus, sink);
     run<M_ONLY>(cus, sink);
