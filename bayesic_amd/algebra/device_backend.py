@@ -518,6 +518,7 @@ class DeviceBackend(Backend):
         if K % 4 or D % 4 or E % 4 or E > 32 or n == 0 or \
                 r.stride(ax_r) != 1 or xx.stride(ax_x) != 1 or y.stride(ye) != 1 or \
                 ldr % 4 or ldx % 4 or ldy % 4 or ldr < K or ldx < D or ldy < E or \
+                max(ldr, ldx, ldy) >= 1 << 22 or \
                 (r.data_ptr() | xx.data_ptr() | y.data_ptr()) % 16:
             return None
         out = self._empty((K, D, E), torch.float32)

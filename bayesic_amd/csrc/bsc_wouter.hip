@@ -269,6 +269,8 @@ extern "C" int bsc_weighted_outer(bsc_ctx* ctx, const float* R, int64_t ldr, con
                         "bsc_weighted_outer: operands must be 16-byte aligned with leading "
                         "dimensions that are multiples of 4");
     BSC_REQUIRE(N == 0 || (ldr >= K && ldx >= D && ldy >= E), "bsc_weighted_outer: leading dimension");
+    if ((ldr | ldx | ldy) >= ((int64_t)1 << 22))   // 64 rows x ld x 4 B must fit a 32-bit buffer offset
+        return bsc_fail(BSC_ERR_UNSUPPORTED, "bsc_weighted_outer: leading dimensions must be below 2^22");
     WOArgs a{};
     a.R = R; a.X = X; a.Y = Y;
     a.ldr = ldr; a.ldx = ldx; a.ldy = ldy; a.N = N;
