@@ -25,6 +25,7 @@ struct bsc_ctx {
     int gemm_pipe = 1;                // GEMM: LDS operand reads one k-pair ahead of the MFMAs
     int fused_nt_store = 1;           // dense map: non-temporal stores of the result
     int bbvi_waves = 4;          // bsc_logreg_bbvi_loglik: waves per workgroup (4: one wave per 16 samples, 8: per (16 samples, 16 rows))
+    int csc_fast = 1;            // bsc_lda_sstats_csc: buffer-descriptor gathers (BSC_CSC_FAST=0 turns them off)
     int wo_wg_per_cu = 2;        // bsc_weighted_outer: resident workgroups per CU the grid is sized for
     int fused_waves_per_cu = 16; // bsc_map_reduce: reduce splits target this many waves per CU
     int blr_nt_loads = 1;        // non-temporal loads of X (read once per pass): +9% measured
