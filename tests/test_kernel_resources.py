@@ -31,6 +31,11 @@ LIMITS = {
     },
     "bsc_lda.hip": {
         "lda_sstats_kernelILi4E": (256, 0),
+        "lda_sstats_csc_kernelILi8ELb1E": (96, 0),
+    },
+    "bsc_gemm.hip": {
+        "gemm_f32_mfma_kernelILb1ELb1ELb1E": (256, 0),
+        "gemm_f32_mfma_kernelILb0ELb1ELb1E": (256, 0),
     },
     "bsc_mog.hip": {
         "mog_estep_kernel": (256, 0),
@@ -41,8 +46,9 @@ LIMITS = {
     "bsc_wouter.hip": {
         # a lambda capturing the prefetch registers once sent them to scratch behind flat
         # loads (3.07 ms instead of 1.77 ms, every parity test green)
-        "weighted_outer_kernelILi2ELi5E": (128, 0),
-        "weighted_outer_kernelILi2ELi8E": (168, 0),      # three waves per SIMD
+        # all KT * CT accumulators live in one wave: two waves per SIMD by design
+        "weighted_outer_kernelILi2ELi5E": (256, 0),
+        "weighted_outer_kernelILi1ELi8E": (256, 0),
     },
 }
 
