@@ -38,6 +38,7 @@ constexpr int WAVE_LDS = MT * XT_STRIDE + MT * RT_STRIDE;
 constexpr int MOG_SLAB = MK * (1 + MF) + 1;          // [comp][R | S(32)] + L
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int drow(int q, int lane) {  // C/D row of accumulator register q
     return (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
     float* rt = xt + MT * XT_STRIDE;
 
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-    // A operand of the forward product: W[comp = 32cb + l31][feature 2s + half]
+    // A operand of the forward product: W[comp = 32cb + l31][feature s + 16 half]
     float wreg[2][MF / 2];
     f32x16 bias_q[2];   // bias of the component each accumulator register holds
 #pragma unroll
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
         const int comp = 32 * cb + l31;
 #pragma unroll
         for (int s = 0; s < MF / 2; ++s) {
-            const int f = 2 * s + half;            // f < 16: x_f ; else x^2_{f-16}
+            const int f = s + MD * half;           // lower half of the wave: x_s ; upper half: x_s^2
             const int d = f & (MD - 1);
             float v = 0.f;
             if (comp < K && d < D) v = Wmat[(int64_t)comp * 2 * D + (f < MD ? d : D + d)];
@@ -152,13 +153,16 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
         // forward: logits[comp][row] -- lane (row = l31, half) gets comps 32cb + drow(q, lane);
         // the C operand of the first k-step carries the bias
         f32x16 logit[2];
+        // k-step s contracts feature x_s in the lower half of the wave and x_s^2 in the upper:
+        // one selector per column gives the operand here AND, times 1/sum, the staged backward
+        // operand below (lower half writes x/sum, upper half x^2/sum)
+        float feat[MD];
+#pragma unroll
+        for (int s = 0; s < MD; ++s) feat[s] = cur.x[s] * (half ? cur.x[s] : 1.0f);
 #pragma unroll
         for (int s = 0; s < MF / 2; ++s) {
-            const int t = s & 7;
-            float a = half ? cur.x[2 * t + 1] : cur.x[2 * t];
-            if (s >= 8) a = a * a;
-            logit[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[0][s], a, s == 0 ? bias_q[0] : logit[0], 0, 0, 0);
-            logit[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[1][s], a, s == 0 ? bias_q[1] : logit[1], 0, 0, 0);
+            logit[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[0][s], feat[s], s == 0 ? bias_q[0] : logit[0], 0, 0, 0);
+            logit[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[1][s], feat[s], s == 0 ? bias_q[1] : logit[1], 0, 0, 0);
         }
         // softmax over the row's 64 components: 32 in this lane, 32 in lane ^ 32
         const bool valid = row0 + l31 < N;
@@ -168,23 +172,35 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
 #pragma unroll
             for (int q = 0; q < 16; ++q) m = fmaxf(m, logit[cb][q]);
         m = swap32_max(m);
-        float ssum = 0.f;
+        // Pairs of values go through v_pk_add / v_pk_fma / v_pk_mul: a packed instruction takes
+        // the same ~5 cycles from the MFMA pipe as a scalar one (profiles/r01_ubench_mfma_valu_mix.txt)
+        const f32x2 m2 = {m, m};
+        f32x2 ssum2 = {0.f, 0.f};
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                logit[cb][q] = __builtin_amdgcn_exp2f(logit[cb][q] - m);
-                ssum += logit[cb][q];
+            for (int q = 0; q < 16; q += 2) {
+                const f32x2 d = f32x2{logit[cb][q], logit[cb][q + 1]} - m2;
+                const f32x2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+                logit[cb][q] = e[0];
+                logit[cb][q + 1] = e[1];
+                ssum2 += e;
             }
-        ssum = swap32_sum(ssum);
+        const float ssum = swap32_sum(ssum2[0] + ssum2[1]);
         const float inv = valid ? 1.0f / ssum : 0.f;
         if (valid && half == 0) lse_acc += LN2 * (m + __builtin_amdgcn_logf(ssum));
         // unnormalised e -> LDS as [row][comp] (registers 4g..4g+3 are 4 consecutive components);
         // R_k accumulates e * inv
+        const f32x2 inv2 = {inv, inv};
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) rsum[cb][q] = __builtin_fmaf(logit[cb][q], inv, rsum[cb][q]);
+            for (int q = 0; q < 16; q += 2) {
+                const f32x2 e = {logit[cb][q], logit[cb][q + 1]};
+                const f32x2 r = __builtin_elementwise_fma(e, inv2, f32x2{rsum[cb][q], rsum[cb][q + 1]});
+                rsum[cb][q] = r[0];
+                rsum[cb][q + 1] = r[1];
+            }
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq)
                 *reinterpret_cast<float4*>(rt + l31 * RT_STRIDE + 32 * cb + 8 * gq + 4 * half) =
@@ -195,14 +211,10 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
         // x / sum (features 0..15), lanes 32-63 x^2 / sum (features 16..31)
 #pragma unroll
         for (int c4 = 0; c4 < MD / 4; ++c4) {
-            float f[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f[j] = cur.x[4 * c4 + j] * inv;
-                if (half) f[j] *= cur.x[4 * c4 + j];
-            }
+            const f32x2 fa = f32x2{feat[4 * c4], feat[4 * c4 + 1]} * inv2;
+            const f32x2 fb = f32x2{feat[4 * c4 + 2], feat[4 * c4 + 3]} * inv2;
             *reinterpret_cast<float4*>(xt + l31 * XT_STRIDE + MD * half + 4 * c4) =
-                make_float4(f[0], f[1], f[2], f[3]);
+                make_float4(fa[0], fa[1], fb[0], fb[1]);
         }
         wave_lds_sync();
         // backward: S[comp][feat] += e[row][comp] * (f[row][feat] / sum[row]), two rows per MFMA
