@@ -229,30 +229,17 @@ __global__ __launch_bounds__(64 * NW, 2) void logreg_loglik_kernel(
         slab[((int64_t)blockIdx.x * (NW / 4) + (wave >> 2)) * LS + 16 * sb + lane] = (float)acc_ll;
 }
 
-__global__ __launch_bounds__(1024) void loglik_reduce_kernel(const float* __restrict__ slab,
-                                                             int n_rows, double* __restrict__ ell) {
-    __shared__ double part[16][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// ell[s] = sum over the block partials, float64, fixed order.  One wave per sample (a single
+// 1024-thread workgroup walking all 64 columns took 10 us, mostly latency: a third of what the
+// whole parameter side of an update costs).
+__global__ __launch_bounds__(256) void loglik_reduce_kernel(const float* __restrict__ slab,
+                                                            int n_rows, double* __restrict__ ell) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     double sum = 0.0;
-    constexpr int BATCH = 16;
-    for (int b0 = wave; b0 < n_rows; b0 += 16 * BATCH) {
-        float v[BATCH];
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-            const int b = b0 + 16 * j;
-            v[j] = b < n_rows ? slab[(int64_t)b * LS + lane] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) sum += (double)v[j];
-    }
-    part[wave][lane] = sum;
-    __syncthreads();
-    if (wave == 0) {
-        double tot = part[0][lane];
-#pragma unroll
-        for (int k = 1; k < 16; ++k) tot += part[k][lane];
-        ell[lane] = tot;
-    }
+    for (int b = lane; b < n_rows; b += 64) sum += (double)slab[(int64_t)b * LS + s];
+    sum = wave_allsum_f64(sum);
+    if (lane == 0) ell[s] = sum;
 }
 
 // ---- parameter side (float64, tiny) -----------------------------------------
@@ -467,7 +454,7 @@ int bsc_logreg_bbvi_loglik(bsc_ctx* ctx, const float* X, int64_t ldx, const floa
 #undef BSC_LL
     }
     BSC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loglik_reduce_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const float*)ws,
+    hipLaunchKernelGGL(loglik_reduce_kernel, dim3(LS / 4), dim3(256), 0, ctx->stream, (const float*)ws,
                        n_blocks * (nw / 4), ell);
     BSC_LAUNCH_CHECK();
     return BSC_OK;
