@@ -119,6 +119,17 @@ __device__ __forceinline__ void axpy4(float4& acc, float c, const float4& x) {
     acc.w = fmaf(c, x.w, acc.w);
 }
 
+// The same four FMAs as two packed ones (v_pk_fma_f32, the scalar broadcast through op_sel):
+// a packed FMA costs the MFMA pipe of the other wave what ONE scalar FMA does
+// (profiles/r01_ubench_mfma_valu_mix.txt), and the results are the same bits.
+typedef float pass_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void axpy4_pk(float4& acc, float c, const float4& x) {
+    const pass_f32x2 c2 = {c, c};
+    const pass_f32x2 lo = __builtin_elementwise_fma(c2, pass_f32x2{x.x, x.y}, pass_f32x2{acc.x, acc.y});
+    const pass_f32x2 hi = __builtin_elementwise_fma(c2, pass_f32x2{x.z, x.w}, pass_f32x2{acc.z, acc.w});
+    acc.x = lo[0]; acc.y = lo[1]; acc.z = hi[0]; acc.w = hi[1];
+}
+
 // Forward + backward for one tile; `wl` is this wave's LDS region.
 template <int ROWS>
 __device__ __forceinline__ void compute_tile(const Tile<ROWS>& t, const float4 (&w)[SG],
@@ -310,7 +321,7 @@ __device__ __forceinline__ void load_mtile(MTile& t, const float* __restrict__ X
                        __uint_as_float(v[3]));
 }
 
-template <bool NT>
+template <bool NT, bool PK>
 __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_mfma_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ y, int64_t B,
     const float* __restrict__ W, int S, float* __restrict__ slab, int n_iter) {
@@ -387,10 +398,17 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_mfma_kernel(
             const float4 x4 = *reinterpret_cast<const float4*>(tl + r * MT_RS + 4 * lane);
             const float4 c0 = *reinterpret_cast<const float4*>(rb + r * SG);
             const float4 c1 = *reinterpret_cast<const float4*>(rb + r * SG + 4);
-            axpy4(acc[0], c0.x, x4); axpy4(acc[1], c0.y, x4);
-            axpy4(acc[2], c0.z, x4); axpy4(acc[3], c0.w, x4);
-            axpy4(acc[4], c1.x, x4); axpy4(acc[5], c1.y, x4);
-            axpy4(acc[6], c1.z, x4); axpy4(acc[7], c1.w, x4);
+            if (PK) {
+                axpy4_pk(acc[0], c0.x, x4); axpy4_pk(acc[1], c0.y, x4);
+                axpy4_pk(acc[2], c0.z, x4); axpy4_pk(acc[3], c0.w, x4);
+                axpy4_pk(acc[4], c1.x, x4); axpy4_pk(acc[5], c1.y, x4);
+                axpy4_pk(acc[6], c1.z, x4); axpy4_pk(acc[7], c1.w, x4);
+            } else {
+                axpy4(acc[0], c0.x, x4); axpy4(acc[1], c0.y, x4);
+                axpy4(acc[2], c0.z, x4); axpy4(acc[3], c0.w, x4);
+                axpy4(acc[4], c1.x, x4); axpy4(acc[5], c1.y, x4);
+                axpy4(acc[6], c1.z, x4); axpy4(acc[7], c1.w, x4);
+            }
         }
         wave_lds_sync();   // the next iteration overwrites the tile
     }
@@ -1055,12 +1073,14 @@ void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int6
     const bool nt = ctx->blr_nt_loads != 0;
     const int rows = pass_rows(ctx, D, y);
     if (rows == 16) {
-        if (nt)
-            hipLaunchKernelGGL(blr_pass_mfma_kernel<true>, dim3(g.n_blocks), dim3(PASS_BLOCK), 0,
-                               ctx->stream, X, ldx, y, B, W, sg, slab, g.n_iter);
-        else
-            hipLaunchKernelGGL(blr_pass_mfma_kernel<false>, dim3(g.n_blocks), dim3(PASS_BLOCK), 0,
-                               ctx->stream, X, ldx, y, B, W, sg, slab, g.n_iter);
+#define BSC_PASS_MFMA(NT_, PK_)                                                                    \
+    hipLaunchKernelGGL((blr_pass_mfma_kernel<NT_, PK_>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0,   \
+                       ctx->stream, X, ldx, y, B, W, sg, slab, g.n_iter)
+        if (nt && ctx->blr_pk) BSC_PASS_MFMA(true, true);
+        else if (nt) BSC_PASS_MFMA(true, false);
+        else if (ctx->blr_pk) BSC_PASS_MFMA(false, true);
+        else BSC_PASS_MFMA(false, false);
+#undef BSC_PASS_MFMA
     } else if (rows == 8) {
         if (nt) launch_pass_rows<8, true>(ctx, X, ldx, y, B, D, W, sg, g, slab);
         else launch_pass_rows<8, false>(ctx, X, ldx, y, B, D, W, sg, g, slab);

@@ -17,8 +17,9 @@ from bayesic_amd.device import Context
 
 
 def main():
-    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-    per = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    nums = [a for a in sys.argv[1:] if a.isdigit()]
+    rounds = int(nums[0]) if len(nums) > 0 else 8
+    per = int(nums[1]) if len(nums) > 1 else 20
     B, D, S = 1_000_000, 256, 8
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(1234)
@@ -26,10 +27,18 @@ def main():
     y = torch.randn(B, generator=g, device=dev)
     W = torch.randn((S, D), generator=g, device=dev) / 16
     ctxs = {}
+    # (tile rows, waves/SIMD cap, non-temporal loads); append "pk" on the command line to
+    # compare the MFMA pass with scalar vs packed backward FMAs instead
     variants = [(8, 0, 1), (16, 0, 1)]
+    pk_mode = "pk" in sys.argv
+    if pk_mode:
+        variants = [(16, 0, 1), (16, 1000, 1)]      # second entry: BSC_BLR_PK=1 (cap field reused as a tag)
     for rows, wps, nt in variants:
+        os.environ["BSC_BLR_PK"] = "1" if (pk_mode and wps == 1000) else "0"
+        if pk_mode:
+            wps = 0 if wps != 1000 else 1000
         os.environ["BSC_BLR_TILE_ROWS"] = str(rows)
-        os.environ["BSC_BLR_WAVES_PER_SIMD"] = str(wps)
+        os.environ["BSC_BLR_WAVES_PER_SIMD"] = str(0 if wps == 1000 else wps)
         os.environ["BSC_BLR_NT"] = str(nt)
         ctxs[(rows, wps, nt)] = Context(0)
         ctxs[(rows, wps, nt)].reserve(16 << 20)
