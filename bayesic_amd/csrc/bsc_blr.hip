@@ -334,12 +334,16 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_mfma_kernel(
     float* tl = lds + wave * MT_WAVE_LDS;      // this wave's tile
     float* rb = tl + MT_ROWS * MT_RS;          // residuals [row][sample]
 
-    // B operand: W[sample i16][16 j + 4 kq + c]; samples >= S (and MFMA columns 8..15) are zero
+    // B operand: W[sample i16][64 kq + 4 j + c]; samples >= S (and MFMA columns 8..15) are zero.
+    // Lane group kq contracts columns 64 kq .. 64 kq + 63, so the four 16-byte A reads of a row
+    // lie 256 B apart on the same banks and each ds_read_b128 lane group (all 16 rows once,
+    // two different kq) is conflict-free; interleaved columns (16 j + 4 kq) gave every lane
+    // group a 2-way conflict (SQ_LDS_BANK_CONFLICT 18 % of the LDS cycles).
     float wreg[GCOLS / 4];
 #pragma unroll
     for (int j = 0; j < GCOLS / 16; ++j) {
         float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i16 < S) w4 = *reinterpret_cast<const float4*>(W + (int64_t)i16 * GCOLS + 16 * j + 4 * kq);
+        if (i16 < S) w4 = *reinterpret_cast<const float4*>(W + (int64_t)i16 * GCOLS + 64 * kq + 4 * j);
         wreg[4 * j + 0] = w4.x; wreg[4 * j + 1] = w4.y;
         wreg[4 * j + 2] = w4.z; wreg[4 * j + 3] = w4.w;
     }
@@ -366,11 +370,11 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_mfma_kernel(
 
         // forward on the MFMA pipe; two accumulators so that no MFMA waits on its predecessor
         mfma_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-        const float* arow = tl + i16 * MT_RS + 4 * kq;
+        const float* arow = tl + i16 * MT_RS + 64 * kq;
 #pragma unroll
         for (int j = 0; j < GCOLS / 16; j += 2) {
-            const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * j);
-            const float4 a1 = *reinterpret_cast<const float4*>(arow + 16 * j + 16);
+            const float4 a0 = *reinterpret_cast<const float4*>(arow + 4 * j);
+            const float4 a1 = *reinterpret_cast<const float4*>(arow + 4 * j + 4);
             d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wreg[4 * j + 0], d0, 0, 0, 0);
             d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wreg[4 * j + 4], d1, 0, 0, 0);
             d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wreg[4 * j + 1], d0, 0, 0, 0);
