@@ -545,6 +545,23 @@ int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, 
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
         if (splits > 1024) splits = 1024;
+    } else if (tiles % want != 0 && tiles < 8 * want) {
+        // A grid of a few rounds wastes the tail of its last round (33 x 33 tiles on 512 slots:
+        // 2.1 rounds cost 3).  Splitting K makes the rounds shorter; take the split with the
+        // best slot efficiency when that buys more than the extra pass over the partial
+        // results costs (taken as 4 % per split: an M x N float slab written and read back).
+        auto eff = [&](int64_t sp) {
+            const int64_t wgs = tiles * sp;
+            return (double)wgs / (double)(want * ((wgs + want - 1) / want));
+        };
+        double best = eff(1);
+        for (int64_t sp = 2; sp <= 6 && K / sp >= 1024; ++sp) {
+            const double e = eff(sp) - 0.04 * (double)(sp - 1);
+            if (e > best + 0.03) {
+                best = e;
+                splits = sp;
+            }
+        }
     }
     int64_t chunk = (K + splits - 1) / splits;
     chunk = (chunk + BK - 1) / BK * BK;
