@@ -9,12 +9,13 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { M_CHAIN1, M_CHAIN2, M_ONLY, M_VALU1, M_VALU2, M_VALU4, M_VALU8, M_DEP1, M_LDS1, M_LDS2, M_LDS2_DEP, M_EXP1, M_PK2, M_PK4, M_KINDS };
+enum { M_CHAIN1, M_CHAIN2, M_ONLY, M_VALU1, M_VALU2, M_VALU4, M_VALU8, M_DEP1, M_LDS1, M_LDS2, M_LDS2_DEP, M_EXP1, M_PK2, M_PK4, M_B128_4, M_B128_2, M_B128_1, M_KINDS };
 static const char* NAMES[M_KINDS] = {
     "MFMA only, ONE dependent chain", "MFMA only, two dependent chains", "MFMA only", "+1 independent v_mul / MFMA", "+2 independent v_fma / MFMA", "+4 independent v_fma / MFMA",
     "+8 independent v_fma / MFMA", "+1 v_mul feeding the MFMA's B operand", "+1 ds_read_b32 / MFMA",
     "+2 ds_read_b32 / MFMA", "+2 ds_read_b32 -> v_mul -> B operand (read one MFMA ahead)", "+1 v_exp_f32 / MFMA",
-    "+2 v_pk_fma_f32 (= 4 fma) / MFMA", "+4 v_pk_fma_f32 (= 8 fma) / MFMA"};
+    "+2 v_pk_fma_f32 (= 4 fma) / MFMA", "+4 v_pk_fma_f32 (= 8 fma) / MFMA",
+    "+1 ds_read_b128 / 4 MFMA (4 B/cycle/SIMD)", "+1 ds_read_b128 / 2 MFMA (8 B/cycle/SIMD)", "+1 ds_read_b128 / MFMA (16 B/cycle/SIMD)"};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void mix_loop(int iters, float* sink) {
@@ -28,6 +29,9 @@ __global__ __launch_bounds__(256) void mix_loop(int iters, float* sink) {
     for (int j = 0; j < 8; ++j) v[j] = threadIdx.x * 1e-3f + j;
     const unsigned la = (threadIdx.x & 63) * 4u, lb = ((threadIdx.x & 63) + 64) * 4u + 2048u;
     float l0 = 1.f, l1 = 1.f, n0 = 1.f, n1 = 1.f;
+    typedef float f32x4q __attribute__((ext_vector_type(4)));
+    f32x4q q0 = {0}, q1 = {0}, q2 = {0}, q3 = {0};
+    const unsigned lq = (threadIdx.x & 63) * 16u;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 w0 = {v[0], v[1]}, w1 = {v[2], v[3]}, w2 = {v[4], v[5]}, w3 = {1.0000001f, 1e-7f};
     if (KIND == M_LDS2_DEP) {
@@ -75,6 +79,18 @@ __global__ __launch_bounds__(256) void mix_loop(int iters, float* sink) {
             EXTRA(a0) EXTRA(a1) EXTRA(a0) EXTRA(a1)
             continue;
         }
+        if (KIND == M_B128_4 || KIND == M_B128_2 || KIND == M_B128_1) {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(q0) : "v"(lq));
+            EXTRA(a0)
+            if (KIND == M_B128_1) asm volatile("ds_read_b128 %0, %1" : "=v"(q1) : "v"(lq));
+            EXTRA(a1)
+            if (KIND == M_B128_2 || KIND == M_B128_1) asm volatile("ds_read_b128 %0, %1" : "=v"(q2) : "v"(lq));
+            EXTRA(a2)
+            if (KIND == M_B128_1) asm volatile("ds_read_b128 %0, %1" : "=v"(q3) : "v"(lq));
+            EXTRA(a3)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            continue;
+        }
         EXTRA(a0)
         EXTRA(a1)
         EXTRA(a2)
@@ -85,7 +101,7 @@ __global__ __launch_bounds__(256) void mix_loop(int iters, float* sink) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float s = a0[0] + a1[1] + a2[2] + a3[3] + l0 + l1 + n0 + n1 + y;
     for (int j = 0; j < 8; ++j) s += v[j];
-    s += w0[0] + w0[1] + w1[0] + w1[1] + w2[0] + w2[1];
+    s += w0[0] + w0[1] + w1[0] + w1[1] + w2[0] + w2[1] + q0[0] + q1[1] + q2[2] + q3[3];
     if (s == 12345.f) sink[0] = 1.f;
 }
 
@@ -176,5 +192,8 @@ int main() {
     run<M_EXP1>(cus, sink);
     run<M_PK2>(cus, sink);
     run<M_PK4>(cus, sink);
+    run<M_B128_4>(cus, sink);
+    run<M_B128_2>(cus, sink);
+    run<M_B128_1>(cus, sink);
     return 0;
 }
