@@ -152,9 +152,9 @@ __global__ __launch_bounds__(64 * NW, 2) void logreg_loglik_kernel(
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
         // A operands one k-group ahead in registers: the MFMAs of group q cover the LDS
-        // latency of group q+1.  With two row blocks they alternate so that no MFMA waits on
-        // its predecessor (16x16x4: 32-cycle issue, 40-cycle dependent latency); with one,
-        // the other waves of the SIMD fill the 8-cycle gaps.
+        // latency of group q+1.  (A single dependent accumulator chain runs at the full
+        // 32-cycle rate -- tools/ubench_mfma_mix.hip -- so the row blocks need not alternate
+        // for the pipe's sake; they do because one A read then feeds four MFMAs.)
         const float* ta = t + (16 * rb0 + i16) * LSTR + 64 * kq;
         float4 an[RB];
 #pragma unroll
