@@ -9,13 +9,14 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { M_CHAIN1, M_CHAIN2, M_ONLY, M_VALU1, M_VALU2, M_VALU4, M_VALU8, M_DEP1, M_LDS1, M_LDS2, M_LDS2_DEP, M_EXP1, M_PK2, M_PK4, M_B128_4, M_B128_2, M_B128_1, M_KINDS };
+enum { M_CHAIN1, M_CHAIN2, M_ONLY, M_VALU1, M_VALU2, M_VALU4, M_VALU8, M_DEP1, M_LDS1, M_LDS2, M_LDS2_DEP, M_EXP1, M_PK2, M_PK4, M_B128_4, M_B128_2, M_B128_1, M_DEP_AHEAD4, M_KINDS };
 static const char* NAMES[M_KINDS] = {
     "MFMA only, ONE dependent chain", "MFMA only, two dependent chains", "MFMA only", "+1 independent v_mul / MFMA", "+2 independent v_fma / MFMA", "+4 independent v_fma / MFMA",
     "+8 independent v_fma / MFMA", "+1 v_mul feeding the MFMA's B operand", "+1 ds_read_b32 / MFMA",
     "+2 ds_read_b32 / MFMA", "+2 ds_read_b32 -> v_mul -> B operand (read one MFMA ahead)", "+1 v_exp_f32 / MFMA",
     "+2 v_pk_fma_f32 (= 4 fma) / MFMA", "+4 v_pk_fma_f32 (= 8 fma) / MFMA",
-    "+1 ds_read_b128 / 4 MFMA (4 B/cycle/SIMD)", "+1 ds_read_b128 / 2 MFMA (8 B/cycle/SIMD)", "+1 ds_read_b128 / MFMA (16 B/cycle/SIMD)"};
+    "+1 ds_read_b128 / 4 MFMA (4 B/cycle/SIMD)", "+1 ds_read_b128 / 2 MFMA (8 B/cycle/SIMD)", "+1 ds_read_b128 / MFMA (16 B/cycle/SIMD)",
+    "+2 ds_read_b32 -> v_mul -> B operand, reads issued FOUR MFMAs ahead"};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void mix_loop(int iters, float* sink) {
@@ -36,6 +37,13 @@ __global__ __launch_bounds__(256) void mix_loop(int iters, float* sink) {
     f32x2 w0 = {v[0], v[1]}, w1 = {v[2], v[3]}, w2 = {v[4], v[5]}, w3 = {1.0000001f, 1e-7f};
     if (KIND == M_LDS2_DEP) {
         asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=v"(n0), "=v"(n1) : "v"(la), "v"(lb));
+    }
+    float r0a = 1.f, r0b = 1.f, r1a = 1.f, r1b = 1.f, r2a = 1.f, r2b = 1.f, r3a = 1.f, r3b = 1.f;
+    if (KIND == M_DEP_AHEAD4) {
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=v"(r0a), "=v"(r0b) : "v"(la), "v"(lb));
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=v"(r1a), "=v"(r1b) : "v"(la), "v"(lb));
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=v"(r2a), "=v"(r2b) : "v"(la), "v"(lb));
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=v"(r3a), "=v"(r3b) : "v"(la), "v"(lb));
     }
 #define EXTRA(ACC)                                                                                  \
     if (KIND == M_VALU1) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[0]) : "v"(v[1]));            \
@@ -79,6 +87,23 @@ __global__ __launch_bounds__(256) void mix_loop(int iters, float* sink) {
             EXTRA(a0) EXTRA(a1) EXTRA(a0) EXTRA(a1)
             continue;
         }
+        if (KIND == M_DEP_AHEAD4) {
+            // four operand pairs in flight: pair j was requested four MFMAs ago
+            float y0, y1, y2, y3;
+            asm volatile("s_waitcnt lgkmcnt(6)\n\tv_mul_f32 %0, %1, %2" : "=v"(y0) : "v"(r0a), "v"(r0b));
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=v"(r0a), "=v"(r0b) : "v"(la), "v"(lb));
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y0, a0, 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(6)\n\tv_mul_f32 %0, %1, %2" : "=v"(y1) : "v"(r1a), "v"(r1b));
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=v"(r1a), "=v"(r1b) : "v"(la), "v"(lb));
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y1, a1, 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(6)\n\tv_mul_f32 %0, %1, %2" : "=v"(y2) : "v"(r2a), "v"(r2b));
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=v"(r2a), "=v"(r2b) : "v"(la), "v"(lb));
+            a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y2, a2, 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(6)\n\tv_mul_f32 %0, %1, %2" : "=v"(y3) : "v"(r3a), "v"(r3b));
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=v"(r3a), "=v"(r3b) : "v"(la), "v"(lb));
+            a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y3, a3, 0, 0, 0);
+            continue;
+        }
         if (KIND == M_B128_4 || KIND == M_B128_2 || KIND == M_B128_1) {
             asm volatile("ds_read_b128 %0, %1" : "=v"(q0) : "v"(lq));
             EXTRA(a0)
@@ -101,7 +126,7 @@ __global__ __launch_bounds__(256) void mix_loop(int iters, float* sink) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float s = a0[0] + a1[1] + a2[2] + a3[3] + l0 + l1 + n0 + n1 + y;
     for (int j = 0; j < 8; ++j) s += v[j];
-    s += w0[0] + w0[1] + w1[0] + w1[1] + w2[0] + w2[1] + q0[0] + q1[1] + q2[2] + q3[3];
+    s += w0[0] + w0[1] + w1[0] + w1[1] + w2[0] + w2[1] + q0[0] + q1[1] + q2[2] + q3[3] + r0a + r0b + r1a + r1b + r2a + r2b + r3a + r3b;
     if (s == 12345.f) sink[0] = 1.f;
 }
 
@@ -195,5 +220,6 @@ int main() {
     run<M_B128_4>(cus, sink);
     run<M_B128_2>(cus, sink);
     run<M_B128_1>(cus, sink);
+    run<M_DEP_AHEAD4>(cus, sink);
     return 0;
 }
