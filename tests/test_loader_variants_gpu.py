@@ -69,3 +69,24 @@ def test_sparse_lda_fast_gathers_match_the_general_path(monkeypatch):
     npt.assert_allclose(outs[0], outs[1], rtol=2e-6)
     from oracle import svi
     npt.assert_allclose(outs[0], svi.lda_sstats(C, Th.cpu().numpy(), Bt.cpu().numpy()), rtol=3e-5)
+
+
+def test_pass_packed_backward_gives_the_same_bits(monkeypatch):
+    """BSC_BLR_PK: v_pk_fma_f32 is two fused multiply-adds -- the statistics must not change."""
+    import torch
+    pk = _context_with(monkeypatch, BSC_BLR_PK="1")
+    scalar = _context_with(monkeypatch, BSC_BLR_PK="0")
+    g = torch.Generator(device=pk.device).manual_seed(5)
+    B, D, S = 50_000, 256, 8
+    X = torch.randn((B, D), generator=g, device=pk.device)
+    y = torch.randn(B, generator=g, device=pk.device)
+    W = torch.randn((S, D), generator=g, device=pk.device) / 16
+    outs = []
+    for c in (pk, scalar):
+        Q = torch.zeros(S, dtype=torch.float64, device=c.device)
+        G = torch.zeros((S, D), dtype=torch.float64, device=c.device)
+        c.call("bsc_blr_data_pass", X, D, y, B, D, W, S, Q, G)
+        c.sync()
+        outs.append((Q.cpu().numpy(), G.cpu().numpy()))
+    npt.assert_array_equal(outs[0][0], outs[1][0])
+    npt.assert_array_equal(outs[0][1], outs[1][1])
