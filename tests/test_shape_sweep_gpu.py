@@ -136,3 +136,53 @@ def test_gemm_strided_sweep(ctx, seed):
     want = A64 @ B.astype(np.float64)
     bound = np.abs(A64) @ np.abs(B.astype(np.float64))
     assert (np.abs(C.cpu().numpy() - want) <= 1e-5 * bound + 1e-30).all()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_sparse_lda_sweep(ctx, seed):
+    import scipy.sparse as sp
+    import torch
+    rs = np.random.RandomState(600 + seed)
+    docs = int(rs.choice([1, 40, 333]))
+    V = int(rs.choice([1, 63, 64, 65, 500]))
+    K = int(rs.choice([32, 64, 96, 128]))
+    pt = int(rs.choice([0, 4]))
+    density = float(rs.choice([0.0, 0.02, 0.5]))
+    C = (rs.poisson(1.0, (docs, V)) * (rs.uniform(size=(docs, V)) < density)).astype(np.float32)
+    Th = rs.uniform(0.1, 1.0, (docs, K)).astype(np.float32)
+    Bt = rs.uniform(0.1, 1.0, (K, V)).astype(np.float32)
+    csc = sp.csc_matrix(C)
+    dev = ctx.device
+    colptr = torch.from_numpy(csc.indptr.astype(np.int64)).to(dev)
+    rowidx = torch.from_numpy(csc.indices.astype(np.int32)).to(dev) if csc.nnz else torch.zeros(1, dtype=torch.int32, device=dev)
+    vals = torch.from_numpy(csc.data.astype(np.float32)).to(dev) if csc.nnz else torch.zeros(1, device=dev)
+    Thd = padded(ctx, Th, pt)
+    out = torch.full((K, V), float("nan"), device=dev)
+    ctx.call("bsc_lda_sstats_csc", colptr, rowidx, vals, docs, V, K, Thd, Thd.stride(0), ctx.to_device(Bt), V, out, V)
+    ctx.sync()
+    np.testing.assert_allclose(out.cpu().numpy(), svi.lda_sstats(C, Th, Bt), rtol=3e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_weighted_outer_sweep(ctx, seed):
+    import torch
+    rs = np.random.RandomState(700 + seed)
+    N = int(rs.choice([1, 63, 64, 65, 5000]))
+    K = int(rs.choice([4, 28, 32, 36, 64]))
+    D = int(rs.choice([4, 12, 16, 32]))
+    E = int(rs.choice([4, 8, 32]))
+    sym = bool(rs.randint(2))
+    pr, px = int(rs.choice([0, 4])), int(rs.choice([0, 8]))
+    R = rs.standard_normal((N, K)).astype(np.float32)
+    X = rs.standard_normal((N, D)).astype(np.float32)
+    Y = X if sym else rs.standard_normal((N, E)).astype(np.float32)
+    Rd, Xd = padded(ctx, R, pr), padded(ctx, X, px)
+    Yd = Xd if sym else padded(ctx, Y, 4)
+    out = torch.full((K, D, Y.shape[1]), float("nan"), device=ctx.device)
+    ctx.call("bsc_weighted_outer", Rd, Rd.stride(0), Xd, Xd.stride(0), Yd, Yd.stride(0), N, K, D,
+             Y.shape[1], 1.0, out)
+    ctx.sync()
+    R64, X64, Y64 = (a.astype(np.float64) for a in (R, X, Y))
+    want = np.einsum("nk,nd,ne->kde", R64, X64, Y64)
+    bound = np.einsum("nk,nd,ne->kde", np.abs(R64), np.abs(X64), np.abs(Y64))
+    assert (np.abs(out.cpu().numpy() - want) <= 2e-5 * bound + 1e-30).all()
