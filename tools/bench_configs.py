@@ -44,7 +44,19 @@ def timed(ctx, fn, reps, warm=3, warm_ms=60.0):
     ms, n = ctx.profile_read()
     ctx.profile(0)
     kern = (ms / n * 1e-3) if n else float("nan")
+    # per-call distribution (SURVEY 8(d) asks for median and min): one event pair per call, which
+    # adds ~4 us of stream time to each -- kept out of the mean above
+    evs = [(ctx.event(), ctx.event()) for _ in range(min(reps, 20))]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    per = sorted(a.elapsed_ms(b) * 1e3 for a, b in evs)
+    LAST_DISTRIBUTION.update(median_us=per[len(per) // 2], min_us=per[0])
     return wall, kern
+
+
+LAST_DISTRIBUTION = {}
 
 
 def main():
@@ -58,7 +70,9 @@ def main():
 
     def row(name, wall, kern, nbytes, flops, bound):
         t = kern if kern == kern else wall
-        rec = dict(config=name, wall_us=wall * 1e6, kernel_us=kern * 1e6, bytes=nbytes, flops=flops,
+        rec = dict(config=name, wall_us=wall * 1e6, kernel_us=kern * 1e6,
+                   call_median_us=LAST_DISTRIBUTION.get("median_us"), call_min_us=LAST_DISTRIBUTION.get("min_us"),
+                   bytes=nbytes, flops=flops,
                    GBps=nbytes / t / 1e9, TFLOPs=flops / t / 1e12, hbm_frac=nbytes / t / HBM,
                    f32_frac=flops / t / F32, bound=bound)
         out.append(rec)
