@@ -3,7 +3,8 @@ log-joint (the purpose bayesic/algebra.py:1-6 and
 README.md:30-37 state for the algebra front end)."""
 from .conjugacy import (NotConjugate, conjugate_coefficients, depends_on, expand_terms)
 from .bbvi import ScoreFunctionVI
-from .vmp import GammaNode, MeanFieldVMP, NormalNode
+from .vmp import CategoricalNode, DirichletNode, GammaNode, MeanFieldVMP, NormalNode
 
 __all__ = ["NotConjugate", "conjugate_coefficients", "depends_on", "expand_terms",
-           "MeanFieldVMP", "NormalNode", "GammaNode", "ScoreFunctionVI"]
+           "MeanFieldVMP", "NormalNode", "GammaNode", "DirichletNode", "CategoricalNode",
+           "ScoreFunctionVI"]

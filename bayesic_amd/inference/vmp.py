@@ -96,6 +96,47 @@ class GammaNode(LatentNode):
         return [psi(self.shape) - np.log(self.rate), self.shape / self.rate]
 
 
+class DirichletNode(LatentNode):
+    """q(theta) = Dirichlet(alpha) over the LAST axis of theta: t = (log theta,),
+    eta = (alpha - 1,).  E[log theta_k] = psi(alpha_k) - psi(sum_k alpha_k)."""
+
+    def __init__(self, variable, alpha=1.0):
+        LatentNode.__init__(self, variable)
+        self.eta = [np.asarray(alpha, np.float64) - 1.0]
+
+    @property
+    def statistics(self):
+        return (A.log(self.var),)
+
+    @property
+    def alpha(self):
+        return self.eta[0] + 1.0
+
+    def expectations(self):
+        from scipy.special import digamma as psi       # parameter-sized, host side
+        a = self.alpha
+        return [psi(a) - psi(a.sum(axis=-1, keepdims=True))]
+
+
+class CategoricalNode(LatentNode):
+    """q(z) = product over leading axes of Categorical over the LAST axis, z one-hot
+    (the discrete latent of a mixture, README.md:43): t = (z,), eta = (unnormalised log
+    probabilities,).  E[z] = softmax(eta) -- responsibilities."""
+
+    def __init__(self, variable, log_prob):
+        LatentNode.__init__(self, variable)
+        self.eta = [np.asarray(log_prob, np.float64)]
+
+    @property
+    def statistics(self):
+        return (self.var,)
+
+    def expectations(self):
+        e = self.eta[0] - self.eta[0].max(axis=-1, keepdims=True)
+        w = np.exp(e)
+        return [w / w.sum(axis=-1, keepdims=True)]
+
+
 class MeanFieldVMP(object):
     """Coordinate-ascent mean field on a conjugate-exponential log-joint.
 

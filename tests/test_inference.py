@@ -215,3 +215,107 @@ def test_generic_score_function_vi_matches_the_fused_config5_path(ctx):
     # both paths move lam the same way (same draws, same estimator)
     d_eng, d_fused = eng.lam - lam0, fused.lam.cpu().numpy() - lam0
     assert np.mean(np.sign(d_eng) == np.sign(d_fused)) > 0.95
+
+
+# ---- Dirichlet / Categorical nodes: the discrete side of a mixture ---------------------------
+
+def mixture_log_joint(x, Z, theta, mu, alpha0, v, m0, v0):
+    """x_n ~ N(mu_{z_n}, v) with one-hot z_n ~ Categorical(theta), theta ~ Dirichlet(alpha0),
+    mu_k ~ N(m0, v0); constants dropped.  Z is [N, K] one-hot, theta and mu are [K]."""
+    lt = A.dimshuffle(A.log(theta), "x", 0)
+    mu_row, mu2_row = A.dimshuffle(mu, "x", 0), A.dimshuffle(mu ** 2, "x", 0)
+    x_col = A.dimshuffle(x, 0, "x")
+    lik = A.sum(Z * x_col * mu_row) * (1.0 / v) + A.sum(Z * mu2_row) * (-0.5 / v) \
+        + A.sum(Z * A.dimshuffle(x * x, 0, "x")) * (-0.5 / v)
+    return lik + A.sum(Z * lt) + A.sum(A.log(theta)) * (alpha0 - 1.0) \
+        + A.sum(mu) * (m0 / v0) + A.sum(mu ** 2) * (-0.5 / v0)
+
+
+def test_dirichlet_weights_land_on_the_exact_posterior_when_assignments_are_observed():
+    from bayesic_amd.inference import DirichletNode
+    K, N = 4, 300
+    x, Z, theta, mu = f64("x", 1), f64("Z", 2), f64("theta", 1), f64("mu", 1)
+    z = rs.randint(K, size=N)
+    Zs = np.eye(K)[z]
+    xs = rs.standard_normal(N)
+    lj = mixture_log_joint(x, Z, theta, mu, alpha0=1.5, v=1.0, m0=0.0, v0=10.0)
+    (c,), _ = conjugate_coefficients(lj, theta, (A.log(theta),))
+    npt.assert_allclose(run(c, Z=Zs), Zs.sum(0) + 0.5, rtol=1e-12)      # counts + alpha0 - 1
+    node = DirichletNode(theta, alpha=np.ones(K))
+    mus = NormalNode(mu, mean=np.zeros(K), variance=np.ones(K))
+    vmp = MeanFieldVMP(lj, [node, mus], dict(x=xs, Z=Zs), backend=B64)
+    vmp.update("theta")
+    npt.assert_allclose(node.alpha, 1.5 + np.bincount(z, minlength=K), rtol=1e-12)
+    from scipy.special import digamma as psi
+    npt.assert_allclose(node.expectations()[0], psi(node.alpha) - psi(node.alpha.sum()), rtol=1e-12)
+
+
+def test_mixture_coordinate_ascent_matches_the_textbook_updates():
+    """Latent assignments: q(z_n) = softmax_k(E[log theta_k] + (x_n E[mu_k] - E[mu_k^2]/2)/v),
+    then the component means and the weights from the responsibilities (Bishop 10.2 with known
+    variance)."""
+    from bayesic_amd.inference import CategoricalNode, DirichletNode
+    from scipy.special import digamma as psi
+    K, N, v, a0, m0, v0 = 3, 400, 0.25, 2.0, 0.0, 25.0
+    x, Z, theta, mu = f64("x", 1), f64("Z", 2), f64("theta", 1), f64("mu", 1)
+    centres = np.array([-3.0, 0.5, 4.0])
+    z = rs.randint(K, size=N)
+    xs = centres[z] + np.sqrt(v) * rs.standard_normal(N)
+    lj = mixture_log_joint(x, Z, theta, mu, alpha0=a0, v=v, m0=m0, v0=v0)
+    zn = CategoricalNode(Z, log_prob=np.zeros((N, K)))
+    tn = DirichletNode(theta, alpha=np.full(K, a0))
+    mn = NormalNode(mu, mean=np.array([-1.0, 0.0, 1.0]), variance=np.ones(K))
+    vmp = MeanFieldVMP(lj, [zn, mn, tn], dict(x=xs), backend=B64)
+
+    # one sweep by hand
+    Elt = psi(tn.alpha) - psi(tn.alpha.sum())
+    Em, Em2 = mn.mean, mn.mean ** 2 + mn.variance
+    logit = Elt[None, :] + (xs[:, None] * Em[None, :] - 0.5 * Em2[None, :] - 0.5 * xs[:, None] ** 2) / v
+    R = np.exp(logit - logit.max(1, keepdims=True))
+    R /= R.sum(1, keepdims=True)
+    prec = R.sum(0) / v + 1.0 / v0
+    mean = (R.T @ xs / v + m0 / v0) / prec
+    alpha = a0 + R.sum(0)
+
+    vmp.sweep()
+    npt.assert_allclose(zn.expectations()[0], R, rtol=1e-10, atol=1e-14)
+    npt.assert_allclose(mn.mean, mean, rtol=1e-10)
+    npt.assert_allclose(mn.variance, 1.0 / prec, rtol=1e-10)
+    npt.assert_allclose(tn.alpha, alpha, rtol=1e-10)
+    for _ in range(30):
+        vmp.sweep()
+    order = np.argsort(mn.mean)
+    npt.assert_allclose(mn.mean[order], centres, atol=0.15)              # finds the three clusters
+    npt.assert_allclose(tn.alpha[order] - a0, np.bincount(z, minlength=K), rtol=0.1)
+
+
+@pytest.mark.gpu
+def test_mixture_vmp_on_device_matches_the_float64_backend(ctx):
+    """The same derived updates with the data-sized messages (responsibility-weighted sums over
+    20 000 points) evaluated by the HIP executor; float32 data and expectations."""
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from bayesic_amd.inference import CategoricalNode, DirichletNode
+    K, N, v, a0 = 3, 20000, 0.25, 2.0
+    centres = np.array([-3.0, 0.5, 4.0])
+    r = np.random.RandomState(5)
+    z = r.randint(K, size=N)
+    xs = (centres[z] + np.sqrt(v) * r.standard_normal(N)).astype(np.float32)
+
+    def build(backend, dtype):
+        x, Z = A.var("x", 1, dtype), A.var("Z", 2, dtype)
+        theta, mu = A.var("theta", 1, dtype), A.var("mu", 1, dtype)
+        lj = mixture_log_joint(x, Z, theta, mu, alpha0=a0, v=v, m0=0.0, v0=25.0)
+        nodes = [CategoricalNode(Z, log_prob=np.zeros((N, K))),
+                 NormalNode(mu, mean=np.array([-1.0, 0.0, 1.0]), variance=np.ones(K)),
+                 DirichletNode(theta, alpha=np.full(K, a0))]
+        return MeanFieldVMP(lj, nodes, dict(x=xs), backend=backend), nodes
+
+    dev, dn = build(DeviceBackend(ctx), "float32")
+    ref, rn = build(B64, "float64")
+    for _ in range(5):
+        dev.sweep()
+        ref.sweep()
+    npt.assert_allclose(dn[1].mean, rn[1].mean, rtol=2e-4, atol=2e-4)
+    npt.assert_allclose(dn[1].variance, rn[1].variance, rtol=2e-4)
+    npt.assert_allclose(dn[2].alpha, rn[2].alpha, rtol=2e-4)
+    npt.assert_allclose(dn[0].expectations()[0], rn[0].expectations()[0], atol=5e-4)
