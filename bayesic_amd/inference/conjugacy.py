@@ -100,10 +100,19 @@ def conjugate_coefficients(log_joint, latent, statistics):
     terms = [t for piece in pieces for t in expand_terms(piece)]
     found = [[] for _ in statistics]
     rest = []
+    # a statistic may be carried by a variable of its own (the second moment of a vector
+    # latent, see MVNormalNode): a term then belongs to the latent when it mentions any of them
+    carriers = {latent.name}
+    for t in statistics:
+        carriers.update(A.wrap_if_literal(t).input_types)
+
+    def mentions(expr):
+        return any(name in expr.input_types for name in carriers)
+
     for term in terms:
         if term.ndim != 0:
             raise ValueError("log-joint terms must be scalars, got ndim %d: %r" % (term.ndim, term))
-        if not depends_on(term, latent):
+        if not mentions(term):
             rest.append(term)
             continue
         for j in reversed(range(len(statistics))):
@@ -111,7 +120,7 @@ def conjugate_coefficients(log_joint, latent, statistics):
             slot = A.var("_coefficient_%d" % j, t.ndim)
             template = A.sum(t * slot) if t.ndim else t * slot
             coefficient = A.match(term, template, slot)
-            if coefficient is not None and not depends_on(coefficient, latent):
+            if coefficient is not None and not mentions(coefficient):
                 found[j].append(coefficient)
                 break
         else:

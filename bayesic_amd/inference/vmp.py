@@ -96,6 +96,43 @@ class GammaNode(LatentNode):
         return [psi(self.shape) - np.log(self.rate), self.shape / self.rate]
 
 
+class MVNormalNode(LatentNode):
+    """q(w) = N(m, Sigma) over a vector w: t = (w, w w^T), eta = (Lambda m, -Lambda / 2).
+
+    The second moment enters the log-joint through a variable of its own (``second_moment``, a
+    [D, D] ``var``): the front end flattens ``outer(w, w)`` into the surrounding einsum
+    (bayesic/algebra.py:314-508), which would leave no sub-expression to bind E[w w^T] to and
+    would bind E[w] twice instead.  Write ``sum(dot(X.T, X) * W2)`` for w^T X^T X w."""
+
+    def __init__(self, variable, second_moment, mean, covariance):
+        LatentNode.__init__(self, variable)
+        self.second = second_moment
+        mean = np.asarray(mean, np.float64)
+        precision = np.linalg.inv(np.asarray(covariance, np.float64))
+        self.eta = [precision @ mean, -0.5 * precision]
+
+    @property
+    def statistics(self):
+        return (self.var, self.second)
+
+    @property
+    def precision(self):
+        lam = -2.0 * self.eta[1]
+        return 0.5 * (lam + lam.T)          # a message is symmetric up to rounding
+
+    @property
+    def covariance(self):
+        return np.linalg.inv(self.precision)
+
+    @property
+    def mean(self):
+        return np.linalg.solve(self.precision, self.eta[0])
+
+    def expectations(self):
+        m = self.mean
+        return [m, self.covariance + np.outer(m, m)]
+
+
 class DirichletNode(LatentNode):
     """q(theta) = Dirichlet(alpha) over the LAST axis of theta: t = (log theta,),
     eta = (alpha - 1,).  E[log theta_k] = psi(alpha_k) - psi(sum_k alpha_k)."""
@@ -163,8 +200,8 @@ class MeanFieldVMP(object):
                 bindings = {}
                 for m in others:
                     for k, t in enumerate(m.statistics):
-                        if t is m.var:
-                            continue                 # the identity statistic binds the var itself
+                        if self._carrier(t) is not None:
+                            continue                 # a statistic that IS a variable feeds it directly
                         bindings[t] = "_E_%s_%d" % (m.var.name, k)
                 compiled.append((c, self.backend.compile(c, bindings), bindings))
             self._messages[node.var.name] = compiled
@@ -175,10 +212,18 @@ class MeanFieldVMP(object):
                     types.update(entry[0].input_types)
         self._data = {name: self.backend.from_host(value, *types[name])
                       for name, value in data.items() if name in types}
-        missing = [n for n in types if n not in self._data and n not in self._by_name]
+        carried = {self._carrier(t) for n in self.nodes for t in n.statistics} - {None}
+        missing = [n for n in types
+                   if n not in self._data and n not in carried and n not in self._by_name]
         if missing:
             raise TypeError("log-joint inputs neither given as data nor declared latent: %s"
                             % ", ".join(sorted(missing)))
+
+    @staticmethod
+    def _carrier(statistic):
+        """Name of the input variable a statistic is carried by (the latent itself for the
+        identity statistic, a second-moment variable, ...), or None for a derived expression."""
+        return statistic.name if isinstance(statistic, A.var) else None
 
     def _expectation_inputs(self, exclude):
         values = {}
@@ -186,7 +231,7 @@ class MeanFieldVMP(object):
             if m is exclude:
                 continue
             for k, (t, e) in enumerate(zip(m.statistics, m.expectations())):
-                name = m.var.name if t is m.var else "_E_%s_%d" % (m.var.name, k)
+                name = self._carrier(t) or "_E_%s_%d" % (m.var.name, k)
                 values[name] = self.backend.from_host(np.asarray(e, np.float64), "float32", t.ndim)
         return values
 

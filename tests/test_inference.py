@@ -319,3 +319,93 @@ def test_mixture_vmp_on_device_matches_the_float64_backend(ctx):
     npt.assert_allclose(dn[1].variance, rn[1].variance, rtol=2e-4)
     npt.assert_allclose(dn[2].alpha, rn[2].alpha, rtol=2e-4)
     npt.assert_allclose(dn[0].expectations()[0], rn[0].expectations()[0], atol=5e-4)
+
+
+# ---- vector latent with a full covariance: Bayesian linear regression (config 2's model) ------
+
+def blr_log_joint(X, y, w, W2, tau, P0, a0, b0):
+    """y_n ~ N(x_n.w, 1/tau), w ~ N(0, P0^-1), tau ~ Gamma(a0, rate b0) (tau may be a number);
+    W2 stands for w w^T (MVNormalNode).  Constants dropped."""
+    N = A.shape(y, 0)
+    quad = A.sum(A.dot(X.T, X) * W2) - 2.0 * A.sum(A.dot(X.T, y) * w) + A.sum(y * y)
+    lj = quad * (-0.5 * tau) + A.sum(W2 * P0) * (-0.5)
+    if isinstance(tau, A.Expression):
+        lj = lj + N * (0.5 * A.log(tau)) + (a0 - 1.0) * A.log(tau) - b0 * tau
+    return lj
+
+
+def test_linear_regression_with_known_noise_is_exact_in_one_step():
+    from bayesic_amd.inference import MVNormalNode
+    N, D, tau = 500, 6, 4.0
+    Xs = rs.standard_normal((N, D))
+    ys = Xs @ rs.standard_normal(D) + rs.standard_normal(N) / np.sqrt(tau)
+    P0s = np.diag(rs.uniform(0.5, 2.0, D))
+    X, y, w, W2, P0 = f64("X", 2), f64("y", 1), f64("w", 1), f64("W2", 2), f64("P0", 2)
+    lj = blr_log_joint(X, y, w, W2, tau, P0, None, None)
+    node = MVNormalNode(w, W2, mean=np.zeros(D), covariance=np.eye(D))
+    vmp = MeanFieldVMP(lj, [node], dict(X=Xs, y=ys, P0=P0s), backend=B64)
+    vmp.update("w")
+    lam = tau * Xs.T @ Xs + P0s
+    npt.assert_allclose(node.precision, lam, rtol=1e-12)
+    npt.assert_allclose(node.mean, np.linalg.solve(lam, tau * Xs.T @ ys), rtol=1e-10)
+
+
+def blr_mean_field_by_hand(Xs, ys, P0s, a0, b0, sweeps):
+    N, D = Xs.shape
+    XtX, Xty, yty = Xs.T @ Xs, Xs.T @ ys, ys @ ys
+    Etau = 1.0
+    for _ in range(sweeps):
+        lam = Etau * XtX + P0s
+        m = np.linalg.solve(lam, Etau * Xty)
+        S2 = np.linalg.inv(lam) + np.outer(m, m)
+        a = a0 + 0.5 * N
+        b = b0 + 0.5 * ((XtX * S2).sum() - 2.0 * Xty @ m + yty)
+        Etau = a / b
+    return m, lam, a, b
+
+
+def test_linear_regression_with_unknown_noise_matches_hand_written_coordinate_ascent():
+    from bayesic_amd.inference import MVNormalNode
+    N, D, a0, b0 = 400, 5, 2.0, 1.5
+    Xs = rs.standard_normal((N, D))
+    ys = Xs @ rs.standard_normal(D) + 0.3 * rs.standard_normal(N)
+    P0s = np.eye(D) * 0.7
+    X, y, w, W2, P0, tau = f64("X", 2), f64("y", 1), f64("w", 1), f64("W2", 2), f64("P0", 2), f64("tau", 0)
+    lj = blr_log_joint(X, y, w, W2, tau, P0, a0, b0)
+    qw = MVNormalNode(w, W2, mean=np.zeros(D), covariance=np.eye(D))
+    qt = GammaNode(tau, shape=1.0, rate=1.0)
+    vmp = MeanFieldVMP(lj, [qw, qt], dict(X=Xs, y=ys, P0=P0s), backend=B64)
+    for _ in range(8):
+        vmp.sweep()
+    m, lam, a, b = blr_mean_field_by_hand(Xs, ys, P0s, a0, b0, 8)
+    npt.assert_allclose(qt.shape, a, rtol=1e-12)
+    npt.assert_allclose(qt.rate, b, rtol=1e-9)
+    # the last w update used the tau of the sweep before: redo it with the final E[tau]
+    vmp.update("w")
+    lam_f = (a / b) * Xs.T @ Xs + P0s
+    npt.assert_allclose(qw.precision, lam_f, rtol=1e-9)
+    npt.assert_allclose(qw.mean, np.linalg.solve(lam_f, (a / b) * Xs.T @ ys), rtol=1e-8)
+
+
+@pytest.mark.gpu
+def test_linear_regression_vmp_on_device(ctx):
+    """Config 2's shapes in small: the D x D Gram message is one MFMA GEMM over the resident X."""
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from bayesic_amd.inference import MVNormalNode
+    N, D, a0, b0 = 50_000, 256, 1.0, 1.0
+    r = np.random.RandomState(11)
+    Xs = r.standard_normal((N, D)).astype(np.float32)
+    ys = (Xs @ (r.standard_normal(D) / 16) + 0.5 * r.standard_normal(N)).astype(np.float32)
+    P0s = np.eye(D, dtype=np.float32)
+    X, y, w, W2, P0, tau = A.var("X", 2), A.var("y", 1), A.var("w", 1), A.var("W2", 2), A.var("P0", 2), A.var("tau", 0)
+    lj = blr_log_joint(X, y, w, W2, tau, P0, a0, b0)
+    qw = MVNormalNode(w, W2, mean=np.zeros(D), covariance=np.eye(D))
+    qt = GammaNode(tau, shape=1.0, rate=1.0)
+    vmp = MeanFieldVMP(lj, [qw, qt], dict(X=Xs, y=ys, P0=P0s), backend=DeviceBackend(ctx))
+    for _ in range(4):
+        vmp.sweep()
+    m, lam, a, b = blr_mean_field_by_hand(Xs.astype(np.float64), ys.astype(np.float64),
+                                         P0s.astype(np.float64), a0, b0, 4)
+    npt.assert_allclose(qt.shape, a, rtol=1e-6)
+    npt.assert_allclose(qt.rate, b, rtol=1e-4)
+    npt.assert_allclose(qw.mean, m, rtol=2e-3, atol=2e-5)
