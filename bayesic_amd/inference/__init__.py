@@ -3,9 +3,9 @@ log-joint (the purpose bayesic/algebra.py:1-6 and
 README.md:30-37 state for the algebra front end)."""
 from .conjugacy import (NotConjugate, conjugate_coefficients, depends_on, expand_terms)
 from .bbvi import ScoreFunctionVI
-from .vmp import (CategoricalNode, DirichletNode, GammaNode, MeanFieldVMP, MVNormalNode,
-                  NormalNode)
+from .vmp import (CategoricalNode, DirichletNode, GammaNode, InverseGammaNode, MeanFieldVMP,
+                  MVNormalNode, NormalNode)
 
 __all__ = ["NotConjugate", "conjugate_coefficients", "depends_on", "expand_terms",
-           "MeanFieldVMP", "NormalNode", "GammaNode", "DirichletNode", "CategoricalNode", "MVNormalNode",
+           "MeanFieldVMP", "NormalNode", "GammaNode", "DirichletNode", "CategoricalNode", "MVNormalNode", "InverseGammaNode",
            "ScoreFunctionVI"]

@@ -96,6 +96,31 @@ class GammaNode(LatentNode):
         return [psi(self.shape) - np.log(self.rate), self.shape / self.rate]
 
 
+class InverseGammaNode(LatentNode):
+    """q(z) = InverseGamma(shape a, scale b): t = (log z, 1 / z), eta = (-(a + 1), -b) -- a
+    variance (config 2's sigma^2 ~ InvGamma(1, 1)).  Write the reciprocal as ``z ** -1``."""
+
+    def __init__(self, variable, shape=1.0, scale=1.0):
+        LatentNode.__init__(self, variable)
+        self.eta = [-(np.asarray(shape, np.float64) + 1.0), -np.asarray(scale, np.float64)]
+
+    @property
+    def statistics(self):
+        return (A.log(self.var), self.var ** -1)
+
+    @property
+    def shape(self):
+        return -self.eta[0] - 1.0
+
+    @property
+    def scale(self):
+        return -self.eta[1]
+
+    def expectations(self):
+        from scipy.special import digamma as psi       # parameter-sized, host side
+        return [np.log(self.scale) - psi(self.shape), self.shape / self.scale]
+
+
 class MVNormalNode(LatentNode):
     """q(w) = N(m, Sigma) over a vector w: t = (w, w w^T), eta = (Lambda m, -Lambda / 2).
 

@@ -409,3 +409,38 @@ def test_linear_regression_vmp_on_device(ctx):
     npt.assert_allclose(qt.shape, a, rtol=1e-6)
     npt.assert_allclose(qt.rate, b, rtol=1e-4)
     npt.assert_allclose(qw.mean, m, rtol=2e-3, atol=2e-5)
+
+
+def test_config2_model_normal_inverse_gamma_by_derived_mean_field():
+    """BASELINE config 2's model as stated: w | s2 ~ N(0, s2 I), s2 ~ InvGamma(1, 1),
+    y_n ~ N(x_n.w, s2).  The derived coordinate ascent against the hand-written one, and its
+    E[w] against the exact Normal-Inverse-Gamma posterior mean (which mean field shares)."""
+    from bayesic_amd.inference import InverseGammaNode, MVNormalNode
+    from oracle import svi
+    N, D, a0, b0 = 600, 8, 1.0, 1.0
+    Xs = rs.standard_normal((N, D))
+    ys = Xs @ (rs.standard_normal(D) / 4) + 0.5 * rs.standard_normal(N)
+    X, y, w, W2, Id, s2 = f64("X", 2), f64("y", 1), f64("w", 1), f64("W2", 2), f64("Id", 2), f64("s2", 0)
+    quad = A.sum(A.dot(X.T, X) * W2) - 2.0 * A.sum(A.dot(X.T, y) * w) + A.sum(y * y)
+    prec = s2 ** -1
+    lj = quad * (-0.5 * prec) + A.sum(W2 * Id) * (-0.5 * prec) \
+        - (0.5 * (N + D) + a0 + 1.0) * A.log(s2) - b0 * prec
+    qw = MVNormalNode(w, W2, mean=np.zeros(D), covariance=np.eye(D))
+    qs = InverseGammaNode(s2, shape=1.0, scale=1.0)
+    vmp = MeanFieldVMP(lj, [qw, qs], dict(X=Xs, y=ys, Id=np.eye(D)), backend=B64)
+    for _ in range(10):
+        vmp.sweep()
+    # by hand
+    XtX, Xty, yty = Xs.T @ Xs, Xs.T @ ys, ys @ ys
+    Eprec = 1.0
+    for _ in range(10):
+        lam = Eprec * (XtX + np.eye(D))
+        m = np.linalg.solve(lam, Eprec * Xty)
+        S2 = np.linalg.inv(lam) + np.outer(m, m)
+        a = a0 + 0.5 * (N + D)
+        b = b0 + 0.5 * ((XtX * S2).sum() - 2.0 * Xty @ m + yty + np.trace(S2))
+        Eprec = a / b
+    npt.assert_allclose(qs.shape, a, rtol=1e-12)
+    npt.assert_allclose(qs.scale, b, rtol=1e-9)
+    mu_exact, _, _, _ = svi.blr_exact_posterior(Xs, ys)      # (the oracle rounds X, y to float32 first)
+    npt.assert_allclose(qw.mean, mu_exact, rtol=1e-6, atol=1e-8)
