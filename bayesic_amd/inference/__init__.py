@@ -4,8 +4,8 @@ README.md:30-37 state for the algebra front end)."""
 from .conjugacy import (NotConjugate, conjugate_coefficients, depends_on, expand_terms)
 from .bbvi import ScoreFunctionVI
 from .vmp import (CategoricalNode, DirichletNode, GammaNode, InverseGammaNode, MeanFieldVMP,
-                  MVNormalNode, NormalNode)
+                  MVNormalNode, NormalNode, WishartNode)
 
 __all__ = ["NotConjugate", "conjugate_coefficients", "depends_on", "expand_terms",
-           "MeanFieldVMP", "NormalNode", "GammaNode", "DirichletNode", "CategoricalNode", "MVNormalNode", "InverseGammaNode",
+           "MeanFieldVMP", "NormalNode", "GammaNode", "DirichletNode", "CategoricalNode", "MVNormalNode", "InverseGammaNode", "WishartNode",
            "ScoreFunctionVI"]

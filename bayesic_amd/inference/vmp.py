@@ -158,6 +158,39 @@ class MVNormalNode(LatentNode):
         return [m, self.covariance + np.outer(m, m)]
 
 
+class WishartNode(LatentNode):
+    """q(Lambda) = Wishart(nu, V) over a D x D precision matrix: t = (log det Lambda, Lambda),
+    eta = ((nu - D - 1) / 2, -V^-1 / 2).  E[Lambda] = nu V,
+    E[log det Lambda] = sum_i psi((nu + 1 - i) / 2) + D log 2 + log det V."""
+
+    def __init__(self, variable, dof, scale):
+        LatentNode.__init__(self, variable)
+        scale = np.asarray(scale, np.float64)
+        self.dim = scale.shape[-1]
+        self.eta = [np.asarray(0.5 * (dof - self.dim - 1.0), np.float64), -0.5 * np.linalg.inv(scale)]
+
+    @property
+    def statistics(self):
+        from ..distribution.core import logdet
+        return (logdet(self.var), self.var)
+
+    @property
+    def dof(self):
+        return 2.0 * float(self.eta[0]) + self.dim + 1.0
+
+    @property
+    def scale(self):
+        inv = -2.0 * self.eta[1]
+        return np.linalg.inv(0.5 * (inv + inv.T))
+
+    def expectations(self):
+        from scipy.special import digamma as psi       # parameter-sized, host side
+        nu, V = self.dof, self.scale
+        elogdet = psi(0.5 * (nu - np.arange(self.dim))).sum() + self.dim * math.log(2.0) \
+            + np.linalg.slogdet(V)[1]
+        return [np.asarray(elogdet), nu * V]
+
+
 class DirichletNode(LatentNode):
     """q(theta) = Dirichlet(alpha) over the LAST axis of theta: t = (log theta,),
     eta = (alpha - 1,).  E[log theta_k] = psi(alpha_k) - psi(sum_k alpha_k)."""

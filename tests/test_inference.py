@@ -444,3 +444,43 @@ def test_config2_model_normal_inverse_gamma_by_derived_mean_field():
     npt.assert_allclose(qs.scale, b, rtol=1e-9)
     mu_exact, _, _, _ = svi.blr_exact_posterior(Xs, ys)      # (the oracle rounds X, y to float32 first)
     npt.assert_allclose(qw.mean, mu_exact, rtol=1e-6, atol=1e-8)
+
+
+def test_multivariate_gaussian_with_normal_wishart_mean_field():
+    """x_n ~ N(mu, Lambda^-1) with mu ~ N(0, (k0 I)^-1) and Lambda ~ Wishart(nu0, V0): the derived
+    coordinate ascent (Bishop 10.1.3 without the coupling of the priors) against the hand-written
+    one.  t(x) = (x, x x^T) of bayesic/distribution/core.py:41-44 in full-covariance form."""
+    from bayesic_amd.distribution import logdet
+    from bayesic_amd.inference import MVNormalNode, WishartNode
+    N, D, k0, nu0 = 300, 3, 0.1, 5.0
+    Ltrue = np.array([[2.0, 0.5, 0.0], [0.5, 1.0, 0.2], [0.0, 0.2, 1.5]])
+    Xs = rs.multivariate_normal([1.0, -2.0, 0.5], np.linalg.inv(Ltrue), size=N)
+    V0 = np.eye(D) / nu0
+    X, mu, M2, Lam, Id = f64("X", 2), f64("mu", 1), f64("M2", 2), f64("Lam", 2), f64("Id", 2)
+    Nn = A.shape(X, 0)
+    sx = A.sum(X, axis=0)
+    lj = Nn * (0.5 * logdet(Lam)) + A.sum(Lam * A.dot(X.T, X)) * (-0.5) \
+        + A.sum(Lam * A.outer(sx, mu)) + Nn * (A.sum(Lam * M2) * (-0.5)) \
+        + A.sum(M2 * Id) * (-0.5 * k0) \
+        + (0.5 * (nu0 - D - 1.0)) * logdet(Lam) + A.sum(Lam * Id) * (-0.5 * nu0)    # V0^-1 = nu0 I
+    qm = MVNormalNode(mu, M2, mean=np.zeros(D), covariance=np.eye(D))
+    ql = WishartNode(Lam, dof=nu0, scale=V0)
+    vmp = MeanFieldVMP(lj, [qm, ql], dict(X=Xs, Id=np.eye(D)), backend=B64)
+    for _ in range(6):
+        vmp.sweep()
+    # by hand
+    S, sxs = Xs.T @ Xs, Xs.sum(0)
+    EL = nu0 * V0
+    for _ in range(6):
+        prec = N * EL + k0 * np.eye(D)
+        m = np.linalg.solve(prec, EL @ sxs)
+        M2s = np.linalg.inv(prec) + np.outer(m, m)
+        nu = nu0 + N
+        Vinv = nu0 * np.eye(D) + S - np.outer(sxs, m) - np.outer(m, sxs) + N * M2s
+        EL = nu * np.linalg.inv(Vinv)
+    npt.assert_allclose(ql.dof, nu, rtol=1e-12)
+    npt.assert_allclose(np.linalg.inv(ql.scale), Vinv, rtol=1e-8)
+    vmp.update("mu")
+    prec = N * EL + k0 * np.eye(D)
+    npt.assert_allclose(qm.mean, np.linalg.solve(prec, EL @ sxs), rtol=1e-8)
+    npt.assert_allclose(ql.expectations()[1], Ltrue, rtol=0.35, atol=0.2)     # recovers the precision
