@@ -122,10 +122,11 @@ class InverseGammaNode(LatentNode):
 
 
 class MVNormalNode(LatentNode):
-    """q(w) = N(m, Sigma) over a vector w: t = (w, w w^T), eta = (Lambda m, -Lambda / 2).
+    """q(w) = N(m, Sigma) over the LAST axis of w (leading axes index independent vectors, e.g.
+    mixture components): t = (w, w w^T), eta = (Lambda m, -Lambda / 2).
 
-    The second moment enters the log-joint through a variable of its own (``second_moment``, a
-    [D, D] ``var``): the front end flattens ``outer(w, w)`` into the surrounding einsum
+    The second moment enters the log-joint through a variable of its own (``second_moment``, of
+    shape w.shape + (D,)): the front end flattens ``outer(w, w)`` into the surrounding einsum
     (bayesic/algebra.py:314-508), which would leave no sub-expression to bind E[w w^T] to and
     would bind E[w] twice instead.  Write ``sum(dot(X.T, X) * W2)`` for w^T X^T X w."""
 
@@ -134,7 +135,7 @@ class MVNormalNode(LatentNode):
         self.second = second_moment
         mean = np.asarray(mean, np.float64)
         precision = np.linalg.inv(np.asarray(covariance, np.float64))
-        self.eta = [precision @ mean, -0.5 * precision]
+        self.eta = [np.einsum("...ij,...j->...i", precision, mean), -0.5 * precision]
 
     @property
     def statistics(self):
@@ -143,7 +144,7 @@ class MVNormalNode(LatentNode):
     @property
     def precision(self):
         lam = -2.0 * self.eta[1]
-        return 0.5 * (lam + lam.T)          # a message is symmetric up to rounding
+        return 0.5 * (lam + np.swapaxes(lam, -1, -2))     # a message is symmetric up to rounding
 
     @property
     def covariance(self):
@@ -151,23 +152,24 @@ class MVNormalNode(LatentNode):
 
     @property
     def mean(self):
-        return np.linalg.solve(self.precision, self.eta[0])
+        return np.linalg.solve(self.precision, self.eta[0][..., None])[..., 0]
 
     def expectations(self):
         m = self.mean
-        return [m, self.covariance + np.outer(m, m)]
+        return [m, self.covariance + m[..., :, None] * m[..., None, :]]
 
 
 class WishartNode(LatentNode):
-    """q(Lambda) = Wishart(nu, V) over a D x D precision matrix: t = (log det Lambda, Lambda),
-    eta = ((nu - D - 1) / 2, -V^-1 / 2).  E[Lambda] = nu V,
-    E[log det Lambda] = sum_i psi((nu + 1 - i) / 2) + D log 2 + log det V."""
+    """q(Lambda) = Wishart(nu, V) over the last two axes of a [..., D, D] precision (leading axes:
+    independent matrices): t = (log det Lambda, Lambda), eta = ((nu - D - 1) / 2, -V^-1 / 2).
+    E[Lambda] = nu V,  E[log det Lambda] = sum_i psi((nu + 1 - i) / 2) + D log 2 + log det V."""
 
     def __init__(self, variable, dof, scale):
         LatentNode.__init__(self, variable)
         scale = np.asarray(scale, np.float64)
         self.dim = scale.shape[-1]
-        self.eta = [np.asarray(0.5 * (dof - self.dim - 1.0), np.float64), -0.5 * np.linalg.inv(scale)]
+        dof = np.broadcast_to(np.asarray(dof, np.float64), scale.shape[:-2])
+        self.eta = [0.5 * (dof - self.dim - 1.0), -0.5 * np.linalg.inv(scale)]
 
     @property
     def statistics(self):
@@ -176,19 +178,19 @@ class WishartNode(LatentNode):
 
     @property
     def dof(self):
-        return 2.0 * float(self.eta[0]) + self.dim + 1.0
+        return 2.0 * self.eta[0] + self.dim + 1.0
 
     @property
     def scale(self):
         inv = -2.0 * self.eta[1]
-        return np.linalg.inv(0.5 * (inv + inv.T))
+        return np.linalg.inv(0.5 * (inv + np.swapaxes(inv, -1, -2)))
 
     def expectations(self):
         from scipy.special import digamma as psi       # parameter-sized, host side
-        nu, V = self.dof, self.scale
-        elogdet = psi(0.5 * (nu - np.arange(self.dim))).sum() + self.dim * math.log(2.0) \
-            + np.linalg.slogdet(V)[1]
-        return [np.asarray(elogdet), nu * V]
+        nu, V = np.asarray(self.dof), self.scale
+        elogdet = psi(0.5 * (nu[..., None] - np.arange(self.dim))).sum(-1) \
+            + self.dim * math.log(2.0) + np.linalg.slogdet(V)[1]
+        return [np.asarray(elogdet), nu[..., None, None] * V]
 
 
 class DirichletNode(LatentNode):

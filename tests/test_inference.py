@@ -484,3 +484,118 @@ def test_multivariate_gaussian_with_normal_wishart_mean_field():
     prec = N * EL + k0 * np.eye(D)
     npt.assert_allclose(qm.mean, np.linalg.solve(prec, EL @ sxs), rtol=1e-8)
     npt.assert_allclose(ql.expectations()[1], Ltrue, rtol=0.35, atol=0.2)     # recovers the precision
+
+
+# ---- full-covariance Gaussian mixture: every node type at once ----------------------------------
+
+def full_mixture_log_joint(X, Z, theta, mu, M2, Lam, Id, alpha0, k0, nu0, D):
+    """x_n ~ N(mu_{z_n}, Lambda_{z_n}^-1); theta ~ Dirichlet(alpha0); mu_k ~ N(0, (k0 I)^-1);
+    Lambda_k ~ Wishart(nu0, I / nu0).  Z [N,K] one-hot, mu [K,D], M2 [K,D,D] stands for
+    mu_k mu_k^T, Lam [K,D,D], Id the D x D identity.  Constants dropped."""
+    from bayesic_amd.distribution import logdet
+    ld = logdet(Lam)                                                     # [K]
+    Zb = A.dimshuffle(Z, 0, 1, "x", "x")                                 # [N,K,1,1]
+    Xd, Xe = A.dimshuffle(X, 0, "x", 1, "x"), A.dimshuffle(X, 0, "x", "x", 1)
+    Lb = A.dimshuffle(Lam, "x", 0, 1, 2)
+    Idb = A.dimshuffle(Id, "x", 0, 1)
+    lik = A.sum(Z * A.dimshuffle(A.log(theta), "x", 0)) \
+        + A.sum(Z * A.dimshuffle(ld, "x", 0)) * 0.5 \
+        + A.sum(Zb * Xd * Xe * Lb) * (-0.5) \
+        + A.sum(Zb * Xd * Lb * A.dimshuffle(mu, "x", 0, "x", 1)) \
+        + A.sum(Zb * Lb * A.dimshuffle(M2, "x", 0, 1, 2)) * (-0.5)
+    prior = A.sum(A.log(theta)) * (alpha0 - 1.0) + A.sum(M2 * Idb) * (-0.5 * k0) \
+        + A.sum(ld) * (0.5 * (nu0 - D - 1.0)) + A.sum(Lam * Idb) * (-0.5 * nu0)
+    return lik + prior
+
+
+def full_mixture_by_hand(Xs, R0, m0, K, alpha0, k0, nu0, sweeps):
+    from scipy.special import digamma as psi
+    N, D = Xs.shape
+    alpha, m, C = np.full(K, alpha0), m0.copy(), np.stack([np.eye(D)] * K)
+    nu, V = np.full(K, nu0), np.stack([np.eye(D) / nu0] * K)
+    R = R0
+    for _ in range(sweeps):
+        EL = nu[:, None, None] * V
+        Eld = psi(0.5 * (nu[:, None] - np.arange(D))).sum(1) + D * np.log(2.0) + np.linalg.slogdet(V)[1]
+        Elt = psi(alpha) - psi(alpha.sum())
+        M2 = C + m[:, :, None] * m[:, None, :]
+        quad = np.einsum("nd,kde,ne->nk", Xs, EL, Xs) - 2.0 * np.einsum("nd,kde,ke->nk", Xs, EL, m) \
+            + np.einsum("kde,kde->k", EL, M2)[None, :]
+        logit = Elt[None, :] + 0.5 * Eld[None, :] - 0.5 * quad
+        R = np.exp(logit - logit.max(1, keepdims=True))
+        R /= R.sum(1, keepdims=True)
+        Nk, Sx = R.sum(0), R.T @ Xs
+        prec = Nk[:, None, None] * EL + k0 * np.eye(D)
+        m = np.linalg.solve(prec, np.einsum("kde,ke->kd", EL, Sx)[..., None])[..., 0]
+        C = np.linalg.inv(prec)
+        M2 = C + m[:, :, None] * m[:, None, :]
+        Sxx = np.einsum("nk,nd,ne->kde", R, Xs, Xs)
+        Vinv = nu0 * np.eye(D) + Sxx - Sx[:, :, None] * m[:, None, :] - m[:, :, None] * Sx[:, None, :] \
+            + Nk[:, None, None] * M2
+        nu, V = nu0 + Nk, np.linalg.inv(Vinv)
+        alpha = alpha0 + Nk
+    return R, m, C, nu, V, alpha
+
+
+def _full_mixture(backend, dtype, Xs, K, m_init, alpha0=2.0, k0=0.05, nu0=6.0):
+    from bayesic_amd.inference import CategoricalNode, DirichletNode, MVNormalNode, WishartNode
+    N, D = Xs.shape
+    X, Z, theta = A.var("X", 2, dtype), A.var("Z", 2, dtype), A.var("theta", 1, dtype)
+    mu, M2, Lam, Id = A.var("mu", 2, dtype), A.var("M2", 3, dtype), A.var("Lam", 3, dtype), A.var("Id", 2, dtype)
+    lj = full_mixture_log_joint(X, Z, theta, mu, M2, Lam, Id, alpha0, k0, nu0, D)
+    nodes = [CategoricalNode(Z, log_prob=np.zeros((N, K))),
+             MVNormalNode(mu, M2, mean=m_init, covariance=np.stack([np.eye(D)] * K)),
+             WishartNode(Lam, dof=nu0, scale=np.stack([np.eye(D) / nu0] * K)),
+             DirichletNode(theta, alpha=np.full(K, alpha0))]
+    return MeanFieldVMP(lj, nodes, dict(X=Xs, Id=np.eye(D)), backend=backend), nodes
+
+
+def _mixture_data(N, K, D, seed):
+    r = np.random.RandomState(seed)
+    centres = r.standard_normal((K, D)) * 4.0
+    Ls = [np.linalg.cholesky(np.eye(D) * 0.5 + 0.3 * np.cov(r.standard_normal((D, 3 * D)))) for _ in range(K)]
+    z = r.randint(K, size=N)
+    Xs = np.stack([centres[k] + Ls[k] @ r.standard_normal(D) for k in z])
+    return Xs, centres + 0.5 * r.standard_normal((K, D))
+
+
+def test_full_covariance_mixture_matches_hand_written_updates():
+    K, D, N = 3, 2, 500
+    Xs, m_init = _mixture_data(N, K, D, 31)
+    vmp, (qz, qm, ql, qt) = _full_mixture(B64, "float64", Xs, K, m_init)
+    for sweeps in (1, 4):
+        vmp2, (qz, qm, ql, qt) = _full_mixture(B64, "float64", Xs, K, m_init)
+        for _ in range(sweeps):
+            vmp2.sweep()
+        R, m, C, nu, V, alpha = full_mixture_by_hand(Xs, None, m_init, K, 2.0, 0.05, 6.0, sweeps)
+        npt.assert_allclose(qz.expectations()[0], R, rtol=1e-8, atol=1e-12)
+        npt.assert_allclose(qm.mean, m, rtol=1e-8)
+        npt.assert_allclose(qm.covariance, C, rtol=1e-8)
+        npt.assert_allclose(ql.dof, nu, rtol=1e-10)
+        npt.assert_allclose(ql.scale, V, rtol=1e-7)
+        npt.assert_allclose(qt.alpha, alpha, rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_full_covariance_mixture_on_device_uses_the_one_pass_second_moment_kernel(ctx):
+    """The same derived updates on the MI355X backend.  The Wishart message contains
+    sum_n E[z_nk] x_n x_n^T: the executor must run it through bsc_weighted_outer (one pass over
+    the data) and not materialise the K x D x N product."""
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from test_fusion_gpu import Counting
+    K, D, N = 4, 4, 20000
+    Xs, m_init = _mixture_data(N, K, D, 32)
+    Xs = Xs.astype(np.float32)
+    dev, (dz, dm, dl, dt) = _full_mixture(DeviceBackend(ctx), "float32", Xs, K, m_init)
+    ref, (rz, rm, rl, rt) = _full_mixture(B64, "float64", Xs.astype(np.float64), K, m_init)
+    with Counting(ctx) as c:
+        dev.update("Lam")
+    assert c.count("bsc_weighted_outer") >= 1, c.calls
+    dev, (dz, dm, dl, dt) = _full_mixture(DeviceBackend(ctx), "float32", Xs, K, m_init)
+    for _ in range(3):
+        dev.sweep()
+        ref.sweep()
+    npt.assert_allclose(dm.mean, rm.mean, rtol=1e-3, atol=1e-3)
+    npt.assert_allclose(dl.dof, rl.dof, rtol=1e-4)
+    npt.assert_allclose(dl.expectations()[1], rl.expectations()[1], rtol=5e-3, atol=5e-3)
+    npt.assert_allclose(dt.alpha, rt.alpha, rtol=1e-3)
