@@ -43,6 +43,10 @@ class LatentNode(object):
         """E_q[t_j(z)] for the current natural parameters, as numpy arrays."""
         raise NotImplementedError
 
+    def entropy(self):
+        """H[q] (a float), for the evidence lower bound."""
+        raise NotImplementedError
+
 
 class NormalNode(LatentNode):
     """q(z) = N(mean, variance), element-wise over z's shape: t = (z, z^2),
@@ -71,6 +75,9 @@ class NormalNode(LatentNode):
     def expectations(self):
         return [self.mean, self.mean ** 2 + self.variance]
 
+    def entropy(self):
+        return float(np.sum(0.5 * np.log(2.0 * math.pi * math.e * self.variance)))
+
 
 class GammaNode(LatentNode):
     """q(z) = Gamma(shape a, rate b): t = (log z, z), eta = (a - 1, -b)."""
@@ -94,6 +101,11 @@ class GammaNode(LatentNode):
     def expectations(self):
         from scipy.special import digamma as psi       # parameter-sized, host side
         return [psi(self.shape) - np.log(self.rate), self.shape / self.rate]
+
+    def entropy(self):
+        from scipy.special import digamma as psi, gammaln
+        a, b = self.shape, self.rate
+        return float(np.sum(a - np.log(b) + gammaln(a) + (1.0 - a) * psi(a)))
 
 
 class InverseGammaNode(LatentNode):
@@ -119,6 +131,11 @@ class InverseGammaNode(LatentNode):
     def expectations(self):
         from scipy.special import digamma as psi       # parameter-sized, host side
         return [np.log(self.scale) - psi(self.shape), self.shape / self.scale]
+
+    def entropy(self):
+        from scipy.special import digamma as psi, gammaln
+        a, b = self.shape, self.scale
+        return float(np.sum(a + np.log(b) + gammaln(a) - (1.0 + a) * psi(a)))
 
 
 class MVNormalNode(LatentNode):
@@ -158,6 +175,11 @@ class MVNormalNode(LatentNode):
         m = self.mean
         return [m, self.covariance + m[..., :, None] * m[..., None, :]]
 
+    def entropy(self):
+        d = self.eta[0].shape[-1]
+        return float(np.sum(0.5 * (d * math.log(2.0 * math.pi * math.e)
+                                   - np.linalg.slogdet(self.precision)[1])))
+
 
 class WishartNode(LatentNode):
     """q(Lambda) = Wishart(nu, V) over the last two axes of a [..., D, D] precision (leading axes:
@@ -192,6 +214,14 @@ class WishartNode(LatentNode):
             + self.dim * math.log(2.0) + np.linalg.slogdet(V)[1]
         return [np.asarray(elogdet), nu[..., None, None] * V]
 
+    def entropy(self):
+        from scipy.special import multigammaln
+        d, nu, V = self.dim, np.asarray(self.dof), self.scale
+        elogdet = self.expectations()[0]
+        log_b = -0.5 * nu * np.linalg.slogdet(V)[1] - 0.5 * nu * d * math.log(2.0) \
+            - np.vectorize(lambda t: multigammaln(0.5 * t, d))(nu)
+        return float(np.sum(-log_b - 0.5 * (nu - d - 1.0) * elogdet + 0.5 * nu * d))
+
 
 class DirichletNode(LatentNode):
     """q(theta) = Dirichlet(alpha) over the LAST axis of theta: t = (log theta,),
@@ -214,6 +244,13 @@ class DirichletNode(LatentNode):
         a = self.alpha
         return [psi(a) - psi(a.sum(axis=-1, keepdims=True))]
 
+    def entropy(self):
+        from scipy.special import digamma as psi, gammaln
+        a = self.alpha
+        a0 = a.sum(axis=-1)
+        log_b = gammaln(a).sum(axis=-1) - gammaln(a0)
+        return float(np.sum(log_b + (a0 - a.shape[-1]) * psi(a0) - ((a - 1.0) * psi(a)).sum(axis=-1)))
+
 
 class CategoricalNode(LatentNode):
     """q(z) = product over leading axes of Categorical over the LAST axis, z one-hot
@@ -233,6 +270,10 @@ class CategoricalNode(LatentNode):
         w = np.exp(e)
         return [w / w.sum(axis=-1, keepdims=True)]
 
+    def entropy(self):
+        r = self.expectations()[0]
+        return float(-np.sum(np.where(r > 0.0, r * np.log(np.where(r > 0.0, r, 1.0)), 0.0)))
+
 
 class MeanFieldVMP(object):
     """Coordinate-ascent mean field on a conjugate-exponential log-joint.
@@ -246,6 +287,8 @@ class MeanFieldVMP(object):
     def __init__(self, log_joint, nodes, data, backend=None):
         from ..algebra.backend import resolve_backend
         self.backend = resolve_backend(backend)
+        self._log_joint = list(log_joint) if isinstance(log_joint, (list, tuple)) else [log_joint]
+        self._elbo_fns = None
         self.nodes = list(nodes)
         self._by_name = {n.var.name: n for n in self.nodes}
         self._messages = {}
@@ -309,6 +352,32 @@ class MeanFieldVMP(object):
             needed = {k: v for k, v in inputs.items()}
             out.append(np.asarray(self.backend.to_host(f.device_fn(**needed)), np.float64))
         return out
+
+    def elbo(self):
+        """E_q[log p(data, latents)] + sum of the factors' entropies, up to whatever constants
+        the log-joint was written without.  The expectation is taken the way the messages are:
+        the log-joint is multilinear in the nodes' statistics, so it is evaluated with every
+        statistic bound to its expectation.  Coordinate ascent can only raise it -- the check
+        the tests apply to every update rule."""
+        if self._elbo_fns is None:
+            bindings = {}
+            for m in self.nodes:
+                for k, t in enumerate(m.statistics):
+                    if self._carrier(t) is None:
+                        bindings[t] = "_E_%s_%d" % (m.var.name, k)
+            self._elbo_fns = [self.backend.compile(A.wrap_if_literal(piece), bindings)
+                              for piece in self._log_joint]
+            types = {}
+            for piece in self._log_joint:
+                types.update(A.wrap_if_literal(piece).input_types)
+            self._elbo_data = {n: v for n, v in self._data.items()}
+            self._elbo_extra = [n for n in types if n not in self._data]
+        inputs = dict(self._elbo_data)
+        inputs.update(self._expectation_inputs(None))
+        total = 0.0
+        for f in self._elbo_fns:
+            total += float(np.asarray(self.backend.to_host(f.device_fn(**inputs)), np.float64))
+        return total + sum(n.entropy() for n in self.nodes)
 
     def update(self, name, rho=1.0):
         """eta <- (1 - rho) eta + rho * message; rho = 1 is the VMP update."""
