@@ -313,6 +313,7 @@ class MeanFieldVMP(object):
             for entry in compiled:
                 if entry is not None:
                     types.update(entry[0].input_types)
+        self._types = types
         self._data = {name: self.backend.from_host(value, *types[name])
                       for name, value in data.items() if name in types}
         carried = {self._carrier(t) for n in self.nodes for t in n.statistics} - {None}
@@ -352,6 +353,18 @@ class MeanFieldVMP(object):
             needed = {k: v for k, v in inputs.items()}
             out.append(np.asarray(self.backend.to_host(f.device_fn(**needed)), np.float64))
         return out
+
+    def set_data(self, **arrays):
+        """Replace data inputs (a new mini-batch): with the data terms of the log-joint written
+        times N / B, ``update(name, rho_t)`` is then the stochastic natural-gradient step of
+        README.md:69-79 (SVI) for that node -- global nodes only; a local latent such as the
+        assignments of a mixture is simply re-created per mini-batch."""
+        for name, value in arrays.items():
+            if name not in self._types:
+                raise TypeError("%s is not an input of the log-joint" % name)
+            self._data[name] = self.backend.from_host(value, *self._types[name])
+        if self._elbo_fns is not None:
+            self._elbo_data = dict(self._data)
 
     def elbo(self):
         """E_q[log p(data, latents)] + sum of the factors' entropies, up to whatever constants

@@ -692,3 +692,26 @@ def test_bound_on_device_matches_the_float64_backend_and_rises(ctx):
             npt.assert_allclose(b_dev, b_ref, rtol=2e-5)
             assert b_dev >= last - 1e-4 * abs(b_dev)
             last = b_dev
+
+
+def test_stochastic_updates_on_mini_batches_converge_to_the_full_batch_posterior():
+    """README.md:69-79: mini-batches, the data term scaled by N / B, Robbins-Monro steps.  Known
+    variance, unknown mean: the fixed point is the exact posterior of the whole data set."""
+    N, B, v, m0, v0 = 4000, 100, 2.0, 0.0, 50.0
+    xs = rs.standard_normal(N) * np.sqrt(v) + 1.7
+    x, mu, scale = f64("x", 1), f64("mu", 0), f64("scale", 0)
+    lj = (A.sum(x * mu) * (1.0 / v) + A.shape(x, 0) * ((mu ** 2) * (-0.5 / v))) * scale \
+        + mu * (m0 / v0) + (mu ** 2) * (-0.5 / v0)
+    q = NormalNode(mu)
+    vmp = MeanFieldVMP(lj, [q], dict(x=xs[:B], scale=np.asarray(N / B)), backend=B64)
+    order = rs.permutation(N)
+    for t in range(400):
+        idx = order[(t * B) % N:(t * B) % N + B]
+        vmp.set_data(x=xs[idx])
+        vmp.update("mu", rho=(t + 2.0) ** -0.7)
+    post_v = 1.0 / (N / v + 1.0 / v0)
+    post_m = post_v * (xs.sum() / v + m0 / v0)
+    npt.assert_allclose(q.variance, post_v, rtol=1e-6)      # the precision message is the same for every batch
+    npt.assert_allclose(q.mean, post_m, atol=4 * np.sqrt(post_v))
+    with pytest.raises(TypeError):
+        vmp.set_data(nope=xs)
