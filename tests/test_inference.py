@@ -715,3 +715,90 @@ def test_stochastic_updates_on_mini_batches_converge_to_the_full_batch_posterior
     npt.assert_allclose(q.mean, post_m, atol=4 * np.sqrt(post_v))
     with pytest.raises(TypeError):
         vmp.set_data(nope=xs)
+
+
+# ---- general reparameterisation-trick engine ----------------------------------------------------
+
+def _linear_model(dtype, s2):
+    X, y, W = A.var("X", 2, dtype), A.var("y", 1, dtype), A.var("W", 2, dtype)     # W: [S, D]
+    r = A.dimshuffle(y, "x", 0) - A.dot(W, X.T)                                   # [S, N]
+    return A.sum(r * r, axis=1) * (-0.5 / s2) + A.sum(W * W, axis=1) * (-0.5), W
+
+
+def _mc_close(estimate, exact, samples):
+    """|mean of the samples - exact| within five standard errors (plus float slack)."""
+    se = samples.std(axis=0, ddof=1) / np.sqrt(samples.shape[0])
+    assert (np.abs(estimate - exact) <= 5.0 * se + 1e-9 * (1.0 + np.abs(exact))).all(), \
+        (estimate, exact, se)
+
+
+def test_pathwise_gradient_is_the_gradient_of_the_gaussian_elbo():
+    """Quadratic log-joint, Gaussian q: the ELBO and its gradient are known in closed form; the
+    estimator must agree within Monte-Carlo error, and ascent must find the mean-field optimum."""
+    from bayesic_amd.inference import ReparamVI
+    r = np.random.RandomState(2718)
+    N, D, s2, S = 300, 5, 0.5, 4096
+    Xs = r.standard_normal((N, D))
+    ys = Xs @ r.standard_normal(D) + np.sqrt(s2) * r.standard_normal(N)
+    lj, W = _linear_model("float64", s2)
+    eps0 = np.random.RandomState(77).standard_normal((S, D))
+    eng = ReparamVI(lj, [(W, D)], dict(X=Xs, y=ys), n_samples=S, backend=B64, lr=0.05,
+                    noise=lambda step: eps0)
+    eng.lam[:D] = 0.3 * r.standard_normal(D)
+    eng.lam[D:] = np.log(0.2)
+    elbo, grad = eng.estimate(0)
+    prec = Xs.T @ Xs / s2 + np.eye(D)
+    mu, sig = eng.lam[:D], np.exp(eng.lam[D:])
+    f, g = eng.log_joint_and_gradient(mu[None, :] + sig[None, :] * eps0)
+    _mc_close(grad[:D], Xs.T @ (ys - Xs @ mu) / s2 - mu, g)
+    _mc_close(grad[D:], -sig ** 2 * np.diag(prec) + 1.0, g * eps0 * sig[None, :] + 1.0)
+    exact = -0.5 / s2 * ((ys - Xs @ mu) ** 2).sum() - 0.5 * mu @ mu - 0.5 * (sig ** 2 * np.diag(prec)).sum() \
+        + eng.lam[D:].sum() + 0.5 * D * (1 + np.log(2 * np.pi))
+    _mc_close(elbo, exact, f + eng.lam[D:].sum() + 0.5 * D * (1 + np.log(2 * np.pi)))
+    small = ReparamVI(lj, [(W, D)], dict(X=Xs, y=ys), n_samples=64, backend=B64, lr=0.05,
+                      noise=lambda step: np.random.RandomState(step).standard_normal((64, D)))
+    for _ in range(600):
+        small.step()
+    post_mean = np.linalg.solve(prec, Xs.T @ ys / s2)
+    npt.assert_allclose(small.lam[:D], post_mean, atol=0.05)
+    npt.assert_allclose(np.exp(small.lam[D:]), 1.0 / np.sqrt(np.diag(prec)), rtol=0.3)   # 64 draws a step
+
+
+@pytest.mark.gpu
+def test_reparam_engine_on_device_shares_draws_with_the_score_function_engine(ctx):
+    """Same model, same Philox noise: the two estimators' ELBO values agree, their gradients agree
+    within Monte-Carlo error (the pathwise one with far less variance), and the device gradient of
+    log p equals the float64 one."""
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from bayesic_amd.inference import ReparamVI, ScoreFunctionVI
+    N, D, s2, S = 20_000, 8, 0.5, 512
+    r = np.random.RandomState(9)
+    Xs = r.standard_normal((N, D)).astype(np.float32)
+    ys = (Xs @ r.standard_normal(D) + np.sqrt(s2) * r.standard_normal(N)).astype(np.float32)
+    lj, W = _linear_model("float32", s2)
+    lam0 = np.concatenate([0.1 * r.standard_normal(D), np.full(D, np.log(0.01))])
+    dev = DeviceBackend(ctx)
+    rp = ReparamVI(lj, [(W, D)], dict(X=Xs, y=ys), n_samples=S, seed=5, backend=dev, lam0=lam0)
+    sf = ScoreFunctionVI(lj, [(W, D)], dict(X=Xs, y=ys), n_samples=S, seed=5, backend=dev, lam0=lam0)
+    np.testing.assert_array_equal(rp.draw(3), sf.draw(3))
+    e_rp, g_rp = rp.estimate(3)
+    e_sf, g_sf, _ = sf.estimate(3)
+    npt.assert_allclose(e_rp, e_sf, rtol=2e-3)      # same f values; the entropy enters exactly vs sampled
+    # exact gradient
+    X64, y64 = Xs.astype(np.float64), ys.astype(np.float64)
+    prec = X64.T @ X64 / s2 + np.eye(D)
+    mu, sig2 = lam0[:D], np.exp(2 * lam0[D:])
+    g_mu = X64.T @ (y64 - X64 @ mu) / s2 - mu
+    eps3, sig = rp.draw(3), np.exp(lam0[D:])
+    z = mu[None, :] + sig[None, :] * eps3
+    f_dev, g_dev = rp.log_joint_and_gradient(z)
+    _mc_close(g_rp[:D], g_mu, g_dev)
+    _mc_close(g_rp[D:], -sig2 * np.diag(prec) + 1.0, g_dev * eps3 * sig[None, :] + 1.0)
+    assert np.abs(g_rp[:D] - g_mu).max() < np.abs(g_sf[:D] - g_mu).max()      # the point of the trick
+    # the device derivative of log p itself against float64 on the same draws
+    lj64, W64 = _linear_model("float64", s2)
+    ref = ReparamVI(lj64, [(W64, D)], dict(X=X64, y=y64), n_samples=S, backend=B64, lam0=lam0,
+                    noise=lambda step: rp.draw(step))
+    f_ref, g_ref = ref.log_joint_and_gradient(z.astype(np.float32).astype(np.float64))
+    npt.assert_allclose(f_dev, f_ref, rtol=2e-5)
+    npt.assert_allclose(g_dev, g_ref, rtol=2e-3, atol=2e-3 * np.abs(g_ref).max())
