@@ -69,6 +69,13 @@ class ScoreFunctionVI(object):
         self._eps_dev = torch.zeros((self.S, self.P), dtype=torch.float64, device=self.backend.ctx.device)
         self.elbo, self.grad, self.f = None, None, None
 
+    def set_data(self, **arrays):
+        """Replace data inputs (the next mini-batch; write the data term times N / B)."""
+        for name, value in arrays.items():
+            if name not in self._types or name in {v.name for v, _ in self.latents}:
+                raise TypeError("%s is not a data input of the log-joint" % name)
+            self._data[name] = self.backend.from_host(value, *self._types[name])
+
     def draw(self, step):
         """eps [S, P] for Philox step `step` (device draw, downloaded: parameter-sized)."""
         ctx = self.backend.ctx

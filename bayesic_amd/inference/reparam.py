@@ -68,6 +68,13 @@ class ReparamVI(object):
         self._eps_dev = None
         self.elbo, self.grad = None, None
 
+    def set_data(self, **arrays):
+        """Replace data inputs (the next mini-batch; write the data term times N / B)."""
+        for name, value in arrays.items():
+            if name not in self._types or name in {v.name for v, _ in self.latents}:
+                raise TypeError("%s is not a data input of the log-joint" % name)
+            self._data[name] = self.backend.from_host(value, *self._types[name])
+
     def draw(self, step):
         if self._noise is not None:
             return np.asarray(self._noise(step), np.float64).reshape(self.S, self.P)

@@ -802,3 +802,26 @@ def test_reparam_engine_on_device_shares_draws_with_the_score_function_engine(ct
     f_ref, g_ref = ref.log_joint_and_gradient(z.astype(np.float32).astype(np.float64))
     npt.assert_allclose(f_dev, f_ref, rtol=2e-5)
     npt.assert_allclose(g_dev, g_ref, rtol=2e-3, atol=2e-3 * np.abs(g_ref).max())
+
+
+def test_reparam_engine_on_mini_batches_reaches_the_full_data_optimum():
+    """Stochastic optimisation proper: a fresh mini-batch every step, the data term scaled by
+    N / B inside the log-joint (README.md:69-79)."""
+    from bayesic_amd.inference import ReparamVI
+    r = np.random.RandomState(99)
+    N, B, D, s2 = 2000, 100, 4, 0.5
+    Xs = r.standard_normal((N, D))
+    ys = Xs @ r.standard_normal(D) + np.sqrt(s2) * r.standard_normal(N)
+    X, y, W = f64("X", 2), f64("y", 1), f64("W", 2)
+    res = A.dimshuffle(y, "x", 0) - A.dot(W, X.T)
+    lj = A.sum(res * res, axis=1) * (-0.5 / s2 * (N / B)) + A.sum(W * W, axis=1) * (-0.5)
+    eng = ReparamVI(lj, [(W, D)], dict(X=Xs[:B], y=ys[:B]), n_samples=16, backend=B64, lr=0.02,
+                    noise=lambda step: np.random.RandomState(1000 + step).standard_normal((16, D)))
+    for t in range(1500):
+        idx = r.randint(N, size=B)
+        eng.set_data(X=Xs[idx], y=ys[idx])
+        eng.step()
+    prec = Xs.T @ Xs / s2 + np.eye(D)
+    npt.assert_allclose(eng.lam[:D], np.linalg.solve(prec, Xs.T @ ys / s2), atol=0.05)
+    with pytest.raises(TypeError):
+        eng.set_data(W=np.zeros((16, D)))
