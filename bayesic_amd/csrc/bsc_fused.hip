@@ -47,6 +47,8 @@ struct MapArgs {
     int nt_store;     // dense map: streaming stores
     int bcast;        // dense kernels: bit k = operand k is constant along the fast axis (one
                       // scalar load, splat) instead of a 16-byte load
+    int64_t col_chunk;  // map_rows: columns per blockIdx.y (a multiple of 256); short-and-wide
+                        // matrices (8 x 1M) are split along the columns as well as the rows
 };
 
 __device__ __forceinline__ void unravel(int64_t flat, const Dims& d, int64_t (&idx)[MAXR]) {
@@ -204,8 +206,10 @@ __global__ __launch_bounds__(256) void map_rows_f32_kernel(MapArgs a) {
     const int64_t R = a.keep.shape[0], C = a.keep.shape[1];
     const float id = a.combine == BSC_OP_MUL ? 1.f : 0.f;
     constexpr int U = 2;
+    const int64_t c_begin = (int64_t)blockIdx.y * a.col_chunk;
+    const int64_t c_end = c_begin + a.col_chunk < C ? c_begin + a.col_chunk : C;
     for (int64_t rb = gwave; rb < R; rb += n_waves * U) {
-        for (int64_t c = 4 * lane; c < C; c += 256) {
+        for (int64_t c = c_begin + 4 * lane; c < c_end; c += 256) {
             float4 u[N][U];
 #pragma unroll
             for (int k = 0; k < N; ++k) {
@@ -682,10 +686,23 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
             const int64_t cap = (int64_t)ctx->cu_count * ctx->fused_map_blocks_per_cu;
             if (blocks > cap) blocks = cap;
             if (blocks < 1) blocks = 1;
+            // few rows (an 8 x 1M matrix of per-sample values): also split the columns, or
+            // eight waves would walk 32 MB alone (10 ms instead of ~20 us)
+            int64_t chunks = 1;
+            if (blocks < cap) {
+                chunks = (cap + blocks - 1) / blocks;
+                const int64_t max_chunks = (keep.shape[1] + 1023) / 1024;      // >= 1024 columns per chunk
+                if (chunks > max_chunks) chunks = max_chunks;
+                if (chunks > 65535) chunks = 65535;
+                if (chunks < 1) chunks = 1;
+            }
+            m.col_chunk = ((keep.shape[1] + chunks - 1) / chunks + 255) / 256 * 256;
+            chunks = (keep.shape[1] + m.col_chunk - 1) / m.col_chunk;
+            const dim3 rgrid((unsigned)blocks, (unsigned)chunks);
             switch (n_in) {
-                case 1: hipLaunchKernelGGL(map_rows_f32_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, m); break;
-                case 2: hipLaunchKernelGGL(map_rows_f32_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, m); break;
-                default: hipLaunchKernelGGL(map_rows_f32_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, m); break;
+                case 1: hipLaunchKernelGGL(map_rows_f32_kernel<1>, rgrid, dim3(256), 0, ctx->stream, m); break;
+                case 2: hipLaunchKernelGGL(map_rows_f32_kernel<2>, rgrid, dim3(256), 0, ctx->stream, m); break;
+                default: hipLaunchKernelGGL(map_rows_f32_kernel<3>, rgrid, dim3(256), 0, ctx->stream, m); break;
             }
             BSC_LAUNCH_CHECK();
             return BSC_OK;

@@ -299,3 +299,18 @@ def test_row_and_column_broadcasts_take_the_vector_paths(dev, R, C):
         got = expr.compile(dev)(**{n: vals[n] for n in expr.input_types})
         assert got.shape == want.shape, repr(expr)
         npt.assert_allclose(got, want, rtol=2e-5, atol=1e-4, err_msg=repr(expr))
+
+
+def test_short_and_wide_matrices_are_split_along_the_columns(dev):
+    """[8, 1M]-shaped per-sample values (the general VI engines make them): the row/column
+    broadcast kernel must also spread the columns over the machine -- a wave per row walked
+    32 MB with eight waves (10 ms).  Correctness of the chunked column ranges, ragged tail included."""
+    Xv, v, u = var("X", ndim=2), var("v", ndim=1), var("u", ndim=1)
+    for R, C in [(3, 100_004), (8, 262_144), (1, 70_000), (17, 9_996)]:
+        X_ = RNG.standard_normal((R, C)).astype(np.float32)
+        v_ = RNG.standard_normal(C).astype(np.float32)
+        u_ = RNG.standard_normal(R).astype(np.float32)
+        got = (dimshuffle(v, "x", 0) - Xv).compile(dev)(X=X_, v=v_)
+        npt.assert_array_equal(got, v_[None, :] - X_)
+        got = (Xv * dimshuffle(u, 0, "x") + 1).compile(dev)(X=X_, u=u_)
+        npt.assert_allclose(got, X_ * u_[:, None] + 1, rtol=1e-6, atol=1e-6)
