@@ -27,6 +27,13 @@ SIGNATURES = {
     "bsc_ctx_sync": (c_int, [c_void_p]),
     "bsc_ctx_profile": (c_int, [c_void_p, c_int]),
     "bsc_ctx_profile_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
+    "bsc_ctx_profile_read_slot": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int64)]),
+    "bsc_comm_unique_id": (c_int, [c_void_p]),
+    "bsc_comm_init_rank": (c_int, [c_void_p, c_void_p, c_int32, c_int32]),
+    "bsc_comm_destroy": (c_int, [c_void_p]),
+    "bsc_comm_info": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
+    "bsc_allreduce_sum": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
+    "bsc_allreduce_max": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
     "bsc_device_info": (c_int, [c_void_p, POINTER(c_int64)]),
     "bsc_last_error": (c_char_p, []),
     "bsc_version": (c_int, []),
@@ -108,6 +115,20 @@ SIGNATURES = {
     "bsc_logdet_spd": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                c_int64, c_void_p]),
 }
+
+COMM_ID_BYTES = 128   # BSC_COMM_ID_BYTES
+F32, F64 = 0, 1       # bsc_dtype
+
+
+def dtype_code(dtype):
+    """bsc_dtype of a torch / numpy dtype (float32 | float64 only)."""
+    name = str(dtype).replace("torch.", "")
+    if name == "float32":
+        return F32
+    if name == "float64":
+        return F64
+    raise TypeError("bayesic_amd handles float32 and float64, got %s" % (dtype,))
+
 
 _lib = None
 

@@ -94,7 +94,8 @@ int bsc_ctx_destroy(bsc_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->workspace) (void)hipFree(ctx->workspace);
-    for (auto* v : {&ctx->prof_events, &ctx->prof_pool})
+    (void)bsc_comm_destroy(ctx);
+    for (auto* v : {&ctx->prof_events[0], &ctx->prof_events[1], &ctx->prof_events[2], &ctx->prof_pool})
         for (auto& ev : *v) {
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);
@@ -118,25 +119,31 @@ int bsc_ctx_reserve(bsc_ctx* ctx, size_t bytes) {
 int bsc_ctx_profile(bsc_ctx* ctx, int enable) {
     BSC_CHECK_CTX(ctx);
     ctx->profile = enable > 0 ? enable : 0;
-    ctx->profile_tick = 0;
+    for (int s = 0; s < BSC_PROF_SLOTS; ++s) ctx->profile_tick[s] = 0;
     return BSC_OK;
 }
 
-int bsc_ctx_profile_read(bsc_ctx* ctx, double* host_total_ms, int64_t* host_launches) {
+int bsc_ctx_profile_read_slot(bsc_ctx* ctx, int slot, double* host_total_ms, int64_t* host_launches) {
     BSC_CHECK_CTX(ctx);
     BSC_REQUIRE(host_total_ms && host_launches, "bsc_ctx_profile_read: null output");
+    BSC_REQUIRE(slot >= 0 && slot < BSC_PROF_SLOTS, "bsc_ctx_profile_read_slot: slot %d", slot);
     BSC_HIP(hipStreamSynchronize(ctx->stream));
     double total = 0.0;
-    for (auto& ev : ctx->prof_events) {
+    auto& events = ctx->prof_events[slot];
+    for (auto& ev : events) {
         float ms = 0.f;
         BSC_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
         total += ms;
         ctx->prof_pool.push_back(ev);
     }
     *host_total_ms = total;
-    *host_launches = (int64_t)ctx->prof_events.size();
-    ctx->prof_events.clear();
+    *host_launches = (int64_t)events.size();
+    events.clear();
     return BSC_OK;
+}
+
+int bsc_ctx_profile_read(bsc_ctx* ctx, double* host_total_ms, int64_t* host_launches) {
+    return bsc_ctx_profile_read_slot(ctx, 0, host_total_ms, host_launches);
 }
 
 int bsc_ctx_sync(bsc_ctx* ctx) {

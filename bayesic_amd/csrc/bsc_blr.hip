@@ -1228,8 +1228,11 @@ int bsc_blr_fused_update(bsc_ctx* ctx, const double* stats, const double* lam_in
     a.log_prior_const = alpha0 * log(beta0) - lgamma(alpha0);
     a.seed = seed;
     a.next_step = next_step;
-    hipLaunchKernelGGL(blr_fused_update_kernel, dim3((D + 7) / 8 + 1), dim3(FUSED_BLOCK), 0,
-                       ctx->stream, a);
+    {
+        bsc_prof_scope prof(ctx, /*slot=*/2);  // the finish kernel, timed apart from the pass
+        hipLaunchKernelGGL(blr_fused_update_kernel, dim3((D + 7) / 8 + 1), dim3(FUSED_BLOCK), 0,
+                           ctx->stream, a);
+    }
     BSC_LAUNCH_CHECK();
     return BSC_OK;
 }

@@ -11,6 +11,8 @@
 
 #include "../../include/bayesic_hip.h"
 
+constexpr int BSC_PROF_SLOTS = 3;
+
 struct bsc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -33,9 +35,14 @@ struct bsc_ctx {
     int slab_rows = 0;  // block partials left in `workspace` by bsc_blr_data_pass_partial
     // optional per-kernel timing of the dominant kernel (bsc_ctx_profile)
     int profile = 0;        // 0 = off, n = time every n-th launch of a dominant kernel
-    int profile_tick = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;  // recorded pairs
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;    // reusable pairs
+    // slot 0: the dominant kernel of an entry point; slot 1: the collective; slot 2: the finish kernel
+    int profile_tick[BSC_PROF_SLOTS] = {0, 0, 0};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[BSC_PROF_SLOTS];  // recorded pairs
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;                    // reusable pairs
+    // data-parallel exchange (csrc/bsc_comm.hip): an ncclComm_t, NULL = a world of one
+    void* comm = nullptr;
+    int comm_rank = 0;
+    int comm_world = 1;
 };
 
 // Records an event pair around one launch when ctx->profile is on.
@@ -65,10 +72,11 @@ __device__ inline double bsc_digamma_f64(double x) {
 
 struct bsc_prof_scope {
     bsc_ctx* ctx;
+    int slot;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-    explicit bsc_prof_scope(bsc_ctx* c) : ctx(c) {
+    explicit bsc_prof_scope(bsc_ctx* c, int slot_ = 0) : ctx(c), slot(slot_) {
         if (ctx->profile <= 0) return;
-        if ((ctx->profile_tick++ % ctx->profile) != 0) return;
+        if ((ctx->profile_tick[slot]++ % ctx->profile) != 0) return;
         if (!ctx->prof_pool.empty()) {
             ev = ctx->prof_pool.back();
             ctx->prof_pool.pop_back();
@@ -81,7 +89,7 @@ struct bsc_prof_scope {
     ~bsc_prof_scope() {
         if (!ev.first) return;
         (void)hipEventRecord(ev.second, ctx->stream);
-        ctx->prof_events.push_back(ev);
+        ctx->prof_events[slot].push_back(ev);
     }
 };
 

@@ -27,6 +27,7 @@ class Context:
         _ffi.check(self.lib.bsc_ctx_create(self.device_index, self._stream.cuda_stream,
                                            ctypes.byref(handle)), "bsc_ctx_create")
         self.handle = handle
+        self.has_comm = False   # an RCCL communicator (comm_init), even of one rank
 
     # -- plumbing ----------------------------------------------------------
     def close(self):
@@ -60,12 +61,55 @@ class Context:
         `every` = 0/False: off, n: every n-th launch."""
         _ffi.check(self.lib.bsc_ctx_profile(self.handle, int(every)), "bsc_ctx_profile")
 
-    def profile_read(self):
-        """(total_ms, launches) of the dominant kernel since the last read; syncs."""
+    def profile_read(self, slot=0):
+        """(total_ms, launches) of timing slot `slot` since the last read; syncs.  Slot 0 = the
+        dominant kernel, 1 = the collective (bsc_allreduce_sum), 2 = the finish kernel."""
         ms, n = ctypes.c_double(), ctypes.c_int64()
-        _ffi.check(self.lib.bsc_ctx_profile_read(self.handle, ctypes.byref(ms), ctypes.byref(n)),
-                   "bsc_ctx_profile_read")
+        _ffi.check(self.lib.bsc_ctx_profile_read_slot(self.handle, int(slot), ctypes.byref(ms),
+                                                      ctypes.byref(n)),
+                   "bsc_ctx_profile_read_slot")
         return float(ms.value), int(n.value)
+
+    # -- the exchange step: RCCL behind the C ABI ---------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes from rank 0 (ncclGetUniqueId); ship them to every rank."""
+        buf = ctypes.create_string_buffer(_ffi.COMM_ID_BYTES)
+        _ffi.check(_ffi.load_library().bsc_comm_unique_id(buf), "bsc_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        """Collective over all ranks: gives this context its RCCL communicator."""
+        if len(unique_id) != _ffi.COMM_ID_BYTES:
+            raise ValueError("unique_id must be %d bytes" % _ffi.COMM_ID_BYTES)
+        buf = ctypes.create_string_buffer(bytes(unique_id), _ffi.COMM_ID_BYTES)
+        _ffi.check(self.lib.bsc_comm_init_rank(self.handle, buf, int(rank), int(world)),
+                   "bsc_comm_init_rank")
+        self.has_comm = True
+
+    def comm_destroy(self):
+        _ffi.check(self.lib.bsc_comm_destroy(self.handle), "bsc_comm_destroy")
+        self.has_comm = False
+
+    def comm_info(self):
+        r, w, v = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        _ffi.check(self.lib.bsc_comm_info(self.handle, ctypes.byref(r), ctypes.byref(w),
+                                          ctypes.byref(v)), "bsc_comm_info")
+        return {"rank": r.value, "world": w.value, "rccl_version": v.value}
+
+    @property
+    def comm_world(self):
+        """Ranks of this context's RCCL communicator (1 when it has none)."""
+        return self.comm_info()["world"]
+
+    def allreduce_sum(self, tensor):
+        """In-place all-reduce(sum) over the context's communicator, on the context stream."""
+        _ffi.check(self.lib.bsc_allreduce_sum(self.handle, tensor.data_ptr(), tensor.numel(),
+                                              _ffi.dtype_code(tensor.dtype)), "bsc_allreduce_sum")
+
+    def allreduce_max(self, tensor):
+        _ffi.check(self.lib.bsc_allreduce_max(self.handle, tensor.data_ptr(), tensor.numel(),
+                                              _ffi.dtype_code(tensor.dtype)), "bsc_allreduce_max")
 
     def read_probe(self, tensor, reps=10):
         """Best pure streaming-read rate (GB/s) over `tensor` on this device; syncs."""

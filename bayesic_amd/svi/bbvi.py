@@ -11,6 +11,7 @@ import math
 import torch
 
 from ..device import default_context
+from .exchange import Exchange
 
 
 class LogRegBBVI:
@@ -31,14 +32,9 @@ class LogRegBBVI:
         self.P = self.D + self.G + 1
         self.seed, self.lr, self.a0, self.b0 = int(seed), float(lr), float(a0), float(b0)
         self.group = group
-        self.world = 1
-        if group is not None or (torch.distributed.is_available()
-                                 and torch.distributed.is_initialized()):
-            self.world = torch.distributed.get_world_size(group)
-        rows = torch.tensor([float(self.B)], dtype=torch.float64, device=dev)
-        if self.world > 1:
-            torch.distributed.all_reduce(rows, group=self.group)
-        self.batch_rows = float(rows.item())
+        self.exchange = Exchange(self.ctx, group)   # RCCL behind the C ABI when ctx has a communicator
+        self.world = self.exchange.world
+        self.batch_rows = self.exchange.global_count(self.B, dev)
         self.n_total = float(n_total) if n_total is not None else self.batch_rows
         f64 = torch.float64
         P, S = self.P, self.S
@@ -66,8 +62,7 @@ class LogRegBBVI:
                self.eps, self.Wz, self.Bz, self.zeta)
         c.call("bsc_logreg_bbvi_loglik", self.X, self.X.stride(0), self.y, self.g, self.B, self.D,
                self.G, self.Wz, self.Bz, self.S, self.ell)
-        if self.world > 1:
-            torch.distributed.all_reduce(self.ell, group=self.group)
+        self.exchange.all_reduce(self.ell)
         c.call("bsc_bbvi_grad", self.lam, self.eps, self.ell, self.D, self.G, self.S,
                self.n_total / self.batch_rows, self.a0, self.b0, self.elbo, self.grad, self.f)
         c.call("bsc_adam_ascent", self.lam, self.grad, self.m1, self.m2, self.lam.numel(), self.t,

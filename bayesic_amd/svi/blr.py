@@ -24,6 +24,7 @@ import math
 import torch
 
 from ..device import default_context
+from .exchange import Exchange
 
 
 class BLRReparamSVI:
@@ -48,15 +49,10 @@ class BLRReparamSVI:
         self.lr = float(lr)
         self.alpha0, self.beta0 = float(alpha0), float(beta0)
         self.group = group
-        self.world = 1
-        if group is not None or (torch.distributed.is_available()
-                                 and torch.distributed.is_initialized()):
-            self.world = torch.distributed.get_world_size(group)
+        self.exchange = Exchange(self.ctx, group)   # RCCL behind the C ABI when ctx has a communicator
+        self.world = self.exchange.world
         # global mini-batch rows (all ranks); ranks may hold unequal blocks
-        rows = torch.tensor([float(self.B)], dtype=torch.float64, device=dev)
-        if self.world > 1:
-            torch.distributed.all_reduce(rows, group=self.group)
-        self.batch_rows = float(rows.item())
+        self.batch_rows = self.exchange.global_count(self.B, dev)
         self.n_total = float(n_total) if n_total is not None else self.batch_rows
         self.fused = bool(fused)
         D, S = self.D, self.S
@@ -148,8 +144,7 @@ class BLRReparamSVI:
                       self.D, self.W, self.S, self.Q, self.G)
 
     def all_reduce(self):
-        if self.world > 1:
-            torch.distributed.all_reduce(self.stats, group=self.group)
+        self.exchange.all_reduce(self.stats)
 
     def _finish(self, stats):
         """Fused gradient + Adam + next draw; flips the double buffer."""
@@ -169,7 +164,7 @@ class BLRReparamSVI:
         """One ELBO-gradient update; asynchronous on the context stream."""
         if not self._drawn:
             self.sample(self.t)  # Philox step index == number of completed updates
-        if self.fused and self.world == 1 and self.S <= 8:
+        if self.fused and self.world == 1 and not self.exchange.rccl and self.S <= 8:
             self.ctx.call("bsc_blr_data_pass_partial", self._Xarg, self._ldx,
                           self._yarg, self.B, self.D, self.W, self.S)
             self._finish(None)

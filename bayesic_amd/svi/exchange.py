@@ -1,0 +1,66 @@
+"""The one exchange step of a data-parallel update (README.md:69-79).
+
+Rows are iid (bayesic/distribution/base.py:146-172) and every per-batch quantity is a sum
+over rows, so rank r holds a row block and the ranks exchange ONE vector per update: the
+all-reduce(sum) of the concatenated statistic / gradient vector.
+
+The product route is RCCL behind the C ABI: ``bsc_allreduce_sum`` on the context's own
+stream (pass -> all-reduce -> finish is one in-order queue).  ``init_comm`` builds that
+communicator from a torch.distributed job -- torch is only the host channel that carries
+the 128-byte unique id from rank 0; any other channel does.
+
+A context WITHOUT a communicator inside a torch.distributed job (the gloo CPU tests with
+the oracle test double, or several ranks rehearsing on one GPU, where RCCL cannot run)
+exchanges through ``torch.distributed.all_reduce`` instead.
+"""
+import torch
+
+
+def _dist_ready():
+    return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
+def init_comm(ctx, group=None):
+    """Give ``ctx`` an RCCL communicator spanning the ranks of the torch.distributed job
+    (or of ``group``).  Collective.  Returns the world size."""
+    if not _dist_ready():
+        raise RuntimeError("init_comm needs an initialised torch.distributed job to carry the "
+                           "unique id (any backend); for a world of one call "
+                           "ctx.comm_init(ctx.comm_unique_id(), 0, 1)")
+    rank = torch.distributed.get_rank(group)
+    world = torch.distributed.get_world_size(group)
+    box = [ctx.comm_unique_id() if rank == 0 else None]
+    src = torch.distributed.get_global_rank(group, 0) if group is not None else 0
+    torch.distributed.broadcast_object_list(box, src=src, group=group)
+    ctx.comm_init(box[0], rank, world)
+    return world
+
+
+class Exchange:
+    """all-reduce(sum) over the ranks that share one mini-batch."""
+
+    def __init__(self, ctx, group=None):
+        self.ctx = ctx
+        self.group = group
+        self.rccl = getattr(ctx, "comm_world", 1) > 1 or bool(getattr(ctx, "has_comm", False))
+        if self.rccl:
+            self.world = ctx.comm_world
+        elif group is not None or _dist_ready():
+            self.world = torch.distributed.get_world_size(group)
+        else:
+            self.world = 1
+
+    def all_reduce(self, tensor):
+        """In place; asynchronous on the context stream on the RCCL route."""
+        if self.rccl:
+            self.ctx.allreduce_sum(tensor)
+        elif self.world > 1:
+            torch.distributed.all_reduce(tensor, group=self.group)
+        return tensor
+
+    def global_count(self, local, device):
+        """Sum of a per-rank scalar (the rank's rows) over all ranks, as a float."""
+        t = torch.tensor([float(local)], dtype=torch.float64, device=device)
+        if self.rccl or self.world > 1:
+            self.all_reduce(t)
+        return float(t.item())

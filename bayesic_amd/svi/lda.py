@@ -22,6 +22,7 @@ import torch
 from .. import algebra as A
 from ..algebra.device_backend import DeviceBackend
 from ..device import default_context
+from .exchange import Exchange
 
 
 class LDAFixedGammaSVI:
@@ -60,14 +61,9 @@ class LDAFixedGammaSVI:
             raise ValueError("shapes: C [docs, V], gamma [docs, K], lambda [K, V]")
         self.eta = float(eta)
         self.group = group
-        self.world = 1
-        if group is not None or (torch.distributed.is_available()
-                                 and torch.distributed.is_initialized()):
-            self.world = torch.distributed.get_world_size(group)
-        n = torch.tensor([float(self.docs)], dtype=torch.float64, device=dev)
-        if self.world > 1:
-            torch.distributed.all_reduce(n, group=self.group)
-        self.batch_docs = float(n.item())
+        self.exchange = Exchange(self.ctx, group)   # RCCL behind the C ABI when ctx has a communicator
+        self.world = self.exchange.world
+        self.batch_docs = self.exchange.global_count(self.docs, dev)
         self.docs_total = float(docs_total) if docs_total is not None else self.batch_docs
         self.Th = torch.empty((self.docs, self.K), dtype=f32, device=dev)
         self.Bt = torch.empty((self.K, self.V), dtype=f32, device=dev)
@@ -109,7 +105,6 @@ class LDAFixedGammaSVI:
         if rho is None:
             rho = (self.t + 1.0) ** -0.7
         self.local_step()
-        if self.world > 1:
-            torch.distributed.all_reduce(self.sstats, group=self.group)
+        self.exchange.all_reduce(self.sstats)
         self.ctx.call("bsc_natgrad_update_f32", self.lam, self.eta, self.sstats, self.lam.numel(),
                       self.docs_total / self.batch_docs, float(rho))

@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from ..device import default_context
+from .exchange import Exchange
 
 
 # -- natural-parameter layout (host side, parameter-sized) ------------------------------------
@@ -64,14 +65,9 @@ class MoGNatGradSVI:
         self.B, self.D = self.X.shape
         self.K = int(K)
         self.group = group
-        self.world = 1
-        if group is not None or (torch.distributed.is_available()
-                                 and torch.distributed.is_initialized()):
-            self.world = torch.distributed.get_world_size(group)
-        rows = torch.tensor([float(self.B)], dtype=torch.float64, device=dev)
-        if self.world > 1:
-            torch.distributed.all_reduce(rows, group=self.group)
-        self.batch_rows = float(rows.item())
+        self.exchange = Exchange(self.ctx, group)   # RCCL behind the C ABI when ctx has a communicator
+        self.world = self.exchange.world
+        self.batch_rows = self.exchange.global_count(self.B, dev)
         self.n_total = float(n_total) if n_total is not None else self.batch_rows
         f64 = torch.float64
         n_eta = self.K + 4 * self.K * self.D
@@ -103,7 +99,6 @@ class MoGNatGradSVI:
             rho = (self.t + 1.0) ** -0.6
         self.expected_params()
         self.local_step()
-        if self.world > 1:
-            torch.distributed.all_reduce(self.buf, group=self.group)
+        self.exchange.all_reduce(self.buf)
         self.ctx.call("bsc_mog_natgrad", self.eta, self.eta0, self.stats, self.K,
                       self.D, self.n_total / self.batch_rows, float(rho))

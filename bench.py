@@ -1,24 +1,30 @@
-"""ELBO-gradient updates/sec on BASELINE config 2 (Bayesian linear regression,
-1M x 256 float32 mini-batch per GPU, reparameterisation-trick ELBO, S=8).
+"""ELBO-gradient updates/sec on a 1M-row mini-batch (BASELINE.json's metric), MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
-        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--config cfg2]
 
-One "step" = one full update on the resident mini-batch: Philox sample ->
-fused data pass over X,y -> float64 slab reduce -> (all-reduce of 16 KB over
-RCCL when N>1) -> ELBO + pathwise gradient -> Adam step.  Inputs are resident in
-HBM before the timed region.  Before the W warm-up steps the device is spun up with untimed
-data-pass launches (--spin-up-ms, default 60): a process that has just started using the GPU
-runs its first ~35 ms of kernels 10-40 % slower (tools/ramp_probe.py), and the metric is the
-steady rate of a long-running job.  Weak scaling: every rank holds its own 1M rows, so
-`value` counts 1M-row mini-batch equivalents per second over all ranks.
+Default workload = BASELINE config 2 (the configuration the metric is quoted on): Bayesian
+linear regression, 1M x 256 float32 mini-batch, reparameterisation-trick ELBO, S = 8, Adam.
+One "step" = one full update on the HBM-resident mini-batch: Philox draw -> fused data pass
+over X, y -> float64 reduction -> (all-reduce over RCCL when N > 1, through the C ABI on the
+context's stream) -> ELBO + pathwise gradient -> Adam step.  --config cfg3 | cfg4 | cfg5 run
+the other BASELINE configurations' updates through the same harness and schema.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+N > 1: one process per GPU.  Started by the driver's torch.distributed.run (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment) -- or bare, `python bench.py --gpus N`: then THIS
+process never touches the GPU, starts N rank processes itself, relays rank 0's JSON line and
+exits non-zero if any rank failed.  torch.distributed (gloo) is only the host channel (unique
+id, barrier, max over ranks); the data path's one collective is bsc_allreduce_sum (RCCL/xGMI).
+
+--scaling weak (default): every rank holds its own full-size mini-batch, `value` counts
+1M-row mini-batch equivalents per second over all ranks.  --scaling strong: ONE global
+mini-batch of the configured size is split into N row blocks.
+
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,203 +32,626 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:36
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:36
+F32_MFMA_PEAK_TF = 157.3  # fp32-input MFMA = fp32 vector peak, same guide :41-42
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rows", type=int, default=1_000_000, help="mini-batch rows per GPU")
-    ap.add_argument("--dim", type=int, default=256)
-    ap.add_argument("--samples", type=int, default=8)
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--rows", type=int, default=None,
+                    help="mini-batch rows (cfg4: documents): per GPU when weak, global when strong; "
+                         "default = the BASELINE size of the config")
+    ap.add_argument("--dim", type=int, default=256, help="cfg2 / cfg5 columns")
+    ap.add_argument("--samples", type=int, default=None, help="Monte-Carlo draws (cfg2: 8, cfg5: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=12.0,
+                    help="CPU seconds per leg of the cpu_baseline (there are up to three legs)")
     ap.add_argument("--unfused", action="store_true",
-                    help="N=1 through the multi-GPU code path (float64 statistics between the pass "
-                         "and the finish, no collective): what the N>1 step costs besides RCCL")
+                    help="cfg2, N=1 through the multi-GPU code path (float64 statistics between the "
+                         "pass and the finish, no collective): what the N>1 step costs besides RCCL")
+    ap.add_argument("--rccl-world1", action="store_true",
+                    help="N=1 with a one-rank RCCL communicator: the collective is really enqueued")
     ap.add_argument("--no-kernel-timing", action="store_true",
-                    help="skip the hipEvent pair around the pass kernel")
+                    help="no hipEvent pairs inside the timed region and no timed burst after it")
     ap.add_argument("--spin-up-ms", type=float, default=60.0,
-                    help="untimed data-pass launches before the W warm-up steps, until about this "
-                         "much GPU work has been queued: a process that has just started using the "
-                         "GPU runs the pass at 230 -> 165 us over its first ~35 ms "
+                    help="untimed launches of the dominant kernel before the W warm-up steps, until "
+                         "about this much GPU work has been queued: a process that has just started "
+                         "using the GPU runs its first ~35 ms of kernels 10-40 %% slow "
                          "(tools/ramp_probe.py); a training job lives in the steady state")
     ap.add_argument("--time-every", type=int, default=8,
-                    help="time every n-th pass-kernel launch inside the timed region (an event "
-                         "pair costs ~4 us of stream time per use)")
-    return ap.parse_args()
+                    help="inside the timed region, time every n-th launch per slot (an event pair "
+                         "costs ~4 us of stream time per use)")
+    ap.add_argument("--burst", type=int, default=64,
+                    help="dominant-kernel launches timed one by one AFTER the timed region; "
+                         "roofline.avg_launch_us comes from these")
+    ap.add_argument("--synthetic", default="survey", choices=["survey", "device"],
+                    help="survey: the SURVEY 8(d) numpy RandomState inputs (host-generated, seconds); "
+                         "device: torch.randn on the GPU")
+    return ap.parse_args(argv)
 
 
-def make_data(torch, device, rank, rows, dim):
-    """Synthetic cfg-2-shaped shard, generated on the device (seed depends on the
-    rank so shards differ): X ~ N(0,1), y = X w* + 0.5 noise."""
-    g = torch.Generator(device=device).manual_seed(1234 + rank)
-    X = torch.randn((rows, dim), generator=g, device=device, dtype=torch.float32)
-    gw = torch.Generator(device=device).manual_seed(1)
-    w_true = torch.randn(dim, generator=gw, device=device, dtype=torch.float32) / 16.0
-    noise = torch.randn(rows, generator=g, device=device, dtype=torch.float32)
-    y = X @ w_true + 0.5 * noise
-    return X, y
+# ------------------------------------------------------------------------------------------
+# bare `--gpus N`: start the ranks.  Nothing in this function may touch the GPU or import torch.
+# ------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", BSC_BENCH_SPAWNED="1")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env, stdout=subprocess.PIPE if rank == 0 else sys.stderr,
+                                      stderr=sys.stderr))
+    deadline = time.time() + float(os.environ.get("BSC_BENCH_TIMEOUT_S", "1500"))
+    failed = None
+    pending = set(range(args.gpus))
+    while pending and failed is None:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is not None:
+                pending.discard(r)
+                if rc != 0:
+                    failed = (r, rc)
+        if time.time() > deadline:
+            failed = (-1, 124)
+        if pending and failed is None:
+            time.sleep(0.2)
+    if failed is not None:
+        for r in pending:                 # exact PIDs of our own children, nothing else
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    out = procs[0].stdout.read().decode() if procs[0].stdout else ""
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if failed is not None:
+        sys.stderr.write("bench.py: rank %d exited with status %d\n" % failed)
+        return failed[1] if failed[1] > 0 else 1
+    return 0
 
 
-def cpu_baseline(X_host, y_host, samples, n_total, budget_s=12.0, max_updates=100):
-    """The oracle timed on this host: the data pass in plain C + OpenMP (oracle/c, float64
-    accumulate) when gcc built it, else the numpy restatement.  Bounded sample: full 1M-row
-    updates until ~budget_s of CPU work."""
-    import numpy as np
-    from oracle import svi
-    data_pass, how = None, "numpy float64 restatement (oracle.svi.blr_step)"
-    try:
-        from oracle import cbuild
-        threads = cbuild.load().oracle_threads()
-        data_pass, how = cbuild.blr_data_pass, "C + OpenMP data pass (oracle/c), numpy finish"
-    except Exception:
+# ------------------------------------------------------------------------------------------
+# synthetic inputs; rank r of a weak-scaling run draws from seed + r
+# ------------------------------------------------------------------------------------------
+def _normal_f32(np, seed, shape, chunk_rows=125_000):
+    """RandomState(seed).standard_normal(shape) as float32, drawn in row chunks (the stream of
+    one RandomState is the same whether it is drawn at once or in pieces)."""
+    rs = np.random.RandomState(seed)
+    if len(shape) == 1:
+        return rs.standard_normal(shape[0]).astype(np.float32)
+    out = np.empty(shape, np.float32)
+    for r0 in range(0, shape[0], chunk_rows):
+        r1 = min(shape[0], r0 + chunk_rows)
+        out[r0:r1] = rs.standard_normal((r1 - r0,) + tuple(shape[1:]))
+    return out
+
+
+def rank_rows(total, rank, world):
+    """Contiguous row block of `rank`: [rank*total/world, (rank+1)*total/world)."""
+    return (total * rank) // world, (total * (rank + 1)) // world
+
+
+class Workload:
+    """One BASELINE configuration behind the harness."""
+    name = ""
+    dtype = "f32"
+
+    def spin(self):            # one untimed launch of the dominant kernel (state untouched)
+        raise NotImplementedError
+
+    def step(self):
+        raise NotImplementedError
+
+
+class Cfg2(Workload):
+    """Bayesian linear regression, reparameterisation-trick ELBO (the metric's config)."""
+    name = "cfg2"
+    default_rows, default_samples = 1_000_000, 8
+    kernel_ms = 0.17
+
+    def __init__(self, args, ctx, torch, rank, world):
+        import numpy as np
+        from bayesic_amd.svi.blr import BLRReparamSVI
+        self.ctx, self.args = ctx, args
+        D, S = args.dim, args.samples or self.default_samples
+        total = args.rows or self.default_rows
+        if args.scaling == "strong":
+            r0, r1 = rank_rows(total, rank, world)
+            global_rows, seed_off = total, 0
+        else:
+            r0, r1, global_rows, seed_off = 0, total, total * world, rank
+        rows = r1 - r0
+        dev = ctx.device
+        if args.synthetic == "survey":
+            # X = RandomState(1234).standard_normal((N, D)), w* = RandomState(1)/16,
+            # y = X w* + 0.5 RandomState(2) -- the rank keeps its row block
+            Xh = _normal_f32(np, 1234 + seed_off, (r1, D))[r0:]
+            w_true = np.random.RandomState(1).standard_normal(D) / 16.0
+            noise = np.random.RandomState(2 + 7 * seed_off).standard_normal(r1)[r0:]
+            yh = (Xh.astype(np.float64) @ w_true + 0.5 * noise).astype(np.float32)
+            X, y = torch.from_numpy(Xh).to(dev), torch.from_numpy(yh).to(dev)
+            self.host = (Xh, yh)
+        else:
+            g = torch.Generator(device=dev).manual_seed(1234 + seed_off)
+            X = torch.randn((rows, D), generator=g, device=dev, dtype=torch.float32)
+            w_true = torch.randn(D, generator=torch.Generator(device=dev).manual_seed(1), device=dev) / 16
+            y = X @ w_true + 0.5 * torch.randn(rows, generator=g, device=dev)
+            self.host = None
+        self.X, self.y, self.rows, self.D, self.S = X, y, rows, D, S
+        self.n_total = float(global_rows)       # the resident global batch is the data set
+        self.model = BLRReparamSVI(X, y, n_total=self.n_total, n_samples=S, seed=1234, lr=1e-3, ctx=ctx,
+                                   fused=not args.unfused)
+        self.units_per_step = global_rows / 1e6 if args.scaling == "strong" else world * rows / 1e6
+        self.describe = ("cfg2: Bayesian linear regression (Normal-InverseGamma), %dx%d f32 mini-batch %s, "
+                         "reparam-trick ELBO, S=%d, Adam"
+                         % (rows, D, "per GPU" if args.scaling == "weak" else
+                            "block of a global %d-row batch" % global_rows, S))
+        self.config = {"rows_per_gpu": rows, "global_rows": global_rows, "dim": D, "mc_samples": S}
+
+    def spin(self):
+        self.ctx.call("bsc_blr_data_pass_partial", self.X, self.X.stride(0), self.y, self.rows, self.D,
+                      self.model.W, min(self.S, 8))
+
+    def step(self):
+        self.model.step()
+
+    def result(self):
+        return {"final_elbo": float(self.model.elbo.item())}
+
+    def roofline(self, avg_s):
+        algo = 4.0 * self.rows * self.D + 4.0 * self.rows      # X and y read once per launch
+        kernel = "blr_pass_mfma_kernel" if self.D == 256 and \
+            os.environ.get("BSC_BLR_TILE_ROWS", "16") == "16" else "blr_pass_kernel"
+        achieved = algo / avg_s / 1e9
+        return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(kernel, self.rows == 1_000_000 and self.D == 256),
+                "algorithmic_bytes_per_launch": algo,
+                "launches_per_step": (self.S + 7) // 8}
+
+    def cpu_baseline(self, budget_s):
+        """Three legs on this host, each bounded to ~budget_s: (a) numpy float32/BLAS executing the
+        lowered op tree at all cores [the reported baseline, SURVEY 8(d)], (b) the same at 1 core,
+        (c) the float64 C + OpenMP restatement of the pass (oracle/c)."""
+        import numpy as np
+        from oracle import lowered_baseline as lb
+        from oracle import svi
+        Xh, yh = self.host if self.host is not None else (self.X.cpu().numpy(), self.y.cpu().numpy())
+        S, D = self.S, self.D
+
+        def run(data_pass, budget, max_updates=100):
+            lam = svi.blr_init_lam(D)
+            m1, m2 = np.zeros_like(lam), np.zeros_like(lam)
+            lam, m1, m2, _, _ = svi.blr_step(lam, m1, m2, 1, Xh, yh, S, 1234, self.n_total, 0.01,
+                                             chunked=True, data_pass=data_pass)    # warm-up
+            done, t0 = 0, time.perf_counter()
+            while done < max_updates and (time.perf_counter() - t0 < budget or done == 0):
+                lam, m1, m2, _, _ = svi.blr_step(lam, m1, m2, done + 2, Xh, yh, S, 1234, self.n_total,
+                                                 0.01, chunked=True, data_pass=data_pass)
+                done += 1
+            dt = time.perf_counter() - t0
+            return done, dt
+
+        unit = "updates/s (%d-row mini-batch)" % Xh.shape[0]
+        all_cores = os.cpu_count() or 1
+        n, dt = run(lb.blr_data_pass_lowered, budget_s)
+        out = {"value": n / dt, "unit": unit, "cores": all_cores, "kind": "port",
+               "sample": "%d full updates on the same %dx%d mini-batch in %.1f s: numpy float32 / BLAS "
+                         "executing the lowered op tree of the pass (%s), float64 numpy finish; "
+                         "numpy restatement, not Theano"
+                         % (n, Xh.shape[0], D, dt, lb.blr_pass_functions()["lowered"]),
+               "host": lb.host_facts()}
+        with lb.threads(1):
+            n, dt = run(lb.blr_data_pass_lowered, budget_s)
+        out["one_core"] = {"value": n / dt, "unit": unit, "cores": 1,
+                           "sample": "%d updates in %.1f s, BLAS threads = 1" % (n, dt)}
         try:
-            from threadpoolctl import threadpool_info
-            threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-        except Exception:
-            threads = os.cpu_count() or 1
-    D = X_host.shape[1]
-    lam = svi.blr_init_lam(D)
-    m1, m2 = np.zeros_like(lam), np.zeros_like(lam)
-    done, t0 = 0, time.perf_counter()
-    while done < max_updates and (time.perf_counter() - t0 < budget_s or done == 0):
-        lam, m1, m2, _, _ = svi.blr_step(lam, m1, m2, done + 1, X_host, y_host, samples, 1234,
-                                         n_total, 0.01, chunked=True, data_pass=data_pass)
-        done += 1
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "updates/s (1M-row mini-batch)", "cores": int(threads),
-            "kind": "port",
-            "sample": "%d full updates on the same %dx%d mini-batch, %s, %.1f s"
-                      % (done, X_host.shape[0], D, how, dt)}
+            from oracle import cbuild
+            threads = int(cbuild.load().oracle_threads())
+            n, dt = run(cbuild.blr_data_pass, budget_s)
+            out["c_port"] = {"value": n / dt, "unit": unit, "cores": threads,
+                             "sample": "%d updates in %.1f s: float64 C + OpenMP restatement of the pass "
+                                       "(oracle/c), scalar inner loops" % (n, dt)}
+        except Exception as e:   # no gcc and no prebuilt library on this host
+            out["c_port"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+        return out
 
 
-def main():
-    args = parse_args()
-    import torch
-    import torch.distributed as dist
+def _mfma_roofline(kernel, flops, algo_bytes, avg_s, traffic):
+    achieved = flops / avg_s / 1e12
+    return {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": F32_MFMA_PEAK_TF,
+            "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TF, "traffic": traffic,
+            "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": algo_bytes,
+            "hbm_frac": algo_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "launches_per_step": 1}
 
+
+class Cfg3(Workload):
+    """Mixture of Gaussians K=64, discrete latent marginalised by summation, natural-gradient SVI."""
+    name = "cfg3"
+    default_rows = 10_000_000
+    kernel_ms = 0.72
+
+    def __init__(self, args, ctx, torch, rank, world):
+        import numpy as np
+        from bayesic_amd.svi import mog as mog_mod
+        self.ctx = ctx
+        D, K = 16, 64
+        total = args.rows or self.default_rows
+        if args.scaling == "strong":
+            r0, r1 = rank_rows(total, rank, world)
+            global_rows, seed_off = total, 0
+        else:
+            r0, r1, global_rows, seed_off = 0, total, total * world, rank
+        rows = r1 - r0
+        # centres RandomState(3)*4, labels RandomState(4), unit noise RandomState(5)
+        centres = np.random.RandomState(3).standard_normal((K, D)) * 4.0
+        labels = np.random.RandomState(4 + 11 * seed_off).randint(K, size=r1)[r0:]
+        Xh = (centres[labels] + _normal_f32(np, 5 + 11 * seed_off, (r1, D))[r0:]).astype(np.float32)
+        self.host = Xh
+        self.X = torch.from_numpy(Xh).to(ctx.device)
+        self.rows, self.D, self.K = rows, D, K
+        eta0 = mog_mod.prior_eta(K, D)
+        eta_init = mog_mod.init_eta(_normal_f32(np, 5, (2000, D)) +
+                                    centres[np.random.RandomState(4).randint(K, size=2000)], K, D, seed=2)
+        self.n_total = float(global_rows)
+        self.model = mog_mod.MoGNatGradSVI(self.X, K, eta0, eta_init, n_total=self.n_total, ctx=ctx)
+        self.model.expected_params()
+        self.units_per_step = 1.0 if args.scaling == "strong" else float(world)
+        self.describe = ("cfg3: mixture of Gaussians K=%d, %dx%d f32 mini-batch %s, discrete latent "
+                         "marginalised by summation, natural-gradient SVI"
+                         % (K, rows, D, "per GPU" if args.scaling == "weak" else "block of a global "
+                            "%d-row batch" % global_rows))
+        self.config = {"rows_per_gpu": rows, "global_rows": global_rows, "dim": D, "components": K}
+
+    def spin(self):
+        self.model.local_step()
+
+    def step(self):
+        self.model.step()
+
+    def result(self):
+        return {"final_bound_term": float(self.model.lse.item())}
+
+    def roofline(self, avg_s):
+        return _mfma_roofline("mog_estep_kernel", 8.0 * self.K * self.D * self.rows,
+                              4.0 * self.rows * self.D, avg_s, pmc_traffic("mog_estep_kernel",
+                                                                           self.rows == 10_000_000))
+
+    def cpu_baseline(self, budget_s):
+        from oracle import cbuild
+        import numpy as np
+        n = min(self.rows, 1_000_000)
+        W, c = self.model.Wmat.cpu().numpy(), self.model.c.cpu().numpy()
+        threads = int(cbuild.load().oracle_threads())
+        cbuild.mog_estep(self.host[:50_000], W, c)
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s or done == 0:
+            cbuild.mog_estep(self.host[:n], W, c)
+            done += 1
+        dt = time.perf_counter() - t0
+        return {"value": done * (n / self.rows) / dt, "unit": "updates/s (%d-row mini-batch)" % self.rows,
+                "cores": threads, "kind": "port",
+                "sample": "%d E-step passes over the first %d rows (scaled to the %d-row batch) in %.1f s: "
+                          "float64 C + OpenMP restatement (oracle/c); the parameter-sized steps are not "
+                          "timed" % (done, n, self.rows, dt)}
+
+
+class Cfg5(Workload):
+    """Hierarchical logistic regression, BBVI score-function gradient + control variate, S=64."""
+    name = "cfg5"
+    default_rows, default_samples = 1_000_000, 64
+    kernel_ms = 0.31
+
+    def __init__(self, args, ctx, torch, rank, world):
+        import numpy as np
+        from bayesic_amd.svi.bbvi import LogRegBBVI
+        self.ctx = ctx
+        D, G, S = args.dim, 1000, args.samples or self.default_samples
+        total = args.rows or self.default_rows
+        if args.scaling == "strong":
+            r0, r1 = rank_rows(total, rank, world)
+            global_rows, seed_off = total, 0
+        else:
+            r0, r1, global_rows, seed_off = 0, total, total * world, rank
+        rows = r1 - r0
+        Xh = _normal_f32(np, 1234 + seed_off, (r1, D))[r0:]
+        w_true = np.random.RandomState(1).standard_normal(D) / 16.0
+        b_true = np.random.RandomState(7).standard_normal(G) * 0.5
+        gh = np.random.RandomState(6 + 13 * seed_off).randint(G, size=r1).astype(np.int32)[r0:]
+        logits = Xh.astype(np.float64) @ w_true + b_true[gh]
+        yh = (np.random.RandomState(8 + 13 * seed_off).uniform(size=r1)[r0:] <
+              1.0 / (1.0 + np.exp(-logits))).astype(np.float32)
+        self.host = (Xh, yh, gh)
+        dev = ctx.device
+        self.X, self.y, self.g = (torch.from_numpy(a).to(dev) for a in (Xh, yh, gh))
+        self.rows, self.D, self.G, self.S = rows, D, G, S
+        self.n_total = float(global_rows)
+        self.model = LogRegBBVI(self.X, self.y, self.g, G, n_total=self.n_total, n_samples=S, seed=1234,
+                                lr=1e-3, ctx=ctx)
+        self.units_per_step = global_rows / 1e6 if args.scaling == "strong" else world * rows / 1e6
+        self.describe = ("cfg5: hierarchical logistic regression, %dx%d f32 mini-batch %s, G=%d groups, "
+                         "BBVI score-function gradient with control variate, S=%d, Adam"
+                         % (rows, D, "per GPU" if args.scaling == "weak" else "block of a global %d-row "
+                            "batch" % global_rows, G, S))
+        self.config = {"rows_per_gpu": rows, "global_rows": global_rows, "dim": D, "groups": G,
+                       "mc_samples": S}
+
+    def spin(self):
+        m = self.model
+        self.ctx.call("bsc_logreg_bbvi_loglik", m.X, m.X.stride(0), m.y, m.g, m.B, m.D, m.G, m.Wz, m.Bz,
+                      m.S, m.ell)
+
+    def step(self):
+        self.model.step()
+
+    def result(self):
+        return {"final_elbo": float(self.model.elbo.item())}
+
+    def roofline(self, avg_s):
+        # 32 flop/B: the fp32-MFMA time (209 us) exceeds the HBM time (129 us) -> MFMA binds
+        return _mfma_roofline("logreg_loglik_kernel", 2.0 * self.rows * self.D * self.S,
+                              4.0 * self.rows * self.D + 8.0 * self.rows, avg_s,
+                              pmc_traffic("logreg_loglik_kernel", self.rows == 1_000_000 and self.D == 256))
+
+    def cpu_baseline(self, budget_s):
+        from oracle import cbuild
+        Xh, yh, gh = self.host
+        n = min(self.rows, 200_000)
+        m = self.model
+        Wz = m.Wz.cpu().numpy().reshape(self.S, self.D)
+        Bz = m.Bz.cpu().numpy().reshape(self.G, self.S)
+        threads = int(cbuild.load().oracle_threads())
+        cbuild.logreg_loglik(Xh[:20_000], yh[:20_000], gh[:20_000], Wz, Bz)
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s or done == 0:
+            cbuild.logreg_loglik(Xh[:n], yh[:n], gh[:n], Wz, Bz)
+            done += 1
+        dt = time.perf_counter() - t0
+        return {"value": done * (n / self.rows) / dt * (self.rows / 1e6),
+                "unit": "updates/s (1M-row mini-batch)", "cores": threads, "kind": "port",
+                "sample": "%d log-likelihood passes over the first %d rows (scaled to 1M rows) in %.1f s: "
+                          "float64 C + OpenMP restatement (oracle/c)" % (done, n, dt)}
+
+
+class Cfg4(Workload):
+    """LDA-style Dirichlet-Multinomial, fixed-gamma local step, K=128 topics, V=100k words."""
+    name = "cfg4"
+    default_rows = 6_250          # documents per GPU (50 000 over 8 GPUs)
+    kernel_ms = 2.7
+
+    def __init__(self, args, ctx, torch, rank, world):
+        from bayesic_amd.svi.lda import LDAFixedGammaSVI
+        self.ctx = ctx
+        V, K = 100_000, 128
+        if args.scaling == "strong":
+            total = args.rows or 50_000
+            r0, r1 = rank_rows(total, rank, world)
+            docs, global_docs = r1 - r0, total
+        else:
+            docs = args.rows or self.default_rows
+            global_docs = docs * world
+        dev = ctx.device
+        # C ~ Poisson(0.05) (SURVEY 8(d): RandomState(5).poisson) drawn on the device: 2.5 GB per
+        # 6250-document shard is minutes of numpy; gamma, lambda as tools/bench_configs.py
+        g = torch.Generator(device=dev).manual_seed(5 + rank)
+        C = torch.empty((docs, V), device=dev)
+        for d0 in range(0, docs, 1024):
+            d1 = min(docs, d0 + 1024)
+            C[d0:d1] = torch.poisson(torch.full((d1 - d0, V), 0.05, device=dev), generator=g)
+        gp = torch.Generator(device=dev).manual_seed(17)
+        gamma = torch.rand((docs, K), generator=g, device=dev) + 0.5
+        lam = torch.rand((K, V), generator=gp, device=dev) + 0.5      # replicated: same on every rank
+        self.docs, self.V, self.K = docs, V, K
+        self.model = LDAFixedGammaSVI(C, gamma, lam, docs_total=float(global_docs), ctx=ctx)
+        self.units_per_step = 1.0 if args.scaling == "strong" else float(world)
+        self.describe = ("cfg4: LDA-style Dirichlet-Multinomial, %d docs x %d vocab f32 dense counts %s, "
+                         "K=%d, fixed-gamma local step + natural-gradient step (all-reduce of %d x %d f32)"
+                         % (docs, V, "per GPU" if args.scaling == "weak" else "block of %d docs" % global_docs,
+                            K, K, V))
+        self.config = {"docs_per_gpu": docs, "global_docs": global_docs, "vocab": V, "topics": K}
+
+    def spin(self):
+        self.model.local_step()
+
+    def step(self):
+        self.model.step()
+
+    def result(self):
+        return {"lambda_sum": float(self.model.lam.sum().item())}
+
+    def roofline(self, avg_s):
+        return _mfma_roofline("lda_sstats_kernel", 4.0 * self.docs * self.V * self.K,
+                              4.0 * self.docs * self.V, avg_s,
+                              pmc_traffic("lda_sstats_kernel", self.docs == 6250))
+
+    def cpu_baseline(self, budget_s):
+        from oracle import cbuild
+        m = self.model
+        n = min(self.docs, 64)
+        C, Th, Bt = m.C[:n].cpu().numpy(), m.Th[:n].cpu().numpy(), m.Bt.cpu().numpy()
+        threads = int(cbuild.load().oracle_threads())
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s or done == 0:
+            cbuild.lda_sstats(C, Th, Bt)
+            done += 1
+        dt = time.perf_counter() - t0
+        return {"value": done * (n / self.docs) / dt, "unit": "updates/s (%d-document shard)" % self.docs,
+                "cores": threads, "kind": "port",
+                "sample": "%d statistic passes over the first %d documents (scaled to %d) in %.1f s: "
+                          "float64 C + OpenMP restatement (oracle/c)" % (done, n, self.docs, dt)}
+
+
+WORKLOADS = {"cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4, "cfg5": Cfg5}
+
+
+def pmc_traffic(kernel, at_counted_size):
+    """HBM bytes per launch from the PMC pass recorded in profiles/pmc_traffic.json -- only when
+    the counters were taken at this problem size AND from the kernel source as it is now (the file
+    stores the sha1 of the .hip file the counted build came from)."""
+    if not at_counted_size:
+        return None
+    try:
+        import hashlib
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(kernel)
+        if not rec:
+            return None
+        src = os.path.join(ROOT, "bayesic_amd", "csrc", rec.get("source", ""))
+        if rec.get("source_sha1") and os.path.exists(src):
+            if hashlib.sha1(open(src, "rb").read()).hexdigest() != rec["source_sha1"]:
+                return None      # counters predate the current kernel: not this kernel's traffic
+        return rec.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    # rehearsal on a one-GPU box: BSC_BENCH_REHEARSAL=1 puts every rank on GPU 0 and uses gloo
-    # for the collective (RCCL needs one device per rank); numbers from it mean nothing
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # rehearsal on a one-GPU box: BSC_BENCH_REHEARSAL=1 puts every rank on GPU 0 and exchanges
+    # over gloo (RCCL needs one device per rank); numbers from it mean nothing
     rehearsal = os.environ.get("BSC_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # before the HSA runtime starts
+    import torch
+    import torch.distributed as dist
+
     torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if rehearsal:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=device)
+        # host channel only: unique id, barrier, max over ranks
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     from bayesic_amd.device import Context
-    from bayesic_amd.svi.blr import BLRReparamSVI
+    from bayesic_amd.svi.exchange import init_comm
 
     ctx = Context(local_rank)
-    X, y = make_data(torch, device, rank, args.rows, args.dim)
-    n_total = float(args.rows * world)  # the resident global batch is the data set
-    model = BLRReparamSVI(X, y, n_total=n_total, n_samples=args.samples, seed=1234, lr=1e-3,
-                          ctx=ctx, fused=not args.unfused)
+    if world > 1 and not rehearsal:
+        init_comm(ctx)
+    elif world == 1 and args.rccl_world1:
+        ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+    wl = WORKLOADS[args.config](args, ctx, torch, rank, world)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    # device spin-up (not steps: the model state is untouched, only the partial slab is written)
-    spin_launches = int(args.spin_up_ms / 0.17) if args.spin_up_ms > 0 else 0
+    # device spin-up (not steps: the model state is untouched)
+    spin_launches = int(args.spin_up_ms / wl.kernel_ms) if args.spin_up_ms > 0 else 0
     for _ in range(spin_launches):
-        ctx.call("bsc_blr_data_pass_partial", X, X.stride(0), y, args.rows, args.dim, model.W,
-                 args.samples if args.samples <= 8 else 8)
+        wl.spin()
     for _ in range(args.warmup):
-        model.step()
+        wl.step()
     torch.cuda.synchronize()
-    ctx.profile(0 if args.no_kernel_timing else max(1, args.time_every))
+    timing = not args.no_kernel_timing
+    ctx.profile(max(1, args.time_every) if timing else 0)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        model.step()
+        wl.step()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    pass_ms, launches = ctx.profile_read() if not args.no_kernel_timing else (0.0, 0)
+    in_region = {s: ctx.profile_read(s) for s in (0, 1, 2)} if timing else {}
     ctx.profile(0)
-    # what a kernel that only reads X achieves on THIS box (boxes differ by up to 20 %)
-    read_ceiling = ctx.read_probe(X) if rank == 0 else None
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    # dedicated burst AFTER the timed region: every launch of the dominant kernel timed on the
+    # launch stream, so roofline.avg_launch_us rests on >= 50 samples whatever --steps was
+    burst_ms, burst_n = 0.0, 0
+    if timing and args.burst > 0:
+        ctx.profile(1)
+        for _ in range(args.burst):
+            wl.spin()
+        burst_ms, burst_n = ctx.profile_read(0)
+        ctx.profile(0)
+    read_ceiling = ctx.read_probe(wl.X) if (rank == 0 and args.config == "cfg2") else None
+
+    t = torch.tensor([elapsed], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    elbo = float(model.elbo.item())
+    extra = wl.result()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * (args.rows / 1e6) * args.steps / elapsed
-        algo_bytes = 4.0 * args.rows * args.dim + 4.0 * args.rows  # X and y read once
-        launches_per_step = (args.samples + 7) // 8
+        value = wl.units_per_step * args.steps / elapsed
         roofline = None
-        if launches:
-            avg_s = pass_ms / launches * 1e-3
-            achieved = algo_bytes / avg_s / 1e9
-            traffic = None
-            # D == 256: the variant with the forward pass on the MFMA pipe (csrc/bsc_blr.hip)
-            kernel_name = "blr_pass_mfma_kernel" if args.dim == 256 and \
-                os.environ.get("BSC_BLR_TILE_ROWS", "16") == "16" else "blr_pass_kernel"
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
-                try:
-                    if args.rows == 1_000_000 and args.dim == 256:   # the size the counters were taken at
-                        traffic = json.load(open(pmc)).get(kernel_name, {}).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
-                        "avg_launch_us": avg_s * 1e6, "launches": launches,
-                        "timed_every": args.time_every,
-                        "launches_per_step": launches_per_step,
-                        "read_ceiling_this_box": read_ceiling,
-                        "frac_of_read_ceiling": achieved / read_ceiling if read_ceiling else None}
+        if burst_n:
+            avg_s = burst_ms / burst_n * 1e-3
+            roofline = wl.roofline(avg_s)
+            roofline.update({"avg_launch_us": avg_s * 1e6, "launches": burst_n,
+                             "timed": "burst of %d consecutive launches after the timed region, one "
+                                      "hipEvent pair each on the launch stream" % burst_n})
+            ms0, n0 = in_region.get(0, (0.0, 0))
+            if n0:
+                roofline["avg_launch_us_in_timed_region"] = ms0 / n0 * 1e3
+                roofline["launches_in_timed_region"] = n0
+            if read_ceiling:
+                roofline["read_ceiling_this_box"] = read_ceiling
+                roofline["frac_of_read_ceiling"] = roofline["achieved"] / read_ceiling
+        ms1, n1 = in_region.get(1, (0.0, 0))
+        ms2, n2 = in_region.get(2, (0.0, 0))
+        info = ctx.comm_info()
         out = {
             "metric": "ELBO-grad updates/sec (1M-row mini-batch)",
             "value": value,
-            "unit": "updates/s (1M-row mini-batch equivalents, all GPUs)",
+            "unit": "updates/s (1M-row mini-batch equivalents, all GPUs)" if args.config in ("cfg2", "cfg5")
+                    else "updates/s (whole-job mini-batch updates, all GPUs)",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {
-                "workload": "cfg2: Bayesian linear regression (Normal-InverseGamma), "
-                            "%dx%d f32 mini-batch per GPU, reparam-trick ELBO, S=%d, Adam"
-                            % (args.rows, args.dim, args.samples),
-                "rows_per_gpu": args.rows, "dim": args.dim, "mc_samples": args.samples,
-                "parallelism": "dp%d" % world,
-            },
+            "config": dict({"workload": wl.describe, "parallelism": "dp%d" % world}, **wl.config),
             "roofline": roofline,
+            "allreduce_us": (ms1 / n1 * 1e3) if n1 else None,
+            "finish_us": (ms2 / n2 * 1e3) if n2 else None,
+            "rccl_ranks": info["world"] if ctx.has_comm else 0,
+            "rccl_version": info["rccl_version"] if ctx.has_comm else None,
+            "exchange": ("rccl via bsc_allreduce_sum on the ctx stream" if ctx.has_comm else
+                         ("gloo (rehearsal: all ranks on one GPU)" if world > 1 else "none (one rank)")),
             "spin_up_launches": spin_launches,
-            "final_elbo": elbo,
         }
+        out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(X.cpu().numpy(), y.cpu().numpy(), args.samples,
-                                               n_total)
+            try:
+                out["cpu_baseline"] = wl.cpu_baseline(args.cpu_budget_s)
+            except Exception as e:
+                out["cpu_baseline"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    barrier()
+    ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -71,6 +71,37 @@ int bsc_memset(bsc_ctx* ctx, void* dst, int value, size_t bytes);
  * duration and the number of TIMED launches since the last read, and resets both. */
 int bsc_ctx_profile(bsc_ctx* ctx, int enable);
 int bsc_ctx_profile_read(bsc_ctx* ctx, double* host_total_ms, int64_t* host_launches);
+/* The same reading per timing slot: 0 = the dominant kernel (what bsc_ctx_profile_read
+ * returns), 1 = the collective of bsc_allreduce_sum, 2 = the finish kernel of
+ * bsc_blr_fused_update.  Every slot is sampled with the period given to bsc_ctx_profile. */
+int bsc_ctx_profile_read_slot(bsc_ctx* ctx, int slot, double* host_total_ms,
+                              int64_t* host_launches);
+
+/* ---- the exchange step of the data-parallel update: RCCL over xGMI -------------------
+ * (ABSENT in reference; README.md:69-79 mini-batch SVI)  Rows are iid
+ * (bayesic/distribution/base.py:146-172), every per-batch quantity is a SUM over rows, so
+ * rank r of p holds a row block and the ranks exchange ONE vector per update: the
+ * all-reduce(sum) of the concatenated statistic / gradient vector, after which every rank
+ * applies the identical update.  The communicator is an ncclComm_t owned by the context;
+ * the collective is enqueued on the context's own stream (pass -> all-reduce -> finish is
+ * one in-order queue).  librccl is bound at run time by the first bsc_comm_* call, so a
+ * single-GPU caller never maps it.
+ *
+ * bsc_comm_unique_id: rank 0 fills host_id[BSC_COMM_ID_BYTES] (ncclGetUniqueId) and hands
+ *   the bytes to the other ranks over any host channel (a file, MPI, torch.distributed's
+ *   store).  bsc_comm_init_rank: collective over all `world` ranks, synchronous; one
+ *   communicator per context; world == 1 is allowed (the RCCL path at world size 1).
+ *   bsc_comm_destroy is implied by bsc_ctx_destroy.
+ * bsc_allreduce_sum / _max: in place over buf[n] (BSC_F32 | BSC_F64) on the ctx stream;
+ *   on a context without a communicator they are the identity (a world of one). */
+#define BSC_COMM_ID_BYTES 128
+int bsc_comm_unique_id(void* host_id);
+int bsc_comm_init_rank(bsc_ctx* ctx, const void* host_id, int32_t rank, int32_t world);
+int bsc_comm_destroy(bsc_ctx* ctx);
+int bsc_comm_info(bsc_ctx* ctx, int32_t* host_rank, int32_t* host_world,
+                  int32_t* host_rccl_version);
+int bsc_allreduce_sum(bsc_ctx* ctx, void* buf, int64_t n, int dtype);
+int bsc_allreduce_max(bsc_ctx* ctx, void* buf, int64_t n, int dtype);
 
 /* hipEvent wrappers so a ctypes caller can time the ctx stream. */
 /* Measurement aid: best pure streaming-read rate (GB/s) over `buf` on this device, from

@@ -1,0 +1,78 @@
+"""bench.py's own launcher (no GPU here): `python bench.py --gpus N` without WORLD_SIZE must start
+N rank processes itself -- before importing torch or touching a GPU -- and exit non-zero, promptly,
+when a rank fails (here every rank fails: there is no GPU)."""
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bare_multi_gpu_invocation_spawns_ranks_and_reports_failure():
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("the failure leg needs a box without a GPU")
+    env = dict(os.environ, BSC_BENCH_TIMEOUT_S="240")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                           "--warmup", "1", "--rows", "1000"], env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=300)
+    err = proc.stderr.decode()
+    assert proc.returncode != 0
+    assert "bench.py: rank" in err and "exited with status" in err, err[-2000:]
+    assert "launch with torch.distributed.run" not in err
+    assert time.time() - t0 < 200
+
+
+def test_parent_does_not_import_torch_before_spawning():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src.split("def run_rank", 1)[0]
+    body = head.split("def spawn_ranks", 1)[1].split("\ndef ", 1)[0]
+    assert "import torch" not in body and "cuda" not in body
+    main = src.split("def main():", 1)[1]
+    assert main.index("spawn_ranks") < main.index("run_rank")
+
+
+def test_rank_rows_partition_is_contiguous_and_complete():
+    sys.path.insert(0, ROOT)
+    import bench
+    for total in (1_000_000, 999_983, 50_000):
+        for world in (1, 2, 4, 8):
+            cuts = [bench.rank_rows(total, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == total
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+    assert bench.rank_rows(1_000_000, 3, 8) == (375_000, 500_000)      # r*N/p
+
+
+def test_chunked_survey_inputs_equal_the_one_shot_stream():
+    """bench.py draws SURVEY 8(d)'s RandomState matrices in row chunks; a rank of a strong-scaling
+    run keeps rows [r0, r1) of the same stream."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import svi
+    X, y, _ = svi.make_cfg2(1001, 7)
+    got = bench._normal_f32(np, 1234, (1001, 7), chunk_rows=97)
+    np.testing.assert_array_equal(got, X)
+    np.testing.assert_array_equal(bench._normal_f32(np, 1234, (700, 7), chunk_rows=64), X[:700])
+
+
+def test_lowered_tree_baseline_equals_the_oracle_pass():
+    import numpy as np
+    from oracle import lowered_baseline as lb
+    from oracle import svi
+    X, y, _ = svi.make_cfg2(5000, 32)
+    W = (np.random.RandomState(0).standard_normal((4, 32)) / 16).astype(np.float32)
+    Q, G = lb.blr_data_pass_lowered(X, y, W)
+    Q0, G0 = svi.blr_data_pass(X, y, W)
+    np.testing.assert_allclose(Q, Q0, rtol=1e-5)                       # float32 BLAS vs float64
+    np.testing.assert_allclose(G, G0, rtol=1e-4, atol=1e-4 * np.abs(G0).max())
+    assert "_tensordot(W, _dimshuffle(X, 1, 0), [1], [0])" in lb.blr_pass_functions()["lowered"]
+    with lb.threads(1):
+        Q1, _ = lb.blr_data_pass_lowered(X, y, W)
+    np.testing.assert_allclose(Q1, Q0, rtol=1e-5)
+    assert lb.host_facts()["cpu_count"] == os.cpu_count()
