@@ -80,6 +80,8 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
         if (v >= 1 && v <= 64) ctx->fused_waves_per_cu = v;
     }
     if (const char* e = getenv("BSC_BBVI_WAVES")) ctx->bbvi_waves = atoi(e) == 8 ? 8 : 4;
+    if (const char* e = getenv("BSC_BBVI_KERNEL")) ctx->bbvi_kernel = atoi(e);
+    if (const char* e = getenv("BSC_BBVI_DBG")) ctx->bbvi_dbg = atoi(e);
     if (const char* e = getenv("BSC_CSC_FAST")) ctx->csc_fast = atoi(e) != 0;
     if (const char* e = getenv("BSC_WO_WG_PER_CU")) {
         const int v = atoi(e);

@@ -229,6 +229,497 @@ __global__ __launch_bounds__(64 * NW, 2) void logreg_loglik_kernel(
         slab[((int64_t)blockIdx.x * (NW / 4) + (wave >> 2)) * LS + 16 * sb + lane] = (float)acc_ll;
 }
 
+// ---- second generation: a wave owns rows, the draws live in LDS -----------------------------
+// The kernel above stages X tiles in LDS (a store, a workgroup barrier and an A-operand read per
+// tile) and keeps the draws in registers.  What its time is made of was measured this round:
+//   * fp32 MFMA and VALU share the SIMD's issue: every VALU instruction between MFMAs costs the
+//     matrix pipe ~4.6 cycles (profiles/r01_ubench_mfma_valu_mix.txt);
+//   * a vector load that RETURNS TO REGISTERS costs the issuing SIMD ~115 cycles of MFMA time,
+//     whatever its width (a dword gather as much as a 1-KiB dwordx4), an LDS-DMA
+//     (buffer_load ... lds) ~45 (tools/ubench_mfma_vmem.hip, profiles/r02_ubench_mfma_vmem.txt);
+//     the 32-row tile of the first kernel took 8 + 8 such loads per wave and 128 MFMAs.
+// Both kernels below give a wave 16-row tiles of X for ALL sample blocks:
+//   * the S <= 128 draws Wz (static for the whole launch) are written ONCE to LDS in exactly the
+//     order the MFMA B operand is read: block (sb, j) = 1 KiB, lane l's 16 bytes at l*16 --
+//     every ds_read_b128 is conflict-free, no padding, no per-tile stores, no barrier per tile;
+//   * lane i16 owns the NSB consecutive samples NSB i16 .. NSB i16 + NSB - 1, so the intercepts
+//     b[g_n, s] of a row are ONE 4 NSB-byte gather per lane (the first kernel: one dword gather
+//     per row and sample block), and they enter as the MFMA's C input (the C layout is the
+//     result layout): l = x.w + b costs no add;
+//   * epilogue on packed f32 math with two transcendentals per element:
+//       y l - softplus(l) = y l - (l + |l|)/2 - ln2 log2(1 + 2^(-|l| log2 e)),
+//     the four rows a lane holds per sample share ONE v_log_f32 (log2 of the product of their
+//     (1 + t) in (1, 16]); sums of y l, l, |l| run on v_pk_fma/add_f32;
+//   * waves never synchronise; a wave leaves the loop as soon as its tiles are done.
+constexpr int XT = 16;        // rows per wave tile
+constexpr int XW = 8;         // waves per workgroup (2 per SIMD, one workgroup per CU)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+// s_waitcnt immediate (gfx9 layout) that waits for vmcnt <= n only: vmcnt = [3:0] and [15:14],
+// expcnt [6:4] and lgkmcnt [11:8] left at "no wait"
+constexpr int vmcnt_only(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
+
+// descriptors that cover exactly the rows left from `row0` on: rows past N read as zero
+__device__ __forceinline__ auto x_tile_rsrc(const float* X, int64_t ldx, int D, int64_t N, int64_t row0) {
+    const int64_t rem = N - row0;
+    uint64_t xb = 0;
+    if (rem > 0) xb = ((uint64_t)(rem - 1) * (uint64_t)ldx + (uint64_t)D) * 4u;
+    const unsigned rec = xb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)xb;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(X + (rem > 0 ? row0 : 0) * ldx), 0, rec, 0x00020000);
+}
+__device__ __forceinline__ auto row_vec_rsrc(const void* base, int64_t N, int64_t row0) {   // y or g: 4 B per row
+    const int64_t rem = N - row0;
+    const uint64_t b = rem > 0 ? (uint64_t)rem * 4u : 0;
+    const unsigned rec = b > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)b;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + (rem > 0 ? row0 : 0) * 4), 0, rec, 0x00020000);
+}
+
+// One tile's epilogue: acc[sb][r] = logit of row 4 kq + r, sample NSB i16 + sb; yv = y of those rows.
+// Adds sum_r (y l - softplus(l)) per sample block to acc_ll (float64).
+template <int NSB>
+__device__ __forceinline__ void loglik_epilogue(const f32x4 (&acc)[NSB], const f32x4 yv, bool whole, int64_t row0,
+                                                int64_t N, int kq, double (&acc_ll)[NSB]) {
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    if (whole) {
+        const f32x2 y01 = {yv[0], yv[1]}, y23 = {yv[2], yv[3]};
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) {
+            const f32x4 l = acc[sb];
+            const f32x2 l01 = {l[0], l[1]}, l23 = {l[2], l[3]};
+            f32x2 u01, u23, t01, t23;
+            u01[0] = -LOG2E * __builtin_fabsf(l[0]); u01[1] = -LOG2E * __builtin_fabsf(l[1]);
+            u23[0] = -LOG2E * __builtin_fabsf(l[2]); u23[1] = -LOG2E * __builtin_fabsf(l[3]);
+            t01[0] = __builtin_amdgcn_exp2f(u01[0]); t01[1] = __builtin_amdgcn_exp2f(u01[1]);
+            t23[0] = __builtin_amdgcn_exp2f(u23[0]); t23[1] = __builtin_amdgcn_exp2f(u23[1]);
+            f32x2 p = t01 + 1.0f;                                   // (1 + t0, 1 + t1)
+            p = __builtin_elementwise_fma(p, t23, p);               // * (1 + t2), * (1 + t3)
+            const float g2 = __builtin_amdgcn_logf(p[0] * p[1]);    // log2 of the product, in (0, 4]
+            f32x2 yl = y01 * l01;
+            yl = __builtin_elementwise_fma(y23, l23, yl);
+            const f32x2 sl = l01 + l23;                             // sum l
+            const f32x2 su = u01 + u23;                             // -log2e sum |l|
+            // y l - (l + |l|)/2 - ln2 g2
+            f32x2 v = __builtin_elementwise_fma(sl, f32x2{-0.5f, -0.5f}, yl);
+            v = __builtin_elementwise_fma(su, f32x2{0.5f * LN2, 0.5f * LN2}, v);
+            acc_ll[sb] += (double)(__builtin_fmaf(-LN2, g2, v[0] + v[1]));
+        }
+    } else {       // (wave-uniform) the tile that holds row N: rows past it count nothing
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) {
+            float tile_ll = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float l = acc[sb][r];
+                const float g2 = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-__builtin_fabsf(l) * LOG2E));
+                float v = __builtin_fmaf(yv[r], l, -fmaxf(l, 0.f));
+                v = __builtin_fmaf(-LN2, g2, v);
+                if (row0 + 4 * kq + r >= N) v = 0.f;
+                tile_ll += v;
+            }
+            acc_ll[sb] += (double)tile_ll;
+        }
+    }
+}
+
+// The wave's per-sample sums -> one float64 row of the slab per workgroup (fixed order).
+template <int NSB>
+__device__ __forceinline__ void loglik_finish(const double (&acc_ll)[NSB], double (*red)[16 * NSB], int wave,
+                                              int lane, int tid, int S, double* __restrict__ slab) {
+    // lanes with the same samples (lane & 15) hold different rows: fold bits 4, 5; then the
+    // workgroup's waves in a fixed order
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) {
+        double v = acc_ll[sb];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 16) red[wave][NSB * lane + sb] = v;
+    }
+    __syncthreads();
+    if (tid < 16 * NSB && tid < S) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < XW; ++w) v += red[w][tid];
+        slab[(int64_t)blockIdx.x * S + tid] = v;
+    }
+}
+
+// ---- X through VGPRs (any NSB <= 8; the S > 64 path, and the A/B partner of the DMA kernel) ----
+// A wave loads its tile straight into the A operand layout: lane (i, kq) holds
+// X[row i][16 j + 4 kq .. +3] for j = 0..15 (sixteen 16-byte buffer loads; the four kq lanes of a
+// row read 64 contiguous bytes).  Register set j is refilled for the NEXT tile as soon as its last
+// MFMA has issued, so 64 VGPRs hold the tile and the prefetch.
+// DBG != 0: deletion builds for profiling only (results wrong): bit 0 drops the X refill loads,
+// bit 1 the epilogue, bit 2 the LDS operand reads, bit 3 the intercept / y / id loads.
+template <bool FULL, int NSB, int DBG = 0>   // FULL: D == 256; NSB: 16-sample blocks (S <= 16 NSB)
+__global__ __launch_bounds__(64 * XW, 2) void logreg_loglik_xreg_kernel(
+    const float* __restrict__ X, int64_t ldx, const float* __restrict__ y,
+    const int* __restrict__ g, int64_t N, int D, const float* __restrict__ Wz,
+    const float* __restrict__ Bz, int n_groups, int S, double* __restrict__ slab, int n_iter) {
+    __shared__ __attribute__((aligned(16))) f32x4 wl[NSB * 16 * 64];   // [sb][j][lane] -> 4 columns
+    __shared__ double red[XW][16 * NSB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+
+    for (int idx = tid; idx < NSB * 16 * 64; idx += 64 * XW) {
+        const int ln = idx & 63, j = (idx >> 6) & 15, sb = idx >> 10;
+        const int sample = NSB * (ln & 15) + sb, col = 16 * j + 4 * (ln >> 4);
+        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+        if (sample < S && col < D) w = *reinterpret_cast<const f32x4*>(Wz + (int64_t)sample * D + col);
+        wl[idx] = w;
+    }
+    __syncthreads();
+
+    const int64_t n_waves = (int64_t)gridDim.x * XW;
+    int64_t tile = (int64_t)blockIdx.x * XW + wave;
+    const int x_voff = i16 * (int)(ldx * 4) + 16 * kq;
+    auto x_load = [&](decltype(x_tile_rsrc(X, ldx, D, N, 0)) rs, int j) {
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, x_voff, 64 * j, 2);   // nt: X is read once
+        f32x4 f = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+        if (!FULL && 16 * j + 4 * kq >= D) f = f32x4{0.f, 0.f, 0.f, 0.f};
+        return f;
+    };
+    // Bz[g, s] through a buffer descriptor: 32-bit offsets, ids outside [0, n_groups) read 0
+    const auto bz_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Bz, 0, (unsigned)n_groups * (unsigned)S * 4u,
+                                                           0x00020000);
+    const int row_b = S * 4;
+    struct Side {          // what the epilogue / the next tile's C input need, per tile
+        f32x4 yv;          // y of rows 4 kq .. 4 kq + 3
+        f32x4 bz[NSB];     // intercepts [sample block][row]
+    };
+    int gi[4];             // group-id byte offsets of the tile after next
+    auto g_load = [&](int64_t row0) {
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(row_vec_rsrc(g, N, row0), 16 * kq, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gi[r] = (int)v[r] * row_b;
+    };
+    auto side_load = [&](Side& sd, int64_t row0) {      // uses gi = ids of this tile
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(row_vec_rsrc(y, N, row0), 16 * kq, 0, 0);
+        sd.yv = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+        // (padded samples >= S read the neighbouring bytes or 0; their W is 0 and they are never stored)
+        const int soff = 4 * NSB * i16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if constexpr (NSB == 1) {
+                sd.bz[0][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bz_rsrc, gi[r] + soff, 0, 0));
+            } else if constexpr (NSB == 2) {
+                auto w = __builtin_amdgcn_raw_buffer_load_b64(bz_rsrc, gi[r] + soff, 0, 0);
+                sd.bz[0][r] = __uint_as_float(w[0]);
+                sd.bz[1][r] = __uint_as_float(w[1]);
+            } else {
+#pragma unroll
+                for (int h = 0; h < NSB / 4; ++h) {
+                    auto w = __builtin_amdgcn_raw_buffer_load_b128(bz_rsrc, gi[r] + soff + 16 * h, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) sd.bz[4 * h + c][r] = __uint_as_float(w[c]);
+                }
+            }
+        }
+    };
+
+    f32x4 A[16];
+    {
+        const auto rs = x_tile_rsrc(X, ldx, D, N, tile * XT);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) A[j] = x_load(rs, j);
+    }
+    Side sa, sb_;
+    g_load(tile * XT);
+    side_load(sa, tile * XT);
+    g_load((tile + n_waves) * XT);
+
+    double acc_ll[NSB];
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) acc_ll[sb] = 0.0;
+
+    auto one_tile = [&](const Side& cur, Side& nxt) {
+        const int64_t row0 = tile * XT;
+        const auto rs_next = x_tile_rsrc(X, ldx, D, N, (tile + n_waves) * XT);
+        f32x4 acc[NSB];
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) acc[sb] = cur.bz[sb];          // C input = intercepts
+        // next tile's y and intercepts (its ids arrived a tile ago) and the ids of the tile after,
+        // requested FIRST: they are then older than the 16 refill loads below, so the next tile's
+        // first MFMA (which takes the intercepts as its C input) waits for nothing recent
+        if (!(DBG & 8)) {
+            side_load(nxt, (tile + n_waves) * XT);
+            g_load((tile + 2 * n_waves) * XT);
+        }
+        // The draws in LDS never change, so the compiler would hoist all 16 NSB operand reads out
+        // of the tile loop (and spill them): the address is made opaque once per tile.  B operands
+        // run one k-group ahead of the MFMAs that consume them.
+        int wo = lane;          // (an integer, so the reads stay ds_read: an opaque POINTER would turn them flat)
+        asm volatile("" : "+v"(wo));
+        const f32x4* wp = wl + wo;
+        f32x4 bn[NSB];
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) bn[sb] = wp[(sb * 16) * 64];
+        __builtin_amdgcn_sched_group_barrier(0x100, NSB, 0);             // the reads of group 0
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            f32x4 b[NSB];
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) b[sb] = bn[sb];
+            if (j + 1 < 16 && !(DBG & 4)) {
+#pragma unroll
+                for (int sb = 0; sb < NSB; ++sb) bn[sb] = wp[(sb * 16 + j + 1) * 64];
+            }
+            const f32x4 a = A[j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int sb = 0; sb < NSB; ++sb)
+                    acc[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[sb][r], acc[sb], 0, 0, 0);
+            if (!(DBG & 1)) A[j] = x_load(rs_next, j);                   // refill for the next tile
+            if (j + 1 < 16 && !(DBG & 4)) __builtin_amdgcn_sched_group_barrier(0x100, NSB, 0);   // LDS reads of group j+1 ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NSB, 0);               // ... the MFMAs of group j ...
+            if (!(DBG & 1)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // ... the refill load
+        }
+        if (DBG & 2) {
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) acc_ll[sb] += (double)(acc[sb][0] + acc[sb][1] + acc[sb][2] + acc[sb][3]);
+        } else {
+            loglik_epilogue<NSB>(acc, cur.yv, row0 + XT <= N, row0, N, kq, acc_ll);
+        }
+        tile += n_waves;
+    };
+    for (int it = 0; it < n_iter; it += 2) {   // n_iter is even (host)
+        if (tile * XT >= N) break;             // (wave-uniform) nothing left for this wave
+        one_tile(sa, sb_);
+        if (tile * XT >= N) break;
+        one_tile(sb_, sa);
+    }
+    loglik_finish<NSB>(acc_ll, red, wave, lane, tid, S, slab);
+}
+
+// ---- X by LDS-DMA (NSB <= 4: the default up to S = 64) ------------------------------------------
+// Nothing a tile needs passes through a VGPR-returning load.  Each wave owns in LDS
+//   * a ring of XR 1-KiB slots: strip j of a tile (16 rows x 64 B = the A-operand block of
+//     k-group j: lane l's 16 bytes land at slot + 16 l) is DMA'd XR strips ahead of its use and
+//     read back with one conflict-free ds_read_b128;
+//   * y and the group ids of the next tiles (a 256-B dword DMA each: lane l <- row0 + l);
+//   * the 4-KiB block of intercepts b[g_row, NSB i16 ..] of the next tile, gathered by four
+//     dwordx4 DMAs whose per-lane offsets come from the ids, read back as the MFMA's C input.
+// LDS-DMA completes in issue order and is covered ONLY by the issuing wave's vmcnt; the compiler
+// cannot tell the slots apart and would wait for vmcnt(0) at every ds_read it can see next to a
+// DMA in flight, so (1) every read of DMA'd bytes is inline asm, paired with a hand-placed
+// lgkmcnt(0) a k-group later, and (2) strip waits are counted by hand (see DMA_WAIT).  With four
+// sample blocks the draws of block 0 stay in 64 registers, so that W (48 KiB) + 8 waves x 13 KiB
+// fit the CU's 160 KiB; it also saves one of the four B-operand reads per k-group.
+constexpr int XR = 8;         // ring slots per wave (divides 16: the slot of strip j is j % XR)
+constexpr int DMA_SIDE = 6;   // vector-memory operations a tile issues before its first strip wait
+constexpr int DMA_WAVE_BYTES = XR * 1024 + 4096 + 4 * 256;   // ring | intercepts | y[2] | ids[2]
+
+template <bool FULL, int NSB, int DBG = 0>
+__global__ __launch_bounds__(64 * XW, 2) void logreg_loglik_dma_kernel(
+    const float* __restrict__ X, int64_t ldx, const float* __restrict__ y,
+    const int* __restrict__ g, int64_t N, int D, const float* __restrict__ Wz,
+    const float* __restrict__ Bz, int n_groups, int S, double* __restrict__ slab, int n_iter) {
+    static_assert(NSB == 1 || NSB == 2 || NSB == 4, "eight sample blocks of draws and the rings do not fit 160 KiB");
+    constexpr int WREG = NSB == 4 ? 1 : 0;          // sample blocks whose draws stay in registers
+    constexpr int NL = NSB - WREG;                  // sample blocks read from LDS
+    __shared__ __attribute__((aligned(16))) f32x4 wl[NL * 16 * 64];   // [sb - WREG][j][lane] -> 4 columns
+    __shared__ __attribute__((aligned(16))) char dma[XW * DMA_WAVE_BYTES];
+    __shared__ double red[XW][16 * NSB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+
+    for (int idx = tid; idx < NL * 16 * 64; idx += 64 * XW) {
+        const int ln = idx & 63, j = (idx >> 6) & 15, sb = (idx >> 10) + WREG;
+        const int sample = NSB * (ln & 15) + sb, col = 16 * j + 4 * (ln >> 4);
+        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+        if (sample < S && col < D) w = *reinterpret_cast<const f32x4*>(Wz + (int64_t)sample * D + col);
+        wl[idx] = w;
+    }
+    f32x4 wreg[WREG ? 16 : 1];      // draws of sample NSB i16 + 0: [j] -> columns 16 j + 4 kq .. +3
+    if constexpr (WREG) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int sample = NSB * i16, col = 16 * j + 4 * kq;
+            wreg[j] = (sample < S && col < D) ? *reinterpret_cast<const f32x4*>(Wz + (int64_t)sample * D + col)
+                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
+
+    const int64_t n_waves = (int64_t)gridDim.x * XW;
+    int64_t tile = (int64_t)blockIdx.x * XW + wave;
+    const int x_voff = i16 * (int)(ldx * 4) + 16 * kq;
+    char* const my = dma + wave * DMA_WAVE_BYTES;                       // this wave's DMA region
+    const unsigned my_addr = (unsigned)(uintptr_t)(lds_ptr)my;
+    constexpr int BZ_OFF = XR * 1024, Y_OFF = BZ_OFF + 4096, G_OFF = Y_OFF + 512;
+
+    // ---- the DMAs (every one counts in vmcnt, in this order) ----
+    auto x_dma = [&](decltype(x_tile_rsrc(X, ldx, D, N, 0)) rs, int j) {            // strip j -> slot j % XR
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(my + (j % XR) * 1024), 16, x_voff, 64 * j, 0, 2);
+    };
+    auto row_dma = [&](const void* base, int64_t row0, int lds_off) {              // lane l <- 4 bytes of row0 + l
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(row_vec_rsrc(base, N, row0), (lds_ptr)(my + lds_off), 4, 4 * lane, 0, 0, 0);
+    };
+    const auto bz_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Bz, 0, (unsigned)n_groups * (unsigned)S * 4u,
+                                                           0x00020000);
+    const int row_b = S * 4, soff = 4 * NSB * i16;
+    auto bz_dma = [&](const f32x4 ids) {    // ids (as int bits) of rows 4 kq .. +3 -> intercepts [r][lane][NSB]
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(bz_rsrc, (lds_ptr)(my + BZ_OFF + r * 1024), 16,
+                                                     __float_as_int(ids[r]) * row_b + soff, 0, 0, 0);
+    };
+    // ---- reads of DMA'd bytes: inline asm (see the header), valid after lds_ready() ----
+    const unsigned addr_lane = my_addr + 16u * lane;     // lane l's 16 bytes of a 1-KiB block
+    const unsigned addr_kq = my_addr + 16u * kq;         // the 4 rows 4 kq .. 4 kq + 3 of a row vector
+#define BSC_LDS_B128(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+    auto a_read = [&](int j) {
+        f32x4 f;
+        BSC_LDS_B128(f, addr_lane, (j % XR) * 1024);
+        return f;
+    };
+
+    // ---- prologue: strips 0 .. XR-1, y, ids and intercepts of the first tile, ids of the second ----
+    {
+        const auto rs = x_tile_rsrc(X, ldx, D, N, tile * XT);
+#pragma unroll
+        for (int j = 0; j < XR; ++j) x_dma(rs, j);
+    }
+    row_dma(y, tile * XT, Y_OFF);
+    row_dma(g, tile * XT, G_OFF);
+    row_dma(g, (tile + n_waves) * XT, G_OFF + 256);
+    __builtin_amdgcn_s_waitcnt(vmcnt_only(0));
+    asm volatile("" ::: "memory");
+    {
+        f32x4 ids;
+        BSC_LDS_B128(ids, addr_kq, G_OFF);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+        bz_dma(ids);
+    }
+    __builtin_amdgcn_s_waitcnt(vmcnt_only(0));
+    asm volatile("" ::: "memory");
+    f32x4 an = a_read(0);           // the A operand of the next k-group, read one group ahead
+
+    double acc_ll[NSB];
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) acc_ll[sb] = 0.0;
+
+    // LDS -> registers for the tile of parity `par`: its intercepts q[r] (lane l's 16 bytes = samples
+    // NSB i16 .., the first NSB count), its y, and the ids of the tile after it.  Valid after the
+    // next lgkmcnt(0).
+    f32x4 q[4], yv_n, ids_n;
+    auto side_read = [&](int par) {
+        BSC_LDS_B128(q[0], addr_lane, BZ_OFF);
+        BSC_LDS_B128(q[1], addr_lane, BZ_OFF + 1024);
+        BSC_LDS_B128(q[2], addr_lane, BZ_OFF + 2048);
+        BSC_LDS_B128(q[3], addr_lane, BZ_OFF + 3072);
+        if (par) {
+            BSC_LDS_B128(yv_n, addr_kq, Y_OFF + 256);
+            BSC_LDS_B128(ids_n, addr_kq, G_OFF);
+        } else {
+            BSC_LDS_B128(yv_n, addr_kq, Y_OFF);
+            BSC_LDS_B128(ids_n, addr_kq, G_OFF + 256);
+        }
+    };
+    side_read(0);
+
+    // `par` = parity of the tile within this wave's sequence (y and ids are double-buffered)
+    auto one_tile = [&](int par) {
+        const int64_t row0 = tile * XT;
+        const auto rs_cur = x_tile_rsrc(X, ldx, D, N, row0);
+        const auto rs_next = x_tile_rsrc(X, ldx, D, N, (tile + n_waves) * XT);
+        // this tile's intercepts (C input) and y and the next tile's ids were requested from LDS
+        // before the previous tile's epilogue (side_read): back long ago, the wait is for the compiler
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[NSB];
+        const f32x4 yv = yv_n, ids_next = ids_n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) acc[sb][r] = q[r][sb];
+        }
+        // side DMAs of the tiles ahead, FIRST (DMA_SIDE = 6 of them): older than this tile's strips,
+        // so the last strip wait of this tile also covers them
+        if (!(DBG & 8)) {
+            row_dma(y, (tile + n_waves) * XT, Y_OFF + (par ^ 1) * 256);
+            row_dma(g, (tile + 2 * n_waves) * XT, G_OFF + par * 256);
+            bz_dma(ids_next);
+        }
+        int wo = lane;          // opaque once per tile: keeps the static B-operand reads inside the loop
+        asm volatile("" : "+v"(wo));
+        const f32x4* wp = wl + wo;
+        f32x4 bn[NL];
+#pragma unroll
+        for (int sb = 0; sb < NL; ++sb) bn[sb] = wp[(sb * 16) * 64];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            // `an` was read a k-group ago, like this group's B operands: the wait finds them done --
+            // placed BEFORE the next group's reads are issued, or it would wait for those as well.
+            // The builtin (0xC07F = lgkmcnt(0) alone), so that the compiler's own bookkeeping knows
+            // its B reads are back: with an asm wait it would add lgkmcnt(N) waits that count the
+            // asm read it cannot see, and stall on the reads just issued.
+            if (j > 0) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            f32x4 b[NSB];
+            if constexpr (WREG) b[0] = wreg[j];
+#pragma unroll
+            for (int sb = 0; sb < NL; ++sb) b[sb + WREG] = bn[sb];
+            if (j + 1 < 16 && !(DBG & 4)) {
+#pragma unroll
+                for (int sb = 0; sb < NL; ++sb) bn[sb] = wp[(sb * 16 + j + 1) * 64];
+            }
+            f32x4 a = an;
+            if (!FULL && 16 * j + 4 * kq >= D) a = f32x4{0.f, 0.f, 0.f, 0.f};
+            // DMA_WAIT: strip j+1 (of the next tile for j = 15) must have landed.  LDS-DMA completes
+            // in issue order, so "at most as many outstanding as were issued after it": a strip issued
+            // in the previous tile (j+1 < XR) is followed by the rest of that batch, this tile's side
+            // DMAs and this tile's j strips = XR - 2 + DMA_SIDE; one issued in this tile by XR - 2.
+            if (j + 1 < XR) __builtin_amdgcn_s_waitcnt(vmcnt_only(XR - 2 + ((DBG & 8) ? 0 : DMA_SIDE)));
+            else __builtin_amdgcn_s_waitcnt(vmcnt_only(XR - 2));
+            asm volatile("" ::: "memory");
+            if (!(DBG & 4)) an = a_read((j + 1) % 16);
+            // MFMAs have no memory semantics and would float above the asm read (and the next group's
+            // lgkmcnt wait would then sit right behind it): pin "reads, then MFMAs, then the DMA"
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int sb = 0; sb < NSB; ++sb)
+                    acc[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[sb][r], acc[sb], 0, 0, 0);
+            // slot j % XR is free (its strip is in `a`): strip j + XR
+            if (!(DBG & 1)) {
+                if (j + XR < 16) x_dma(rs_cur, j + XR);
+                else x_dma(rs_next, j + XR - 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the next tile's side data: its DMAs were this tile's first, and the last strip wait
+        // (vmcnt <= XR - 2) has covered them; the epilogue below covers the LDS latency
+        if (!(DBG & 8)) side_read(par ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (DBG & 2) {
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) acc_ll[sb] += (double)(acc[sb][0] + acc[sb][1] + acc[sb][2] + acc[sb][3]);
+        } else {
+            loglik_epilogue<NSB>(acc, yv, row0 + XT <= N, row0, N, kq, acc_ll);
+        }
+        tile += n_waves;
+    };
+    for (int it = 0; it < n_iter; it += 2) {   // n_iter is even (host)
+        if (tile * XT >= N) break;             // (wave-uniform) nothing left for this wave
+        one_tile(0);
+        if (tile * XT >= N) break;
+        one_tile(1);
+    }
+    // no LDS-DMA of this wave may still be in flight when the workgroup's LDS is released
+    __builtin_amdgcn_s_waitcnt(vmcnt_only(0));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    loglik_finish<NSB>(acc_ll, red, wave, lane, tid, S, slab);
+#undef BSC_LDS_B128
+}
+
 // ell[s] = sum over the block partials, float64, fixed order.  One wave per sample (a single
 // 1024-thread workgroup walking all 64 columns took 10 us, mostly latency: a third of what the
 // whole parameter side of an update costs).
@@ -238,6 +729,19 @@ __global__ __launch_bounds__(256) void loglik_reduce_kernel(const float* __restr
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     double sum = 0.0;
     for (int b = lane; b < n_rows; b += 64) sum += (double)slab[(int64_t)b * LS + s];
+    sum = wave_allsum_f64(sum);
+    if (lane == 0) ell[s] = sum;
+}
+
+// The same for the float64 workgroup partials of logreg_loglik_xreg_kernel and any S.
+__global__ __launch_bounds__(256) void loglik_reduce_f64_kernel(const double* __restrict__ slab,
+                                                                int n_rows, int S,
+                                                                double* __restrict__ ell) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= S) return;
+    double sum = 0.0;
+    for (int b = lane; b < n_rows; b += 64) sum += slab[(int64_t)b * S + s];
     sum = wave_allsum_f64(sum);
     if (lane == 0) ell[s] = sum;
 }
@@ -416,46 +920,103 @@ int bsc_logreg_bbvi_loglik(bsc_ctx* ctx, const float* X, int64_t ldx, const floa
     BSC_CHECK_CTX(ctx);
     BSC_REQUIRE(N >= 0 && ((X && y && g) || N == 0) && Wz && Bz && ell,
                 "bsc_logreg_bbvi_loglik: null pointer");
-    if (S != LS || D < 4 || D > LD || (D % 4) != 0)
+    if (S < 1 || S > 128 || D < 4 || D > LD || (D % 4) != 0)
         return bsc_fail(BSC_ERR_UNSUPPORTED,
-                        "bsc_logreg_bbvi_loglik: needs S == %d and D %% 4 == 0 in [4,%d] (got S=%d D=%d)",
-                        LS, LD, S, D);
+                        "bsc_logreg_bbvi_loglik: needs 1 <= S <= 128 and D %% 4 == 0 in [4,%d] (got S=%d D=%d)",
+                        LD, S, D);
     BSC_REQUIRE(n_groups >= 1, "bsc_logreg_bbvi_loglik: n_groups=%d", n_groups);
-    if (n_groups > (1 << 22))
+    if ((int64_t)n_groups * S > ((int64_t)1 << 28))
         return bsc_fail(BSC_ERR_UNSUPPORTED,
-                        "bsc_logreg_bbvi_loglik: n_groups=%d exceeds the 32-bit gather range (4M groups)",
-                        n_groups);
+                        "bsc_logreg_bbvi_loglik: n_groups * S = %lld exceeds the 32-bit gather range (2^28)",
+                        (long long)n_groups * S);
     BSC_REQUIRE(ldx >= D && ldx % 4 == 0 && ldx < ((int64_t)1 << 26),
                 "bsc_logreg_bbvi_loglik: bad ldx=%lld", (long long)ldx);
-    BSC_REQUIRE(((uintptr_t)X & 15) == 0, "bsc_logreg_bbvi_loglik: X must be 16-byte aligned");
-    const int64_t n_tiles = (N + LT - 1) / LT;
-    const int64_t max_blocks = 2 * (int64_t)ctx->cu_count;
-    int n_iter = 0, n_blocks = 1;
-    if (n_tiles > 0) {
-        const int64_t it = (n_tiles + max_blocks - 1) / max_blocks;
-        n_iter = (int)(it + (it & 1));   // even: the kernel alternates two register sets per tile pair
-        n_blocks = (int)((n_tiles + it - 1) / it);
-    }
-    void* ws = nullptr;
-    const int nw = ctx->bbvi_waves == 8 ? 8 : 4;   // 8 measured 1 % slower (346 vs 342 us): kept as a knob
-    int rc = bsc_workspace(ctx, (size_t)n_blocks * (nw / 4) * LS * sizeof(float), &ws);
-    if (rc != BSC_OK) return rc;
-    ctx->slab_rows = 0;
-    {
-        bsc_prof_scope prof(ctx);
+    BSC_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)Wz & 15) == 0 && (N == 0 || ((uintptr_t)y & 15) == 0) &&
+                    (N == 0 || ((uintptr_t)g & 15) == 0),
+                "bsc_logreg_bbvi_loglik: X, y, g and Wz must be 16-byte aligned");
+    if (ctx->bbvi_kernel == 0 && S == LS) {
+        // first-generation kernel (X tiles staged in LDS, draws in registers): kept for in-process A/B
+        const int64_t n_tiles = (N + LT - 1) / LT;
+        const int64_t max_blocks = 2 * (int64_t)ctx->cu_count;
+        int n_iter = 0, n_blocks = 1;
+        if (n_tiles > 0) {
+            const int64_t it = (n_tiles + max_blocks - 1) / max_blocks;
+            n_iter = (int)(it + (it & 1));   // even: the kernel alternates two register sets per tile pair
+            n_blocks = (int)((n_tiles + it - 1) / it);
+        }
+        void* ws = nullptr;
+        const int nw = ctx->bbvi_waves == 8 ? 8 : 4;   // 8 measured 1 % slower (346 vs 342 us): kept as a knob
+        int rc = bsc_workspace(ctx, (size_t)n_blocks * (nw / 4) * LS * sizeof(float), &ws);
+        if (rc != BSC_OK) return rc;
+        ctx->slab_rows = 0;
+        {
+            bsc_prof_scope prof(ctx);
 #define BSC_LL(FULL, NW)                                                                         \
     hipLaunchKernelGGL((logreg_loglik_kernel<FULL, NW>), dim3(n_blocks), dim3(64 * NW), 0,        \
                        ctx->stream, X, ldx, y, (const int*)g, N, (int)D, Wz, Bz, (int)n_groups,  \
                        (float*)ws, n_iter)
-        if (D == LD && nw == 8) BSC_LL(true, 8);
-        else if (D == LD) BSC_LL(true, 4);
-        else if (nw == 8) BSC_LL(false, 8);
-        else BSC_LL(false, 4);
+            if (D == LD && nw == 8) BSC_LL(true, 8);
+            else if (D == LD) BSC_LL(true, 4);
+            else if (nw == 8) BSC_LL(false, 8);
+            else BSC_LL(false, 4);
 #undef BSC_LL
+        }
+        BSC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(loglik_reduce_kernel, dim3(LS / 4), dim3(256), 0, ctx->stream, (const float*)ws,
+                           n_blocks * (nw / 4), ell);
+        BSC_LAUNCH_CHECK();
+        return BSC_OK;
+    }
+    // X in registers, draws in LDS: one 512-thread workgroup per CU, waves take 16-row tiles
+    const int64_t n_tiles = (N + XT - 1) / XT;
+    int n_blocks = (int)((n_tiles + XW - 1) / XW);
+    if (n_blocks > ctx->cu_count) n_blocks = ctx->cu_count;
+    if (n_blocks < 1) n_blocks = 1;
+    const int64_t n_waves = (int64_t)n_blocks * XW;
+    int64_t it = (n_tiles + n_waves - 1) / n_waves;
+    const int n_iter = (int)(it + (it & 1));   // even: the kernel alternates two register sets per tile pair
+    void* ws = nullptr;
+    int rc = bsc_workspace(ctx, (size_t)n_blocks * S * sizeof(double), &ws);
+    if (rc != BSC_OK) return rc;
+    ctx->slab_rows = 0;
+    const int nsb = S <= 16 ? 1 : S <= 32 ? 2 : S <= 64 ? 4 : 8;
+    {
+        bsc_prof_scope prof(ctx);
+#define BSC_LL_ARGS                                                                                   \
+    dim3(n_blocks), dim3(64 * XW), 0, ctx->stream, X, ldx, y, (const int*)g, N, (int)D, Wz, Bz,           \
+        (int)n_groups, (int)S, (double*)ws, n_iter
+#define BSC_LLX_D(NSB)                                                                                \
+    do {                                                                                              \
+        if (D == LD) hipLaunchKernelGGL((logreg_loglik_xreg_kernel<true, NSB>), BSC_LL_ARGS);         \
+        else hipLaunchKernelGGL((logreg_loglik_xreg_kernel<false, NSB>), BSC_LL_ARGS);                \
+    } while (0)
+        // X by LDS-DMA when the intercept gathers are 16-byte aligned four-sample runs (S in 36..64,
+        // S % 4 == 0: config 5's S = 64); X through VGPRs otherwise
+        const bool dma_ok = nsb == 4 && S % 4 == 0 && ((uintptr_t)Bz & 15) == 0 && ctx->bbvi_kernel != 2;
+        if (dma_ok && ctx->bbvi_dbg && D == LD) {
+            // profiling-only deletion builds (BSC_BBVI_DBG): wrong results by construction
+            switch (ctx->bbvi_dbg) {
+                case 1: hipLaunchKernelGGL((logreg_loglik_dma_kernel<true, 4, 1>), BSC_LL_ARGS); break;
+                case 2: hipLaunchKernelGGL((logreg_loglik_dma_kernel<true, 4, 2>), BSC_LL_ARGS); break;
+                case 3: hipLaunchKernelGGL((logreg_loglik_dma_kernel<true, 4, 3>), BSC_LL_ARGS); break;
+                case 7: hipLaunchKernelGGL((logreg_loglik_dma_kernel<true, 4, 7>), BSC_LL_ARGS); break;
+                case 11: hipLaunchKernelGGL((logreg_loglik_dma_kernel<true, 4, 11>), BSC_LL_ARGS); break;
+                case 15: hipLaunchKernelGGL((logreg_loglik_dma_kernel<true, 4, 15>), BSC_LL_ARGS); break;
+                default: hipLaunchKernelGGL((logreg_loglik_dma_kernel<true, 4>), BSC_LL_ARGS); break;
+            }
+        } else if (dma_ok) {
+            if (D == LD) hipLaunchKernelGGL((logreg_loglik_dma_kernel<true, 4>), BSC_LL_ARGS);
+            else hipLaunchKernelGGL((logreg_loglik_dma_kernel<false, 4>), BSC_LL_ARGS);
+        } else if (nsb == 1) BSC_LLX_D(1);
+        else if (nsb == 2) BSC_LLX_D(2);
+        else if (nsb == 4) BSC_LLX_D(4);
+        else BSC_LLX_D(8);
+#undef BSC_LLX_D
+#undef BSC_LL_ARGS
     }
     BSC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loglik_reduce_kernel, dim3(LS / 4), dim3(256), 0, ctx->stream, (const float*)ws,
-                       n_blocks * (nw / 4), ell);
+    hipLaunchKernelGGL(loglik_reduce_f64_kernel, dim3((S + 3) / 4), dim3(256), 0, ctx->stream,
+                       (const double*)ws, n_blocks, (int)S, ell);
     BSC_LAUNCH_CHECK();
     return BSC_OK;
 }

@@ -27,6 +27,8 @@ struct bsc_ctx {
     int gemm_pipe = 1;                // GEMM: LDS operand reads one k-pair ahead of the MFMAs
     int fused_nt_store = 1;           // dense map: non-temporal stores of the result
     int bbvi_waves = 4;          // bsc_logreg_bbvi_loglik: waves per workgroup (4: one wave per 16 samples, 8: per (16 samples, 16 rows))
+    int bbvi_kernel = 1;         // bsc_logreg_bbvi_loglik: 1 = draws in LDS, X by LDS-DMA strips (S <= 64; S <= 128 X through VGPRs), 2 = X through VGPRs, 0 = first-generation LDS-staged tiles (S == 64)
+    int bbvi_dbg = 0;            // BSC_BBVI_DBG: profiling-only deletion builds of the xreg kernel (wrong results)
     int csc_fast = 1;            // bsc_lda_sstats_csc: buffer-descriptor gathers (BSC_CSC_FAST=0 turns them off)
     int wo_wg_per_cu = 2;        // bsc_weighted_outer: resident workgroups per CU the grid is sized for
     int fused_waves_per_cu = 16; // bsc_map_reduce: reduce splits target this many waves per CU

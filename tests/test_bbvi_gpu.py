@@ -112,6 +112,49 @@ def test_unsupported_shapes_fail_loudly(ctx):
     from bayesic_amd._ffi import BayesicHipError
     X, y = ctx.zeros((8, 256)), ctx.zeros(8)
     g = torch.zeros(8, dtype=torch.int32, device=ctx.device)
-    W, Bz, ell = ctx.zeros((8, 256)), ctx.zeros((2, 8)), ctx.zeros(8, torch.float64)
-    with pytest.raises(BayesicHipError, match="S == 64"):
-        ctx.call("bsc_logreg_bbvi_loglik", X, 256, y, g, 8, 256, 2, W, Bz, 8, ell)
+    W, Bz, ell = ctx.zeros((129, 256)), ctx.zeros((2, 129)), ctx.zeros(129, torch.float64)
+    with pytest.raises(BayesicHipError, match="S <= 128"):
+        ctx.call("bsc_logreg_bbvi_loglik", X, 256, y, g, 8, 256, 2, W, Bz, 129, ell)
+    with pytest.raises(BayesicHipError, match="D % 4"):
+        ctx.call("bsc_logreg_bbvi_loglik", X, 256, y, g, 8, 258, 2, W, Bz, 64, ell)
+
+
+@pytest.mark.parametrize("S", [1, 8, 16, 17, 32, 48, 64, 100, 128])
+@pytest.mark.parametrize("N,D,G", [(1003, 256, 37), (4099, 64, 11), (50, 252, 3)])
+def test_loglik_any_sample_count(ctx, S, N, D, G):
+    """S Monte-Carlo draws in 16-sample blocks (1, 2, 4 or 8 of them), ragged last block."""
+    rs = np.random.RandomState(S * 7 + N)
+    X = rs.standard_normal((N, D)).astype(np.float32)
+    g = rs.randint(G, size=N).astype(np.int32)
+    y = (rs.uniform(size=N) < 0.4).astype(np.float32)
+    Wz = (rs.standard_normal((S, D)) / math.sqrt(D)).astype(np.float32)
+    Bz = rs.standard_normal((G, S)).astype(np.float32)
+    ell = _loglik(ctx, X, y, g, Wz, Bz)
+    want = svi.logreg_loglik(X, y, g, Wz, Bz)
+    L = np.abs(X.astype(np.float64) @ Wz.astype(np.float64).T + Bz.astype(np.float64)[g])
+    bound = (L + 1.0).sum(axis=0)
+    assert ell.shape == (S,)
+    assert (np.abs(ell - want) <= 2e-5 * bound + 1e-9).all(), np.abs((ell - want) / bound).max()
+
+
+def test_first_generation_kernel_still_agrees(ctx):
+    """BSC_BBVI_KERNEL=0 keeps the LDS-staged kernel for in-process A/B runs; same oracle."""
+    import os
+    from bayesic_amd.device import Context
+    os.environ["BSC_BBVI_KERNEL"] = "0"
+    try:
+        old = Context(0)
+    finally:
+        del os.environ["BSC_BBVI_KERNEL"]
+    rs = np.random.RandomState(5)
+    N, D, G = 3001, 256, 19
+    X = rs.standard_normal((N, D)).astype(np.float32)
+    g = rs.randint(G, size=N).astype(np.int32)
+    y = (rs.uniform(size=N) < 0.4).astype(np.float32)
+    Wz = (rs.standard_normal((64, D)) / 16).astype(np.float32)
+    Bz = rs.standard_normal((G, 64)).astype(np.float32)
+    a, b = _loglik(old, X, y, g, Wz, Bz), _loglik(ctx, X, y, g, Wz, Bz)
+    want = svi.logreg_loglik(X, y, g, Wz, Bz)
+    npt.assert_allclose(a, want, rtol=2e-6)
+    npt.assert_allclose(b, want, rtol=2e-6)
+    old.close()

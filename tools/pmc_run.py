@@ -1,0 +1,81 @@
+"""Launches ONE config's dominant kernel a few times at its BASELINE size, for rocprofv3 --pmc
+passes (tools/pmc_collect.sh).  Inputs are random device tensors (counters do not depend on the
+values); the call is the same C-ABI entry point bench.py / the drivers use.
+
+    python3 tools/pmc_run.py cfg2|cfg3|cfg4|cfg5|wouter|gram|skinny [reps]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+
+from bayesic_amd.device import Context
+
+
+def main():
+    which = sys.argv[1]
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+    ctx = Context(0)
+    dev = ctx.device
+    g = torch.Generator(device=dev).manual_seed(0)
+    ctx.reserve(64 << 20)
+    if which == "cfg2":
+        N, D, S = 1_000_000, 256, 8
+        X = torch.randn((N, D), generator=g, device=dev)
+        y = torch.randn(N, generator=g, device=dev)
+        W = torch.randn((S, D), generator=g, device=dev) / 16
+        fn = lambda: ctx.call("bsc_blr_data_pass_partial", X, D, y, N, D, W, S)
+    elif which == "cfg3":
+        N, D, K = 10_000_000, 16, 64
+        X = torch.randn((N, D), generator=g, device=dev) * 3
+        Wm = torch.randn((K, 2 * D), generator=g, device=dev) * 0.1
+        Wm[:, D:] = -0.5
+        c = torch.zeros(K, device=dev)
+        stats = torch.zeros(K * (1 + 2 * D), dtype=torch.float64, device=dev)
+        lse = torch.zeros(1, dtype=torch.float64, device=dev)
+        fn = lambda: ctx.call("bsc_mog_estep", X, D, N, D, K, Wm, c, stats, lse)
+    elif which == "wouter":
+        N, D, K = 10_000_000, 16, 64
+        X = torch.randn((N, D), generator=g, device=dev) * 3
+        R = torch.softmax(torch.randn((N, K), generator=g, device=dev), dim=1)
+        cov = torch.empty((K, D, D), device=dev)
+        fn = lambda: ctx.call("bsc_weighted_outer", R, K, X, D, X, D, N, K, D, D, 1.0, cov)
+    elif which == "cfg5":
+        N, D, G, S = 1_000_000, 256, 1000, 64
+        X = torch.randn((N, D), generator=g, device=dev)
+        y = (torch.rand(N, generator=g, device=dev) < 0.4).float()
+        gi = torch.randint(0, G, (N,), generator=g, device=dev, dtype=torch.int32)
+        Wz = torch.randn((S, D), generator=g, device=dev) / 16
+        Bz = torch.randn((G, S), generator=g, device=dev)
+        ell = torch.zeros(S, dtype=torch.float64, device=dev)
+        fn = lambda: ctx.call("bsc_logreg_bbvi_loglik", X, D, y, gi, N, D, G, Wz, Bz, S, ell)
+    elif which == "cfg4":
+        docs, V, K = 6250, 100_000, 128
+        C = torch.poisson(torch.full((docs, V), 0.05, device=dev), generator=g)
+        Th = torch.rand((docs, K), generator=g, device=dev) + 0.5
+        Bt = torch.rand((K, V), generator=g, device=dev) + 0.5
+        out = torch.empty((K, V), device=dev)
+        fn = lambda: ctx.call("bsc_lda_sstats", C, V, docs, V, K, Th, K, Bt, V, out, V)
+    elif which == "gram":
+        N, D = 1_000_000, 256
+        X = torch.randn((N, D), generator=g, device=dev)
+        C = torch.empty((D, D), device=dev)
+        fn = lambda: ctx.call("bsc_gemm_strided_batched", 0, 1, D, D, N, X, 0, 1, D, X, 0, D, 1, C, 0, D, 1)
+    elif which == "skinny":
+        N, D, S = 1_000_000, 256, 8
+        X = torch.randn((N, D), generator=g, device=dev)
+        W = torch.randn((S, D), generator=g, device=dev)
+        P = torch.empty((S, N), device=dev)
+        fn = lambda: ctx.call("bsc_gemm_strided_batched", 0, 1, S, N, D, W, 0, D, 1, X, 0, 1, D, P, 0, N, 1)
+    else:
+        raise SystemExit("unknown config %r" % which)
+    for _ in range(reps):
+        fn()
+    ctx.sync()
+
+
+if __name__ == "__main__":
+    main()
