@@ -39,10 +39,13 @@ class _Tape(object):
         return self.b.mul(*factors)
 
     def like(self, g, value):
-        """g broadcast to the full shape of `value` (g has the same rank, extents 1 or full)."""
+        """g broadcast to the full shape of `value` (g is rank-less, or has the same rank with
+        extents 1 or full).  From the SHAPE only: arithmetic with the forward value (g + 0*value)
+        would re-read a data-sized operand per sum VJP and turn a non-finite forward value into a
+        NaN gradient where the true gradient is finite or inf."""
         if _shape_of(g) == _shape_of(value):
             return g
-        return self.plus(g, self.times(self.const(0.0), value))
+        return self.b.broadcast_to(g, _shape_of(value))
 
     def fit(self, term, parent_value):
         """The adjoint contribution `term` in the form the parent needs: a backend may keep a

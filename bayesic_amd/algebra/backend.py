@@ -53,6 +53,12 @@ class Backend(object):
     def diagonal(self, x, axis1, axis2):
         raise NotImplementedError
 
+    def broadcast_to(self, g, shape):
+        """g (rank-less, or of len(shape) axes with extents 1 or full) as a value of `shape`,
+        without arithmetic on any data-sized operand: a view with stride-0 axes where the
+        backend has views.  Used by the reverse-mode derivative (algebra/autodiff.py)."""
+        raise NotImplementedError
+
     def logdet(self, x):
         """log det over the trailing two axes (bayesic/distribution/core.py:50)."""
         raise NotImplementedError

@@ -102,6 +102,7 @@ class DeviceBackend(Backend):
         """fuse=False launches every element-wise node on its own (the unfused
         baseline of tools/bench_fusion.py); results are identical up to rounding."""
         self.fuse = bool(fuse)
+        self._one = None          # a resident float32 1.0 (broadcast_to of a host scalar)
         self.ctx = ctx if ctx is not None else default_context()
         if not isinstance(self.ctx, Context):
             raise TypeError("ctx must be a bayesic_amd.device.Context")
@@ -162,7 +163,7 @@ class DeviceBackend(Backend):
         k-th buffer of the previous evaluation of the same expression."""
         shape = tuple(int(n) for n in shape)
         if self._plan is None:
-            return torch.empty(shape, dtype=dtype, device=self.ctx.device)
+            return self.ctx.empty(shape, dtype)       # (checks torch's current stream is the context's)
         numel = math.prod(shape)
         k = self._cursor
         self._cursor += 1
@@ -170,7 +171,7 @@ class DeviceBackend(Backend):
             buf = self._plan[k]
             if buf is not None and buf.dtype == dtype and buf.numel() == numel:
                 return buf.view(shape)
-        buf = torch.empty((numel,), dtype=dtype, device=self.ctx.device)
+        buf = self.ctx.empty((numel,), dtype)
         if k < len(self._plan):
             self._plan[k] = buf
         else:
@@ -421,6 +422,20 @@ class DeviceBackend(Backend):
     def diagonal(self, x, axis1, axis2):
         x = self._force(x)
         return torch.diagonal(x, 0, axis1, axis2)     # view; the diagonal axis goes last
+
+    def broadcast_to(self, g, shape):
+        """A stride-0 view of g over `shape` (a stride of 0 broadcasts in every C-ABI entry point);
+        a host scalar becomes scale * (one resident 1.0 viewed over `shape`), still deferred."""
+        shape = [int(d) for d in shape]
+        if isinstance(g, HostScalar):
+            if self._one is None:
+                self._one = self.from_host(np.ones(1, np.float32), "float32", 1)
+            base = self._one.expand(shape) if shape else self._one.reshape(())
+            return base if float(g.value) == 1.0 else self.mul(g, base)
+        g = self._force(g)
+        if g.dim() == 0:
+            g = g.reshape([1] * len(shape))
+        return g.expand(shape)
 
     def logdet(self, x):
         x = self._force(x)

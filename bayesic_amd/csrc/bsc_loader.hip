@@ -102,6 +102,11 @@ int bsc_loader_submit(bsc_loader* L, const float* host_X, int64_t ldx, const flo
     BSC_REQUIRE(L->submitted - L->released < n,
                 "bsc_loader_submit: all %lld slots are in flight (release one first)", (long long)n);
     auto& s = L->slots[L->submitted % n];
+    // The HOST may not run further ahead than the slots: the copy that last targeted this slot
+    // (submission number submitted - n) must have left its host buffer before the caller is told,
+    // by this call returning, that it may reuse or free that buffer.  acquire/release only enqueue
+    // stream waits, so without this the caller could drop a pinned source whose copy has not started.
+    if (L->submitted >= n) BSC_HIP(hipEventSynchronize(s.copied));
     // the copy may not overtake the kernels that last read this slot
     if (s.has_consumed) BSC_HIP(hipStreamWaitEvent(L->copy_stream, s.consumed, 0));
     if (ldx == L->D)

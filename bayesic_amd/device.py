@@ -46,9 +46,23 @@ class Context:
         return self._stream
 
     def set_stream(self, stream):
+        """Move the context (kernels, collectives) to `stream` AND make it torch's current stream
+        on this device: torch's caching allocator ties a block to the stream that was current when
+        it was allocated, so allocating on one stream and launching on another lets a freed
+        intermediate be handed out while kernels on the context stream still use it."""
         self._stream = stream
+        torch.cuda.set_stream(stream)
         _ffi.check(self.lib.bsc_ctx_set_stream(self.handle, stream.cuda_stream),
                    "bsc_ctx_set_stream")
+
+    def _check_stream(self):
+        """Allocations made through this context must come from the context's stream (see
+        set_stream); inside `with torch.cuda.stream(other):` that is not the case."""
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != self._stream.cuda_stream:
+            raise _ffi.BayesicHipError(
+                "torch's current stream on %s is not the context's stream: allocate and launch on "
+                "one stream (Context.set_stream(s) switches both)" % (self.device,))
 
     def sync(self):
         _ffi.check(self.lib.bsc_ctx_sync(self.handle), "bsc_ctx_sync")
@@ -126,9 +140,11 @@ class Context:
         return dict(zip(keys, list(buf)))
 
     def empty(self, shape, dtype=torch.float32):
+        self._check_stream()
         return torch.empty(shape, dtype=dtype, device=self.device)
 
     def zeros(self, shape, dtype=torch.float32):
+        self._check_stream()
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
     def to_device(self, array, dtype=None):

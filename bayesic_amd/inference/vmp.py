@@ -313,6 +313,11 @@ class MeanFieldVMP(object):
             for entry in compiled:
                 if entry is not None:
                     types.update(entry[0].input_types)
+        # inputs that occur only in latent-free terms of the log-joint carry no message but are
+        # part of the bound: elbo() needs them too
+        for piece in self._log_joint:
+            for name, t in A.wrap_if_literal(piece).input_types.items():
+                types.setdefault(name, t)
         self._types = types
         self._data = {name: self.backend.from_host(value, *types[name])
                       for name, value in data.items() if name in types}
@@ -380,11 +385,7 @@ class MeanFieldVMP(object):
                         bindings[t] = "_E_%s_%d" % (m.var.name, k)
             self._elbo_fns = [self.backend.compile(A.wrap_if_literal(piece), bindings)
                               for piece in self._log_joint]
-            types = {}
-            for piece in self._log_joint:
-                types.update(A.wrap_if_literal(piece).input_types)
             self._elbo_data = {n: v for n, v in self._data.items()}
-            self._elbo_extra = [n for n in types if n not in self._data]
         inputs = dict(self._elbo_data)
         inputs.update(self._expectation_inputs(None))
         total = 0.0
@@ -397,8 +398,10 @@ class MeanFieldVMP(object):
         node = self._by_name[name]
         message = self.message(name)
         for j, m in enumerate(message):
-            if m is not None:
-                node.eta[j] = (1.0 - rho) * node.eta[j] + rho * m.reshape(np.shape(node.eta[j]))
+            # a statistic no term of the log-joint touches receives the message 0: under damping
+            # its natural parameter decays like the others instead of keeping its initial value
+            m = 0.0 if m is None else m.reshape(np.shape(node.eta[j]))
+            node.eta[j] = (1.0 - rho) * node.eta[j] + rho * m
         return node
 
     def sweep(self, rho=1.0):

@@ -13,7 +13,9 @@ kernels only ever see device-resident batches, so the hot path is unchanged.
         model.step()
         loader.release()                            # slot reusable once step t has run
 
-Host arrays should be page-locked: ``MiniBatchLoader.pin(array)`` registers a numpy
+A submitted host batch must stay valid and unchanged until ``n_slots`` further submits have
+returned (the loader keeps a reference that long); sources handed over as raw pointers through
+the C ABI must outlive their copy the same way.  Host arrays should be page-locked: ``MiniBatchLoader.pin(array)`` registers a numpy
 array in place (bsc_host_register); torch tensors made with ``pin_memory=True`` work
 too.  A pageable source is staged by the HIP runtime at a fraction of the PCIe rate.
 """
@@ -69,8 +71,11 @@ class MiniBatchLoader(object):
         _ffi.check(self.ctx.lib.bsc_loader_submit(self.handle, _host_pointer(X), int(ldx),
                                                   _host_pointer(y), int(X.shape[0])),
                    "bsc_loader_submit")
+        # bsc_loader_submit host-synchronises on the copy that last used the slot it reuses, so once
+        # submission k + n_slots has returned the source of submission k has been read: the last
+        # n_slots sources are the ones that may still be crossing PCIe
         self._in_flight.append((X, y))
-        del self._in_flight[:-2 * self.n_slots]     # older copies were waited for by acquire()
+        del self._in_flight[:-self.n_slots]
 
     def acquire(self):
         """(device pointer of X, device pointer of y, rows) of the oldest submitted batch;

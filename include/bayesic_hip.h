@@ -120,7 +120,10 @@ int bsc_hbm_read_probe(bsc_ctx* ctx, const void* buf, size_t bytes, int reps, do
  * stream after which the slot may be overwritten.  At most n_slots batches may be
  * between submit and release.  Host buffers should be page-locked
  * (bsc_host_register); a pageable source is staged by the runtime at a fraction of
- * the PCIe rate.  Not thread-safe. */
+ * the PCIe rate.  HOST BUFFER LIFETIME: the source of submission k must stay valid and
+ * unchanged until submission k + n_slots has returned (submit host-synchronises on the
+ * copy that last targeted the slot it is about to reuse), or until bsc_loader_destroy.
+ * Not thread-safe. */
 typedef struct bsc_loader bsc_loader;
 int bsc_host_register(void* host_ptr, size_t bytes);
 int bsc_host_unregister(void* host_ptr);

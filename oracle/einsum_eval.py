@@ -116,6 +116,9 @@ class NumpyBackend(Backend):
     def diagonal(self, x, axis1, axis2):
         return np.diagonal(x, 0, axis1, axis2)
 
+    def broadcast_to(self, g, shape):
+        return np.broadcast_to(np.asarray(g), tuple(shape))
+
     def logdet(self, x):
         sign, value = np.linalg.slogdet(np.asarray(x, dtype=np.float64))
         return value.astype(x.dtype)

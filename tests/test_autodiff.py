@@ -85,3 +85,18 @@ def test_device_gradient_matches_float64(ctx, seed):
         assert got.shape == want[n].shape, (repr(expr), n)
         scale = builtins.max(float(np.abs(want[n]).max()), 1e-3)
         assert np.abs(got - want[n]).max() <= 3e-4 * scale, (repr(expr), n, np.abs(got - want[n]).max(), scale)
+
+
+def test_sum_vjp_broadcasts_from_shape_not_from_the_forward_value():
+    """d sum(exp(x)) / dx at x = [0, 800]: exp(800) is inf in float64, the gradient is [1, inf].
+    Broadcasting the adjoint as g + 0 * value made it [1, nan] (0 * inf)."""
+    import numpy as np
+    from bayesic_amd import algebra as A
+    from bayesic_amd.algebra.autodiff import value_and_grad
+    from oracle.einsum_eval import NumpyBackend
+    be = NumpyBackend(np.float64)
+    x = A.var("x", 1)
+    with np.errstate(over="ignore"):
+        _, grads = value_and_grad(be, A.sum(A.exp(x)), {"x": np.array([0.0, 800.0])}, ["x"])
+    g = np.asarray(grads["x"])
+    assert g[0] == 1.0 and np.isposinf(g[1])

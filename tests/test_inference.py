@@ -825,3 +825,33 @@ def test_reparam_engine_on_mini_batches_reaches_the_full_data_optimum():
     npt.assert_allclose(eng.lam[:D], np.linalg.solve(prec, Xs.T @ ys / s2), atol=0.05)
     with pytest.raises(TypeError):
         eng.set_data(W=np.zeros((16, D)))
+
+
+def test_elbo_sees_data_that_occurs_only_in_latent_free_terms_and_untouched_statistics_decay():
+    """(1) An input of the log-joint that no message depends on (here the offsets z of a
+    latent-free term) must still be uploaded: elbo() evaluates that term.  (2) A statistic no
+    term touches receives the message 0, so a damped update shrinks its natural parameter
+    instead of leaving the initial value in place."""
+    x, z, mu = f64("x", 1), f64("z", 1), f64("mu", 0)
+    xs, zs = rs.standard_normal(40) + 1.0, rs.standard_normal(40)
+    # known unit variance, flat prior on mu: the log-joint is linear + quadratic in mu ...
+    lj = A.sum(x * mu) - 0.5 * A.shape(x, 0) * (mu ** 2) - 0.5 * A.sum(z * z)
+    node = NormalNode(mu)
+    vmp = MeanFieldVMP(lj, [node], {"x": xs, "z": zs}, backend=B64)
+    vmp.sweep()
+    npt.assert_allclose(node.mean, xs.mean(), rtol=1e-12)
+    e = vmp.elbo()
+    want = xs.sum() * node.mean - 0.5 * 40 * (node.mean ** 2 + node.variance) - 0.5 * (zs ** 2).sum() \
+        + node.entropy()
+    npt.assert_allclose(e, want, rtol=1e-12)
+    vmp.set_data(z=2.0 * zs)                       # ... and set_data refreshes the bound's copy
+    npt.assert_allclose(vmp.elbo(), want - 1.5 * (zs ** 2).sum(), rtol=1e-12)
+    # (2): only the linear statistic has a coefficient here
+    lin = A.sum(x * mu)
+    (c1, c2), _ = conjugate_coefficients(lin, mu, (mu, mu ** 2))
+    assert c1 is not None and c2 is None
+    node2 = NormalNode(mu, mean=0.0, variance=1.0)
+    before = float(node2.eta[1])
+    MeanFieldVMP(lin, [node2], {"x": xs}, backend=B64).update("mu", rho=0.25)
+    npt.assert_allclose(node2.eta[1], 0.75 * before, rtol=1e-14)
+    npt.assert_allclose(node2.eta[0], 0.25 * xs.sum(), rtol=1e-12)
