@@ -254,25 +254,13 @@ __global__ __launch_bounds__(64 * NW, 2) void logreg_loglik_kernel(
 constexpr int XT = 16;        // rows per wave tile
 constexpr int XW = 8;         // waves per workgroup (2 per SIMD, one workgroup per CU)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) void* lds_ptr;
-
-// s_waitcnt immediate (gfx9 layout) that waits for vmcnt <= n only: vmcnt = [3:0] and [15:14],
-// expcnt [6:4] and lgkmcnt [11:8] left at "no wait"
-constexpr int vmcnt_only(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
-
-// descriptors that cover exactly the rows left from `row0` on: rows past N read as zero
+typedef bsc_lds_ptr lds_ptr;
+constexpr int vmcnt_only(int n) { return bsc_vmcnt_only(n); }
 __device__ __forceinline__ auto x_tile_rsrc(const float* X, int64_t ldx, int D, int64_t N, int64_t row0) {
-    const int64_t rem = N - row0;
-    uint64_t xb = 0;
-    if (rem > 0) xb = ((uint64_t)(rem - 1) * (uint64_t)ldx + (uint64_t)D) * 4u;
-    const unsigned rec = xb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)xb;
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(X + (rem > 0 ? row0 : 0) * ldx), 0, rec, 0x00020000);
+    return bsc_rows_rsrc(X, ldx, D, N, row0);       // rows past N read as zero
 }
 __device__ __forceinline__ auto row_vec_rsrc(const void* base, int64_t N, int64_t row0) {   // y or g: 4 B per row
-    const int64_t rem = N - row0;
-    const uint64_t b = rem > 0 ? (uint64_t)rem * 4u : 0;
-    const unsigned rec = b > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)b;
-    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + (rem > 0 ? row0 : 0) * 4), 0, rec, 0x00020000);
+    return bsc_vec_rsrc(base, N, row0);
 }
 
 // One tile's epilogue: acc[sb][r] = logit of row 4 kq + r, sample NSB i16 + sb; yv = y of those rows.

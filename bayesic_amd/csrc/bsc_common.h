@@ -24,6 +24,7 @@ struct bsc_ctx {
     int fused_map_blocks_per_cu = 8;  // bsc_map_reduce, pure map: grid cap (256-thread blocks)
     int fused_map_unroll = 2;         // float4 per operand in flight per lane (1 | 2); 2 is +18% measured
     int gemm_fast = 1;                // GEMM: scalar-base loads for interior tiles (BSC_GEMM_FAST=0 turns them off)
+    int gemm_skinny = 1;              // GEMM: the LDS-DMA kernels of csrc/bsc_skinny.hip for products with one tiny extent (BSC_GEMM_SKINNY=0 turns them off)
     int gemm_pipe = 1;                // GEMM: LDS operand reads one k-pair ahead of the MFMAs
     int fused_nt_store = 1;           // dense map: non-temporal stores of the result
     int bbvi_waves = 4;          // bsc_logreg_bbvi_loglik: waves per workgroup (4: one wave per 16 samples, 8: per (16 samples, 16 rows))
@@ -101,6 +102,11 @@ int bsc_fail(int code, const char* fmt, ...);
 // Make sure ctx->workspace holds at least `bytes`; may hipMalloc (synchronous).
 int bsc_workspace(bsc_ctx* ctx, size_t bytes, void** out);
 
+// csrc/bsc_skinny.hip: float32 products with one tiny extent that stream their large operand once
+// through LDS-DMA.  Sets *handled = 1 when it took the product (then C is written / enqueued).
+int bsc_gemm_skinny(bsc_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, int64_t sa_k,
+                    const float* B, int64_t sb_k, int64_t sb_n, float* C, int64_t sc_m, int64_t sc_n, int* handled);
+
 #define BSC_HIP(call)                                                            \
     do {                                                                         \
         hipError_t err__ = (call);                                               \
@@ -176,6 +182,31 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- LDS-DMA helpers (csrc/bsc_bbvi.hip, csrc/bsc_skinny.hip) -------------------------------
+typedef __attribute__((address_space(3))) void* bsc_lds_ptr;
+
+// s_waitcnt immediate (gfx9 layout) that waits for vmcnt <= n only: vmcnt = [3:0] and [15:14],
+// expcnt [6:4] and lgkmcnt [11:8] left at "no wait"
+constexpr int bsc_vmcnt_only(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
+constexpr int BSC_LGKMCNT0 = 0xC07F;   // lgkmcnt(0) alone
+
+// A descriptor over the rows of a row-major matrix from `row0` on (`rows` in all, `ld` floats
+// apart, `width` floats wide): everything past the last row reads as zero.
+__device__ __forceinline__ auto bsc_rows_rsrc(const float* X, int64_t ld, int width, int64_t rows, int64_t row0) {
+    const int64_t rem = rows - row0;
+    uint64_t xb = 0;
+    if (rem > 0) xb = ((uint64_t)(rem - 1) * (uint64_t)ld + (uint64_t)width) * 4u;
+    const unsigned rec = xb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)xb;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(X + (rem > 0 ? row0 : 0) * ld), 0, rec, 0x00020000);
+}
+// ... over a vector of 4-byte elements (one per row) from element `row0` on
+__device__ __forceinline__ auto bsc_vec_rsrc(const void* base, int64_t n, int64_t row0) {
+    const int64_t rem = n - row0;
+    const uint64_t b = rem > 0 ? (uint64_t)rem * 4u : 0;
+    const unsigned rec = b > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)b;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + (rem > 0 ? row0 : 0) * 4), 0, rec, 0x00020000);
 }
 
 __device__ __forceinline__ float readlane_f32(float v, int lane) {

@@ -527,6 +527,13 @@ int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, 
         }
         return BSC_OK;
     }
+    if (batch == 1) {
+        // one tiny extent, the large operand streamed once by LDS-DMA (csrc/bsc_skinny.hip)
+        int handled = 0;
+        int rc = bsc_gemm_skinny(ctx, M, N, K, (const float*)A, sa_m, sa_k, (const float*)B, sb_k, sb_n,
+                                 (float*)C, sc_m, sc_n, &handled);
+        if (rc != BSC_OK || handled) return rc;
+    }
     GemmArgs g;
     g.A = (const float*)A; g.B = (const float*)B;
     g.M = M; g.N = N; g.K = K;

@@ -194,3 +194,56 @@ def test_matrix_vector_paths(dev, n, d):
     npt.assert_allclose(run(dev, dot(w, X.T), X=Xv, w=wv), wv @ X64.T, **tol)
     got = run(dev, dot(X.T, y), X=Xv, y=yv)
     assert (got == run(dev, dot(X.T, y), X=Xv, y=yv)).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(8, 100003, 256), (1, 4099, 256), (16, 70000, 64), (17, 50001, 252),
+                                   (32, 9000, 128), (5, 20000, 4), (31, 33333, 200), (8, 4096, 16)])
+def test_skinny_products_one_tiny_extent_nt(dev, M, N, K):
+    """dot(W, X.T) -> _tensordot(W, _dimshuffle(X,1,0), [1],[0]) with M <= 32 draws, and the same
+    product the other way round (dot(X, W.T)): the LDS-DMA kernel of csrc/bsc_skinny.hip, against
+    float64 numpy and against the 128 x 128-tile GEMM on the same operands."""
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from bayesic_amd.device import Context
+    import os
+    rs = np.random.RandomState(M * 7 + K)
+    W_ = rs.standard_normal((M, K)).astype(np.float32)
+    X_ = rs.standard_normal((N, K)).astype(np.float32)
+    W, X = var("W", 2), var("X", 2)
+    want = W_.astype(np.float64) @ X_.astype(np.float64).T
+    bound = np.sqrt((W_.astype(np.float64) ** 2).sum(1))[:, None] * \
+        np.sqrt((X_.astype(np.float64) ** 2).sum(1))[None, :]
+    got = run(dev, dot(W, X.T), W=W_, X=X_)
+    assert got.shape == (M, N)
+    assert (np.abs(got - want) <= 1e-5 * bound + 1e-12).all(), np.abs(got - want).max()
+    got_t = run(dev, dot(X, W.T), W=W_, X=X_)                # C^T: strided stores
+    assert (np.abs(got_t - want.T) <= 1e-5 * bound.T + 1e-12).all()
+    os.environ["BSC_GEMM_SKINNY"] = "0"
+    try:
+        plain = DeviceBackend(Context(0))
+    finally:
+        del os.environ["BSC_GEMM_SKINNY"]
+    ref = dot(W, X.T).compile(plain)(W=W_, X=X_)
+    # both are k-ordered fp32 fma chains over different groupings: equal to rounding, not bitwise
+    assert (np.abs(got - ref) <= 2e-5 * bound + 1e-12).all()
+    assert (got == run(dev, dot(W, X.T), W=W_, X=X_)).all()          # deterministic
+
+
+@pytest.mark.parametrize("M,D,K", [(8, 256, 100003), (1, 256, 20000), (16, 64, 70001), (3, 252, 16384),
+                                   (8, 4, 50000), (13, 128, 1000003)])
+def test_skinny_products_long_contraction_tn(dev, M, D, K):
+    """dot(R, X) -> _tensordot(R, X, [1],[0]) with M <= 16 rows and a long contracted axis (the
+    pathwise gradient G = R X of config 2's estimator in general form), and its transpose
+    dot(X.T, R.T); deterministic float64 finish."""
+    rs = np.random.RandomState(M * 11 + D)
+    R_ = rs.standard_normal((M, K)).astype(np.float32)
+    X_ = rs.standard_normal((K, D)).astype(np.float32)
+    R, X = var("R", 2), var("X", 2)
+    want = R_.astype(np.float64) @ X_.astype(np.float64)
+    bound = np.sqrt((R_.astype(np.float64) ** 2).sum(1))[:, None] * \
+        np.sqrt((X_.astype(np.float64) ** 2).sum(0))[None, :]
+    got = run(dev, dot(R, X), R=R_, X=X_)
+    assert got.shape == (M, D)
+    assert (np.abs(got - want) <= 1e-5 * bound + 1e-12).all(), np.abs(got - want).max()
+    got_t = run(dev, dot(X.T, R.T), R=R_, X=X_)
+    assert (np.abs(got_t - want.T) <= 1e-5 * bound.T + 1e-12).all()
+    assert (got == run(dev, dot(R, X), R=R_, X=X_)).all()
