@@ -63,6 +63,15 @@ class Backend(object):
         """log det over the trailing two axes (bayesic/distribution/core.py:50)."""
         raise NotImplementedError
 
+    def softmax_rows(self, x):
+        """(softmax over the LAST axis, log-sum-exp over the last axis): the expectation of a
+        Categorical node whose natural parameters live on the backend (inference/vmp.py)."""
+        raise NotImplementedError
+
+    def materialize(self, value):
+        """A backend value that can be kept (a deferred element-wise value is computed)."""
+        return value
+
     # -- tree walk -------------------------------------------------------------
     def evaluate(self, expr, inputs, bindings=None):
         """Post-order walk.  ``bindings`` maps sub-expressions (by value) to input

@@ -423,6 +423,23 @@ class DeviceBackend(Backend):
         x = self._force(x)
         return torch.diagonal(x, 0, axis1, axis2)     # view; the diagonal axis goes last
 
+    def softmax_rows(self, x):
+        x = self._force(x)
+        if x.dtype != torch.float32:
+            raise TypeError("softmax_rows: float32 only")
+        cols = x.shape[-1]
+        x2 = x.reshape(-1, cols) if x.dim() != 2 else x
+        if x2.stride(1) != 1:
+            x2 = self._contiguous(x2)
+        rows = x2.shape[0]
+        out = self._empty((rows, cols), torch.float32)
+        lse = self._empty((rows,), torch.float32)
+        self.ctx.call("bsc_softmax_rows", _ffi.ptr(x2), rows, cols, x2.stride(0), _ffi.ptr(out), cols, _ffi.ptr(lse))
+        return out.reshape(x.shape), lse.reshape(x.shape[:-1])
+
+    def materialize(self, value):
+        return self._force(value)
+
     def broadcast_to(self, g, shape):
         """A stride-0 view of g over `shape` (a stride of 0 broadcasts in every C-ABI entry point);
         a host scalar becomes scale * (one resident 1.0 viewed over `shape`), still deferred."""

@@ -146,8 +146,11 @@ __global__ __launch_bounds__(256) void map_strided_kernel(MapArgs a) {
 
 // every operand dense in the output's order (or one broadcast value): 16 B per lane,
 // U float4 per operand in flight
+// (period_mask: operand k is a row vector of `period4` float4 repeated down the rows -- a bias
+// added to every row of a narrow [R, C] matrix: its float4 index is i mod period4)
 template <int U>
-__global__ __launch_bounds__(256) void map_dense_f32_kernel(MapArgs a, int64_t n4, int scalar_mask) {
+__global__ __launch_bounds__(256) void map_dense_f32_kernel(MapArgs a, int64_t n4, int scalar_mask,
+                                                            int period_mask = 0, int period4 = 1) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const float id = a.combine == BSC_OP_MUL ? 1.f : 0.f;
     for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += stride * U) {
@@ -159,6 +162,13 @@ __global__ __launch_bounds__(256) void map_dense_f32_kernel(MapArgs a, int64_t n
                 const float s = static_cast<const float*>(a.in[k])[0];
 #pragma unroll
                 for (int j = 0; j < U; ++j) u[k][j] = make_float4(s, s, s, s);
+            } else if (period_mask & (1 << k)) {
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int64_t i = i0 + stride * j;
+                    u[k][j] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.in[k]) +
+                                                               4 * (int)((i < n4 ? i : n4 - 1) % period4));
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < U; ++j) {
@@ -668,6 +678,33 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
             const int64_t s = keep.rank ? m.keep_strides[k][0] : 0;
             if (s == 0) scalar_mask |= 1 << k;
             else if (s != 1 || (((uintptr_t)m.in[k]) & 15) != 0) dense = false;
+        }
+        // a narrow [R, C] result (or more than three operands) whose operands are dense, one scalar,
+        // or a C-vector repeated down the rows (biases: dimshuffle(v, 'x', 0)): the flat dense kernel
+        // with periodic operands -- the row kernel below gives a whole wave to 64 columns
+        if (!dense && !special && dtype == BSC_F32 && keep.rank == 2 && m.out_strides[1] == 1 &&
+            m.out_strides[0] == keep.shape[1] && keep.shape[1] % 4 == 0 && keep.shape[1] <= (1 << 20) &&
+            (keep.shape[1] < 256 || n_in > 3) && (((uintptr_t)out) & 15) == 0) {
+            const int64_t C = keep.shape[1];
+            int smask = 0, pmask = 0;
+            bool ok = true;
+            for (int k = 0; k < n_in && ok; ++k) {
+                const int64_t s0 = m.keep_strides[k][0], s1 = m.keep_strides[k][1];
+                if (s0 == 0 && s1 == 0) smask |= 1 << k;
+                else if ((((uintptr_t)m.in[k]) & 15) != 0) ok = false;
+                else if (s0 == 0 && s1 == 1) pmask |= 1 << k;
+                else if (!(s0 == C && s1 == 1)) ok = false;
+            }
+            if (ok) {
+                const int64_t n4 = n_out / 4;
+                int64_t blocks = (n4 + 255) / 256;
+                const int64_t cap = (int64_t)ctx->cu_count * ctx->fused_map_blocks_per_cu;
+                if (blocks > cap) blocks = cap;
+                hipLaunchKernelGGL(map_dense_f32_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, m,
+                                   n4, smask, pmask, (int)(C / 4));
+                BSC_LAUNCH_CHECK();
+                return BSC_OK;
+            }
         }
         // two kept axes with row / column broadcasts
         bool rows2d = !dense && !special && dtype == BSC_F32 && keep.rank == 2 && n_in <= 3 &&

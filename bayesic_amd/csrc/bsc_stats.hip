@@ -182,6 +182,72 @@ __global__ void natgrad_update_f32_kernel(float* __restrict__ eta, float eta0,
         eta[i] = (1.0f - rho) * eta[i] + rho * (eta0 + scale * message[i]);
 }
 
+// ---- row softmax: the expectation of a Categorical node (responsibilities) --------------------
+// out[r, :] = softmax(in[r, :]), lse[r] = log sum exp in[r, :]; float32 in/out, the row's max and
+// sum in float32 with exp2 on pre-scaled values.  cols <= 64: a row occupies P = 2^ceil(log2 cols)
+// lanes and a wave takes 64 / P rows per step (coalesced when the rows are contiguous); wider
+// rows: one wave per row, values held in registers between the two reductions (cols <= 1024).
+template <int P>
+__global__ __launch_bounds__(256) void softmax_rows_small_kernel(const float* __restrict__ in, int64_t rows,
+                                                                 int cols, int64_t ld_in, float* __restrict__ out,
+                                                                 int64_t ld_out, float* __restrict__ lse) {
+    constexpr int RPW = 64 / P;                     // rows per wave step
+    const int lane = threadIdx.x & 63;
+    const int c = lane % P, sub = lane / P;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    for (int64_t r0 = wave * RPW; r0 < rows; r0 += n_waves * RPW) {
+        const int64_t r = r0 + sub;
+        const bool live = r < rows && c < cols;
+        const float v = live ? in[r * ld_in + c] * LOG2E : -INFINITY;
+        float m = v;
+#pragma unroll
+        for (int off = 1; off < P; off <<= 1) m = fmaxf(m, __shfl_xor(m, off));
+        const float e = live ? __builtin_amdgcn_exp2f(v - m) : 0.f;
+        float z = e;
+#pragma unroll
+        for (int off = 1; off < P; off <<= 1) z += __shfl_xor(z, off);
+        if (live) out[r * ld_out + c] = e * __builtin_amdgcn_rcpf(z) * (2.0f - z * __builtin_amdgcn_rcpf(z));
+        if (lse && r < rows && c == 0) lse[r] = (m + __builtin_amdgcn_logf(z)) * LN2;
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_wide_kernel(const float* __restrict__ in, int64_t rows, int cols,
+                                                                int64_t ld_in, float* __restrict__ out,
+                                                                int64_t ld_out, float* __restrict__ lse) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    for (int64_t r = wave; r < rows; r += n_waves) {
+        float v[16];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c = lane + 64 * j;
+            v[j] = c < cols ? in[r * ld_in + c] * LOG2E : -INFINITY;
+            m = fmaxf(m, v[j]);
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off));
+        float z = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            v[j] = lane + 64 * j < cols ? __builtin_amdgcn_exp2f(v[j] - m) : 0.f;
+            z += v[j];
+        }
+        z = wave_allsum(z);
+        const float inv = 1.0f / z;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c = lane + 64 * j;
+            if (c < cols) out[r * ld_out + c] = v[j] * inv;
+        }
+        if (lse && lane == 0) lse[r] = (m + __builtin_amdgcn_logf(z)) * LN2;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -202,6 +268,30 @@ int bsc_dirichlet_expectation(bsc_ctx* ctx, const float* lam, int64_t rows, int6
     if (blocks > 8 * (int64_t)ctx->cu_count) blocks = 8 * (int64_t)ctx->cu_count;
     hipLaunchKernelGGL(dirichlet_expect_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
                        lam, rows, cols, ld, (const double*)ws, out);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_softmax_rows(bsc_ctx* ctx, const float* in, int64_t rows, int64_t cols, int64_t ld_in, float* out,
+                     int64_t ld_out, float* lse) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(rows >= 0 && cols >= 1 && ld_in >= cols && ld_out >= cols && ((in && out) || rows == 0),
+                "bsc_softmax_rows: bad arguments");
+    if (cols > 1024)
+        return bsc_fail(BSC_ERR_UNSUPPORTED, "bsc_softmax_rows: cols=%lld > 1024", (long long)cols);
+    if (rows == 0) return BSC_OK;
+    const int p = cols <= 1 ? 1 : cols <= 2 ? 2 : cols <= 4 ? 4 : cols <= 8 ? 8 : cols <= 16 ? 16 : cols <= 32 ? 32 : 64;
+    const int64_t rows_per_block = cols <= 64 ? 4 * (64 / p) : 4;
+    int64_t blocks = (rows + rows_per_block - 1) / rows_per_block;
+    if (blocks > 16 * (int64_t)ctx->cu_count) blocks = 16 * (int64_t)ctx->cu_count;
+#define BSC_SM(P) hipLaunchKernelGGL(softmax_rows_small_kernel<P>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, \
+                                     in, rows, (int)cols, ld_in, out, ld_out, lse)
+    if (cols > 64)
+        hipLaunchKernelGGL(softmax_rows_wide_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, in, rows,
+                           (int)cols, ld_in, out, ld_out, lse);
+    else if (p == 1) BSC_SM(1); else if (p == 2) BSC_SM(2); else if (p == 4) BSC_SM(4); else if (p == 8) BSC_SM(8);
+    else if (p == 16) BSC_SM(16); else if (p == 32) BSC_SM(32); else BSC_SM(64);
+#undef BSC_SM
     BSC_LAUNCH_CHECK();
     return BSC_OK;
 }

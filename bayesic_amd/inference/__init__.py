@@ -5,8 +5,8 @@ from .conjugacy import (NotConjugate, conjugate_coefficients, depends_on, expand
 from .bbvi import ScoreFunctionVI
 from .reparam import ReparamVI
 from .vmp import (CategoricalNode, DirichletNode, GammaNode, InverseGammaNode, MeanFieldVMP,
-                  MVNormalNode, NormalNode, WishartNode)
+                  MVNormalNode, NormalGammaNode, NormalNode, WishartNode)
 
 __all__ = ["NotConjugate", "conjugate_coefficients", "depends_on", "expand_terms",
-           "MeanFieldVMP", "NormalNode", "GammaNode", "DirichletNode", "CategoricalNode", "MVNormalNode", "InverseGammaNode", "WishartNode",
+           "MeanFieldVMP", "NormalNode", "GammaNode", "DirichletNode", "CategoricalNode", "MVNormalNode", "InverseGammaNode", "WishartNode", "NormalGammaNode",
            "ScoreFunctionVI", "ReparamVI"]

@@ -1,0 +1,67 @@
+"""BASELINE config 3's model written as a symbolic log-joint, its updates DERIVED by the mean-field
+engine (inference/vmp.py) instead of hand-fused (svi/mog.py, csrc/bsc_mog.hip):
+
+    z_n ~ Cat(pi),  x_nd | z_n = k ~ N(mu_kd, 1 / tau_kd),
+    pi ~ Dirichlet(alpha0),  (mu_kd, tau_kd) ~ NormalGamma(m0, kappa0, a0, b0)
+
+README.md:43,72 (finite discrete latents marginalised by summation, also under mini-batching) and
+README.md:36,75-77 (VMP = unit-step natural gradient; SVI).  The N x K assignments are a RESIDENT
+node: their logits, responsibilities and every message computed from them stay on the backend.
+One ``step(rho)`` = local update of q(z) (rho = 1), then the damped natural-gradient step on the
+global factors -- the same update as ``oracle.svi.mog_svi_step`` / ``MoGNatGradSVI.step``.
+"""
+import numpy as np
+
+from .. import algebra as A
+from .vmp import CategoricalNode, DirichletNode, MeanFieldVMP, NormalGammaNode
+
+
+def diagonal_mixture_log_joint(X, Z, pi, TM, TM2, LT, T, scale, alpha0, m0, kappa0, a0, b0):
+    """Constants dropped; data terms times ``scale`` = N / B (README.md:69-79).  TM, TM2, LT, T
+    carry tau mu, tau mu^2, log tau, tau of the NormalGamma factors ([K, D] each)."""
+    row = lambda v: A.dimshuffle(v, "x", 0)
+    lik = A.sum(Z * A.dot(X, TM.T)) + A.sum(Z * A.dot(X * X, T.T)) * (-0.5) \
+        + A.sum(Z * row(A.sum(LT, axis=1))) * 0.5 + A.sum(Z * row(A.sum(TM2, axis=1))) * (-0.5)
+    prior_z = A.sum(Z * row(A.log(pi)))
+    prior_pi = A.sum(A.log(pi)) * (alpha0 - 1.0)
+    prior_ng = A.sum(LT) * (a0 - 0.5) + A.sum(T) * (-b0 - 0.5 * kappa0 * m0 * m0) \
+        + A.sum(TM2) * (-0.5 * kappa0) + A.sum(TM) * (kappa0 * m0)
+    return (lik + prior_z) * scale + prior_pi + prior_ng
+
+
+class DiagonalMixtureVMP(object):
+    def __init__(self, X, K, n_total=None, alpha0=1.0, m0=0.0, kappa0=0.01, a0=1.0, b0=1.0, init=None,
+                 backend=None, dtype="float32", resident=True):
+        """X: [N, D] host array (uploaded once).  ``init`` = (alpha, m, kappa, a, b) of the starting
+        factors ([K] and [K, D] arrays)."""
+        N, D = X.shape
+        self.N, self.D, self.K = int(N), int(D), int(K)
+        scale = float(n_total) / N if n_total is not None else 1.0
+        self.scale = scale
+        v = lambda name, nd: A.var(name, nd, dtype)
+        Xv, Z, pi = v("X", 2), v("Z", 2), v("pi", 1)
+        TM, TM2, LT, T = v("TM", 2), v("TM2", 2), v("LT", 2), v("T", 2)
+        lj = diagonal_mixture_log_joint(Xv, Z, pi, TM, TM2, LT, T, scale, alpha0, m0, kappa0, a0, b0)
+        alpha, m, kappa, a, b = init
+        self.z = CategoricalNode(Z, log_prob=None if resident else np.zeros((N, K)), resident=resident,
+                                 shape=(N, K))
+        self.pi = DirichletNode(pi, alpha=np.asarray(alpha, np.float64))
+        self.ng = NormalGammaNode(TM, TM2, LT, T, m=m, kappa=kappa, a=a, b=b)
+        self.vmp = MeanFieldVMP(lj, [self.z, self.pi, self.ng], {"X": X}, backend=backend)
+        self.t = 0
+
+    def step(self, rho=None):
+        self.t += 1
+        if rho is None:
+            rho = (self.t + 1.0) ** -0.6
+        self.vmp.update("Z", 1.0, message_scale=1.0 / self.scale)     # a local latent: its terms are not replicated
+        self.vmp.update("pi", rho)
+        self.vmp.update("TM", rho)
+        return rho
+
+    def eta_fused_layout(self):
+        """Natural parameters in the layout of svi/mog.py and oracle.svi:
+        [alpha - 1 | kappa m | kappa | 2a - 1 | 2b + kappa m^2]."""
+        ng = self.ng
+        return np.concatenate([self.pi.alpha - 1.0, (ng.kappa * ng.m).ravel(), ng.kappa.ravel(),
+                               (2.0 * ng.a - 1.0).ravel(), (2.0 * ng.b + ng.kappa * ng.m ** 2).ravel()])

@@ -29,7 +29,13 @@ from .conjugacy import conjugate_coefficients
 
 
 class LatentNode(object):
-    """A latent variable with an exponential-family variational distribution."""
+    """A latent variable with an exponential-family variational distribution.
+
+    ``resident`` nodes keep their natural parameters and expectations as BACKEND values (device
+    tensors on the MI355X backend): what a data-sized local latent -- the N x K assignments of a
+    mixture -- needs, so that no update moves it across PCIe.  Parameter-sized global nodes stay on
+    the host in float64 (their transfers are a few KB per message)."""
+    resident = False
 
     def __init__(self, variable):
         self.var = variable
@@ -255,24 +261,126 @@ class DirichletNode(LatentNode):
 class CategoricalNode(LatentNode):
     """q(z) = product over leading axes of Categorical over the LAST axis, z one-hot
     (the discrete latent of a mixture, README.md:43): t = (z,), eta = (unnormalised log
-    probabilities,).  E[z] = softmax(eta) -- responsibilities."""
+    probabilities,).  E[z] = softmax(eta) -- responsibilities.
 
-    def __init__(self, variable, log_prob):
+    ``resident=True``: eta and E[z] live on the backend (``Backend.softmax_rows``: one pass over the
+    N x K logits, bsc_softmax_rows on the device); ``log_prob`` may then be None (uniform start,
+    never materialised on the host) with ``shape`` = (N, K)."""
+
+    def __init__(self, variable, log_prob=None, resident=False, shape=None):
         LatentNode.__init__(self, variable)
-        self.eta = [np.asarray(log_prob, np.float64)]
+        self.resident = bool(resident)
+        self._backend = None
+        self._cache = None          # (E[z], log-sum-exp) of the current eta, on the backend
+        if log_prob is None:
+            if not self.resident or shape is None:
+                raise ValueError("log_prob=None needs resident=True and the shape (N, K)")
+            self._shape = tuple(int(d) for d in shape)
+            self.eta = [None]       # uniform until the first update: E[z] = 1 / K
+        else:
+            self.eta = [np.asarray(log_prob, np.float64)]
+            self._shape = self.eta[0].shape
 
     @property
     def statistics(self):
         return (self.var,)
 
+    # -- resident protocol (MeanFieldVMP) --------------------------------------------------------
+    def bind(self, backend):
+        self._backend = backend
+        if self.eta[0] is not None and isinstance(self.eta[0], np.ndarray):
+            self.eta = [backend.from_host(self.eta[0].astype(np.float32), "float32", len(self._shape))]
+        self._cache = None
+
+    def set_eta(self, j, value):
+        self.eta[j] = value
+        self._cache = None
+
+    def expectations_backend(self):
+        b = self._backend
+        if self._cache is None:
+            if self.eta[0] is None:
+                k = self._shape[-1]
+                r = b.broadcast_to(b.constant(1.0 / k), self._shape)
+                lse = b.broadcast_to(b.constant(math.log(k)), self._shape[:-1])
+                self._cache = (b.materialize(r), lse)
+            else:
+                self._cache = b.softmax_rows(self.eta[0])
+        return [self._cache[0]]
+
     def expectations(self):
+        if self.resident and self._backend is not None:
+            return [np.asarray(self._backend.to_host(self.expectations_backend()[0]), np.float64)]
         e = self.eta[0] - self.eta[0].max(axis=-1, keepdims=True)
         w = np.exp(e)
         return [w / w.sum(axis=-1, keepdims=True)]
 
     def entropy(self):
+        if self.resident and self._backend is not None:
+            # H = sum_n (lse_n - sum_k r_nk eta_nk): no log of a responsibility that underflowed
+            b = self._backend
+            r = self.expectations_backend()[0]
+            if self.eta[0] is None:
+                return float(np.prod(self._shape[:-1]) * math.log(self._shape[-1]))
+            lse = self._cache[1]
+            total = b.to_host(b.sum(lse, list(range(len(self._shape) - 1))))
+            cross = b.to_host(b.sum(b.mul(r, self.eta[0]), list(range(len(self._shape)))))
+            return float(np.asarray(total, np.float64) - np.asarray(cross, np.float64))
         r = self.expectations()[0]
         return float(-np.sum(np.where(r > 0.0, r * np.log(np.where(r > 0.0, r, 1.0)), 0.0)))
+
+
+class NormalGammaNode(LatentNode):
+    """q(mu, tau) = N(mu | m, 1 / (kappa tau)) Gamma(tau | a, rate b), element-wise over the node's
+    shape -- the conjugate pair of a Gaussian with unknown mean AND precision (the per-component,
+    per-column factor of BASELINE config 3's mixture).  Sufficient statistics
+        t = (tau mu, tau mu^2, log tau, tau),   eta = (kappa m, -kappa / 2, a - 1/2, -b - kappa m^2 / 2)
+    are carried by FOUR variables of the log-joint (as MVNormalNode carries w w^T): the front end
+    would flatten tau * mu into the surrounding einsum and leave nothing to bind E[tau mu] to."""
+
+    def __init__(self, tau_mu, tau_mu2, log_tau, tau, m=0.0, kappa=1.0, a=1.0, b=1.0):
+        LatentNode.__init__(self, tau_mu)
+        self._vars = (tau_mu, tau_mu2, log_tau, tau)
+        m, kappa, a, b = (np.asarray(v, np.float64) for v in np.broadcast_arrays(m, kappa, a, b))
+        self.eta = [kappa * m, -0.5 * kappa, a - 0.5, -b - 0.5 * kappa * m * m]
+
+    @property
+    def statistics(self):
+        return self._vars
+
+    @property
+    def kappa(self):
+        return -2.0 * self.eta[1]
+
+    @property
+    def m(self):
+        return self.eta[0] / self.kappa
+
+    @property
+    def a(self):
+        return self.eta[2] + 0.5
+
+    @property
+    def b(self):
+        return -self.eta[3] - 0.5 * self.kappa * self.m ** 2
+
+    def expectations(self):
+        from scipy.special import digamma as psi       # parameter-sized, host side
+        m, kappa, a, b = self.m, self.kappa, self.a, self.b
+        e_tau = a / b
+        return [m * e_tau, 1.0 / kappa + m * m * e_tau, psi(a) - np.log(b), e_tau]
+
+    def entropy(self):
+        from scipy.special import digamma as psi, gammaln
+        kappa, a, b = self.kappa, self.a, self.b
+        # H[N(mu | m, 1/(kappa tau))] averaged over tau, plus H[Gamma(a, b)]
+        h_mu = 0.5 * math.log(2.0 * math.pi * math.e) - 0.5 * (np.log(kappa) + psi(a) - np.log(b))
+        h_tau = a - np.log(b) + gammaln(a) + (1.0 - a) * psi(a)
+        return float(np.sum(h_mu + h_tau))
+
+
+class NotConjugateMessage(ValueError):
+    pass
 
 
 class MeanFieldVMP(object):
@@ -319,6 +427,9 @@ class MeanFieldVMP(object):
             for name, t in A.wrap_if_literal(piece).input_types.items():
                 types.setdefault(name, t)
         self._types = types
+        for node in self.nodes:
+            if node.resident:
+                node.bind(self.backend)
         self._data = {name: self.backend.from_host(value, *types[name])
                       for name, value in data.items() if name in types}
         carried = {self._carrier(t) for n in self.nodes for t in n.statistics} - {None}
@@ -339,6 +450,10 @@ class MeanFieldVMP(object):
         for m in self.nodes:
             if m is exclude:
                 continue
+            if m.resident:          # already backend values: nothing crosses the host
+                for k, (t, e) in enumerate(zip(m.statistics, m.expectations_backend())):
+                    values[self._carrier(t) or "_E_%s_%d" % (m.var.name, k)] = e
+                continue
             for k, (t, e) in enumerate(zip(m.statistics, m.expectations())):
                 name = self._carrier(t) or "_E_%s_%d" % (m.var.name, k)
                 values[name] = self.backend.from_host(np.asarray(e, np.float64), "float32", t.ndim)
@@ -356,7 +471,11 @@ class MeanFieldVMP(object):
                 continue
             c, f, _ = entry
             needed = {k: v for k, v in inputs.items()}
-            out.append(np.asarray(self.backend.to_host(f.device_fn(**needed)), np.float64))
+            value = f.device_fn(**needed)
+            if node.resident:       # a data-sized message stays where it was computed
+                out.append(self.backend.materialize(value))
+            else:
+                out.append(np.asarray(self.backend.to_host(value), np.float64))
         return out
 
     def set_data(self, **arrays):
@@ -393,15 +512,38 @@ class MeanFieldVMP(object):
             total += float(np.asarray(self.backend.to_host(f.device_fn(**inputs)), np.float64))
         return total + sum(n.entropy() for n in self.nodes)
 
-    def update(self, name, rho=1.0):
-        """eta <- (1 - rho) eta + rho * message; rho = 1 is the VMP update."""
+    def update(self, name, rho=1.0, message_scale=1.0):
+        """eta <- (1 - rho) eta + rho * message_scale * message; rho = 1 is the VMP update.
+        ``message_scale``: with the data terms of the log-joint written times N / B (mini-batch
+        SVI), a LOCAL latent -- one factor per datum, like a mixture's assignments -- is updated
+        with 1 / (N / B): its own terms are not replicated."""
         node = self._by_name[name]
         message = self.message(name)
+        if node.resident:
+            b = self.backend
+            for j, m in enumerate(message):
+                if m is None:
+                    raise NotConjugateMessage("resident node %s: statistic %d receives no message" % (name, j))
+                if message_scale != 1.0:
+                    m = b.materialize(b.mul(b.constant(float(message_scale)), m))
+                if rho == 1.0 or node.eta[j] is None:
+                    node.set_eta(j, m)
+                else:
+                    node.set_eta(j, b.materialize(b.elemwise(
+                        "add", b.mul(b.constant(1.0 - rho), node.eta[j]), b.mul(b.constant(rho), m))))
+            return node
         for j, m in enumerate(message):
             # a statistic no term of the log-joint touches receives the message 0: under damping
             # its natural parameter decays like the others instead of keeping its initial value
-            m = 0.0 if m is None else m.reshape(np.shape(node.eta[j]))
-            node.eta[j] = (1.0 - rho) * node.eta[j] + rho * m
+            if m is None:
+                m = 0.0
+            elif m.size == np.size(node.eta[j]):
+                m = m.reshape(np.shape(node.eta[j]))
+            else:
+                # a coefficient that does not depend on one of the statistic's axes comes back
+                # with that axis broadcast (extent 1): sum_d LT_kd inside a term gives c_kd = c_k
+                m = np.broadcast_to(m, np.shape(node.eta[j]))
+            node.eta[j] = (1.0 - rho) * node.eta[j] + rho * message_scale * m
         return node
 
     def sweep(self, rho=1.0):

@@ -230,6 +230,13 @@ int bsc_dirichlet_expectation(bsc_ctx* ctx, const float* lam, int64_t rows, int6
 int bsc_natgrad_update_f32(bsc_ctx* ctx, float* eta, float eta0, const float* message, int64_t n,
                            float scale, float rho);
 
+/* Expectation of a Categorical node: out[r, :] = softmax(in[r, :]) over the LAST axis and, when lse
+ * is not NULL, lse[r] = log sum_c exp in[r, c] (the responsibilities of a mixture's discrete latent
+ * and the bound's normaliser; README.md:43 -- in the derived mean-field engine the data-sized
+ * assignments stay on the device).  float32, rows ld_in / ld_out elements apart, cols <= 1024. */
+int bsc_softmax_rows(bsc_ctx* ctx, const float* in, int64_t rows, int64_t cols, int64_t ld_in, float* out,
+                     int64_t ld_out, float* lse);
+
 /* Fixed-gamma local step of the LDA-style Dirichlet-Multinomial model (BASELINE
  * config 4): sstats[k,v] = Bt[k,v] * sum_d Th[d,k] C[d,v] / (sum_k' Th[d,k'] Bt[k',v]),
  * the algebra expression Bt * dot(Th.T, C / dot(Th, Bt)) (lowered by

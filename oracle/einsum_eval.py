@@ -123,6 +123,13 @@ class NumpyBackend(Backend):
         sign, value = np.linalg.slogdet(np.asarray(x, dtype=np.float64))
         return value.astype(x.dtype)
 
+    def softmax_rows(self, x):
+        x = np.asarray(x)
+        m = x.max(axis=-1, keepdims=True)
+        w = np.exp(x - m)
+        z = w.sum(axis=-1, keepdims=True)
+        return w / z, (m + np.log(z))[..., 0]
+
 
 def einsum_semantics(e, inputs, dtype=np.float64):
     """Evaluate an (un-lowered) Einsum from its definition; factors that are not

@@ -314,3 +314,24 @@ def test_short_and_wide_matrices_are_split_along_the_columns(dev):
         npt.assert_array_equal(got, v_[None, :] - X_)
         got = (Xv * dimshuffle(u, 0, "x") + 1).compile(dev)(X=X_, u=u_)
         npt.assert_allclose(got, X_ * u_[:, None] + 1, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("R,C", [(100_003, 64), (999, 16), (4097, 4), (50, 252), (3000, 1024)])
+def test_narrow_rows_with_several_row_vector_operands(dev, R, C):
+    """The logits of a mixture's assignments: two dense [N, K] products plus three K-vectors
+    repeated down the rows and a scale -- one launch of the flat dense kernel with periodic
+    operands (the row kernel gives a whole wave to one narrow row and takes at most three
+    operands; this used to fall to the generic strided kernel at 0.27 TB/s)."""
+    P, Q = var("P", ndim=2), var("Q", ndim=2)
+    a, b, c = var("a", ndim=1), var("b", ndim=1), var("c", ndim=1)
+    P_ = RNG.standard_normal((R, C)).astype(np.float32)
+    Q_ = RNG.standard_normal((R, C)).astype(np.float32)
+    a_, b_, c_ = (RNG.standard_normal(C).astype(np.float32) for _ in range(3))
+    row = lambda v: dimshuffle(v, "x", 0)
+    e = (P + Q * (-0.5) + row(a) * 0.5 + row(b) * (-0.5) + row(log(exp(c)))) * 0.1
+    want = (P_.astype(np.float64) - 0.5 * Q_ + 0.5 * a_[None, :] - 0.5 * b_[None, :] + c_[None, :]) * 0.1
+    got = e.compile(dev)(P=P_, Q=Q_, a=a_, b=b_, c=c_)
+    npt.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+    e2 = P * row(a) * row(b) * Q
+    npt.assert_allclose(e2.compile(dev)(P=P_, Q=Q_, a=a_, b=b_), P_.astype(np.float64) * a_ * b_ * Q_, rtol=2e-5,
+                        atol=1e-6)

@@ -1,0 +1,53 @@
+"""Config 3 (10M x 16, K = 64) through the DERIVED mean-field engine (inference/mixture.py: symbolic
+log-joint -> conjugacy detection -> messages through the executor, assignments resident on the
+device) against the hand-fused update of svi/mog.py.
+
+    python tools/bench_derived_mog.py [rows]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from bayesic_amd.algebra.device_backend import DeviceBackend
+from bayesic_amd.device import Context
+from bayesic_amd.inference.mixture import DiagonalMixtureVMP
+from bayesic_amd.svi import mog as mog_mod
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+    D, K = 16, 64
+    ctx = Context(0)
+    rs = np.random.RandomState(3)
+    centres = rs.standard_normal((K, D)) * 4.0
+    X = (centres[np.random.RandomState(4).randint(K, size=n)] +
+         np.random.RandomState(5).standard_normal((n, D)).astype(np.float32)).astype(np.float32)
+    eta0 = mog_mod.prior_eta(K, D)
+    eta = mog_mod.init_eta(X[:2000], K, D, seed=2)
+    alpha, m, kappa, a, b = mog_mod.unpack(eta, K, D)
+    fused = mog_mod.MoGNatGradSVI(ctx.to_device(X), K, eta0, eta, n_total=float(n), ctx=ctx)
+    derived = DiagonalMixtureVMP(X, K, n_total=float(n), init=(alpha, m, kappa, a, b), backend=DeviceBackend(ctx))
+    for name, step in (("fused (svi/mog.py)", fused.step), ("derived (inference/mixture.py)", derived.step)):
+        for _ in range(3):
+            step()
+        ctx.sync()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            step()
+        ctx.sync()
+        print("%-34s %9.3f ms per update (%d rows, K = %d, D = %d)" % (name, (time.perf_counter() - t0) / reps * 1e3, n, K, D),
+              flush=True)
+    got, want = derived.eta_fused_layout(), fused.eta.cpu().numpy()
+    scale = np.maximum(np.abs(want), 1.0)
+    print("max relative difference of the natural parameters after 13 updates: %.2e" % np.abs((got - want) / scale).max())
+
+
+if __name__ == "__main__":
+    main()
