@@ -318,33 +318,39 @@ __global__ __launch_bounds__(1024) void mog_expected_params_kernel(const double*
                                                                    float* __restrict__ Wmat,
                                                                    float* __restrict__ cvec) {
     __shared__ double alpha_sum;
-    const int k = threadIdx.x >> 4, dl = threadIdx.x & 15;
+    const int dl = threadIdx.x & 15;
     const double LOG_2PI = 1.8378770664093454835606594728112;
-    if (threadIdx.x < 64) {   // K <= 64
-        const double a = (int)threadIdx.x < K ? eta[threadIdx.x] + 1.0 : 0.0;
+    if (threadIdx.x < 64) {   // one wave: the Dirichlet's total, fixed order
+        double a = 0.0;
+        for (int j = threadIdx.x; j < K; j += 64) a += eta[j] + 1.0;
         const double tot = wave_allsum_f64(a);
         if (threadIdx.x == 0) alpha_sum = tot;
     }
     __syncthreads();
-    double c = 0.0;
     const int64_t KD = (int64_t)K * D;
-    if (k < K) {
-        for (int d = dl; d < D; d += 16) {
-            const int64_t i = (int64_t)k * D + d;
-            const double kappa = eta[K + KD + i];
-            const double m = eta[K + i] / kappa;
-            const double a = 0.5 * (eta[K + 2 * KD + i] + 1.0);
-            const double b = 0.5 * (eta[K + 3 * KD + i] - kappa * m * m);
-            const double T = a / b;
-            c += 0.5 * (digamma_f64(a) - log(b)) - 0.5 * LOG_2PI - 0.5 * T * m * m - 0.5 / kappa;
-            Wmat[(int64_t)k * 2 * D + d] = (float)(T * m);
-            Wmat[(int64_t)k * 2 * D + D + d] = (float)(-0.5 * T);
+    // 16 lanes per component, 64 components per sweep (the trip count is uniform over a wave's
+    // four 16-lane groups only up to the tail, so the shuffles below stay inside a group)
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = k0 + (threadIdx.x >> 4);
+        double c = 0.0;
+        if (k < K) {
+            for (int d = dl; d < D; d += 16) {
+                const int64_t i = (int64_t)k * D + d;
+                const double kappa = eta[K + KD + i];
+                const double m = eta[K + i] / kappa;
+                const double a = 0.5 * (eta[K + 2 * KD + i] + 1.0);
+                const double b = 0.5 * (eta[K + 3 * KD + i] - kappa * m * m);
+                const double T = a / b;
+                c += 0.5 * (digamma_f64(a) - log(b)) - 0.5 * LOG_2PI - 0.5 * T * m * m - 0.5 / kappa;
+                Wmat[(int64_t)k * 2 * D + d] = (float)(T * m);
+                Wmat[(int64_t)k * 2 * D + D + d] = (float)(-0.5 * T);
+            }
         }
-    }
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) c += __shfl_xor(c, off);
-    if (k < K && dl == 0)
-        cvec[k] = (float)(c + digamma_f64(eta[k] + 1.0) - digamma_f64(alpha_sum));
+        for (int off = 8; off > 0; off >>= 1) c += __shfl_xor(c, off);
+        if (k < K && dl == 0)
+            cvec[k] = (float)(c + digamma_f64(eta[k] + 1.0) - digamma_f64(alpha_sum));
+    }
 }
 
 // eta <- (1-rho) eta + rho (eta0 + scale * message(stats)), stats = [K][R | Sx | Sxx]
@@ -376,7 +382,7 @@ int bsc_mog_expected_params(bsc_ctx* ctx, const double* eta, int32_t K, int32_t 
                             float* c) {
     BSC_CHECK_CTX(ctx);
     BSC_REQUIRE(eta && Wmat && c, "bsc_mog_expected_params: null pointer");
-    BSC_REQUIRE(K >= 1 && K <= MK && D >= 1, "bsc_mog_expected_params: K=%d (<=%d) D=%d", K, MK, D);
+    BSC_REQUIRE(K >= 1 && D >= 1, "bsc_mog_expected_params: K=%d D=%d", K, D);
     hipLaunchKernelGGL(mog_expected_params_kernel, dim3(1), dim3(1024), 0, ctx->stream, eta, (int)K,
                        (int)D, Wmat, c);
     BSC_LAUNCH_CHECK();

@@ -56,7 +56,14 @@ def unpack(eta, K, D):
 
 
 class MoGNatGradSVI:
-    def __init__(self, X, K, eta0, eta_init, n_total=None, ctx=None, group=None):
+    """``via="kernel"`` (default when K <= 64 and D <= 16): the fused E-step of csrc/bsc_mog.hip.
+    ``via="executor"`` (any K up to 1024, any D): the same local step written with the algebra
+    front end and run by the MI355X executor -- logits = dot(X, B.T) + dot(X*X, A.T) + c through
+    the GEMM and one fused add, responsibilities by bsc_softmax_rows, the statistics
+    (sum r, r^T X, r^T X^2) as three more contractions.  Slower (the N x K responsibilities are
+    materialised) but not limited to one MFMA tile; it is also the cross-check of the kernel."""
+
+    def __init__(self, X, K, eta0, eta_init, n_total=None, ctx=None, group=None, via=None):
         self.ctx = ctx or default_context()
         dev = self.ctx.device
         self.X = X if isinstance(X, torch.Tensor) else self.ctx.to_device(X, torch.float32)
@@ -82,15 +89,43 @@ class MoGNatGradSVI:
         self.stats = self.buf[:-1]
         self.lse = self.buf[-1:]
         self.t = 0
-        self.ctx.reserve((2 * self.ctx.info()["cu_count"] + 8) * (64 * 33 + 1) * 4)
+        if via is None:
+            via = "kernel" if (self.K <= 64 and self.D <= 16) else "executor"
+        if via not in ("kernel", "executor"):
+            raise ValueError("via must be 'kernel' or 'executor'")
+        self.via = via
+        if via == "kernel":
+            self.ctx.reserve((2 * self.ctx.info()["cu_count"] + 8) * (64 * 33 + 1) * 4)
+        else:
+            from .. import algebra as A
+            from ..algebra.device_backend import DeviceBackend
+            self.backend = be = DeviceBackend(self.ctx)
+            Xv, Bv, Av, cv, Rv = A.var("X", 2), A.var("B", 2), A.var("A", 2), A.var("c", 1), A.var("R", 2)
+            self._logits = (A.dot(Xv, Bv.T) + A.dot(Xv * Xv, Av.T) + A.dimshuffle(cv, "x", 0)).compile(be).device_fn
+            self._s0 = A.sum(Rv, axis=0).compile(be).device_fn
+            self._s1 = A.dot(Rv.T, Xv).compile(be).device_fn
+            self._s2 = A.dot(Rv.T, Xv * Xv).compile(be).device_fn
+            self._lse_sum = A.sum(A.var("l", 1)).compile(be).device_fn
 
     def expected_params(self):
         self.ctx.call("bsc_mog_expected_params", self.eta, self.K, self.D, self.Wmat,
                       self.c)
 
     def local_step(self):
-        self.ctx.call("bsc_mog_estep", self.X, self.X.stride(0), self.B, self.D, self.K,
-                      self.Wmat, self.c, self.stats, self.lse)
+        if self.via == "kernel":
+            self.ctx.call("bsc_mog_estep", self.X, self.X.stride(0), self.B, self.D, self.K,
+                          self.Wmat, self.c, self.stats, self.lse)
+            return
+        be, D = self.backend, self.D
+        logits = self._logits(X=self.X, B=self.Wmat[:, :D], A=self.Wmat[:, D:], c=self.c)
+        R, lse = be.softmax_rows(logits)
+        stats = self.stats.view(self.K, 1 + 2 * D)
+        f64 = torch.float64
+        # (dtype conversion through bsc_convert; the slice copies are device-to-device plumbing)
+        stats[:, 0].copy_(be._convert(be.materialize(self._s0(R=R)), f64))
+        stats[:, 1:1 + D].copy_(be._convert(be.materialize(self._s1(R=R, X=self.X)), f64))
+        stats[:, 1 + D:].copy_(be._convert(be.materialize(self._s2(R=R, X=self.X)), f64))
+        self.lse.copy_(be._convert(be.materialize(self._lse_sum(l=lse)).reshape(1), f64))
 
     def step(self, rho=None):
         """One SVI update; rho defaults to the Robbins-Monro schedule (t+1)^-0.6."""

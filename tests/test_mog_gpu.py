@@ -119,3 +119,32 @@ def test_unsupported_sizes_fail_loudly(ctx):
     stats, lse = ctx.zeros(4 * 35, torch.float64), ctx.zeros(1, torch.float64)
     with pytest.raises(BayesicHipError, match="tile limits"):
         ctx.call("bsc_mog_estep", ptr(X), 17, 8, 17, 4, ptr(W), ptr(c), ptr(stats), ptr(lse))
+
+
+@pytest.mark.parametrize("K,D", [(100, 24), (8, 16), (65, 4), (200, 40)])
+def test_executor_route_beyond_one_tile_matches_oracle(ctx, K, D):
+    """K > 64 or D > 16 (outside the fused kernel's MFMA tile): the same local step through the
+    algebra executor -- GEMMs, one fused add, bsc_softmax_rows, three contractions -- against the
+    oracle, and against the fused kernel where both apply."""
+    from bayesic_amd.svi.mog import MoGNatGradSVI
+    X, _, _ = svi.make_cfg3(20000, D, K)
+    eta0 = svi.mog_prior_eta(K, D)
+    eta = svi.mog_init_eta(X[:4000], K, D, seed=1)
+    model = MoGNatGradSVI(X, K, eta0, eta, n_total=10 * len(X), ctx=ctx, via="executor")
+    assert model.via == "executor"
+    auto = MoGNatGradSVI(X, K, eta0, eta, n_total=10 * len(X), ctx=ctx)
+    assert auto.via == ("kernel" if K <= 64 and D <= 16 else "executor")
+    import torch
+    for t in range(1, 4):
+        # every update starts from the oracle's parameters: with K = 100 overlapping components a
+        # float32-sized difference in a responsibility feeds back through the softmax
+        for mdl in (model, auto):
+            mdl.eta.copy_(torch.as_tensor(eta, dtype=torch.float64))
+        model.step()
+        auto.step()
+        eta, stats, lse = svi.mog_svi_step(eta, eta0, X, 10 * len(X), (t + 1.0) ** -0.6, K, D)
+        ctx.sync()
+        npt.assert_allclose(model.lse.item(), lse, rtol=1e-5)
+        scale = np.maximum(np.abs(eta), 1.0)
+        assert (np.abs(model.eta.cpu().numpy() - eta) <= 2e-3 * scale).all()
+        assert (np.abs(auto.eta.cpu().numpy() - eta) <= 2e-3 * scale).all()
