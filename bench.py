@@ -402,9 +402,10 @@ class Cfg5(Workload):
 
     def roofline(self, avg_s):
         # 32 flop/B: the fp32-MFMA time (209 us) exceeds the HBM time (129 us) -> MFMA binds
-        return _mfma_roofline("logreg_loglik_kernel", 2.0 * self.rows * self.D * self.S,
+        kernel = "logreg_loglik_dma_kernel" if (self.S % 4 == 0 and 32 < self.S <= 64) else "logreg_loglik_xreg_kernel"
+        return _mfma_roofline(kernel, 2.0 * self.rows * self.D * self.S,
                               4.0 * self.rows * self.D + 8.0 * self.rows, avg_s,
-                              pmc_traffic("logreg_loglik_kernel", self.rows == 1_000_000 and self.D == 256))
+                              pmc_traffic(kernel, self.rows == 1_000_000 and self.D == 256))
 
     def cpu_baseline(self, budget_s):
         from oracle import cbuild

@@ -26,10 +26,10 @@ KERNELS = {
     "cfg2": ("blr_pass_mfma_kernel", "bsc_blr.hip", 4.0 * 1_000_000 * 256 + 4.0 * 1_000_000),
     "cfg3": ("mog_estep_kernel", "bsc_mog.hip", 4.0 * 10_000_000 * 16),
     "cfg4": ("lda_sstats_kernel", "bsc_lda.hip", 4.0 * 6250 * 100_000),
-    "cfg5": ("logreg_loglik_kernel", "bsc_bbvi.hip", 4.0 * 1_000_000 * 256 + 8.0 * 1_000_000),
+    "cfg5": ("logreg_loglik_dma_kernel", "bsc_bbvi.hip", 4.0 * 1_000_000 * 256 + 8.0 * 1_000_000),
     "wouter": ("weighted_outer_kernel", "bsc_wouter.hip", 4.0 * 10_000_000 * (64 + 16)),
     "gram": ("gemm_f32_mfma_kernel", "bsc_gemm.hip", 4.0 * 1_000_000 * 256),
-    "skinny": ("gemm_skinny", "bsc_gemm.hip", 4.0 * 1_000_000 * 256 + 4.0 * 8 * 1_000_000),
+    "skinny": ("gemm_skinny_nt_kernel", "bsc_skinny.hip", 4.0 * 1_000_000 * 256 + 4.0 * 8 * 1_000_000),
 }
 
 
@@ -68,7 +68,12 @@ def show(out):
 def derived(out, dur_us):
     v = {k: a for k, (a, _) in out.items()}
     if v.get("SQ_INSTS_MFMA"):
-        print("  VALU per MFMA              %.2f" % (v.get("SQ_INSTS_VALU", 0) / v["SQ_INSTS_MFMA"]))
+        # SQ_INSTS_VALU counts the MFMAs too
+        print("  non-MFMA VALU per MFMA     %.2f" % ((v.get("SQ_INSTS_VALU", 0) - v["SQ_INSTS_MFMA"]) / v["SQ_INSTS_MFMA"]))
+        if v.get("SQ_INSTS_VMEM"):
+            print("  MFMA per VMEM instruction  %.1f" % (v["SQ_INSTS_MFMA"] / v["SQ_INSTS_VMEM"]))
+        if v.get("SQ_INSTS_LDS"):
+            print("  MFMA per LDS instruction   %.2f" % (v["SQ_INSTS_MFMA"] / v["SQ_INSTS_LDS"]))
     if v.get("SQ_LDS_IDX_ACTIVE"):
         print("  LDS bank-conflict share    %.3f" % (v.get("SQ_LDS_BANK_CONFLICT", 0) / v["SQ_LDS_IDX_ACTIVE"]))
     if v.get("SQ_BUSY_CYCLES") and v.get("SQ_VALU_MFMA_BUSY_CYCLES"):
