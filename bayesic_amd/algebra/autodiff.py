@@ -24,9 +24,16 @@ def _shape_of(value):
 
 
 class _Tape(object):
-    def __init__(self, backend):
+    def __init__(self, backend, needs=None):
         self.b = backend
         self.adjoint = {}
+        self._needs = needs or {}      # id(node) -> does it depend on a variable we differentiate by?
+
+    def needs(self, node):
+        """Adjoints only flow to nodes that depend on a `wrt` input: the vector-Jacobian product
+        towards a data operand (g W for dot(W, X.T): an N x D GEMM and a 1-GB store at config 2's
+        size) is never formed."""
+        return self._needs.get(id(node), True)
 
     # -- small helpers on backend values -------------------------------------------------
     def const(self, v):
@@ -78,6 +85,8 @@ class _Tape(object):
         return self.b.dimshuffle(reduced, pattern)
 
     def accumulate(self, node, g):
+        if not self.needs(node):
+            return
         key = id(node)
         self.adjoint[key] = g if key not in self.adjoint else self.plus(self.adjoint[key], g)
 
@@ -86,7 +95,8 @@ def value_and_grad(backend, expr, inputs, wrt):
     """Returns (value, {name: d sum(value) / d input[name]}) as backend values.
 
     inputs: {name: backend value} (as for ``Backend.evaluate``); wrt: input names."""
-    order, values, lowered_of = [], {}, {}
+    order, values, lowered_of, needs = [], {}, {}, {}
+    wrt = list(wrt)
 
     def forward(node):
         key = id(node)
@@ -94,18 +104,21 @@ def value_and_grad(backend, expr, inputs, wrt):
             return values[key]
         if isinstance(node, var):
             value = inputs[node.name]
+            needs[key] = node.name in wrt
         elif isinstance(node, Einsum):
             low = node.lowered()
             lowered_of[key] = low
             value = forward(low)
+            needs[key] = needs[id(low)]
         else:
             value = node._emit(backend, *[forward(p) for p in node.parents])
+            needs[key] = any(needs[id(p)] for p in node.parents)
         values[key] = value
         order.append(node)
         return value
 
     out = forward(expr)
-    tape = _Tape(backend)
+    tape = _Tape(backend, needs)
     out_shape = _shape_of(out)
     seed = tape.const(1.0)
     if out_shape:
@@ -133,9 +146,12 @@ def value_and_grad(backend, expr, inputs, wrt):
             g = tape.like(g, values[id(node)])           # a rank-less uniform adjoint: give it the node's shape
         if isinstance(node, add):
             for p, v in zip(parents, pv):
-                tape.accumulate(p, tape.fit(g, v))
+                if tape.needs(p):
+                    tape.accumulate(p, tape.fit(g, v))
         elif isinstance(node, _mul):
             for i, (p, v) in enumerate(zip(parents, pv)):
+                if not tape.needs(p):
+                    continue
                 rest = [w for j, w in enumerate(pv) if j != i]
                 term = tape.times(g, *rest) if rest else g
                 tape.accumulate(p, tape.fit(term, v))
@@ -224,36 +240,41 @@ def _tensordot_vjp(tape, backend, node, parents, pv, g):
         # the other way round -- no tensordot with a rank-less operand
         px = [yd[xd.index(a)] for a in range(len(_shape_of(X)))]
         py = [xd[yd.index(a)] for a in range(len(_shape_of(Y)))]
-        rx, ry = tape.times(g, Y), tape.times(g, X)
-        tape.accumulate(parents[0], backend.dimshuffle(rx, px) if px != sorted(px) else rx)
-        tape.accumulate(parents[1], backend.dimshuffle(ry, py) if py != sorted(py) else ry)
+        if tape.needs(parents[0]):
+            rx = tape.times(g, Y)
+            tape.accumulate(parents[0], backend.dimshuffle(rx, px) if px != sorted(px) else rx)
+        if tape.needs(parents[1]):
+            ry = tape.times(g, X)
+            tape.accumulate(parents[1], backend.dimshuffle(ry, py) if py != sorted(py) else ry)
         return
     g_batch = list(range(nb))
     g_xo = list(range(nb, nb + nxo))
     g_yo = list(range(nb + nxo, nb + nxo + nyo))
-    # dX = g . Y over Y's free axes: result axes = batch, X others, Y's dot axes (ascending)
-    r = backend.tensordot(g, Y, g_yo, yo, g_batch, yb)
-    yd_sorted = sorted(yd)
-    pattern = []
-    for a in range(len(_shape_of(X))):
-        if a in xb:
-            pattern.append(xb.index(a))
-        elif a in xo:
-            pattern.append(nb + xo.index(a))
-        else:
-            pattern.append(nb + nxo + yd_sorted.index(yd[xd.index(a)]))
-    tape.accumulate(parents[0], backend.dimshuffle(r, pattern)
-                    if pattern != list(range(len(pattern))) else r)
-    # dY = X . g over X's free axes: result axes = batch, X's dot axes (ascending), Y others
-    r = backend.tensordot(X, g, xo, g_xo, xb, g_batch)
-    xd_sorted = sorted(xd)
-    pattern = []
-    for a in range(len(_shape_of(Y))):
-        if a in yb:
-            pattern.append(yb.index(a))
-        elif a in yo:
-            pattern.append(nb + len(xd) + yo.index(a))
-        else:
-            pattern.append(nb + xd_sorted.index(xd[yd.index(a)]))
-    tape.accumulate(parents[1], backend.dimshuffle(r, pattern)
-                    if pattern != list(range(len(pattern))) else r)
+    if tape.needs(parents[0]):
+        # dX = g . Y over Y's free axes: result axes = batch, X others, Y's dot axes (ascending)
+        r = backend.tensordot(g, Y, g_yo, yo, g_batch, yb)
+        yd_sorted = sorted(yd)
+        pattern = []
+        for a in range(len(_shape_of(X))):
+            if a in xb:
+                pattern.append(xb.index(a))
+            elif a in xo:
+                pattern.append(nb + xo.index(a))
+            else:
+                pattern.append(nb + nxo + yd_sorted.index(yd[xd.index(a)]))
+        tape.accumulate(parents[0], backend.dimshuffle(r, pattern)
+                        if pattern != list(range(len(pattern))) else r)
+    if tape.needs(parents[1]):
+        # dY = X . g over X's free axes: result axes = batch, X's dot axes (ascending), Y others
+        r = backend.tensordot(X, g, xo, g_xo, xb, g_batch)
+        xd_sorted = sorted(xd)
+        pattern = []
+        for a in range(len(_shape_of(Y))):
+            if a in yb:
+                pattern.append(yb.index(a))
+            elif a in yo:
+                pattern.append(nb + len(xd) + yo.index(a))
+            else:
+                pattern.append(nb + xd_sorted.index(xd[yd.index(a)]))
+        tape.accumulate(parents[1], backend.dimshuffle(r, pattern)
+                        if pattern != list(range(len(pattern))) else r)

@@ -246,16 +246,25 @@ __global__ __launch_bounds__(64 * SW, 2) void gemm_skinny_tn_kernel(TnArgs a) {
     }
 }
 
-// C[m, d] = sum over workgroup partials, fixed order
-__global__ __launch_bounds__(256) void skinny_tn_finish_kernel(const double* __restrict__ slab, int n_blocks,
-                                                               int M, int D, float* __restrict__ C,
-                                                               int64_t sc_m, int64_t sc_n) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+// C[m, d] = sum over workgroup partials, fixed order.  One thread per output (consecutive threads
+// read consecutive slab words); sixteen loads in flight, added in block order.
+__global__ __launch_bounds__(64) void skinny_tn_finish_kernel(const double* __restrict__ slab, int n_blocks,
+                                                              int M, int D, float* __restrict__ C,
+                                                              int64_t sc_m, int64_t sc_n) {
+    const int idx = blockIdx.x * 64 + threadIdx.x;
     if (idx >= M * 256) return;
     const int m = idx >> 8, d = idx & 255;
     if (d >= D) return;
     double v = 0.0;
-    for (int b = 0; b < n_blocks; ++b) v += slab[(int64_t)b * 4096 + idx];
+    int b = 0;
+    for (; b + 16 <= n_blocks; b += 16) {
+        double t[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t[j] = slab[(int64_t)(b + j) * 4096 + idx];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v += t[j];
+    }
+    for (; b < n_blocks; ++b) v += slab[(int64_t)b * 4096 + idx];
     C[(int64_t)m * sc_m + (int64_t)d * sc_n] = (float)v;
 }
 
@@ -316,7 +325,7 @@ int bsc_gemm_skinny(bsc_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* 
             hipLaunchKernelGGL(gemm_skinny_tn_kernel, dim3(n_blocks), dim3(64 * SW), 0, ctx->stream, a);
         }
         BSC_LAUNCH_CHECK();
-        hipLaunchKernelGGL(skinny_tn_finish_kernel, dim3((Ms * 256 + 255) / 256), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(skinny_tn_finish_kernel, dim3((Ms * 256 + 63) / 64), dim3(64), 0, ctx->stream,
                            (const double*)ws, n_blocks, Ms, Dl, C, sc_ms, sc_ds);
         BSC_LAUNCH_CHECK();
         return (int)BSC_OK;

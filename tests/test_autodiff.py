@@ -100,3 +100,32 @@ def test_sum_vjp_broadcasts_from_shape_not_from_the_forward_value():
         _, grads = value_and_grad(be, A.sum(A.exp(x)), {"x": np.array([0.0, 800.0])}, ["x"])
     g = np.asarray(grads["x"])
     assert g[0] == 1.0 and np.isposinf(g[1])
+
+
+def test_no_adjoint_is_formed_towards_inputs_that_are_not_differentiated():
+    """d/dW of sum((y - dot(W, X.T))^2): the vector-Jacobian product towards the DATA operand X
+    (an N x D product) must never be computed -- counted on a backend that records tensordots."""
+    import numpy as np
+    from bayesic_amd import algebra as A
+    from bayesic_amd.algebra.autodiff import value_and_grad
+    from oracle.einsum_eval import NumpyBackend
+
+    class Counting(NumpyBackend):
+        shapes = []
+
+        def tensordot(self, x, y, *a):
+            out = NumpyBackend.tensordot(self, x, y, *a)
+            Counting.shapes.append(np.shape(out))
+            return out
+
+    be = Counting(np.float64)
+    rs = np.random.RandomState(0)
+    S, N, D = 3, 50, 7
+    Xv, yv, Wv = rs.standard_normal((N, D)), rs.standard_normal(N), rs.standard_normal((S, D))
+    X, y, W = A.var("X", 2, "float64"), A.var("y", 1, "float64"), A.var("W", 2, "float64")
+    r = A.dimshuffle(y, "x", 0) - A.dot(W, X.T)
+    f = A.sum(r * r, axis=1)
+    _, g = value_and_grad(be, f, {"X": Xv, "y": yv, "W": Wv}, ["W"])
+    R = yv[None, :] - Wv @ Xv.T
+    np.testing.assert_allclose(np.asarray(g["W"]), -2.0 * R @ Xv, rtol=1e-12)
+    assert (N, D) not in Counting.shapes and (D, N) not in Counting.shapes, Counting.shapes
