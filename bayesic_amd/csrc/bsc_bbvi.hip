@@ -664,7 +664,10 @@ __global__ __launch_bounds__(64 * XW, 2) void logreg_loglik_dma_kernel(
             // in issue order, so "at most as many outstanding as were issued after it": a strip issued
             // in the previous tile (j+1 < XR) is followed by the rest of that batch, this tile's side
             // DMAs and this tile's j strips = XR - 2 + DMA_SIDE; one issued in this tile by XR - 2.
-            if (j + 1 < XR) __builtin_amdgcn_s_waitcnt(vmcnt_only(XR - 2 + ((DBG & 8) ? 0 : DMA_SIDE)));
+            if (DBG & 16) {
+                // profiling only: no strip wait at all (reads race the DMAs; the time shows what the
+                // waits cost)
+            } else if (j + 1 < XR) __builtin_amdgcn_s_waitcnt(vmcnt_only(XR - 2 + ((DBG & 8) ? 0 : DMA_SIDE)));
             else __builtin_amdgcn_s_waitcnt(vmcnt_only(XR - 2));
             asm volatile("" ::: "memory");
             if (!(DBG & 4)) an = a_read((j + 1) % 16);
@@ -990,6 +993,7 @@ int bsc_logreg_bbvi_loglik(bsc_ctx* ctx, const float* X, int64_t ldx, const floa
                 case 7: hipLaunchKernelGGL((logreg_loglik_dma_kernel<true, 4, 7>), BSC_LL_ARGS); break;
                 case 11: hipLaunchKernelGGL((logreg_loglik_dma_kernel<true, 4, 11>), BSC_LL_ARGS); break;
                 case 15: hipLaunchKernelGGL((logreg_loglik_dma_kernel<true, 4, 15>), BSC_LL_ARGS); break;
+                case 16: hipLaunchKernelGGL((logreg_loglik_dma_kernel<true, 4, 16>), BSC_LL_ARGS); break;
                 default: hipLaunchKernelGGL((logreg_loglik_dma_kernel<true, 4>), BSC_LL_ARGS); break;
             }
         } else if (dma_ok) {

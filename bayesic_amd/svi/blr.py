@@ -13,6 +13,14 @@ One update is two launches on one GPU -- the streaming data pass and a fused
 finish (float64 reduction of the pass partials, ELBO + pathwise gradient, Adam
 step, next step's Philox draws) -- with lam and the draws double-buffered.
 
+``reproducible=True``: results are bit-identical on 1, 2, 4 and 8 GPUs.
+The global mini-batch is cut into V = 8 virtual shards of equal size; a rank runs one data pass
+per shard it holds (the pass's workgroup partition then depends on the shard alone, not on p),
+the ranks all-reduce a [V, S(D+1)] float64 buffer in which every row is non-zero on exactly one
+rank (adding zeros is exact, so the collective's order does not matter), and every rank adds
+the V rows in shard order with one n-ary bsc_elemwise launch.  Off by default: on one GPU it is
+eight 125k-row passes instead of one 1M-row pass.
+
 Data parallelism: each rank holds a contiguous block of mini-batch rows.  The
 only exchange per update is ONE all-reduce(sum) of the float64 vector
 [Q (S), G (S*D)] (16 KB at S=8, D=256) between the pass and the finish; noise is
@@ -30,8 +38,10 @@ from .exchange import Exchange
 class BLRReparamSVI:
     NOISE_BLOCK = 32
 
+    VIRTUAL_SHARDS = 8
+
     def __init__(self, X, y, n_total=None, n_samples=8, seed=1234, lr=1e-2, alpha0=1.0,
-                 beta0=1.0, ctx=None, group=None, lam0=None, fused=True):
+                 beta0=1.0, ctx=None, group=None, lam0=None, fused=True, reproducible=False):
         self.ctx = ctx or default_context()
         dev = self.ctx.device
         self.X = X if isinstance(X, torch.Tensor) else self.ctx.to_device(X, torch.float32)
@@ -55,6 +65,20 @@ class BLRReparamSVI:
         self.batch_rows = self.exchange.global_count(self.B, dev)
         self.n_total = float(n_total) if n_total is not None else self.batch_rows
         self.fused = bool(fused)
+        self.reproducible = bool(reproducible)
+        if self.reproducible:
+            V = self.VIRTUAL_SHARDS
+            total = int(round(self.batch_rows))
+            if total % V != 0:
+                raise ValueError("reproducible=True needs the global mini-batch (%d rows) to be a multiple "
+                                 "of %d virtual shards" % (total, V))
+            self._shard_rows = total // V
+            first = self.exchange.row_offset(self.B, dev)
+            if first % self._shard_rows != 0 or self.B % self._shard_rows != 0:
+                raise ValueError("reproducible=True needs every rank to hold whole virtual shards of %d rows "
+                                 "(this rank: rows %d..%d)" % (self._shard_rows, first, first + self.B))
+            self._first_shard = first // self._shard_rows
+            self._n_shards = self.B // self._shard_rows
         D, S = self.D, self.S
         f64 = torch.float64
         # double-buffered state: index t & 1 is current at the start of step t+1
@@ -75,6 +99,8 @@ class BLRReparamSVI:
         self.grad = torch.zeros(2 * D + 2, dtype=f64, device=dev)
         self.elbo = torch.zeros(1, dtype=f64, device=dev)
         self.stats = torch.zeros(S * (D + 1), dtype=f64, device=dev)  # [Q | G]
+        if self.reproducible:
+            self._vstats = torch.zeros((self.VIRTUAL_SHARDS, S * (D + 1)), dtype=f64, device=dev)
         self.Q = self.stats[:S]
         self.G = self.stats[S:]
         self.t = 0
@@ -140,11 +166,35 @@ class BLRReparamSVI:
         self._drawn = True
 
     def data_pass(self):
+        if self.reproducible:
+            return self._data_pass_by_shard()
         self.ctx.call("bsc_blr_data_pass", self._Xarg, self._ldx, self._yarg, self.B,
                       self.D, self.W, self.S, self.Q, self.G)
 
+    def _data_pass_by_shard(self):
+        """One pass per virtual shard this rank holds, each into its own row of the [V, n] buffer
+        (the other rows stay zero until the all-reduce)."""
+        if self.X is None:
+            raise ValueError("reproducible=True needs tensor batches (set_batch with raw pointers is not sharded)")
+        S, rows = self.S, self._shard_rows
+        self.ctx.call("bsc_memset", self._vstats, 0, self._vstats.numel() * 8)
+        for k in range(self._n_shards):
+            r0 = k * rows
+            out = self._vstats[self._first_shard + k]
+            self.ctx.call("bsc_blr_data_pass", self.X[r0:r0 + rows], self._ldx, self.y[r0:r0 + rows], rows,
+                          self.D, self.W, S, out[:S], out[S:])
+
     def all_reduce(self):
-        self.exchange.all_reduce(self.stats)
+        if not self.reproducible:
+            self.exchange.all_reduce(self.stats)
+            return
+        import ctypes
+        self.exchange.all_reduce(self._vstats)          # every row is non-zero on one rank only: exact
+        V, n = self._vstats.shape
+        i64 = lambda v: (ctypes.c_int64 * len(v))(*v)
+        ptrs = (ctypes.c_void_p * V)(*[self._vstats[v].data_ptr() for v in range(V)])
+        # stats = ((V0 + V1) + V2) + ... in shard order: one n-ary add, the same on every rank count
+        self.ctx.call("bsc_elemwise", 0, 1, 1, i64([n]), self.stats, i64([1]), V, ptrs, i64([1] * V))
 
     def _finish(self, stats):
         """Fused gradient + Adam + next draw; flips the double buffer."""
@@ -164,7 +214,7 @@ class BLRReparamSVI:
         """One ELBO-gradient update; asynchronous on the context stream."""
         if not self._drawn:
             self.sample(self.t)  # Philox step index == number of completed updates
-        if self.fused and self.world == 1 and not self.exchange.rccl and self.S <= 8:
+        if self.fused and self.world == 1 and not self.exchange.rccl and self.S <= 8 and not self.reproducible:
             self.ctx.call("bsc_blr_data_pass_partial", self._Xarg, self._ldx,
                           self._yarg, self.B, self.D, self.W, self.S)
             self._finish(None)

@@ -58,6 +58,25 @@ class Exchange:
             torch.distributed.all_reduce(tensor, group=self.group)
         return tensor
 
+    @property
+    def rank(self):
+        if self.rccl:
+            return self.ctx.comm_info()["rank"]
+        if self.world > 1:
+            return torch.distributed.get_rank(self.group)
+        return 0
+
+    def row_offset(self, local, device):
+        """Global index of this rank's first row when rank r holds the r-th contiguous block:
+        the exclusive prefix sum of the ranks' row counts (one all-reduce of a [world] vector in
+        which every rank fills its own slot -- exact whatever the reduction order)."""
+        if self.world == 1:
+            return 0
+        t = torch.zeros(self.world, dtype=torch.float64, device=device)
+        t[self.rank] = float(local)
+        self.all_reduce(t)
+        return int(round(float(t[:self.rank].sum().item())))
+
     def global_count(self, local, device):
         """Sum of a per-rank scalar (the rank's rows) over all ranks, as a float."""
         t = torch.tensor([float(local)], dtype=torch.float64, device=device)

@@ -35,6 +35,16 @@ def main():
         model.step()
     ctx.sync()
 
+    # reproducible mode: whole virtual shards per rank (8 shards of 2500 rows: 5 + 3)
+    rc = [0, 12500, 20000]
+    rsl = slice(rc[rank], rc[rank + 1])
+    repro = BLRReparamSVI(ctx.to_device(X[rsl]), ctx.to_device(y[rsl]), n_total=200000, n_samples=8,
+                          seed=11, lr=0.02, ctx=ctx, reproducible=True)
+    assert repro._first_shard == (0, 5)[rank] and repro._n_shards == (5, 3)[rank]
+    for _ in range(4):
+        repro.step()
+    ctx.sync()
+
     Xm, _, _ = svi.make_cfg3(30000, 8, 5)
     mc = [0, 17000, 30000]
     eta0 = svi.mog_prior_eta(5, 8)
@@ -45,7 +55,7 @@ def main():
         mog.step()
     ctx.sync()
     np.savez(out_path % rank, lam=model.lam.cpu().numpy(), elbo=model.elbo.cpu().numpy(),
-             eta=mog.eta.cpu().numpy())
+             eta=mog.eta.cpu().numpy(), lam_repro=repro.lam.cpu().numpy(), elbo_repro=repro.elbo.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 

@@ -78,6 +78,20 @@ class OracleContext:
         grad.copy_(torch.from_numpy(g))
         self.bsc_blr_sample(lam_out, D, S, seed, next_step, eps_n, W_n, xi_n)
 
+    def bsc_memset(self, t, value, nbytes):
+        t.view(-1).view(torch.uint8)[:nbytes].fill_(value)
+
+    def bsc_elemwise(self, op, dtype, rank, shape, out, out_strides, n_in, ptrs, strides):
+        """The n-ary float64 add of the reproducible mode: out = ((in0 + in1) + in2) + ..."""
+        import ctypes
+        assert op == 0 and dtype == 1 and rank == 1
+        n = int(shape[0])
+        acc = None
+        for k in range(n_in):
+            a = np.ctypeslib.as_array((ctypes.c_double * n).from_address(int(ptrs[k])))
+            acc = a.copy() if acc is None else acc + a
+        out.copy_(torch.from_numpy(acc))
+
     def bsc_mog_expected_params(self, eta, K, D, Wmat, c):
         w, cc = svi.mog_expected_params(eta.numpy(), K, D)
         Wmat.copy_(torch.from_numpy(w))
@@ -153,6 +167,17 @@ def main():
         model.step()
     lam = model.lam.numpy().copy()
 
+    # --- reproducible mode: whole virtual shards per rank (8 shards of 100 rows: 5 + 3) --------
+    rcut = [0, 500, 800] if world == 2 else np.linspace(0, 800, world + 1).astype(int)
+    rep = BLRReparamSVI(torch.from_numpy(X[rcut[rank]:rcut[rank + 1]].copy()),
+                        torch.from_numpy(y[rcut[rank]:rcut[rank + 1]].copy()), n_total=9000, n_samples=4,
+                        seed=11, lr=0.02, ctx=OracleContext(), reproducible=True)
+    assert rep.batch_rows == 800.0 and rep._shard_rows == 100
+    assert rep._first_shard == rcut[rank] // 100 and rep._n_shards == (rcut[rank + 1] - rcut[rank]) // 100
+    for _ in range(3):
+        rep.step()
+    lam_rep = rep.lam.numpy().copy()
+
     # --- config 3 shape (small) ---------------------------------------------------
     Xm, _, _ = svi.make_cfg3(1200, 4, 3)
     mc = [0, 700, 1200] if world == 2 else np.linspace(0, 1200, world + 1).astype(int)
@@ -189,7 +214,7 @@ def main():
     assert lda.world == world and lda.batch_docs == 90.0
     for _ in range(2):
         lda.step()
-    np.savez(out_path % rank, lam=lam, elbo=model.elbo.numpy(), eta=mog.eta.numpy(),
+    np.savez(out_path % rank, lam=lam, lam_rep=lam_rep, elbo=model.elbo.numpy(), eta=mog.eta.numpy(),
              lse=mog.lse.numpy(), bbvi_lam=bb.lam.numpy(), bbvi_elbo=bb.elbo.numpy(),
              lda_lam=lda.lam.numpy())
     dist.barrier()

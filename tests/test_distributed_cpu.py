@@ -35,6 +35,14 @@ def test_two_gloo_ranks_equal_single_process(tmp_path):
         lam, m1, m2, elbo, _ = svi.blr_step(lam, m1, m2, t, X, y, 4, 11, 9000, 0.02)
     np.testing.assert_allclose(r0["lam"], lam, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(r0["elbo"][0], elbo, rtol=1e-10)
+    # reproducible mode (whole virtual shards per rank, block-sparse all-reduce, ordered add): the
+    # host logic; both ranks identical, and equal to the oracle on the first 800 rows
+    np.testing.assert_array_equal(r0["lam_rep"], r1["lam_rep"])
+    lam = svi.blr_init_lam(16)
+    m1, m2 = np.zeros_like(lam), np.zeros_like(lam)
+    for t in range(1, 4):
+        lam, m1, m2, _, _ = svi.blr_step(lam, m1, m2, t, X[:800], y[:800], 4, 11, 9000, 0.02)
+    np.testing.assert_allclose(r0["lam_rep"], lam, rtol=1e-10, atol=1e-12)
     Xm, _, _ = svi.make_cfg3(1200, 4, 3)
     eta0 = svi.mog_prior_eta(3, 4)
     eta = svi.mog_init_eta(Xm[:300], 3, 4, seed=2)

@@ -38,7 +38,7 @@ def main():
         variants.pop("lds-staged (r1)")
     if "--deletion" in sys.argv:
         # profiling-only builds of the r2 kernel with parts removed (results wrong, time matters)
-        for dbg, what in ((1, "no X refill loads"), (2, "no epilogue"), (3, "no X loads, no epilogue"),
+        for dbg, what in ((16, "no strip waits (reads race the DMAs)"), (1, "no X refill loads"), (2, "no epilogue"), (3, "no X loads, no epilogue"),
                           (11, "no X loads, epilogue, side loads"), (7, "MFMA + side loads only"),
                           (15, "MFMA only")):
             variants["r2b dbg=%d %s" % (dbg, what)] = make_ctx({"BSC_BBVI_KERNEL": "1", "BSC_BBVI_DBG": str(dbg)})
