@@ -66,6 +66,10 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
     }
     if (const char* e = getenv("BSC_BLR_WAVES_PER_SIMD")) ctx->blr_waves_per_simd = atoi(e);
     if (const char* e = getenv("BSC_BLR_NT")) ctx->blr_nt_loads = atoi(e);
+    if (const char* e = getenv("BSC_BLR_FINISH_BLOCK")) {
+        const int v = atoi(e);
+        ctx->blr_finish_block = (v == 256 || v == 512) ? v : 1024;
+    }
     if (const char* e = getenv("BSC_BLR_PK")) ctx->blr_pk = atoi(e) != 0;
     if (const char* e = getenv("BSC_FUSED_MAP_BLOCKS_PER_CU")) {
         const int v = atoi(e);

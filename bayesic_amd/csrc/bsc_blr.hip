@@ -662,8 +662,6 @@ __global__ void blr_sample_kernel(const double* __restrict__ lam, int D, int S, 
 // One workgroup.  Thread d owns column d (strided when D > blockDim).
 constexpr int FIN_BLOCK = 256;
 constexpr int FIN_WAVES = FIN_BLOCK / BSC_WAVE;
-constexpr int FUSED_BLOCK = 1024;  // 16 waves: 32 slab rows per wave at 512 partials
-constexpr int FUSED_WAVES = FUSED_BLOCK / BSC_WAVE;
 constexpr int FIN_MAX_S = 64;
 constexpr double LOG_2PI = 1.8378770664093454835606594728112;
 
@@ -777,7 +775,11 @@ __device__ __forceinline__ double adam_ascent_one(double lam, double g, double& 
     return lam + a.lr * mhat / (sqrt(vhat) + a.adam_eps);
 }
 
+// BLOCK threads per workgroup (1024 = 16 waves: 32 slab rows per wave at 512 partials; fewer waves
+// launch sooner -- BSC_BLR_FINISH_BLOCK, A/B in tools/ab_pass.py)
+template <int FUSED_BLOCK>
 __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs a) {
+    constexpr int FUSED_WAVES = FUSED_BLOCK / BSC_WAVE;
     __shared__ double red[FUSED_WAVES][BSC_WAVE];
     __shared__ double sh[2 * FIN_MAX_S + 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1230,8 +1232,13 @@ int bsc_blr_fused_update(bsc_ctx* ctx, const double* stats, const double* lam_in
     a.next_step = next_step;
     {
         bsc_prof_scope prof(ctx, /*slot=*/2);  // the finish kernel, timed apart from the pass
-        hipLaunchKernelGGL(blr_fused_update_kernel, dim3((D + 7) / 8 + 1), dim3(FUSED_BLOCK), 0,
-                           ctx->stream, a);
+        const dim3 fgrid((D + 7) / 8 + 1);
+        if (ctx->blr_finish_block == 256)
+            hipLaunchKernelGGL(blr_fused_update_kernel<256>, fgrid, dim3(256), 0, ctx->stream, a);
+        else if (ctx->blr_finish_block == 512)
+            hipLaunchKernelGGL(blr_fused_update_kernel<512>, fgrid, dim3(512), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(blr_fused_update_kernel<1024>, fgrid, dim3(1024), 0, ctx->stream, a);
     }
     BSC_LAUNCH_CHECK();
     return BSC_OK;

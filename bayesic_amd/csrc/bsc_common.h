@@ -34,6 +34,7 @@ struct bsc_ctx {
     int wo_wg_per_cu = 2;        // bsc_weighted_outer: resident workgroups per CU the grid is sized for
     int fused_waves_per_cu = 16; // bsc_map_reduce: reduce splits target this many waves per CU
     int blr_pk = 1;              // MFMA pass: backward rank-1 updates as packed FMAs (BSC_BLR_PK=0: scalar; +0.4 % in-process A/B, same bits)
+    int blr_finish_block = 1024; // threads per workgroup of blr_fused_update_kernel (BSC_BLR_FINISH_BLOCK = 256 | 512 | 1024)
     int blr_nt_loads = 1;        // non-temporal loads of X (read once per pass): +9% measured
     int slab_rows = 0;  // block partials left in `workspace` by bsc_blr_data_pass_partial
     // optional per-kernel timing of the dominant kernel (bsc_ctx_profile)
