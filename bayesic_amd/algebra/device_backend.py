@@ -85,6 +85,27 @@ class Lazy(object):
         return self.post is None and self.scale == 1.0 and self.shift == 0.0
 
 
+class LazyGemm(object):
+    """A matrix-matrix _tensordot that has not been launched yet, so that its consumer can be
+    folded into the store (bsc_gemm_epilogue): ``scale * dot(x, y) ** power * E``.  The lowering
+    emits ``_mul(B, _tensordot(...))`` and ``_mul(C, pow(_tensordot(...), -1))`` for
+    ``B * dot(X, Y)`` and ``C / dot(X, Y)`` (bayesic/algebra.py:741-765, 1419-1432); Theano's graph
+    optimiser would have fused them, here the executor does."""
+
+    __slots__ = ("gemm", "shape", "dtype", "power", "scale", "E")
+
+    def __init__(self, gemm, shape, dtype, power=1, scale=1.0, E=None):
+        self.gemm, self.shape, self.dtype = gemm, tuple(shape), dtype
+        self.power, self.scale, self.E = power, scale, E
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def dim(self):
+        return len(self.shape)
+
+
 def _i64(values):
     values = list(values)
     return (ctypes.c_int64 * max(len(values), 1))(*values)
@@ -305,9 +326,35 @@ class DeviceBackend(Backend):
         return out
 
     def _force(self, v):
+        if isinstance(v, LazyGemm):
+            return self._launch_gemm(v)
         return self._launch(v) if isinstance(v, Lazy) else v
 
+    def _launch_gemm(self, g):
+        xb, m, n, k, x, sxb, sxm, sxk, y, syb, syk, syn = g.gemm
+        out = self._empty(g.shape, g.dtype)
+        if g.power == 1 and g.E is None and g.scale == 1.0:
+            self.ctx.call("bsc_gemm_strided_batched", _DT[g.dtype], xb, m, n, k,
+                          _ffi.ptr(x), sxb, sxm, sxk, _ffi.ptr(y), syb, syk, syn,
+                          _ffi.ptr(out), m * n, n, 1)
+            return out
+        E = g.E
+        se_m = se_n = 0
+        if E is not None:
+            se_m = 0 if E.shape[0] == 1 else E.stride(0)
+            se_n = 0 if E.shape[1] == 1 else E.stride(1)
+        self.ctx.call("bsc_gemm_epilogue", _DT[g.dtype], xb, m, n, k,
+                      _ffi.ptr(x), sxb, sxm, sxk, _ffi.ptr(y), syb, syk, syn,
+                      _ffi.ptr(out), m * n, n, 1, int(g.power), float(g.scale),
+                      _ffi.ptr(E) if E is not None else None, 0, se_m, se_n)
+        return out
+
     def _unary(self, op_name, x, arg=0.0):
+        if isinstance(x, LazyGemm):
+            if self.fuse and op_name == "pow" and float(arg) in (1.0, -1.0) and x.E is None and \
+                    x.power == 1 and x.scale == 1.0:
+                return LazyGemm(x.gemm, x.shape, x.dtype, power=int(arg))
+            x = self._force(x)
         if isinstance(x, Lazy):
             if x.post is None and self.fuse:
                 return Lazy(x.combine, x.terms, x.shape, x.dtype, x.scale, x.shift, (op_name, arg))
@@ -322,6 +369,13 @@ class DeviceBackend(Backend):
         rest = [a for a in args if not isinstance(a, HostScalar)]
         if not rest:
             return HostScalar(self._host_elemwise(op_name, host))
+        gemms = [a for a in rest if isinstance(a, LazyGemm)]
+        if gemms:
+            fused = self._fold_into_gemm(rest, host) if (mul and self.fuse and len(gemms) == 1) else None
+            if fused is not None:
+                return fused
+            rest = [self._force(a) if isinstance(a, LazyGemm) else a for a in rest]
+            args = rest + [HostScalar(h) for h in host]
         coef = (math.prod(host) if mul else sum(host)) if host else (1.0 if mul else 0.0)
         ndim = max(a.dim() for a in rest)
         dtype = torch.float64 if any(a.dtype == torch.float64 for a in rest) else torch.float32
@@ -353,6 +407,25 @@ class DeviceBackend(Backend):
         out = Lazy(op_name, terms, shape, dtype, scale=coef if mul else 1.0,
                    shift=0.0 if mul else coef)
         return out if self.fuse else self._launch(out)
+
+    def _fold_into_gemm(self, rest, host):
+        """scale * dot ** power * E as ONE launch when the product has exactly one other operand,
+        a float32 matrix of the result's shape (or broadcast along one of its axes); else None."""
+        g = next(a for a in rest if isinstance(a, LazyGemm))
+        others = [a for a in rest if a is not g]
+        if g.E is not None or len(g.shape) != 2 or g.dtype != torch.float32 or len(others) > 1:
+            return None
+        E = None
+        if others:
+            E = others[0]
+            if isinstance(E, Lazy):
+                if E.dim() != 2 or any(E.shape[a] not in (1, g.shape[a]) for a in range(2)):
+                    return None
+                E = self._force(E)
+            if not isinstance(E, torch.Tensor) or E.dim() != 2 or E.dtype != torch.float32 or \
+                    any(E.shape[a] not in (1, g.shape[a]) for a in range(2)):
+                return None
+        return LazyGemm(g.gemm, g.shape, g.dtype, power=g.power, scale=g.scale * math.prod(host), E=E)
 
     def evaluate(self, expr, inputs, bindings=None):
         entry = self._plans.get(id(expr))
@@ -390,6 +463,8 @@ class DeviceBackend(Backend):
         return self._combine("mul", list(factors))
 
     def sum(self, x, axes):
+        if isinstance(x, LazyGemm):
+            x = self._force(x)
         if isinstance(x, HostScalar):
             return x
         if isinstance(x, Lazy):
@@ -411,6 +486,8 @@ class DeviceBackend(Backend):
         return y
 
     def dimshuffle(self, x, axes):
+        if isinstance(x, LazyGemm):
+            x = self._force(x)
         if isinstance(x, HostScalar):
             return x          # broadcast axes of a scalar are re-created where it is used
         if isinstance(x, Lazy):     # element-wise values commute with views: re-view every operand
@@ -488,6 +565,7 @@ class DeviceBackend(Backend):
         fused pass -- y is broadcast over x's free axes (operands may be deferred
         element-wise values; nothing is materialised)."""
         # line y's axes up with x's, then it is sum(x * y) over x's dot axes
+        x, y = (self._force(v) if isinstance(v, LazyGemm) else v for v in (x, y))
         order = ["x"] * x.dim()
         for ax, ay in zip(list(x_batch) + list(x_dot), list(y_batch) + list(y_dot)):
             order[ax] = ay
@@ -595,6 +673,11 @@ class DeviceBackend(Backend):
         if k != k2 or xb != yb:
             raise ValueError("tensordot: contracted / batch extents differ (%d vs %d, %d vs %d)"
                              % (k, k2, xb, yb))
+        if self.fuse and dtype == torch.float32 and len(out_shape) == 2 and xb == 1 and m > 1 and n > 1 \
+                and k > 0 and self._plan is not None:
+            # deferred: a _mul / pow(., -1) consumer folds into the store (inside evaluate() only --
+            # a value handed to the caller is always a tensor)
+            return LazyGemm((xb, m, n, k, x, sxb, sxm, sxk, y, syb, syk, syn), out_shape, dtype)
         out = self._empty(out_shape, dtype)
         self.ctx.call("bsc_gemm_strided_batched", _DT[dtype], xb, m, n, k,
                       _ffi.ptr(x), sxb, sxm, sxk, _ffi.ptr(y), syb, syk, syn,

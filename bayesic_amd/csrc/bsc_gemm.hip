@@ -37,7 +37,19 @@ struct GemmArgs {
     int64_t k_chunk;   // multiple of BK
     int vec_a, vec_b;  // 16-byte loads allowed along the operand's contiguous axis
     int fast;          // interior tiles may use scalar-base + 32-bit-lane-offset loads (no per-lane address arithmetic)
+    // epilogue (bsc_gemm_epilogue): C = epi_scale * acc^epi_pow * E, epi_pow = 1 | -1, E may be NULL
+    // (the _mul consumer / the division by a contraction folded into the store)
+    const float* E;
+    int64_t se_b, se_m, se_n;
+    float epi_scale;
+    int epi_pow;
 };
+
+__device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int64_t b, int64_t row, int64_t col) {
+    if (g.epi_pow < 0) v = 1.0f / v;
+    if (g.E) v *= g.E[b * g.se_b + row * g.se_m + col * g.se_n];
+    return v * g.epi_scale;
+}
 
 // A [BK x 128] operand tile travels global -> registers -> LDS (k-major rows of
 // 128).  MN_CONTIG: the operand's m (or n) axis has stride 1, a thread takes 4
@@ -243,28 +255,89 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_mfma_kernel(GemmArgs g
         sm = g.sc_m;
         sn = g.sc_n;
     }
+    const bool epi = g.splits == 1 && g.epi_pow;
+    // Whole tiles of an n-contiguous C leave through LDS: the accumulator layout gives a wave-level
+    // store 128-byte segments (2 rows x 32 columns); staged row-major in the operand buffers (exactly
+    // 128 x 132 floats) the workgroup writes eight 512-byte rows per instruction, 16 B per lane, and
+    // the epilogue factor E is read the same way.  What a short-K product is made of: config 4's
+    // dot(Th, Bt) with K = 128 writes 2.5 GB and, with C / . folded in, reads another 2.5 GB.
+    const bool vec_e = !g.E || ((g.se_n == 1 && g.se_m % 4 == 0 && (((uintptr_t)(g.E + b * g.se_b)) & 15) == 0) ||
+                                g.se_n == 0);
+    if (sn == 1 && sm % 4 == 0 && (((uintptr_t)C) & 15) == 0 && m0 + BM <= g.M && n0 + BN <= g.N &&
+        (!epi || vec_e)) {
+        __syncthreads();                               // the last k-tile's operands are still being read
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    lds[row * LDA + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+                }
+        __syncthreads();
+        const int c4 = 4 * (tid & 31);
+#pragma unroll 4
+        for (int p = 0; p < 16; ++p) {
+            const int row = 8 * p + (tid >> 5);
+            float4 v = *reinterpret_cast<const float4*>(lds + row * LDA + c4);
+            if (epi) {
+                if (g.epi_pow < 0) { v.x = 1.0f / v.x; v.y = 1.0f / v.y; v.z = 1.0f / v.z; v.w = 1.0f / v.w; }
+                float4 ev = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (g.E) {
+                    const float* ep = g.E + b * g.se_b + (m0 + row) * g.se_m;
+                    if (g.se_n == 1) ev = *reinterpret_cast<const float4*>(ep + n0 + c4);
+                    else { const float s0 = ep[0]; ev = make_float4(s0, s0, s0, s0); }
+                }
+                const float sc = g.epi_scale;
+                v.x *= ev.x * sc; v.y *= ev.y * sc; v.z *= ev.z * sc; v.w *= ev.w * sc;
+            }
+            *reinterpret_cast<float4*>(C + (m0 + row) * sm + n0 + c4) = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int64_t col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (epi) {
+                // epilogue: all sixteen E values of this 32x32 block are requested before the first
+                // is used (one load, then its store, sixteen times over ran at 1.3 TB/s)
+                float e[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < g.M && col < g.N) C[row * sm + col * sn] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const bool live = row < g.M && col < g.N;
+                    e[r] = (g.E && live) ? g.E[b * g.se_b + row * g.se_m + col * g.se_n] : 1.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float v = acc[i][j][r];
+                    if (g.epi_pow < 0) v = 1.0f / v;
+                    if (row < g.M && col < g.N) C[row * sm + col * sn] = v * e[r] * g.epi_scale;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < g.M && col < g.N) C[row * sm + col * sn] = acc[i][j][r];
+                }
             }
         }
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t M,
                                      int64_t N, float* __restrict__ C, int64_t sc_b, int64_t sc_m,
-                                     int64_t sc_n) {
+                                     int64_t sc_n, GemmArgs g) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t b = blockIdx.y;
     if (idx >= M * N) return;
     const float* p = slab + (b * splits) * M * N + idx;
     float v = p[0];
     for (int s = 1; s < splits; ++s) v += p[(int64_t)s * M * N];
+    if (g.epi_pow) v = gemm_epilogue(g, v, b, idx / N, idx % N);
     C[b * sc_b + (idx / N) * sc_m + (idx % N) * sc_n] = v;
 }
 
@@ -437,12 +510,17 @@ __global__ void gemm_naive_kernel(int64_t M, int64_t N, int64_t K, const T* A, i
 
 }  // namespace
 
-extern "C" {
+struct Epilogue {
+    int pow = 0;            // 0: none
+    float scale = 1.f;
+    const float* E = nullptr;
+    int64_t se_b = 0, se_m = 0, se_n = 0;
+};
 
-int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t N,
-                             int64_t K, const void* A, int64_t sa_b, int64_t sa_m, int64_t sa_k,
-                             const void* B, int64_t sb_b, int64_t sb_k, int64_t sb_n, void* C,
-                             int64_t sc_b, int64_t sc_m, int64_t sc_n) {
+static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t N,
+              int64_t K, const void* A, int64_t sa_b, int64_t sa_m, int64_t sa_k,
+              const void* B, int64_t sb_b, int64_t sb_k, int64_t sb_n, void* C,
+              int64_t sc_b, int64_t sc_m, int64_t sc_n, const Epilogue& epi) {
     BSC_CHECK_CTX(ctx);
     BSC_REQUIRE(dtype == BSC_F32 || dtype == BSC_F64, "bsc_gemm_strided_batched: unknown dtype %d",
                 dtype);
@@ -453,14 +531,18 @@ int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, 
         const size_t es = dtype == BSC_F64 ? 8 : 4;
         for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
             const int64_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
-            int rc = bsc_gemm_strided_batched(
+            Epilogue e2 = epi;
+            if (e2.E) e2.E += b0 * e2.se_b;
+            int rc = gemm_impl(
                 ctx, dtype, nb, M, N, K, A ? (const char*)A + (size_t)(b0 * sa_b) * es : nullptr, sa_b,
                 sa_m, sa_k, B ? (const char*)B + (size_t)(b0 * sb_b) * es : nullptr, sb_b, sb_k, sb_n,
-                (char*)C + (size_t)(b0 * sc_b) * es, sc_b, sc_m, sc_n);
+                (char*)C + (size_t)(b0 * sc_b) * es, sc_b, sc_m, sc_n, e2);
             if (rc != BSC_OK) return rc;
         }
         return BSC_OK;
     }
+    if (epi.pow && (dtype == BSC_F64 || K == 0))
+        return bsc_fail(BSC_ERR_UNSUPPORTED, "bsc_gemm_epilogue: float32 products with K > 0 only");
     if (dtype == BSC_F64 || K == 0) {
         const dim3 grid((unsigned)((M * N + 255) / 256), (unsigned)batch);
         if (dtype == BSC_F64)
@@ -474,7 +556,7 @@ int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, 
         BSC_LAUNCH_CHECK();
         return BSC_OK;
     }
-    if (batch == 1 && (N == 1 || M == 1) && K >= 64) {
+    if (batch == 1 && (N == 1 || M == 1) && K >= 64 && !epi.pow) {
         // matrix-vector: orient so that the matrix is "A[m,k]" and the vector "x[k]"
         GemvArgs v;
         if (N == 1) {
@@ -527,7 +609,7 @@ int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, 
         }
         return BSC_OK;
     }
-    if (batch == 1) {
+    if (batch == 1 && !epi.pow) {
         // one tiny extent, the large operand streamed once by LDS-DMA (csrc/bsc_skinny.hip)
         int handled = 0;
         int rc = bsc_gemm_skinny(ctx, M, N, K, (const float*)A, sa_m, sa_k, (const float*)B, sb_k, sb_n,
@@ -540,6 +622,8 @@ int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, 
     g.sa_b = sa_b; g.sa_m = sa_m; g.sa_k = sa_k;
     g.sb_b = sb_b; g.sb_k = sb_k; g.sb_n = sb_n;
     g.sc_b = sc_b; g.sc_m = sc_m; g.sc_n = sc_n;
+    g.E = epi.E; g.se_b = epi.se_b; g.se_m = epi.se_m; g.se_n = epi.se_n;
+    g.epi_scale = epi.scale; g.epi_pow = epi.pow;
     g.tiles_m = (int)((M + BM - 1) / BM);
     g.tiles_n = (int)((N + BN - 1) / BN);
     const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * batch;
@@ -624,10 +708,34 @@ int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, 
     if (splits > 1) {
         const dim3 rgrid((unsigned)((M * N + 255) / 256), (unsigned)batch);
         hipLaunchKernelGGL(splitk_reduce_kernel, rgrid, dim3(256), 0, ctx->stream, slab, g.splits, M,
-                           N, (float*)C, sc_b, sc_m, sc_n);
+                           N, (float*)C, sc_b, sc_m, sc_n, g);
         BSC_LAUNCH_CHECK();
     }
     return BSC_OK;
+}
+
+extern "C" {
+
+int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t N,
+                             int64_t K, const void* A, int64_t sa_b, int64_t sa_m, int64_t sa_k,
+                             const void* B, int64_t sb_b, int64_t sb_k, int64_t sb_n, void* C,
+                             int64_t sc_b, int64_t sc_m, int64_t sc_n) {
+    return gemm_impl(ctx, dtype, batch, M, N, K, A, sa_b, sa_m, sa_k, B, sb_b, sb_k, sb_n, C, sc_b, sc_m, sc_n,
+                     Epilogue{});
+}
+
+int bsc_gemm_epilogue(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t N, int64_t K, const void* A,
+                      int64_t sa_b, int64_t sa_m, int64_t sa_k, const void* B, int64_t sb_b, int64_t sb_k,
+                      int64_t sb_n, void* C, int64_t sc_b, int64_t sc_m, int64_t sc_n, int power, double scale,
+                      const void* E, int64_t se_b, int64_t se_m, int64_t se_n) {
+    if (power != 1 && power != -1)
+        return bsc_fail(BSC_ERR_INVALID, "bsc_gemm_epilogue: power must be 1 or -1 (got %d)", power);
+    Epilogue e;
+    e.pow = power;
+    e.scale = (float)scale;
+    e.E = (const float*)E;
+    e.se_b = se_b; e.se_m = se_m; e.se_n = se_n;
+    return gemm_impl(ctx, dtype, batch, M, N, K, A, sa_b, sa_m, sa_k, B, sb_b, sb_k, sb_n, C, sc_b, sc_m, sc_n, e);
 }
 
 }  // extern "C"

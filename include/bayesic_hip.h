@@ -389,6 +389,15 @@ int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, 
                              const void* B, int64_t sb_b, int64_t sb_k, int64_t sb_n, void* C,
                              int64_t sc_b, int64_t sc_m, int64_t sc_n);
 
+/* The same product with its consumer folded into the store (what Theano's graph optimiser would do
+ * for `B * dot(X, Y)` and `C / dot(X, Y)`, bayesic/algebra.py:741-765 + 1297-1309):
+ *     C[b,m,n] = scale * (sum_k A[b,m,k] B[b,k,n]) ^ power * E[b,m,n],   power = 1 | -1,
+ * E strided like C (a stride of 0 broadcasts; E == NULL: no factor).  float32, K > 0. */
+int bsc_gemm_epilogue(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t N, int64_t K, const void* A,
+                      int64_t sa_b, int64_t sa_m, int64_t sa_k, const void* B, int64_t sb_b, int64_t sb_k,
+                      int64_t sb_n, void* C, int64_t sc_b, int64_t sc_m, int64_t sc_n, int power, double scale,
+                      const void* E, int64_t se_b, int64_t se_m, int64_t se_n);
+
 /* out[b] = log det A[b] for symmetric positive-definite A[b] (n x n, strides in
  * elements), by float64 Cholesky -- the T.logdet of MultivariateNormal's
  * log-normaliser, bayesic/distribution/core.py:49-52.  NaN when not SPD. */

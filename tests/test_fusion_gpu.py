@@ -240,11 +240,39 @@ def test_lda_statistic_has_no_data_sized_elementwise_intermediate(dev):
     f = e.compile(dev)
     with Counting(dev.ctx) as c:
         got = f(Th=Th_, Bm=Bm_, C=C_)
-    # two GEMMs, one fused C * P**-1, one fused Bm * (...)
-    assert c.count("bsc_gemm_strided_batched") == 2
-    assert c.count("bsc_map_reduce") == 2 and c.count("bsc_elemwise") == 0
+    # two launches in all: C / dot(Th, Bm) and Bm * dot(Th.T, .) each fold into their GEMM's store
+    # (bsc_gemm_epilogue: power -1 with E = C, power 1 with E = Bm) -- no element-wise launch at all
+    assert c.count("bsc_gemm_epilogue") == 2 and c.count("bsc_gemm_strided_batched") == 0
+    assert c.count("bsc_map_reduce") == 0 and c.count("bsc_elemwise") == 0
     want = Bm_ * (Th_.T.astype(np.float64) @ (C_ / (Th_.astype(np.float64) @ Bm_)))
     npt.assert_allclose(got, want, rtol=2e-5)
+    # with fusion off: the same value from four launches
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    npt.assert_allclose(e.compile(DeviceBackend(dev.ctx, fuse=False))(Th=Th_, Bm=Bm_, C=C_), want, rtol=2e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(130, 257, 40), (64, 64, 3000), (5, 300, 700), (256, 256, 40000), (2, 2, 5)])
+def test_gemm_consumers_fold_into_the_store(dev, M, N, K):
+    """B * dot(X, Y), dot(X, Y) * 2.5, C / dot(X, Y), row / column broadcast factors, split-K
+    shapes (the epilogue then runs in the split-K reduce) -- against float64 numpy."""
+    X, Y, E, r, c = var("X", ndim=2), var("Y", ndim=2), var("E", ndim=2), var("r", ndim=1), var("c", ndim=1)
+    X_ = (RNG.rand(M, K) + 0.1).astype(np.float32)
+    Y_ = (RNG.rand(K, N) + 0.1).astype(np.float32)
+    E_ = (RNG.rand(M, N) + 0.5).astype(np.float32)
+    r_, c_ = (RNG.rand(N) + 0.5).astype(np.float32), (RNG.rand(M) + 0.5).astype(np.float32)
+    P = X_.astype(np.float64) @ Y_.astype(np.float64)
+    cases = [(E * dot(X, Y), E_ * P), (dot(X, Y) * 2.5, 2.5 * P), (E / dot(X, Y), E_ / P),
+             (dot(X, Y) * dimshuffle(r, "x", 0), P * r_[None, :]),
+             (dimshuffle(c, 0, "x") / dot(X, Y) * 3.0, 3.0 * c_[:, None] / P),
+             (exp(E) * dot(X, Y), np.exp(E_.astype(np.float64)) * P),          # a deferred factor is computed, then folded
+             (E * dot(X, Y) * E, E_ * P * E_)]                                    # two factors: not folded, still right
+    vals = dict(X=X_, Y=Y_, E=E_, r=r_, c=c_)
+    for expr, want in cases:
+        got = expr.compile(dev)(**{n: vals[n] for n in expr.input_types})
+        npt.assert_allclose(got, want, rtol=3e-5, err_msg=repr(expr))
+    with Counting(dev.ctx) as cnt:
+        (E / dot(X, Y)).compile(dev)(X=X_, Y=Y_, E=E_)
+    assert cnt.count("bsc_gemm_epilogue") == 1 and cnt.count("bsc_map_reduce") == 0
 
 
 def test_memory_plan_reuses_intermediates_but_never_the_result(dev):
