@@ -132,6 +132,98 @@ __device__ __forceinline__ void stage_store(const Staged& st, float* lds, int ti
     }
 }
 
+// The accumulators of one 128 x 128 tile (four waves as 2 x 2, two by two 32 x 32 MFMA tiles each)
+// go to C, or to the split's partial slab.  `lds` is the workgroup's operand buffer (>= 128 * LDL
+// floats), free once the barrier inside has been passed.
+template <int LDL>
+__device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, f32x16 (&acc)[2][2], float* lds, int64_t b,
+                                                int split, int64_t m0, int64_t n0, int wm, int wn, int lane,
+                                                int tid) {
+    // C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    float* C;
+    int64_t sm, sn;
+    if (g.splits > 1) {  // partial slab [batch][split][M][N], dense
+        C = g.C + ((b * g.splits + split) * g.M) * g.N;
+        sm = g.N;
+        sn = 1;
+    } else {
+        C = g.C + b * g.sc_b;
+        sm = g.sc_m;
+        sn = g.sc_n;
+    }
+    const bool epi = g.splits == 1 && g.epi_pow;
+    // Whole tiles of an n-contiguous C leave through LDS: the accumulator layout gives a wave-level
+    // store 128-byte segments (2 rows x 32 columns); staged row-major in the operand buffers
+    // (128 rows of LDL floats) the workgroup writes eight 512-byte rows per instruction, 16 B per lane, and
+    // the epilogue factor E is read the same way.  What a short-K product is made of: config 4's
+    // dot(Th, Bt) with K = 128 writes 2.5 GB and, with C / . folded in, reads another 2.5 GB.
+    const bool vec_e = !g.E || ((g.se_n == 1 && g.se_m % 4 == 0 && (((uintptr_t)(g.E + b * g.se_b)) & 15) == 0) ||
+                                g.se_n == 0);
+    if (sn == 1 && sm % 4 == 0 && (((uintptr_t)C) & 15) == 0 && m0 + BM <= g.M && n0 + BN <= g.N &&
+        (!epi || vec_e)) {
+        __syncthreads();                               // the last k-tile's operands are still being read
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    lds[row * LDL + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+                }
+        __syncthreads();
+        const int c4 = 4 * (tid & 31);
+#pragma unroll 4
+        for (int p = 0; p < 16; ++p) {
+            const int row = 8 * p + (tid >> 5);
+            float4 v = *reinterpret_cast<const float4*>(lds + row * LDL + c4);
+            if (epi) {
+                if (g.epi_pow < 0) { v.x = 1.0f / v.x; v.y = 1.0f / v.y; v.z = 1.0f / v.z; v.w = 1.0f / v.w; }
+                float4 ev = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (g.E) {
+                    const float* ep = g.E + b * g.se_b + (m0 + row) * g.se_m;
+                    if (g.se_n == 1) ev = *reinterpret_cast<const float4*>(ep + n0 + c4);
+                    else { const float s0 = ep[0]; ev = make_float4(s0, s0, s0, s0); }
+                }
+                const float sc = g.epi_scale;
+                v.x *= ev.x * sc; v.y *= ev.y * sc; v.z *= ev.z * sc; v.w *= ev.w * sc;
+            }
+            *reinterpret_cast<float4*>(C + (m0 + row) * sm + n0 + c4) = v;
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (epi) {
+                // epilogue: all sixteen E values of this 32x32 block are requested before the first
+                // is used (one load, then its store, sixteen times over ran at 1.3 TB/s)
+                float e[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const bool live = row < g.M && col < g.N;
+                    e[r] = (g.E && live) ? g.E[b * g.se_b + row * g.se_m + col * g.se_n] : 1.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float v = acc[i][j][r];
+                    if (g.epi_pow < 0) v = 1.0f / v;
+                    if (row < g.M && col < g.N) C[row * sm + col * sn] = v * e[r] * g.epi_scale;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < g.M && col < g.N) C[row * sm + col * sn] = acc[i][j][r];
+                }
+            }
+        }
+}
+
 template <bool A_M_CONTIG, bool B_N_CONTIG, bool PIPE>
 __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_mfma_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE];   // As[2], Bs[2]
@@ -243,89 +335,189 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_mfma_kernel(GemmArgs g
         }
     }
 
-    // C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    float* C;
-    int64_t sm, sn;
-    if (g.splits > 1) {  // partial slab [batch][split][M][N], dense
-        C = g.C + ((b * g.splits + split) * g.M) * g.N;
-        sm = g.N;
-        sn = 1;
-    } else {
-        C = g.C + b * g.sc_b;
-        sm = g.sc_m;
-        sn = g.sc_n;
+    gemm_store_tile<LDA>(g, acc, lds, b, split, m0, n0, wm, wn, lane, tid);
+}
+
+// ---- operands by LDS-DMA -------------------------------------------------------------------
+// The same 128 x 128 x 32 tile and 2 x 2 waves, but the operand tiles go global -> LDS with
+// `buffer_load_dwordx4 ... lds` (1 KiB per wave instruction): no staging registers, no ds_write
+// pass, and -- what pays on this part -- an LDS-DMA takes ~45 cycles from the matrix pipe where
+// a VGPR-returning load takes ~115 whatever its width (profiles/r02_ubench_mfma_vmem.txt); the
+// register-staged kernel above spends 8 of those per wave and k-tile, ~0.2 of its MFMA time.
+//
+// A DMA writes lane l's 16 bytes at (wave-uniform LDS base) + 16 l, so an LDS image is shaped by
+// which GLOBAL address each lane asks for:
+//   operand contiguous along m (or n):  image [k][128] floats; instruction q brings k rows 2q, 2q+1
+//     (lane l: row 2q + l/32, columns 4 (l%32) .. +3); fragments are ds_read_b32, a lane's 32
+//     neighbours read 32 consecutive floats;
+//   operand contiguous along k:  image of 16-byte chunks, row m holds its 8 chunks XOR-swizzled,
+//     chunk (m, c) at position 8 m + (c ^ (m & 7)); instruction q brings rows 8q .. 8q+7, eight
+//     lanes per row cover its 128-byte line; a fragment is ONE ds_read_b128 = four k of one row,
+//     and any 8 neighbouring lanes (8 rows) hit 8 different chunk columns: conflict-free.
+// Both operands agree on the k a lane holds: in the 8-deep group G, lane half h = lane / 32 feeds
+// MFMA t (0..3) with k = 8 G + 4 h + t.
+//
+// Edges: a lane whose row / column / k lies outside the operand asks for offset 2^31 of a
+// descriptor 2^31 bytes long and receives zeros; the masks are per tile (rows, columns) and per
+// the last k-tile only.  Host side: the contiguous extent must be a multiple of 4 (a 16-byte
+// piece is wholly inside or outside) -- otherwise the register-staged kernel runs.
+//
+// Schedule per k-tile (four 8-deep groups of 16 MFMAs): fragments one group ahead in registers;
+// in the last group, once this wave holds its last fragments of the buffer: wait for the own
+// DMAs of the next buffer, barrier (everybody's have landed, nobody still reads this buffer),
+// read the next buffer's first fragments, and only then refill this buffer two k-tiles ahead --
+// one barrier per k-tile, the DMA a whole k-tile in flight.
+constexpr int DMA_STAGE = 32768;            // bytes: A image 16 KiB, B image 16 KiB
+constexpr unsigned DMA_OUTSIDE = 0x80000000u;
+
+#define GEMM_LDS_B128(DST, ADDR, OFF) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+#define GEMM_LDS_B32(DST, ADDR, OFF) \
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+
+typedef float gemm_f32x4 __attribute__((ext_vector_type(4)));
+
+// byte offset, inside the operand's [128 x 32] tile, that lane `lane` asks for in DMA instruction q
+template <bool MN_CONTIG>
+__device__ __forceinline__ unsigned dma_lane_offset(int q, int lane, int64_t s_mn, int64_t s_k, int64_t mn_left) {
+    if (MN_CONTIG) {
+        const int krow = 2 * q + (lane >> 5), mn = 4 * (lane & 31);
+        return mn < mn_left ? (unsigned)(krow * s_k + mn) * 4u : DMA_OUTSIDE;
     }
-    const bool epi = g.splits == 1 && g.epi_pow;
-    // Whole tiles of an n-contiguous C leave through LDS: the accumulator layout gives a wave-level
-    // store 128-byte segments (2 rows x 32 columns); staged row-major in the operand buffers (exactly
-    // 128 x 132 floats) the workgroup writes eight 512-byte rows per instruction, 16 B per lane, and
-    // the epilogue factor E is read the same way.  What a short-K product is made of: config 4's
-    // dot(Th, Bt) with K = 128 writes 2.5 GB and, with C / . folded in, reads another 2.5 GB.
-    const bool vec_e = !g.E || ((g.se_n == 1 && g.se_m % 4 == 0 && (((uintptr_t)(g.E + b * g.se_b)) & 15) == 0) ||
-                                g.se_n == 0);
-    if (sn == 1 && sm % 4 == 0 && (((uintptr_t)C) & 15) == 0 && m0 + BM <= g.M && n0 + BN <= g.N &&
-        (!epi || vec_e)) {
-        __syncthreads();                               // the last k-tile's operands are still being read
+    const int mn = 8 * q + (lane >> 3), c = (lane & 7) ^ ((lane >> 3) & 7);
+    return mn < mn_left ? (unsigned)(mn * s_mn + 4 * c) * 4u : DMA_OUTSIDE;
+}
+// ... and whether its k lies in the `k_left` (< 32) that remain
+template <bool MN_CONTIG>
+__device__ __forceinline__ bool dma_lane_k_inside(int q, int lane, int64_t k_left) {
+    if (MN_CONTIG) return 2 * q + (lane >> 5) < k_left;
+    return 4 * ((lane & 7) ^ ((lane >> 3) & 7)) < k_left;
+}
+
+template <bool MN_CONTIG>
+__device__ __forceinline__ void dma_read_fragments(float (&f)[2][4], unsigned addr) {
+    if (MN_CONTIG) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int t = 0; t < 4; ++t) GEMM_LDS_B32(f[i][t], addr, t * 512 + i * 128);
+    } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    lds[row * LDA + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
-                }
-        __syncthreads();
-        const int c4 = 4 * (tid & 31);
-#pragma unroll 4
-        for (int p = 0; p < 16; ++p) {
-            const int row = 8 * p + (tid >> 5);
-            float4 v = *reinterpret_cast<const float4*>(lds + row * LDA + c4);
-            if (epi) {
-                if (g.epi_pow < 0) { v.x = 1.0f / v.x; v.y = 1.0f / v.y; v.z = 1.0f / v.z; v.w = 1.0f / v.w; }
-                float4 ev = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (g.E) {
-                    const float* ep = g.E + b * g.se_b + (m0 + row) * g.se_m;
-                    if (g.se_n == 1) ev = *reinterpret_cast<const float4*>(ep + n0 + c4);
-                    else { const float s0 = ep[0]; ev = make_float4(s0, s0, s0, s0); }
-                }
-                const float sc = g.epi_scale;
-                v.x *= ev.x * sc; v.y *= ev.y * sc; v.z *= ev.z * sc; v.w *= ev.w * sc;
-            }
-            *reinterpret_cast<float4*>(C + (m0 + row) * sm + n0 + c4) = v;
+        for (int i = 0; i < 2; ++i) {
+            gemm_f32x4 v;
+            GEMM_LDS_B128(v, addr, i * 4096);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) f[i][t] = v[t];
         }
-        return;
     }
+}
+
+template <bool A_M_CONTIG, bool B_N_CONTIG>
+__global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_dma_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * DMA_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = blockIdx.x;
+    const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+    const int split = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int64_t k_begin = (int64_t)split * g.k_chunk;
+    const int64_t k_end = (k_begin + g.k_chunk < g.K) ? k_begin + g.k_chunk : g.K;
+    const int64_t n_kt = (k_end - k_begin + BK - 1) / BK;
+
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t col = n0 + wn * 64 + j * 32 + (lane & 31);
-            if (epi) {
-                // epilogue: all sixteen E values of this 32x32 block are requested before the first
-                // is used (one load, then its store, sixteen times over ran at 1.3 TB/s)
-                float e[16];
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const bool live = row < g.M && col < g.N;
-                    e[r] = (g.E && live) ? g.E[b * g.se_b + row * g.se_m + col * g.se_n] : 1.0f;
-                }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // what each of this wave's 4 + 4 DMA instructions asks for
+    unsigned va[4], vb[4];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    float v = acc[i][j][r];
-                    if (g.epi_pow < 0) v = 1.0f / v;
-                    if (row < g.M && col < g.N) C[row * sm + col * sn] = v * e[r] * g.epi_scale;
-                }
-            } else {
+    for (int jj = 0; jj < 4; ++jj) {
+        va[jj] = dma_lane_offset<A_M_CONTIG>(4 * wave + jj, lane, g.sa_m, g.sa_k, g.M - m0);
+        vb[jj] = dma_lane_offset<B_N_CONTIG>(4 * wave + jj, lane, g.sb_n, g.sb_k, g.N - n0);
+    }
+    const float* a_tile = g.A + b * g.sa_b + m0 * g.sa_m;
+    const float* b_tile = g.B + b * g.sb_b + n0 * g.sb_n;
+    auto issue = [&](int buf, int64_t k0) {
+        const int64_t k_left = k_end - k0;
+        const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a_tile + k0 * g.sa_k), 0, DMA_OUTSIDE, 0x00020000);
+        const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_tile + k0 * g.sb_k), 0, DMA_OUTSIDE, 0x00020000);
+        char* const dst = lds + buf * DMA_STAGE + wave * 4096;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (row < g.M && col < g.N) C[row * sm + col * sn] = acc[i][j][r];
-                }
-            }
+        for (int jj = 0; jj < 4; ++jj) {
+            unsigned v = va[jj];
+            if (k_left < BK && !dma_lane_k_inside<A_M_CONTIG>(4 * wave + jj, lane, k_left)) v = DMA_OUTSIDE;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (bsc_lds_ptr)(dst + jj * 1024), 16, v, 0, 0, 0);
         }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            unsigned v = vb[jj];
+            if (k_left < BK && !dma_lane_k_inside<B_N_CONTIG>(4 * wave + jj, lane, k_left)) v = DMA_OUTSIDE;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (bsc_lds_ptr)(dst + 16384 + jj * 1024), 16, v, 0, 0, 0);
+        }
+    };
+
+    // fragment addresses of group G in buffer 0 (the other buffer: ^ DMA_STAGE)
+    const int fr = lane & 31, fk = lane >> 5;
+    const unsigned lbase = (unsigned)(uintptr_t)(bsc_lds_ptr)lds;
+    unsigned fa[4], fb[4];
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {
+        fa[G] = lbase + (A_M_CONTIG ? (unsigned)((8 * G + 4 * fk) * 512 + (wm * 64 + fr) * 4)
+                                    : (unsigned)((wm * 64 + fr) * 128 + (((2 * G + fk) ^ (fr & 7)) * 16)));
+        fb[G] = lbase + 16384 + (B_N_CONTIG ? (unsigned)((8 * G + 4 * fk) * 512 + (wn * 64 + fr) * 4)
+                                            : (unsigned)((wn * 64 + fr) * 128 + (((2 * G + fk) ^ (fr & 7)) * 16)));
+    }
+
+    float oa[2][2][4], ob[2][2][4];     // [register set][32-row block][t]
+    auto mfmas = [&](int set) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[set][i][t], ob[set][j][t], acc[i][j], 0, 0, 0);
+    };
+
+    issue(0, k_begin);
+    __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    dma_read_fragments<A_M_CONTIG>(oa[0], fa[0]);
+    dma_read_fragments<B_N_CONTIG>(ob[0], fb[0]);
+    if (n_kt > 1) issue(1, k_begin + BK);
+    unsigned tog = 0;
+    for (int64_t kt = 0; kt < n_kt; ++kt) {
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+            const int set = G & 1;
+            __builtin_amdgcn_s_waitcnt(BSC_LGKMCNT0);          // group G's fragments have arrived
+            __builtin_amdgcn_sched_barrier(0);
+            if (G < 3) {
+                dma_read_fragments<A_M_CONTIG>(oa[set ^ 1], fa[G + 1] ^ tog);
+                dma_read_fragments<B_N_CONTIG>(ob[set ^ 1], fb[G + 1] ^ tog);
+            } else if (kt + 1 < n_kt) {
+                __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));  // own DMAs of the next buffer
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                dma_read_fragments<A_M_CONTIG>(oa[set ^ 1], fa[0] ^ tog ^ DMA_STAGE);
+                dma_read_fragments<B_N_CONTIG>(ob[set ^ 1], fb[0] ^ tog ^ DMA_STAGE);
+                if (kt + 2 < n_kt) issue((int)(kt & 1), k_begin + (kt + 2) * BK);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(set);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        tog ^= DMA_STAGE;
+    }
+    gemm_store_tile<BN>(g, acc, reinterpret_cast<float*>(lds), b, split, m0, n0, wm, wn, lane, tid);
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t M,
@@ -686,8 +878,24 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
         return s_mn >= 0 && s_k >= 0 && span < ((int64_t)1 << 31);
     };
     g.fast = ctx->gemm_fast && g.vec_a && g.vec_b && span_ok(sa_m, sa_k) && span_ok(sb_n, sb_k);
+    // LDS-DMA staging: 16-byte pieces wholly inside or outside the operand, lane offsets below 2^31
+    auto dma_ok = [&](const void* p, bool mn, int64_t ext_mn, int64_t s_mn, int64_t s_k, int64_t s_b) {
+        if (((uintptr_t)p & 15) != 0 || s_b % 4 != 0 || s_mn < 0 || s_k < 0) return false;
+        if (mn) return s_mn == 1 && ext_mn % 4 == 0 && s_k % 4 == 0 && (31 * s_k + 128) * 4 < ((int64_t)1 << 31);
+        return s_k == 1 && K % 4 == 0 && s_mn % 4 == 0 && (127 * s_mn + 32) * 4 < ((int64_t)1 << 31);
+    };
+    const bool dma = ctx->gemm_dma && dma_ok(A, a_m, M, sa_m, sa_k, sa_b) && dma_ok(B, b_n, N, sb_n, sb_k, sb_b);
     {
         bsc_prof_scope prof(ctx);
+#define BSC_GEMM_DMA(AM, BN_) \
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<AM, BN_>), grid, dim3(GEMM_BLOCK), 0, ctx->stream, g)
+        if (dma) {
+            if (a_m && b_n) BSC_GEMM_DMA(true, true);
+            else if (a_m) BSC_GEMM_DMA(true, false);
+            else if (b_n) BSC_GEMM_DMA(false, true);
+            else BSC_GEMM_DMA(false, false);
+        } else {
+#undef BSC_GEMM_DMA
 #define BSC_GEMM(AM, BN_)                                                                       \
     do {                                                                                        \
         if (ctx->gemm_pipe)                                                                     \
@@ -702,7 +910,7 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
         else if (b_n) BSC_GEMM(false, true);
         else BSC_GEMM(false, false);
 #undef BSC_GEMM
-#undef BSC_GEMM
+        }
     }
     BSC_LAUNCH_CHECK();
     if (splits > 1) {

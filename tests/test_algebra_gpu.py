@@ -247,3 +247,50 @@ def test_skinny_products_long_contraction_tn(dev, M, D, K):
     got_t = run(dev, dot(X.T, R.T), R=R_, X=X_)
     assert (np.abs(got_t - want.T) <= 1e-5 * bound.T + 1e-12).all()
     assert (got == run(dev, dot(R, X), R=R_, X=X_)).all()
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(128, 128, 32, 1), (132, 260, 1004, 1), (130, 257, 1000, 1), (256, 384, 36, 1),
+                                          (100, 516, 8, 3), (4, 8, 4, 2), (640, 132, 4100, 1), (257, 129, 20, 1)])
+def test_gemm_operands_by_lds_dma_all_layouts(ctx, M, N, K, batch):
+    """bsc_gemm_strided_batched in the four operand layouts (each operand contiguous along its
+    free axis or along k): the LDS-DMA kernel (gemm_f32_dma_kernel) wherever 16-byte pieces fall
+    wholly inside or outside an operand, the register-staged kernel otherwise -- ragged tiles,
+    a last k-tile shorter than 32, batches -- against float64, and the two kernels against each
+    other on the same operands."""
+    import os
+    import torch
+    from bayesic_amd.device import Context
+    os.environ["BSC_GEMM_DMA"] = "0"
+    try:
+        staged = Context(0)
+    finally:
+        del os.environ["BSC_GEMM_DMA"]
+    rs = np.random.RandomState(M + 3 * N + 7 * K)
+    A_ = rs.standard_normal((batch, M, K)).astype(np.float32)
+    B_ = rs.standard_normal((batch, K, N)).astype(np.float32)
+    want = np.einsum("bmk,bkn->bmn", A_.astype(np.float64), B_.astype(np.float64))
+    bound = np.sqrt((A_.astype(np.float64) ** 2).sum(2))[:, :, None] * np.sqrt((B_.astype(np.float64) ** 2).sum(1))[:, None, :]
+    dev = ctx.device
+    for a_m in (False, True):
+        for b_n in (False, True):
+            # A stored [b][m][k] (k contiguous) or [b][k][m] (m contiguous); B likewise
+            At = torch.from_numpy(np.ascontiguousarray(A_.transpose(0, 2, 1)) if a_m else A_).to(dev)
+            Bt = torch.from_numpy(B_ if b_n else np.ascontiguousarray(B_.transpose(0, 2, 1))).to(dev)
+            sa = (M * K, 1, M) if a_m else (M * K, K, 1)
+            sb = (K * N, N, 1) if b_n else (K * N, 1, K)
+            outs = []
+            for c in (ctx, staged):
+                C = torch.full((batch, M, N), np.nan, dtype=torch.float32, device=dev)
+                c.call("bsc_gemm_strided_batched", 0, batch, M, N, K, At, sa[0], sa[1], sa[2], Bt, sb[0], sb[1], sb[2],
+                       C, M * N, N, 1)
+                outs.append(C.cpu().numpy().astype(np.float64))
+            assert (np.abs(outs[0] - want) <= 1e-5 * bound + 1e-12).all(), (a_m, b_n, np.abs(outs[0] - want).max())
+            assert (np.abs(outs[0] - outs[1]) <= 2e-5 * bound + 1e-12).all()
+            # the epilogue on the same product: C = 0.5 * E / acc
+            E = torch.from_numpy(rs.standard_normal((batch, M, N)).astype(np.float32)).to(dev)
+            C = torch.full((batch, M, N), np.nan, dtype=torch.float32, device=dev)
+            ctx.call("bsc_gemm_epilogue", 0, batch, M, N, K, At, sa[0], sa[1], sa[2], Bt, sb[0], sb[1], sb[2],
+                     C, M * N, N, 1, -1, 0.5, E, M * N, N, 1)
+            ref = 0.5 * E.cpu().numpy().astype(np.float64) / outs[0]
+            ok = np.abs(outs[0]) > 1e-2 * bound
+            npt.assert_allclose(C.cpu().numpy()[ok], ref[ok], rtol=2e-5)
