@@ -43,6 +43,12 @@ struct GemmArgs {
     int64_t se_b, se_m, se_n;
     float epi_scale;
     int epi_pow;
+    // gemm_f32_stream_kernel: workgroup w takes the whole tiles w, w + n_wg, ... of `rounds` rounds,
+    // then its share of the k-tile units of the `tail_tiles` tiles that are left: units
+    // [w q + min(w, r), ...) of their tile-major unit list when `sk_stream`, else the tile
+    // rounds n_wg + w whole
+    int n_kt, sk_q, sk_r, sk_stream, n_wg, rounds, tail_tiles, tiles_pb, group, dbg;
+    float* slab;       // [2 n_wg][128 n][128 m] partial tiles
 };
 
 __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int64_t b, int64_t row, int64_t col) {
@@ -389,7 +395,7 @@ __device__ __forceinline__ unsigned dma_lane_offset(int q, int lane, int64_t s_m
 }
 // ... and whether its k lies in the `k_left` (< 32) that remain
 template <bool MN_CONTIG>
-__device__ __forceinline__ bool dma_lane_k_inside(int q, int lane, int64_t k_left) {
+__device__ __forceinline__ bool dma_lane_k_inside(int q, int lane, int k_left) {
     if (MN_CONTIG) return 2 * q + (lane >> 5) < k_left;
     return 4 * ((lane & 7) ^ ((lane >> 3) & 7)) < k_left;
 }
@@ -518,6 +524,431 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_dma_kernel(GemmArgs g)
         tog ^= DMA_STAGE;
     }
     gemm_store_tile<BN>(g, acc, reinterpret_cast<float*>(lds), b, split, m0, n0, wm, wn, lane, tid);
+}
+
+// ---- persistent stream-K on the LDS-DMA pipeline ---------------------------------------------
+// One launch of (at most) two workgroups per CU.  The product's k-tile units -- tile-major,
+// `n_kt` per 128 x 128 tile -- are dealt to the workgroups in equal contiguous runs, so the
+// grid ends together whatever the tile count (33 x 33 tiles on 512 slots used to cost three
+// rounds for 2.1 rounds of work) and the DMA pipeline of a workgroup never drains: the first
+// k-tiles of its next tile are in flight while the current tile's last MFMAs issue and its
+// accumulators are stored.  A run that covers a tile wholly stores it (with the epilogue);
+// the at most two tiles a run shares with its neighbours go to the workgroup's two slab
+// slots and `stream_fixup_kernel` adds the pieces of each such tile in k order --
+// deterministic, no atomics, no spinning on other workgroups.
+//
+// Orientation: the MFMA's D layout gives a lane four CONSECUTIVE rows (A-operand index) of one
+// column, so the host orients the product with its A operand along C's contiguous axis
+// (C = A B is computed as C^T = B^T A^T for a row-major C): stores, epilogue-factor loads and
+// slab traffic are all 16 bytes per lane straight from / into the accumulator registers, no
+// LDS staging (the ring stays busy with the next tile's operands).  The epilogue factor of a
+// whole tile is requested when the tile's first k-tile starts and is long there when the
+// last one ends.
+//
+// Tile order: column strips `group` tiles wide, rows fastest inside a strip, and workgroup
+// slots permuted so that each XCD's 64 slots are neighbours in that order: at any moment an
+// XCD works on a compact block of tiles and its L2 serves every operand panel to several of them.
+// A quotient of wave-uniform values, said to be uniform: the division itself runs on the vector
+// unit, and everything computed from an unmarked result -- tile coordinates, descriptors, loop
+// conditions -- would follow it there (exec-masked branches, readfirstlane loops around each DMA).
+__device__ __forceinline__ unsigned stream_udiv(unsigned a, unsigned b) {
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)(a / b));
+}
+
+// The kernel's arguments, re-read from the kernarg segment where they are needed: the stream
+// kernel touches most of GemmArgs only at tile boundaries, and held in scalar registers across
+// the k-loop they cost it ~120 SGPR spills (v_writelane / v_readlane in the loop: vector
+// instructions, which take their cycles from the matrix pipe).  The empty asm keeps the loads
+// from being hoisted back out.
+typedef __attribute__((address_space(4))) const GemmArgs* gemm_args_cptr;
+__device__ __forceinline__ gemm_args_cptr stream_cold_args() {
+    gemm_args_cptr p = (gemm_args_cptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+template <class GP>
+__device__ __forceinline__ void stream_decode_tile(GP g, int t, int64_t& b, int64_t& m0, int64_t& n0) {
+    const unsigned tiles_pb = (unsigned)g->tiles_pb, group = (unsigned)g->group;
+    const unsigned ub = stream_udiv((unsigned)t, tiles_pb);             // tiles x batch < 2^31 (host)
+    const unsigned tt = (unsigned)t - ub * tiles_pb;
+    const unsigned strip = group * (unsigned)g->tiles_m;
+    const unsigned s = stream_udiv(tt, strip), within = tt - s * strip;
+    const unsigned left = (unsigned)g->tiles_n - s * group;
+    const unsigned gw = left < group ? left : group;
+    const unsigned tm = stream_udiv(within, gw);
+    b = ub;
+    m0 = (int64_t)tm * BM;
+    n0 = (int64_t)(s * group + (within - tm * gw)) * BN;
+}
+
+// first tail unit of workgroup w (w = n_wg: the end of the list)
+template <class GP>
+__device__ __forceinline__ int stream_first_unit(GP g, int w) {
+    if (g->sk_stream) return w * g->sk_q + (w < g->sk_r ? w : g->sk_r);
+    return (w < g->tail_tiles ? w : g->tail_tiles) * g->n_kt;
+}
+
+// Where a workgroup's run stands: k-tile `kt` of tile `t`, `left` more units of that tile to go.
+struct StreamCursor {
+    int t, round, kt, left, tail_left;
+    template <class GP>
+    __device__ __forceinline__ void segment(GP g, int w, int tail_u0) {
+        const int rounds = g->rounds, n_kt = g->n_kt;
+        if (round < rounds) {
+            t = round * g->n_wg + w;
+            kt = 0;
+            left = n_kt;
+        } else {
+            if (round == rounds) {
+                const int tt = (int)stream_udiv((unsigned)tail_u0, (unsigned)n_kt);
+                t = rounds * g->n_wg + tt;
+                kt = tail_u0 - tt * n_kt;
+            } else {
+                ++t;
+                kt = 0;
+            }
+            left = n_kt - kt < tail_left ? n_kt - kt : tail_left;
+            tail_left -= left;
+        }
+    }
+    template <class GP>
+    __device__ __forceinline__ void begin(GP g, int w, int tail_u0, int tail_cnt) {
+        round = 0;
+        tail_left = tail_cnt;
+        t = 0; kt = 0; left = 0;
+        segment(g, w, tail_u0);
+    }
+    // one unit on; true when that was the tile's last unit in this run (the caller then moves
+    // to the next segment)
+    __device__ __forceinline__ bool step() {
+        ++kt;
+        return --left == 0;
+    }
+};
+
+__device__ __forceinline__ const float* stream_uniform_ptr(const float* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const float*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
+template <bool A_M_CONTIG, bool B_N_CONTIG>
+__global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * DMA_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int w = blockIdx.x;
+    int n_units, tail_u0, tail_cnt;
+    {
+        const gemm_args_cptr gc = stream_cold_args();
+        if ((gc->n_wg & 7) == 0) w = (w & 7) * (gc->n_wg >> 3) + (w >> 3);     // an XCD's slots are neighbours
+        tail_u0 = stream_first_unit(gc, w);
+        tail_cnt = stream_first_unit(gc, w + 1) - tail_u0;
+        n_units = gc->rounds * gc->n_kt + tail_cnt;            // < 2^31 (host)
+    }
+    if (n_units == 0) return;
+    // what the k-loop itself needs of the arguments
+    const int64_t step_a = (int64_t)BK * g.sa_k, step_b = (int64_t)BK * g.sb_k;
+    const int last_kt = g.n_kt - 1, k_tail = (int)(g.K - (int64_t)last_kt * BK);   // extent of a tile's last k-tile, 1..32
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- the issuing side: the unit under `ic` is the next to be requested
+    // (always_inline: an out-of-line lambda takes its captures -- cursors, descriptors, the kernel
+    // arguments -- through a closure in scratch memory, and everything read back from there is per-lane)
+    StreamCursor ic;
+    ic.begin(stream_cold_args(), w, tail_u0, tail_cnt);
+    int issued = 0;
+    unsigned va[4], vb[4];
+    const float *a_tile, *b_tile;
+    auto issue_tile = [&]() __attribute__((always_inline)) {
+        const gemm_args_cptr gc = stream_cold_args();
+        int64_t b, m0, n0;
+        stream_decode_tile(gc, ic.t, b, m0, n0);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            va[jj] = dma_lane_offset<A_M_CONTIG>(4 * wave + jj, lane, gc->sa_m, gc->sa_k, gc->M - m0);
+            vb[jj] = dma_lane_offset<B_N_CONTIG>(4 * wave + jj, lane, gc->sb_n, gc->sb_k, gc->N - n0);
+        }
+        a_tile = gc->A + b * gc->sa_b + m0 * gc->sa_m + (int64_t)ic.kt * BK * gc->sa_k;
+        b_tile = gc->B + b * gc->sb_b + n0 * gc->sb_n + (int64_t)ic.kt * BK * gc->sb_k;
+    };
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        // a_tile / b_tile run along k with the units of their tile.  (Wave-uniform by construction;
+        // said explicitly, or a pointer the compiler chose to keep in vector registers turns every
+        // DMA into a readfirstlane loop behind a vmcnt(0).)
+        const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)stream_uniform_ptr(a_tile), 0, DMA_OUTSIDE, 0x00020000);
+        const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)stream_uniform_ptr(b_tile), 0, DMA_OUTSIDE, 0x00020000);
+        char* const dst = lds + buf * DMA_STAGE + wave * 4096;
+        if (__builtin_expect(ic.kt != last_kt || k_tail == BK, 1)) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (bsc_lds_ptr)(dst + jj * 1024), 16, va[jj], 0, 0, 0);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (bsc_lds_ptr)(dst + 16384 + jj * 1024), 16, vb[jj], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const unsigned v = dma_lane_k_inside<A_M_CONTIG>(4 * wave + jj, lane, k_tail) ? va[jj] : DMA_OUTSIDE;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (bsc_lds_ptr)(dst + jj * 1024), 16, v, 0, 0, 0);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const unsigned v = dma_lane_k_inside<B_N_CONTIG>(4 * wave + jj, lane, k_tail) ? vb[jj] : DMA_OUTSIDE;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (bsc_lds_ptr)(dst + 16384 + jj * 1024), 16, v, 0, 0, 0);
+            }
+        }
+        ++issued;
+        a_tile += step_a;
+        b_tile += step_b;
+        if (__builtin_expect(ic.step(), 0) && issued < n_units) {
+            ++ic.round;
+            ic.segment(stream_cold_args(), w, tail_u0);
+            issue_tile();
+        }
+    };
+
+    const int fr = lane & 31, fk = lane >> 5;
+    const unsigned lbase = (unsigned)(uintptr_t)(bsc_lds_ptr)lds;
+    unsigned fa[4], fb[4];
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {
+        fa[G] = lbase + (A_M_CONTIG ? (unsigned)((8 * G + 4 * fk) * 512 + (wm * 64 + fr) * 4)
+                                    : (unsigned)((wm * 64 + fr) * 128 + (((2 * G + fk) ^ (fr & 7)) * 16)));
+        fb[G] = lbase + 16384 + (B_N_CONTIG ? (unsigned)((8 * G + 4 * fk) * 512 + (wn * 64 + fr) * 4)
+                                            : (unsigned)((wn * 64 + fr) * 128 + (((2 * G + fk) ^ (fr & 7)) * 16)));
+    }
+    float oa[2][2][4], ob[2][2][4];
+    auto mfmas = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[set][i][t], ob[set][j][t], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- the computing side
+    StreamCursor cc;
+    cc.begin(stream_cold_args(), w, tail_u0, tail_cnt);
+    bool tile_start = true, whole = false, fast = false;
+    // the epilogue factor's registers: one value chain from here on (the asm loads below update them
+    // in place), so that no copy of a not-yet-arrived register is ever made where control flow joins
+    gemm_f32x4 ev[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) ev[i][j][q4] = gemm_f32x4{1.f, 1.f, 1.f, 1.f};
+    // a lane's quad (i, j, r / 4) of the tile: rows m = wm 64 + i 32 + 8 (r / 4) + 4 (lane / 32) .. + 3 of
+    // column n = wn 64 + j 32 + lane % 32
+
+    issue_tile();
+    issue(0);
+    __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    dma_read_fragments<A_M_CONTIG>(oa[0], fa[0]);
+    dma_read_fragments<B_N_CONTIG>(ob[0], fb[0]);
+    if (n_units > 1) issue(1);
+    unsigned tog = 0;
+    // vector-memory operations younger than the DMAs the next wait is for: the stores of the tile
+    // that just ended and the epilogue-factor loads of the tile that just began.  Completion is in
+    // issue order, so vmcnt(young) retires those DMAs without waiting for a store's acknowledgement.
+    int young = 0;
+    for (int u = 0; u < n_units; ++u) {
+        if (__builtin_expect(tile_start, 0)) {
+            tile_start = false;
+            const gemm_args_cptr gc = stream_cold_args();
+            int64_t cb, cm0, cn0;
+            stream_decode_tile(gc, cc.t, cb, cm0, cn0);
+            whole = cc.kt == 0 && cc.left == gc->n_kt;
+            const float* E = gc->E;
+            const bool c_vec = gc->sc_m == 1 && gc->sc_n % 4 == 0 && gc->sc_b % 4 == 0 && (((uintptr_t)gc->C) & 15) == 0 && gc->M % 4 == 0;
+            const bool e_vec = !E || (gc->se_m == 1 && gc->se_n % 4 == 0 && gc->se_b % 4 == 0 && (((uintptr_t)E) & 15) == 0);
+            fast = whole && c_vec && e_vec && cm0 + BM <= gc->M && cn0 + BN <= gc->N;
+            if (fast && gc->epi_pow != 0 && E) {
+                // the epilogue factor of this tile, 16 x 16 bytes per lane, by loads the compiler does
+                // not track (it would drain the DMA ring at their use): they are older than the DMAs
+                // waited for in the tile's second k-tile (or than the vmcnt(0) before its stores)
+                const int se_n = (int)gc->se_n;
+                const unsigned e_lane = (unsigned)((wn * 64 + (lane & 31)) * se_n + wm * 64 + 4 * (lane >> 5)) * 4u;
+                const float* e_tile = E + cb * gc->se_b + cn0 * se_n + cm0;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float* base = e_tile + (int64_t)(j * 32) * se_n;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4)
+                            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+                                         : "+v"(ev[i][j][q4]) : "v"(e_lane), "s"(base), "n"((i * 32 + 8 * q4) * 4) : "memory");
+                }
+                young += 16;
+            }
+        }
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+            const int set = G & 1;
+            __builtin_amdgcn_s_waitcnt(BSC_LGKMCNT0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (G < 3) {
+                dma_read_fragments<A_M_CONTIG>(oa[set ^ 1], fa[G + 1] ^ tog);
+                dma_read_fragments<B_N_CONTIG>(ob[set ^ 1], fb[G + 1] ^ tog);
+            } else if (u + 1 < n_units) {
+                if (young == 0) __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+                else if (young == 16) __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(16));
+                else __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(32));
+                young = 0;
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                dma_read_fragments<A_M_CONTIG>(oa[set ^ 1], fa[0] ^ tog ^ DMA_STAGE);
+                dma_read_fragments<B_N_CONTIG>(ob[set ^ 1], fb[0] ^ tog ^ DMA_STAGE);
+                if (u + 2 < n_units) issue(u & 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(set);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        tog ^= DMA_STAGE;
+        if (__builtin_expect(cc.step(), 0)) {
+            // ---- this run's share of tile cc.t is complete
+            const gemm_args_cptr gc = stream_cold_args();
+            int64_t cb, cm0, cn0;
+            stream_decode_tile(gc, cc.t, cb, cm0, cn0);
+            // the epilogue factor is older than the DMAs waited for in this tile's second k-tile; a tile
+            // one k-tile long, or the run's last, waits here
+            if (gc->n_kt == 1 || u + 1 == n_units) __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+            if (!whole || fast) young += 16;          // 16 stores per lane below (the guarded path: unknown, wait for all)
+            else young = 0;
+            if (!whole) {
+                float* slot = gc->slab + ((int64_t)2 * w + (cc.round > gc->rounds ? 1 : 0)) * (BM * BN);
+                float* p = slot + (wn * 64 + (lane & 31)) * BM + wm * 64 + 4 * (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            gemm_f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q4 + e];
+                            *reinterpret_cast<gemm_f32x4*>(p + j * 32 * BM + i * 32 + 8 * q4) = v;
+                        }
+            } else if (fast) {
+                const int sc_n = (int)gc->sc_n, epi_pow = gc->epi_pow, dbg = gc->dbg;
+                const float epi_scale = gc->epi_scale;
+                const bool has_e = gc->E != nullptr;
+                float* c_tile = gc->C + cb * gc->sc_b + cn0 * sc_n + cm0;
+                const unsigned c_lane = (unsigned)((wn * 64 + (lane & 31)) * sc_n + wm * 64 + 4 * (lane >> 5)) * 4u;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            gemm_f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q4 + e];
+                            if (epi_pow) {
+                                if (epi_pow < 0) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = 1.0f / v[e];
+                                }
+                                if (has_e) {
+                                    // (a use the scheduler cannot lift above the vmcnt wait that makes
+                                    // the asm-loaded registers valid)
+                                    asm volatile("" : "+v"(ev[i][j][q4]));
+                                    v *= ev[i][j][q4];
+                                }
+                                v *= epi_scale;
+                            }
+                            char* base = reinterpret_cast<char*>(c_tile + (int64_t)(j * 32) * sc_n + i * 32 + 8 * q4);
+                            if (!(dbg & 1)) *reinterpret_cast<gemm_f32x4*>(base + c_lane) = v;
+                        }
+            } else {
+                const int64_t M = gc->M, N = gc->N, sc_m = gc->sc_m, sc_n = gc->sc_n, se_m = gc->se_m, se_n = gc->se_n;
+                const int epi_pow = gc->epi_pow;
+                const float epi_scale = gc->epi_scale;
+                const float* E = gc->E ? gc->E + cb * gc->se_b : nullptr;
+                float* C = gc->C + cb * gc->sc_b;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int64_t col = cn0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int64_t row = cm0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            if (row < M && col < N) {
+                                float v = acc[i][j][r];
+                                if (epi_pow) {
+                                    if (epi_pow < 0) v = 1.0f / v;
+                                    if (E) v *= E[row * se_m + col * se_n];
+                                    v *= epi_scale;
+                                }
+                                C[row * sc_m + col * sc_n] = v;
+                            }
+                        }
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            ++cc.round;
+            cc.segment(gc, w, tail_u0);
+            tile_start = true;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+}
+
+// The tiles that two or more runs share: boundary w (the first unit of workgroup w, 1 <= w < n_wg)
+// lies strictly inside tile t; the FIRST such boundary of a tile adds the tile's pieces in k
+// order -- workgroups w-1, w, w+1, ... up to the tile's end -- applies the epilogue and stores.
+// Slab slots are [n][m] like the accumulators: 16 bytes per lane along m.
+__global__ __launch_bounds__(256) void stream_fixup_kernel(GemmArgs g) {
+    const int w = (int)blockIdx.x + 1;
+    const int b0 = stream_first_unit(&g, w);
+    const int t = b0 / g.n_kt, t_begin = t * g.n_kt, t_end = t_begin + g.n_kt;        // tail tile t
+    if (b0 == t_begin || stream_first_unit(&g, w - 1) > t_begin) return;
+    const int e = (blockIdx.y * 256 + threadIdx.x) * 4;          // element of the [128 n][128 m] tile
+    const int n = e >> 7, m = e & 127;
+    gemm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int x = w - 1; x < g.n_wg; ++x) {
+        const int x0 = stream_first_unit(&g, x);
+        if (x0 >= t_end) break;
+        if (stream_first_unit(&g, x + 1) == x0) continue;             // a workgroup without tail units
+        const float* slot = g.slab + ((int64_t)2 * x + (x0 / g.n_kt != t ? 1 : 0)) * (BM * BN);
+        v += *reinterpret_cast<const gemm_f32x4*>(slot + e);
+    }
+    int64_t b, m0, n0;
+    stream_decode_tile(&g, g.rounds * g.n_wg + t, b, m0, n0);
+    const int64_t col = n0 + n;
+    if (col >= g.N) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t row = m0 + m + q;
+        if (row < g.M) {
+            float c = v[q];
+            if (g.epi_pow) c = gemm_epilogue(g, c, b, row, col);
+            g.C[b * g.sc_b + row * g.sc_m + col * g.sc_n] = c;
+        }
+    }
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t M,
@@ -808,6 +1239,79 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
                                  (float*)C, sc_m, sc_n, &handled);
         if (rc != BSC_OK || handled) return rc;
     }
+    if (ctx->gemm_dma >= 2) {
+        // persistent stream-K on the LDS-DMA pipeline; the A operand goes along C's contiguous axis
+        const bool swap = sc_n == 1 && sc_m != 1;
+        GemmArgs s;
+        s.A = (const float*)(swap ? B : A); s.B = (const float*)(swap ? A : B);
+        s.M = swap ? N : M; s.N = swap ? M : N; s.K = K;
+        s.sa_b = swap ? sb_b : sa_b; s.sa_m = swap ? sb_n : sa_m; s.sa_k = swap ? sb_k : sa_k;
+        s.sb_b = swap ? sa_b : sb_b; s.sb_n = swap ? sa_m : sb_n; s.sb_k = swap ? sa_k : sb_k;
+        s.C = (float*)C; s.sc_b = sc_b; s.sc_m = swap ? sc_n : sc_m; s.sc_n = swap ? sc_m : sc_n;
+        s.E = epi.E; s.se_b = epi.se_b; s.se_m = swap ? epi.se_n : epi.se_m; s.se_n = swap ? epi.se_m : epi.se_n;
+        s.epi_scale = epi.scale; s.epi_pow = epi.pow;
+        s.splits = 1; s.k_chunk = 0; s.vec_a = s.vec_b = s.fast = 0;
+        const bool a_m = s.sa_m == 1, b_n = s.sb_n == 1;
+        auto dma_ok = [&](const void* p, bool mn, int64_t ext_mn, int64_t s_mn, int64_t s_k, int64_t s_b) {
+            if (((uintptr_t)p & 15) != 0 || s_b % 4 != 0 || s_mn < 0 || s_k < 0) return false;
+            if (mn) return ext_mn % 4 == 0 && s_k % 4 == 0 && (31 * s_k + 128) * 4 < ((int64_t)1 << 31);
+            return s_k == 1 && K % 4 == 0 && s_mn % 4 == 0 && (127 * s_mn + 32) * 4 < ((int64_t)1 << 31);
+        };
+        const int64_t c_span = 127 * (s.sc_n < 0 ? -s.sc_n : s.sc_n), e_span = 127 * (s.se_n < 0 ? -s.se_n : s.se_n);
+        if (dma_ok(s.A, a_m, s.M, s.sa_m, s.sa_k, s.sa_b) && dma_ok(s.B, b_n, s.N, s.sb_n, s.sb_k, s.sb_b) &&
+            (c_span + 128) * 4 < ((int64_t)1 << 31) && (e_span + 128) * 4 < ((int64_t)1 << 31) && s.sc_n >= 0 && s.se_n >= 0 &&
+            ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch < ((int64_t)1 << 31) &&
+            ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch / (2 * (int64_t)ctx->cu_count) * ((K + BK - 1) / BK) + 2 * (int64_t)ctx->cu_count * ((K + BK - 1) / BK) < ((int64_t)1 << 31)) {
+            s.tiles_m = (int)((s.M + BM - 1) / BM);
+            s.tiles_n = (int)((s.N + BN - 1) / BN);
+            s.tiles_pb = s.tiles_m * s.tiles_n;
+            s.group = 8;
+            s.n_kt = (int)((K + BK - 1) / BK);
+            s.dbg = ctx->gemm_dbg;
+            // whole rounds of tiles on `slots` workgroups, then the tiles that are left: split along k
+            // among all workgroups when that saves more than the pass over the partial tiles costs
+            // (about five k-tiles' time), else one more -- partly empty -- round
+            const int64_t tiles = (int64_t)s.tiles_pb * batch, slots = 2 * (int64_t)ctx->cu_count;
+            const int64_t left = tiles % slots;
+            s.sk_stream = left > 0 && (int64_t)s.n_kt * (slots - left) >= 6 * slots;
+            if (s.sk_stream) {
+                const int64_t tail_units = left * s.n_kt;            // < 2^31: left < slots, K < 2^36 (checked above)
+                s.rounds = (int)(tiles / slots);
+                s.n_wg = (int)(s.rounds > 0 || tail_units >= slots ? slots : tail_units);
+                s.tail_tiles = (int)left;
+                s.sk_q = (int)(tail_units / s.n_wg);
+                s.sk_r = (int)(tail_units % s.n_wg);
+            } else {
+                s.n_wg = (int)(tiles < slots ? tiles : slots);
+                s.rounds = (int)(tiles / s.n_wg);
+                s.tail_tiles = (int)(tiles % s.n_wg);
+                s.sk_q = 0;
+                s.sk_r = 0;
+            }
+            void* ws = nullptr;
+            int rc = bsc_workspace(ctx, (size_t)2 * s.n_wg * BM * BN * sizeof(float), &ws);
+            if (rc != BSC_OK) return rc;
+            s.slab = (float*)ws;
+            ctx->slab_rows = 0;
+            {
+                bsc_prof_scope prof(ctx);
+#define BSC_GEMM_STREAM(AM, BN_) \
+    hipLaunchKernelGGL((gemm_f32_stream_kernel<AM, BN_>), dim3((unsigned)s.n_wg), dim3(GEMM_BLOCK), 0, ctx->stream, s)
+                if (a_m && b_n) BSC_GEMM_STREAM(true, true);
+                else if (a_m) BSC_GEMM_STREAM(true, false);
+                else if (b_n) BSC_GEMM_STREAM(false, true);
+                else BSC_GEMM_STREAM(false, false);
+#undef BSC_GEMM_STREAM
+            }
+            BSC_LAUNCH_CHECK();
+            if (s.sk_stream && s.n_wg > 1 && !(s.sk_r == 0 && s.sk_q % s.n_kt == 0)) {
+                hipLaunchKernelGGL(stream_fixup_kernel, dim3((unsigned)(s.n_wg - 1), BM * BN / 1024), dim3(256), 0,
+                                   ctx->stream, s);
+                BSC_LAUNCH_CHECK();
+            }
+            return BSC_OK;
+        }
+    }
     GemmArgs g;
     g.A = (const float*)A; g.B = (const float*)B;
     g.M = M; g.N = N; g.K = K;
@@ -816,6 +1320,8 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
     g.sc_b = sc_b; g.sc_m = sc_m; g.sc_n = sc_n;
     g.E = epi.E; g.se_b = epi.se_b; g.se_m = epi.se_m; g.se_n = epi.se_n;
     g.epi_scale = epi.scale; g.epi_pow = epi.pow;
+    g.n_kt = 0; g.sk_q = 0; g.sk_r = 0; g.sk_stream = 0; g.n_wg = 0; g.rounds = 0; g.tail_tiles = 0; g.tiles_pb = 0;
+    g.group = 1; g.dbg = 0; g.slab = nullptr;
     g.tiles_m = (int)((M + BM - 1) / BM);
     g.tiles_n = (int)((N + BN - 1) / BN);
     const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * batch;

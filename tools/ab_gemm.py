@@ -2,7 +2,7 @@
 each burst preceded by its own steady-state warm-up; whole-call time from hipEvent pairs (a
 split-K product counts its reduce), and the two variants' results compared.
 
-    python tools/ab_gemm.py [KNOB] [--quick]
+    python tools/ab_gemm.py [KNOB [VALUE_A VALUE_B]] [--quick]
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,13 +13,14 @@ from bayesic_amd.device import Context
 pos = [a for a in sys.argv[1:] if not a.startswith("--")]
 knob = pos[0] if pos else "BSC_GEMM_DMA"
 quick = "--quick" in sys.argv
+va, vb = (pos[1], pos[2]) if len(pos) > 2 else ("0", "1")
 ctxs = {}
-for v in ("0", "1"):
+for v in (va, vb):
     os.environ[knob] = v
     ctxs[v] = Context(0)
     ctxs[v].reserve(2400 << 20)
 os.environ.pop(knob)
-dev = ctxs["0"].device
+dev = ctxs[va].device
 g = torch.Generator(device=dev).manual_seed(1)
 cases = []
 
@@ -49,7 +50,7 @@ cases.append(("lda dot(Th, Bt) alone", "gemm", (1, docs, V, K, Th, 0, K, 1, Bt, 
 cases.append(("lda S = Bt * dot(Th.T, Q)", "epi", (1, K, V, docs, Th, 0, 1, K, Cn, 0, V, 1, S, 0, V, 1, 1, 1.0, Bt, 0, V, 1), 2.0 * docs * V * K, S))
 
 for name, kind, args, flops, out in cases:
-    res = {"0": [], "1": []}
+    res = {va: [], vb: []}
     outs = {}
     fn = "bsc_gemm_strided_batched" if kind == "gemm" else "bsc_gemm_epilogue"
     for rnd in range(4):
@@ -65,7 +66,7 @@ for name, kind, args, flops, out in cases:
             res[v].append(e0.elapsed_ms(e1) / 6 * 1e3)
             if rnd == 0:
                 outs[v] = out.double().cpu()
-    a, b = np.median(res["0"]), np.median(res["1"])
-    diff = ((outs["0"] - outs["1"]).abs().max() / outs["0"].abs().max()).item()
-    print("%-30s %s=0: %8.1f us (%5.1f TF)   =1: %8.1f us (%5.1f TF)   x%.3f   max|d|/max|.| %.1e" %
-          (name, knob, a, flops / a / 1e6, b, flops / b / 1e6, a / b, diff), flush=True)
+    a, b = np.median(res[va]), np.median(res[vb])
+    diff = ((outs[va] - outs[vb]).abs().max() / outs[va].abs().max()).item()
+    print("%-30s %s=%s: %8.1f us (%5.1f TF)   =%s: %8.1f us (%5.1f TF)   x%.3f   max|d|/max|.| %.1e" %
+          (name, knob, va, a, flops / a / 1e6, vb, b, flops / b / 1e6, a / b, diff), flush=True)
