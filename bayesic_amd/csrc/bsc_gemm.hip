@@ -48,6 +48,10 @@ struct GemmArgs {
     // [w q + min(w, r), ...) of their tile-major unit list when `sk_stream`, else the tile
     // rounds n_wg + w whole
     int n_kt, sk_q, sk_r, sk_stream, n_wg, rounds, tail_tiles, tiles_pb, group, dbg;
+    // tile index -> (batch, strip, row): divisions by tiles_pb, by group * tiles_m and by the last
+    // strip's width as multiply-and-shift on the scalar unit (q = t m >> sh, exact for t < 2^31)
+    unsigned mg_pb, mg_strip, mg_last;
+    int sh_pb, sh_strip, sh_last, group_log2;
     float* slab;       // [2 n_wg][128 n][128 m] partial tiles
 };
 
@@ -356,10 +360,16 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_mfma_kernel(GemmArgs g
 //   operand contiguous along m (or n):  image [k][128] floats; instruction q brings k rows 2q, 2q+1
 //     (lane l: row 2q + l/32, columns 4 (l%32) .. +3); fragments are ds_read_b32, a lane's 32
 //     neighbours read 32 consecutive floats;
-//   operand contiguous along k:  image of 16-byte chunks, row m holds its 8 chunks XOR-swizzled,
-//     chunk (m, c) at position 8 m + (c ^ (m & 7)); instruction q brings rows 8q .. 8q+7, eight
-//     lanes per row cover its 128-byte line; a fragment is ONE ds_read_b128 = four k of one row,
-//     and any 8 neighbouring lanes (8 rows) hit 8 different chunk columns: conflict-free.
+//   operand contiguous along k:  image of 16-byte chunks; instruction q brings the 8 rows x 8 chunks
+//     of rows 8q .. 8q+7 into one KiB = four 256-byte bank lines of sixteen 16-byte slots.  A
+//     fragment is ONE ds_read_b128 = four k of one row, all lanes of a half-wave at the same chunk
+//     index c; the hardware serves a b128 read in the 16-lane groups {0-3,12-15,20-27} and
+//     {4-11,16-19,28-31} (MI355X_MICROARCH.md, LDS), i.e. one half (rows 0-3 or 4-7) of each of four
+//     consecutive 8-row blocks.  Chunk (m, c) therefore sits in line 2 (m/4 % 2) + c/4 of its
+//     block at slot 4 ((m/8 % 4) ^ (c % 4)) + ((m % 4) ^ (c % 4)): the four blocks of a group land
+//     in four different slot quarters, the four rows of a half in four different slots -- no
+//     conflict (the plain 8 m + (c ^ (m & 7)) swizzle is two-way: SQ_LDS_BANK_CONFLICT = half of
+//     SQ_LDS_IDX_ACTIVE in profiles/r02_pmc_gemm_stream.txt's first pass).
 // Both operands agree on the k a lane holds: in the 8-deep group G, lane half h = lane / 32 feeds
 // MFMA t (0..3) with k = 8 G + 4 h + t.
 //
@@ -390,14 +400,22 @@ __device__ __forceinline__ unsigned dma_lane_offset(int q, int lane, int64_t s_m
         const int krow = 2 * q + (lane >> 5), mn = 4 * (lane & 31);
         return mn < mn_left ? (unsigned)(krow * s_k + mn) * 4u : DMA_OUTSIDE;
     }
-    const int mn = 8 * q + (lane >> 3), c = (lane & 7) ^ ((lane >> 3) & 7);
+    // lane = position in the block's KiB: line lane / 16, slot quarter lane / 4 % 4, slot lane % 4
+    const int c = 4 * ((lane >> 4) & 1) + (((lane >> 2) & 3) ^ (q & 3));
+    const int mn = 8 * q + 4 * (lane >> 5) + ((lane & 3) ^ (c & 3));
     return mn < mn_left ? (unsigned)(mn * s_mn + 4 * c) * 4u : DMA_OUTSIDE;
 }
 // ... and whether its k lies in the `k_left` (< 32) that remain
 template <bool MN_CONTIG>
 __device__ __forceinline__ bool dma_lane_k_inside(int q, int lane, int k_left) {
     if (MN_CONTIG) return 2 * q + (lane >> 5) < k_left;
-    return 4 * ((lane & 7) ^ ((lane >> 3) & 7)) < k_left;
+    return 4 * (4 * ((lane >> 4) & 1) + (((lane >> 2) & 3) ^ (q & 3))) < k_left;
+}
+
+// byte offset of chunk c of row `fr` (0..31) in a k-contiguous operand's image
+__device__ __forceinline__ unsigned dma_chunk_offset(int fr, int c) {
+    const int line = 2 * ((fr >> 2) & 1) + (c >> 2), slot = 4 * (((fr >> 3) & 3) ^ (c & 3)) + ((fr & 3) ^ (c & 3));
+    return (unsigned)((fr >> 3) * 1024 + (line * 16 + slot) * 16);
 }
 
 template <bool MN_CONTIG>
@@ -476,9 +494,9 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_dma_kernel(GemmArgs g)
 #pragma unroll
     for (int G = 0; G < 4; ++G) {
         fa[G] = lbase + (A_M_CONTIG ? (unsigned)((8 * G + 4 * fk) * 512 + (wm * 64 + fr) * 4)
-                                    : (unsigned)((wm * 64 + fr) * 128 + (((2 * G + fk) ^ (fr & 7)) * 16)));
+                                    : (unsigned)(wm * 64 * 128) + dma_chunk_offset(fr, 2 * G + fk));
         fb[G] = lbase + 16384 + (B_N_CONTIG ? (unsigned)((8 * G + 4 * fk) * 512 + (wn * 64 + fr) * 4)
-                                            : (unsigned)((wn * 64 + fr) * 128 + (((2 * G + fk) ^ (fr & 7)) * 16)));
+                                            : (unsigned)(wn * 64 * 128) + dma_chunk_offset(fr, 2 * G + fk));
     }
 
     float oa[2][2][4], ob[2][2][4];     // [register set][32-row block][t]
@@ -567,16 +585,26 @@ __device__ __forceinline__ gemm_args_cptr stream_cold_args() {
     return p;
 }
 
+__device__ __forceinline__ unsigned stream_magic_div(unsigned t, unsigned m, int sh) {
+    return (unsigned)(((uint64_t)t * m) >> sh);
+}
+
 template <class GP>
 __device__ __forceinline__ void stream_decode_tile(GP g, int t, int64_t& b, int64_t& m0, int64_t& n0) {
     const unsigned tiles_pb = (unsigned)g->tiles_pb, group = (unsigned)g->group;
-    const unsigned ub = stream_udiv((unsigned)t, tiles_pb);             // tiles x batch < 2^31 (host)
+    const unsigned ub = stream_magic_div((unsigned)t, g->mg_pb, g->sh_pb);             // tiles x batch < 2^31 (host)
     const unsigned tt = (unsigned)t - ub * tiles_pb;
     const unsigned strip = group * (unsigned)g->tiles_m;
-    const unsigned s = stream_udiv(tt, strip), within = tt - s * strip;
+    const unsigned s = stream_magic_div(tt, g->mg_strip, g->sh_strip), within = tt - s * strip;
     const unsigned left = (unsigned)g->tiles_n - s * group;
-    const unsigned gw = left < group ? left : group;
-    const unsigned tm = stream_udiv(within, gw);
+    unsigned tm, gw;
+    if (left >= group) {
+        gw = group;
+        tm = within >> g->group_log2;
+    } else {
+        gw = left;
+        tm = stream_magic_div(within, g->mg_last, g->sh_last);
+    }
     b = ub;
     m0 = (int64_t)tm * BM;
     n0 = (int64_t)(s * group + (within - tm * gw)) * BN;
@@ -723,9 +751,9 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
 #pragma unroll
     for (int G = 0; G < 4; ++G) {
         fa[G] = lbase + (A_M_CONTIG ? (unsigned)((8 * G + 4 * fk) * 512 + (wm * 64 + fr) * 4)
-                                    : (unsigned)((wm * 64 + fr) * 128 + (((2 * G + fk) ^ (fr & 7)) * 16)));
+                                    : (unsigned)(wm * 64 * 128) + dma_chunk_offset(fr, 2 * G + fk));
         fb[G] = lbase + 16384 + (B_N_CONTIG ? (unsigned)((8 * G + 4 * fk) * 512 + (wn * 64 + fr) * 4)
-                                            : (unsigned)((wn * 64 + fr) * 128 + (((2 * G + fk) ^ (fr & 7)) * 16)));
+                                            : (unsigned)(wn * 64 * 128) + dma_chunk_offset(fr, 2 * G + fk));
     }
     float oa[2][2][4], ob[2][2][4];
     auto mfmas = [&](int set) __attribute__((always_inline)) {
@@ -742,6 +770,7 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
     StreamCursor cc;
     cc.begin(stream_cold_args(), w, tail_u0, tail_cnt);
     bool tile_start = true, whole = false, fast = false;
+    int64_t cb = 0, cm0 = 0, cn0 = 0;                     // the tile under `cc`
     // the epilogue factor's registers: one value chain from here on (the asm loads below update them
     // in place), so that no copy of a not-yet-arrived register is ever made where control flow joins
     gemm_f32x4 ev[2][2][4];
@@ -771,7 +800,6 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
         if (__builtin_expect(tile_start, 0)) {
             tile_start = false;
             const gemm_args_cptr gc = stream_cold_args();
-            int64_t cb, cm0, cn0;
             stream_decode_tile(gc, cc.t, cb, cm0, cn0);
             whole = cc.kt == 0 && cc.left == gc->n_kt;
             const float* E = gc->E;
@@ -825,8 +853,6 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
         if (__builtin_expect(cc.step(), 0)) {
             // ---- this run's share of tile cc.t is complete
             const gemm_args_cptr gc = stream_cold_args();
-            int64_t cb, cm0, cn0;
-            stream_decode_tile(gc, cc.t, cb, cm0, cn0);
             // the epilogue factor is older than the DMAs waited for in this tile's second k-tile; a tile
             // one k-tile long, or the run's last, waits here
             if (gc->n_kt == 1 || u + 1 == n_units) __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
@@ -863,8 +889,13 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
                             for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q4 + e];
                             if (epi_pow) {
                                 if (epi_pow < 0) {
+                                    // v_rcp_f32 and one Newton step (3 instructions; the IEEE division
+                                    // sequence is ~10, 640 per tile -- a fifth of a K = 128 tile's MFMA time)
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] = 1.0f / v[e];
+                                    for (int e = 0; e < 4; ++e) {
+                                        const float x = v[e], r = __builtin_amdgcn_rcpf(x);
+                                        v[e] = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+                                    }
                                 }
                                 if (has_e) {
                                     // (a use the scheduler cannot lift above the vmcnt wait that makes
@@ -890,6 +921,7 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
                         const int64_t col = cn0 + wn * 64 + j * 32 + (lane & 31);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
+                            if ((r & 3) == 0) asm volatile("" ::: "memory");      // four loads in flight, not sixty-four (registers)
                             const int64_t row = cm0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                             if (row < M && col < N) {
                                 float v = acc[i][j][r];
@@ -921,21 +953,32 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
 // lies strictly inside tile t; the FIRST such boundary of a tile adds the tile's pieces in k
 // order -- workgroups w-1, w, w+1, ... up to the tile's end -- applies the epilogue and stores.
 // Slab slots are [n][m] like the accumulators: 16 bytes per lane along m.
-__global__ __launch_bounds__(256) void stream_fixup_kernel(GemmArgs g) {
+__global__ __launch_bounds__(64) void stream_fixup_kernel(GemmArgs g) {
     const int w = (int)blockIdx.x + 1;
     const int b0 = stream_first_unit(&g, w);
     const int t = b0 / g.n_kt, t_begin = t * g.n_kt, t_end = t_begin + g.n_kt;        // tail tile t
     if (b0 == t_begin || stream_first_unit(&g, w - 1) > t_begin) return;
-    const int e = (blockIdx.y * 256 + threadIdx.x) * 4;          // element of the [128 n][128 m] tile
+    const int e = (blockIdx.y * 64 + threadIdx.x) * 4;           // element of the [128 n][128 m] tile
     const int n = e >> 7, m = e & 127;
     gemm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    // the pieces in k order, four loads in flight
+    const float* piece[4];
+    int n_piece = 0;
     for (int x = w - 1; x < g.n_wg; ++x) {
         const int x0 = stream_first_unit(&g, x);
         if (x0 >= t_end) break;
         if (stream_first_unit(&g, x + 1) == x0) continue;             // a workgroup without tail units
-        const float* slot = g.slab + ((int64_t)2 * x + (x0 / g.n_kt != t ? 1 : 0)) * (BM * BN);
-        v += *reinterpret_cast<const gemm_f32x4*>(slot + e);
+        piece[n_piece++] = g.slab + ((int64_t)2 * x + (x0 / g.n_kt != t ? 1 : 0)) * (BM * BN) + e;
+        if (n_piece == 4) {
+            gemm_f32x4 p[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p[i] = *reinterpret_cast<const gemm_f32x4*>(piece[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v += p[i];
+            n_piece = 0;
+        }
     }
+    for (int i = 0; i < n_piece; ++i) v += *reinterpret_cast<const gemm_f32x4*>(piece[i]);
     int64_t b, m0, n0;
     stream_decode_tile(&g, g.rounds * g.n_wg + t, b, m0, n0);
     const int64_t col = n0 + n;
@@ -1266,6 +1309,16 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
             s.tiles_n = (int)((s.N + BN - 1) / BN);
             s.tiles_pb = s.tiles_m * s.tiles_n;
             s.group = 8;
+            s.group_log2 = 3;
+            auto magic = [](int64_t d, unsigned& m, int& sh) {       // q = t m >> sh for 0 <= t < 2^31, 1 <= d < 2^31
+                int l = 0;
+                while (((int64_t)1 << l) < d) ++l;
+                sh = 31 + l;
+                m = (unsigned)((((unsigned __int128)1) << sh) / (unsigned __int128)d + 1);
+            };
+            magic(s.tiles_pb, s.mg_pb, s.sh_pb);
+            magic((int64_t)s.group * s.tiles_m, s.mg_strip, s.sh_strip);
+            magic(s.tiles_n % s.group ? s.tiles_n % s.group : s.group, s.mg_last, s.sh_last);
             s.n_kt = (int)((K + BK - 1) / BK);
             s.dbg = ctx->gemm_dbg;
             // whole rounds of tiles on `slots` workgroups, then the tiles that are left: split along k
@@ -1305,7 +1358,7 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
             }
             BSC_LAUNCH_CHECK();
             if (s.sk_stream && s.n_wg > 1 && !(s.sk_r == 0 && s.sk_q % s.n_kt == 0)) {
-                hipLaunchKernelGGL(stream_fixup_kernel, dim3((unsigned)(s.n_wg - 1), BM * BN / 1024), dim3(256), 0,
+                hipLaunchKernelGGL(stream_fixup_kernel, dim3((unsigned)(s.n_wg - 1), BM * BN / 256), dim3(64), 0,
                                    ctx->stream, s);
                 BSC_LAUNCH_CHECK();
             }
@@ -1322,6 +1375,7 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
     g.epi_scale = epi.scale; g.epi_pow = epi.pow;
     g.n_kt = 0; g.sk_q = 0; g.sk_r = 0; g.sk_stream = 0; g.n_wg = 0; g.rounds = 0; g.tail_tiles = 0; g.tiles_pb = 0;
     g.group = 1; g.dbg = 0; g.slab = nullptr;
+    g.mg_pb = g.mg_strip = g.mg_last = 0; g.sh_pb = g.sh_strip = g.sh_last = g.group_log2 = 0;
     g.tiles_m = (int)((M + BM - 1) / BM);
     g.tiles_n = (int)((N + BN - 1) / BN);
     const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * batch;

@@ -28,7 +28,12 @@ KERNELS = {
     "cfg4": ("lda_sstats_kernel", "bsc_lda.hip", 4.0 * 6250 * 100_000),
     "cfg5": ("logreg_loglik_dma_kernel", "bsc_bbvi.hip", 4.0 * 1_000_000 * 256 + 8.0 * 1_000_000),
     "wouter": ("weighted_outer_kernel", "bsc_wouter.hip", 4.0 * 10_000_000 * (64 + 16)),
-    "gram": ("gemm_f32_mfma_kernel", "bsc_gemm.hip", 4.0 * 1_000_000 * 256),
+    "gram": ("gemm_f32_stream_kernel", "bsc_gemm.hip", 4.0 * 1_000_000 * 256),
+    "lda1": ("gemm_f32_stream_kernel", "bsc_gemm.hip", 4.0 * 6250 * 100_000 + 4.0 * 128 * 106_250),
+    "lda1e": ("gemm_f32_stream_kernel", "bsc_gemm.hip", 8.0 * 6250 * 100_000 + 4.0 * 128 * 106_250),
+    "lda2": ("gemm_f32_stream_kernel", "bsc_gemm.hip", 4.0 * 6250 * 100_000 + 4.0 * 128 * 206_250),
+    "sq4096nt": ("gemm_f32_stream_kernel", "bsc_gemm.hip", 12.0 * 4096 * 4096),
+    "sq4096tn": ("gemm_f32_stream_kernel", "bsc_gemm.hip", 12.0 * 4096 * 4096),
     "skinny": ("gemm_skinny_nt_kernel", "bsc_skinny.hip", 4.0 * 1_000_000 * 256 + 4.0 * 8 * 1_000_000),
 }
 

@@ -2,7 +2,7 @@
 passes (tools/pmc_collect.sh).  Inputs are random device tensors (counters do not depend on the
 values); the call is the same C-ABI entry point bench.py / the drivers use.
 
-    python3 tools/pmc_run.py cfg2|cfg3|cfg4|cfg5|wouter|gram|skinny [reps]
+    python3 tools/pmc_run.py cfg2|cfg3|cfg4|cfg5|wouter|gram|skinny|lda1|lda1e|lda2|sq4096nt|sq4096tn [reps]
 """
 import os
 import sys
@@ -70,6 +70,29 @@ def main():
         W = torch.randn((S, D), generator=g, device=dev)
         P = torch.empty((S, N), device=dev)
         fn = lambda: ctx.call("bsc_gemm_strided_batched", 0, 1, S, N, D, W, 0, D, 1, X, 0, 1, D, P, 0, N, 1)
+    elif which in ("lda1", "lda1e", "lda2"):
+        # config 4's statistic through the executor: Q = C / dot(Th, Bt), S = Bt * dot(Th.T, Q)
+        docs, V, K = 6250, 100_000, 128
+        Th = torch.rand((docs, K), generator=g, device=dev) + 0.1
+        Bt = torch.rand((K, V), generator=g, device=dev) + 0.1
+        Cn = torch.rand((docs, V), generator=g, device=dev)
+        Q = torch.empty((docs, V), device=dev)
+        S = torch.empty((K, V), device=dev)
+        if which == "lda1":
+            fn = lambda: ctx.call("bsc_gemm_strided_batched", 0, 1, docs, V, K, Th, 0, K, 1, Bt, 0, V, 1, Q, 0, V, 1)
+        elif which == "lda1e":
+            fn = lambda: ctx.call("bsc_gemm_epilogue", 0, 1, docs, V, K, Th, 0, K, 1, Bt, 0, V, 1, Q, 0, V, 1, -1, 1.0, Cn, 0, V, 1)
+        else:
+            fn = lambda: ctx.call("bsc_gemm_epilogue", 0, 1, K, V, docs, Th, 0, 1, K, Cn, 0, V, 1, S, 0, V, 1, 1, 1.0, Bt, 0, V, 1)
+    elif which in ("sq4096nt", "sq4096tn"):
+        n = 4096
+        A = torch.randn((n, n), generator=g, device=dev)
+        B = torch.randn((n, n), generator=g, device=dev)
+        C = torch.empty((n, n), device=dev)
+        if which == "sq4096nt":
+            fn = lambda: ctx.call("bsc_gemm_strided_batched", 0, 1, n, n, n, A, 0, n, 1, B, 0, 1, n, C, 0, n, 1)
+        else:
+            fn = lambda: ctx.call("bsc_gemm_strided_batched", 0, 1, n, n, n, A, 0, 1, n, B, 0, n, 1, C, 0, n, 1)
     else:
         raise SystemExit("unknown config %r" % which)
     for _ in range(reps):
