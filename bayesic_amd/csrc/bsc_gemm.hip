@@ -17,6 +17,7 @@
 // and a second kernel adds them in split order (deterministic; float atomics
 // would be order-dependent and cap at ~1.3 TB/s).
 #include "bsc_common.h"
+#include "bsc_stream.h"
 
 namespace {
 
@@ -566,25 +567,6 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_dma_kernel(GemmArgs g)
 // Tile order: column strips `group` tiles wide, rows fastest inside a strip, and workgroup
 // slots permuted so that each XCD's 64 slots are neighbours in that order: at any moment an
 // XCD works on a compact block of tiles and its L2 serves every operand panel to several of them.
-// A quotient of wave-uniform values, said to be uniform: the division itself runs on the vector
-// unit, and everything computed from an unmarked result -- tile coordinates, descriptors, loop
-// conditions -- would follow it there (exec-masked branches, readfirstlane loops around each DMA).
-__device__ __forceinline__ unsigned stream_udiv(unsigned a, unsigned b) {
-    return (unsigned)__builtin_amdgcn_readfirstlane((int)(a / b));
-}
-
-// The kernel's arguments, re-read from the kernarg segment where they are needed: the stream
-// kernel touches most of GemmArgs only at tile boundaries, and held in scalar registers across
-// the k-loop they cost it ~120 SGPR spills (v_writelane / v_readlane in the loop: vector
-// instructions, which take their cycles from the matrix pipe).  The empty asm keeps the loads
-// from being hoisted back out.
-typedef __attribute__((address_space(4))) const GemmArgs* gemm_args_cptr;
-__device__ __forceinline__ gemm_args_cptr stream_cold_args() {
-    gemm_args_cptr p = (gemm_args_cptr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
 __device__ __forceinline__ unsigned stream_magic_div(unsigned t, unsigned m, int sh) {
     return (unsigned)(((uint64_t)t * m) >> sh);
 }
@@ -610,56 +592,7 @@ __device__ __forceinline__ void stream_decode_tile(GP g, int t, int64_t& b, int6
     n0 = (int64_t)(s * group + (within - tm * gw)) * BN;
 }
 
-// first tail unit of workgroup w (w = n_wg: the end of the list)
-template <class GP>
-__device__ __forceinline__ int stream_first_unit(GP g, int w) {
-    if (g->sk_stream) return w * g->sk_q + (w < g->sk_r ? w : g->sk_r);
-    return (w < g->tail_tiles ? w : g->tail_tiles) * g->n_kt;
-}
-
-// Where a workgroup's run stands: k-tile `kt` of tile `t`, `left` more units of that tile to go.
-struct StreamCursor {
-    int t, round, kt, left, tail_left;
-    template <class GP>
-    __device__ __forceinline__ void segment(GP g, int w, int tail_u0) {
-        const int rounds = g->rounds, n_kt = g->n_kt;
-        if (round < rounds) {
-            t = round * g->n_wg + w;
-            kt = 0;
-            left = n_kt;
-        } else {
-            if (round == rounds) {
-                const int tt = (int)stream_udiv((unsigned)tail_u0, (unsigned)n_kt);
-                t = rounds * g->n_wg + tt;
-                kt = tail_u0 - tt * n_kt;
-            } else {
-                ++t;
-                kt = 0;
-            }
-            left = n_kt - kt < tail_left ? n_kt - kt : tail_left;
-            tail_left -= left;
-        }
-    }
-    template <class GP>
-    __device__ __forceinline__ void begin(GP g, int w, int tail_u0, int tail_cnt) {
-        round = 0;
-        tail_left = tail_cnt;
-        t = 0; kt = 0; left = 0;
-        segment(g, w, tail_u0);
-    }
-    // one unit on; true when that was the tile's last unit in this run (the caller then moves
-    // to the next segment)
-    __device__ __forceinline__ bool step() {
-        ++kt;
-        return --left == 0;
-    }
-};
-
-__device__ __forceinline__ const float* stream_uniform_ptr(const float* p) {
-    const uint64_t v = (uint64_t)(uintptr_t)p;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return (const float*)(uintptr_t)(((uint64_t)hi << 32) | lo);
-}
+typedef stream_args_cptr<GemmArgs> gemm_args_cptr;
 
 template <bool A_M_CONTIG, bool B_N_CONTIG>
 __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs g) {
@@ -670,7 +603,7 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
     int w = blockIdx.x;
     int n_units, tail_u0, tail_cnt;
     {
-        const gemm_args_cptr gc = stream_cold_args();
+        const gemm_args_cptr gc = stream_cold_args<GemmArgs>();
         if ((gc->n_wg & 7) == 0) w = (w & 7) * (gc->n_wg >> 3) + (w >> 3);     // an XCD's slots are neighbours
         tail_u0 = stream_first_unit(gc, w);
         tail_cnt = stream_first_unit(gc, w + 1) - tail_u0;
@@ -693,12 +626,12 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
     // (always_inline: an out-of-line lambda takes its captures -- cursors, descriptors, the kernel
     // arguments -- through a closure in scratch memory, and everything read back from there is per-lane)
     StreamCursor ic;
-    ic.begin(stream_cold_args(), w, tail_u0, tail_cnt);
+    ic.begin(stream_cold_args<GemmArgs>(), w, tail_u0, tail_cnt);
     int issued = 0;
     unsigned va[4], vb[4];
     const float *a_tile, *b_tile;
     auto issue_tile = [&]() __attribute__((always_inline)) {
-        const gemm_args_cptr gc = stream_cold_args();
+        const gemm_args_cptr gc = stream_cold_args<GemmArgs>();
         int64_t b, m0, n0;
         stream_decode_tile(gc, ic.t, b, m0, n0);
 #pragma unroll
@@ -740,7 +673,7 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
         b_tile += step_b;
         if (__builtin_expect(ic.step(), 0) && issued < n_units) {
             ++ic.round;
-            ic.segment(stream_cold_args(), w, tail_u0);
+            ic.segment(stream_cold_args<GemmArgs>(), w, tail_u0);
             issue_tile();
         }
     };
@@ -768,7 +701,7 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
 
     // ---- the computing side
     StreamCursor cc;
-    cc.begin(stream_cold_args(), w, tail_u0, tail_cnt);
+    cc.begin(stream_cold_args<GemmArgs>(), w, tail_u0, tail_cnt);
     bool tile_start = true, whole = false, fast = false;
     int64_t cb = 0, cm0 = 0, cn0 = 0;                     // the tile under `cc`
     // the epilogue factor's registers: one value chain from here on (the asm loads below update them
@@ -799,7 +732,7 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
     for (int u = 0; u < n_units; ++u) {
         if (__builtin_expect(tile_start, 0)) {
             tile_start = false;
-            const gemm_args_cptr gc = stream_cold_args();
+            const gemm_args_cptr gc = stream_cold_args<GemmArgs>();
             stream_decode_tile(gc, cc.t, cb, cm0, cn0);
             whole = cc.kt == 0 && cc.left == gc->n_kt;
             const float* E = gc->E;
@@ -852,7 +785,7 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
         tog ^= DMA_STAGE;
         if (__builtin_expect(cc.step(), 0)) {
             // ---- this run's share of tile cc.t is complete
-            const gemm_args_cptr gc = stream_cold_args();
+            const gemm_args_cptr gc = stream_cold_args<GemmArgs>();
             // the epilogue factor is older than the DMAs waited for in this tile's second k-tile; a tile
             // one k-tile long, or the run's last, waits here
             if (gc->n_kt == 1 || u + 1 == n_units) __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
@@ -1321,26 +1254,7 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
             magic(s.tiles_n % s.group ? s.tiles_n % s.group : s.group, s.mg_last, s.sh_last);
             s.n_kt = (int)((K + BK - 1) / BK);
             s.dbg = ctx->gemm_dbg;
-            // whole rounds of tiles on `slots` workgroups, then the tiles that are left: split along k
-            // among all workgroups when that saves more than the pass over the partial tiles costs
-            // (about five k-tiles' time), else one more -- partly empty -- round
-            const int64_t tiles = (int64_t)s.tiles_pb * batch, slots = 2 * (int64_t)ctx->cu_count;
-            const int64_t left = tiles % slots;
-            s.sk_stream = left > 0 && (int64_t)s.n_kt * (slots - left) >= 6 * slots;
-            if (s.sk_stream) {
-                const int64_t tail_units = left * s.n_kt;            // < 2^31: left < slots, K < 2^36 (checked above)
-                s.rounds = (int)(tiles / slots);
-                s.n_wg = (int)(s.rounds > 0 || tail_units >= slots ? slots : tail_units);
-                s.tail_tiles = (int)left;
-                s.sk_q = (int)(tail_units / s.n_wg);
-                s.sk_r = (int)(tail_units % s.n_wg);
-            } else {
-                s.n_wg = (int)(tiles < slots ? tiles : slots);
-                s.rounds = (int)(tiles / s.n_wg);
-                s.tail_tiles = (int)(tiles % s.n_wg);
-                s.sk_q = 0;
-                s.sk_r = 0;
-            }
+            stream_plan(s, (int64_t)s.tiles_pb * batch, s.n_kt, 2 * (int64_t)ctx->cu_count);
             void* ws = nullptr;
             int rc = bsc_workspace(ctx, (size_t)2 * s.n_wg * BM * BN * sizeof(float), &ws);
             if (rc != BSC_OK) return rc;
@@ -1357,7 +1271,7 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
 #undef BSC_GEMM_STREAM
             }
             BSC_LAUNCH_CHECK();
-            if (s.sk_stream && s.n_wg > 1 && !(s.sk_r == 0 && s.sk_q % s.n_kt == 0)) {
+            if (stream_has_pieces(s)) {
                 hipLaunchKernelGGL(stream_fixup_kernel, dim3((unsigned)(s.n_wg - 1), BM * BN / 256), dim3(64), 0,
                                    ctx->stream, s);
                 BSC_LAUNCH_CHECK();

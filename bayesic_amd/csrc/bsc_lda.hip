@@ -22,6 +22,7 @@
 // is exactly its B-operand layout when the contraction index is taken to be
 // those rows, so R feeds phase 2 straight from registers.
 #include "bsc_common.h"
+#include "bsc_stream.h"
 
 namespace {
 
@@ -291,6 +292,334 @@ __global__ __launch_bounds__(256) void lda_reduce_kernel(const float* __restrict
     }
 }
 
+// ---- K = 128: persistent, operands by LDS-DMA ---------------------------------------------------
+// The same arithmetic as lda_sstats_kernel<4> (bit for bit: same operand maps, same order), with
+// what csrc/bsc_gemm.hip's stream kernel learned about this part:
+//   * the Th [32 x 128] and C [32 x 128] tiles of a step arrive by `buffer_load_dwordx4 ... lds`
+//     (4 + 4 per wave; ~45 cycles of matrix-pipe time apiece where a VGPR load takes ~115 and
+//     needs a ds_write pass besides).  The Th image keeps rows of 512 B with chunk c of row d at
+//     position c ^ (d % 16): phase 1 (lane = document, one chunk index per read) and phase 2
+//     (lane = chunk, one document per half-wave) both read it with conflict-free ds_read_b128;
+//     the C tile is a plain [32][128].  Documents past the end and columns past V are zeros by
+//     out-of-range descriptor offsets;
+//   * persistent: the (column block, 32-document step) units are dealt as in bsc_stream.h -- whole
+//     rounds of column blocks, then the blocks left over split along the documents among all
+//     workgroups, their partial statistics added in order by lda_stream_fixup_kernel.  (The
+//     one-block-per-workgroup kernel splits ALL blocks five ways at config 4's size: 256 MB of
+//     partials and a last round 4.5 % empty);
+//   * LDS fragments two reads ahead in a ring of registers, hand-counted lgkmcnt; the step body
+//     exists once per LDS buffer so that the buffer is an immediate offset.
+constexpr int LS_STAGE = 32768;        // bytes: Th image 16 KiB, C tile 16 KiB
+constexpr unsigned LS_OUTSIDE = 0x80000000u;
+
+struct LdaStreamArgs {
+    const float* C;
+    const float* Th;
+    const float* Bt;
+    float* out;
+    float* slab;       // [2 n_wg][128 k][128 v] partial statistics
+    int64_t ldc, ldth, ldb, ldo, docs, V;
+    int n_kt, sk_q, sk_r, sk_stream, n_wg, rounds, tail_tiles;   // tiles = 128-column blocks, units = 32-document steps
+    int d_tail;        // documents in a block's last step, 1..32
+};
+typedef stream_args_cptr<LdaStreamArgs> lda_args_cptr;
+
+#define LDA_LDS_B128(DST, ADDR, OFF) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+#define LDA_LDS_B32(DST, ADDR, OFF) \
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+
+typedef float lda_f32x4 __attribute__((ext_vector_type(4)));
+
+// s_waitcnt lgkmcnt(n) alone (n a compile-time constant after unrolling)
+__device__ __forceinline__ void lda_wait_lgkm(int n) {
+    switch (n) {
+        case 0: __builtin_amdgcn_s_waitcnt(0xC07F); break;
+        case 1: __builtin_amdgcn_s_waitcnt(0xC17F); break;
+        case 2: __builtin_amdgcn_s_waitcnt(0xC27F); break;
+        case 3: __builtin_amdgcn_s_waitcnt(0xC37F); break;
+        case 4: __builtin_amdgcn_s_waitcnt(0xC47F); break;
+        case 5: __builtin_amdgcn_s_waitcnt(0xC57F); break;
+        case 6: __builtin_amdgcn_s_waitcnt(0xC67F); break;
+        case 7: __builtin_amdgcn_s_waitcnt(0xC77F); break;
+        default: __builtin_amdgcn_s_waitcnt(0xC87F); break;
+    }
+}
+
+__global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_stream_kernel(LdaStreamArgs a) {
+    constexpr int KT = 4, K = 128;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * LS_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    int w = blockIdx.x;
+    int n_units, tail_u0, tail_cnt;
+    {
+        const lda_args_cptr gc = stream_cold_args<LdaStreamArgs>();
+        if ((gc->n_wg & 7) == 0) w = (w & 7) * (gc->n_wg >> 3) + (w >> 3);
+        tail_u0 = stream_first_unit(gc, w);
+        tail_cnt = stream_first_unit(gc, w + 1) - tail_u0;
+        n_units = gc->rounds * gc->n_kt + tail_cnt;
+    }
+    if (n_units == 0) return;
+    const int64_t step_th = 32 * a.ldth, step_c = 32 * a.ldc;
+    const int last_kt = a.n_kt - 1, d_tail = a.d_tail;
+
+    // ---- issuing side
+    StreamCursor ic;
+    ic.begin(stream_cold_args<LdaStreamArgs>(), w, tail_u0, tail_cnt);
+    int issued = 0;
+    unsigned vth[4], vc[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int row = 2 * (4 * wave + jj) + (lane >> 5);
+        vth[jj] = (unsigned)(row * (int)a.ldth + 4 * ((lane & 31) ^ (row & 15))) * 4u;
+    }
+    const float *th_ptr, *c_ptr;
+    auto issue_tile = [&]() __attribute__((always_inline)) {
+        const lda_args_cptr gc = stream_cold_args<LdaStreamArgs>();
+        const int64_t v_base = (int64_t)ic.t * VT, v_left = gc->V - v_base;
+        const int ldc = (int)gc->ldc;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int row = 2 * (4 * wave + jj) + (lane >> 5), col = 4 * (lane & 31);
+            vc[jj] = col < v_left ? (unsigned)(row * ldc + col) * 4u : LS_OUTSIDE;
+        }
+        th_ptr = gc->Th + (int64_t)ic.kt * 32 * gc->ldth;
+        c_ptr = gc->C + (int64_t)ic.kt * 32 * gc->ldc + v_base;
+    };
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        const auto rth = __builtin_amdgcn_make_buffer_rsrc((void*)stream_uniform_ptr(th_ptr), 0, LS_OUTSIDE, 0x00020000);
+        const auto rc = __builtin_amdgcn_make_buffer_rsrc((void*)stream_uniform_ptr(c_ptr), 0, LS_OUTSIDE, 0x00020000);
+        char* const dst = lds + buf * LS_STAGE + wave * 4096;
+        if (__builtin_expect(ic.kt != last_kt || d_tail == DT, 1)) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rth, (bsc_lds_ptr)(dst + jj * 1024), 16, vth[jj], 0, 0, 0);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (bsc_lds_ptr)(dst + 16384 + jj * 1024), 16, vc[jj], 0, 0, 2);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const bool in = 2 * (4 * wave + jj) + (lane >> 5) < d_tail;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rth, (bsc_lds_ptr)(dst + jj * 1024), 16, in ? vth[jj] : LS_OUTSIDE, 0, 0, 0);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const bool in = 2 * (4 * wave + jj) + (lane >> 5) < d_tail;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (bsc_lds_ptr)(dst + 16384 + jj * 1024), 16, in ? vc[jj] : LS_OUTSIDE, 0, 0, 2);
+            }
+        }
+        ++issued;
+        th_ptr += step_th;
+        c_ptr += step_c;
+        if (__builtin_expect(ic.step(), 0) && issued < n_units) {
+            ++ic.round;
+            ic.segment(stream_cold_args<LdaStreamArgs>(), w, tail_u0);
+            issue_tile();
+        }
+    };
+
+    // ---- fragment addresses in buffer 0 (buffer 1: + LS_STAGE as an immediate)
+    const unsigned lb = (unsigned)(uintptr_t)(bsc_lds_ptr)lds;
+    unsigned p1[16], p2[8];
+#pragma unroll
+    for (int t4 = 0; t4 < 16; ++t4)        // phase 1: document j, chunk 16 h + t4
+        p1[t4] = lb + (unsigned)(j * 512 + (((16 * h + t4) ^ (j & 15)) * 16));
+#pragma unroll
+    for (int c2 = 0; c2 < 8; ++c2)         // phase 2: chunk j of document i + 8 q + 4 h, c2 = i + 4 (q & 1)
+        p2[c2] = lb + (unsigned)(4 * h * 512 + ((j ^ (4 * h) ^ ((c2 & 3) | ((c2 >> 2) << 3))) * 16));
+    const unsigned pc = lb + 16384 + (unsigned)(4 * h * 512 + (32 * wave + j) * 4);
+
+    float bt[K / 2];      // Bt[64 h + t][v]; at the end of a block: the factor Bt[4 row_r + kt][v] in bt[16 kt + r]
+#pragma unroll
+    for (int t = 0; t < K / 2; ++t) bt[t] = 0.f;
+    f32x16 S[KT];
+    f32x16 P;
+    float ring[5][4];
+
+    // ---- computing side
+    StreamCursor cc;
+    cc.begin(stream_cold_args<LdaStreamArgs>(), w, tail_u0, tail_cnt);
+    bool tile_start = true, whole = false, v_ok = false;
+    unsigned v_lane = 0;          // byte offset of this lane's column in a row of Bt / out (clamped inside V)
+
+    auto step_body = [&](auto buf_c, int u) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_c)::value;
+        constexpr int OFF = BUF * LS_STAGE;
+        if (__builtin_expect(tile_start, 0)) {
+            tile_start = false;
+            const lda_args_cptr gc = stream_cold_args<LdaStreamArgs>();
+            const int64_t v = (int64_t)cc.t * VT + 32 * wave + j;
+            v_ok = v < gc->V;
+            v_lane = (unsigned)(v_ok ? v : gc->V - 1) * 4u;
+            whole = cc.kt == 0 && cc.left == gc->n_kt;
+            const unsigned off = v_lane + (unsigned)(64 * h) * (unsigned)gc->ldb * 4u;
+            const float* base = gc->Bt;
+            const int64_t ldb = gc->ldb;
+#pragma unroll
+            for (int t = 0; t < K / 2; ++t) {
+                asm volatile("global_load_dword %0, %1, %2" : "+v"(bt[t]) : "v"(off), "s"(base) : "memory");
+                base += ldb;
+            }
+            __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));      // (also the DMAs in flight: once per block)
+#pragma unroll
+            for (int t = 0; t < K / 2; ++t) {
+                asm volatile("" : "+v"(bt[t]));
+                bt[t] = v_ok ? bt[t] : 0.f;
+            }
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
+        }
+        // slots: 0..15 phase-1 reads (b128); then per q: the four counts (4 x b32), four Th reads (b128)
+        auto slot_size = [](int s) { return s < 16 ? 1 : ((s - 16) % 5 == 0 ? 4 : 1); };
+        auto issue_slot = [&](int s) __attribute__((always_inline)) {
+            float (&dst)[4] = ring[s % 5];
+            if (s < 16) {
+                lda_f32x4 v4;
+                LDA_LDS_B128(v4, p1[s], OFF);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[e] = v4[e];
+            } else {
+                const int q = (s - 16) / 5, r5 = (s - 16) % 5;
+                if (r5 == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) LDA_LDS_B32(dst[i], pc, OFF + (i + 8 * q) * 512);
+                } else {
+                    const int i = r5 - 1;
+                    lda_f32x4 v4;
+                    LDA_LDS_B128(v4, p2[i + 4 * (q & 1)], OFF + (i + 8 * q) * 512);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dst[e] = v4[e];
+                }
+            }
+        };
+        issue_slot(0);
+        issue_slot(1);
+        issue_slot(2);
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            const int after = (s + 1 < 36 ? slot_size(s + 1) : 0) + (s + 2 < 36 ? slot_size(s + 2) : 0);
+            lda_wait_lgkm(after);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 3 < 36) issue_slot(s + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            const float (&f)[4] = ring[s % 5];
+            if (s < 16) {
+                // the first MFMA takes the constant 0 as its C operand: no 16 moves to clear P
+                P = __builtin_amdgcn_mfma_f32_32x32x2f32(f[0], bt[4 * s + 0], s == 0 ? zero16 : P, 0, 0, 0);
+                P = __builtin_amdgcn_mfma_f32_32x32x2f32(f[1], bt[4 * s + 1], P, 0, 0, 0);
+                P = __builtin_amdgcn_mfma_f32_32x32x2f32(f[2], bt[4 * s + 2], P, 0, 0, 0);
+                P = __builtin_amdgcn_mfma_f32_32x32x2f32(f[3], bt[4 * s + 3], P, 0, 0, 0);
+            } else {
+                const int q = (s - 16) / 5, r5 = (s - 16) % 5;
+                if (r5 == 0) {
+                    // ratio in the result layout; padded documents / columns carry zero counts and P = 0:
+                    // the clamp keeps 0 * rcp(0) from becoming NaN (real P are > 0)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                    {
+                        // max as integers: one v_max_i32 (a float max quiets its input first -- a second
+                        // instruction); the same result for every non-NaN P
+                        const int pi = __float_as_int(P[4 * q + i]), lo = __float_as_int(1.0e-30f);
+                        P[4 * q + i] = f[i] * __builtin_amdgcn_rcpf(__int_as_float(pi > lo ? pi : lo));
+                    }
+                } else {
+                    const int i = r5 - 1;
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+                        S[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[kt], P[4 * q + i], S[kt], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (__builtin_expect(cc.step(), 0)) {
+            // ---- this run's share of the block is complete
+            const lda_args_cptr gc = stream_cold_args<LdaStreamArgs>();
+            if (whole) {
+                // sstats = Bt * S: the factors Bt[4 row_r + kt][v] into the (now free) bt registers
+                const int64_t ldb = gc->ldb, ldo = gc->ldo;
+                const unsigned off = v_lane + (unsigned)(16 * h) * (unsigned)ldb * 4u;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float* base = gc->Bt + (int64_t)(4 * ((r & 3) + 8 * (r >> 2)) + kt) * ldb;
+                        asm volatile("global_load_dword %0, %1, %2" : "+v"(bt[16 * kt + r]) : "v"(off), "s"(base) : "memory");
+                    }
+                __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+                float* out = gc->out;
+                if (v_ok) {
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            asm volatile("" : "+v"(bt[16 * kt + r]));
+                            const int64_t k = KT * ((r & 3) + 8 * (r >> 2) + 4 * h) + kt;
+                            *reinterpret_cast<float*>(reinterpret_cast<char*>(out + k * ldo) + v_lane) = S[kt][r] * bt[16 * kt + r];
+                        }
+                }
+            } else {
+                float* slot = gc->slab + ((int64_t)2 * w + (cc.round > gc->rounds ? 1 : 0)) * (K * VT) + 32 * wave + j;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int k = KT * ((r & 3) + 8 * (r >> 2) + 4 * h) + kt;
+                        slot[k * VT] = S[kt][r];
+                    }
+            }
+            ++cc.round;
+            cc.segment(gc, w, tail_u0);
+            tile_start = true;
+        }
+        if (u + 1 < n_units) {
+            __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));      // own DMAs of the next step (and a finished block's stores)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (u + 2 < n_units) issue(BUF);
+        }
+    };
+
+    issue_tile();
+    issue(0);
+    __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (n_units > 1) issue(1);
+    for (int u = 0; u < n_units; u += 2) {
+        step_body(std::integral_constant<int, 0>{}, u);
+        if (u + 1 < n_units) step_body(std::integral_constant<int, 1>{}, u + 1);
+    }
+    __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+}
+
+// The column blocks that two or more runs share (see stream_fixup_kernel in csrc/bsc_gemm.hip):
+// sstats = Bt * (the pieces in document order).
+__global__ __launch_bounds__(64) void lda_stream_fixup_kernel(LdaStreamArgs g) {
+    const int w = (int)blockIdx.x + 1;
+    const int b0 = stream_first_unit(&g, w);
+    const int t = b0 / g.n_kt, t_begin = t * g.n_kt, t_end = t_begin + g.n_kt;        // tail block t
+    if (b0 == t_begin || stream_first_unit(&g, w - 1) > t_begin) return;
+    const int e = (blockIdx.y * 64 + threadIdx.x) * 4;           // element of the [128 k][128 v] block
+    lda_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int x = w - 1; x < g.n_wg; ++x) {
+        const int x0 = stream_first_unit(&g, x);
+        if (x0 >= t_end) break;
+        if (stream_first_unit(&g, x + 1) == x0) continue;
+        v += *reinterpret_cast<const lda_f32x4*>(g.slab + ((int64_t)2 * x + (x0 / g.n_kt != t ? 1 : 0)) * (128 * VT) + e);
+    }
+    const int k = e >> 7;
+    const int64_t col = (int64_t)(g.rounds * g.n_wg + t) * VT + (e & 127);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (col + q < g.V) g.out[k * g.ldo + col + q] = v[q] * g.Bt[k * g.ldb + col + q];
+}
+
 // ---- sparse counts (compressed sparse COLUMN): one pass over the nonzeros ----------
 //
 // Real bag-of-words data is ~1 % dense; the dense kernel above spends its MFMAs on
@@ -477,6 +806,33 @@ int bsc_lda_sstats(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int6
     a.fast = a.vec_c && a.vec_th && (32 * ldc + VT) * 4 < ((int64_t)1 << 31) &&
              (32 * ldth + K) * 4 < ((int64_t)1 << 31);
     const int64_t n_vt = (V + VT - 1) / VT;
+    if (K == 128 && ctx->lda_stream && docs > 0 && a.vec_c && a.vec_th && V % 4 == 0 &&
+        (31 * ldc + VT) * 4 < ((int64_t)1 << 31) && (31 * ldth + K) * 4 < ((int64_t)1 << 31) &&
+        (K * ldb + V) * 4 < ((int64_t)1 << 32) && V * 4 < ((int64_t)1 << 32) && n_vt < ((int64_t)1 << 24) &&
+        (docs + DT - 1) / DT < ((int64_t)1 << 22)) {
+        LdaStreamArgs g{};
+        g.C = C; g.Th = Th; g.Bt = Bt; g.out = sstats;
+        g.ldc = ldc; g.ldth = ldth; g.ldb = ldb; g.ldo = ldo; g.docs = docs; g.V = V;
+        const int n_kt = (int)((docs + DT - 1) / DT);
+        g.d_tail = (int)(docs - (int64_t)(n_kt - 1) * DT);
+        stream_plan(g, n_vt, n_kt, 2 * (int64_t)ctx->cu_count);
+        void* ws = nullptr;
+        int rc = bsc_workspace(ctx, (size_t)2 * g.n_wg * K * VT * sizeof(float), &ws);
+        if (rc != BSC_OK) return rc;
+        ctx->slab_rows = 0;
+        g.slab = (float*)ws;
+        {
+            bsc_prof_scope prof(ctx);
+            hipLaunchKernelGGL(lda_sstats_stream_kernel, dim3((unsigned)g.n_wg), dim3(LDA_BLOCK), 0, ctx->stream, g);
+        }
+        BSC_LAUNCH_CHECK();
+        if (stream_has_pieces(g)) {
+            hipLaunchKernelGGL(lda_stream_fixup_kernel, dim3((unsigned)(g.n_wg - 1), K * VT / 256), dim3(64), 0,
+                               ctx->stream, g);
+            BSC_LAUNCH_CHECK();
+        }
+        return BSC_OK;
+    }
     // Split the documents so that the grid fills whole rounds of the 2 x CU resident
     // workgroups (782 column tiles on 512 slots would leave a quarter of the chip idle).
     const int64_t slots = 2 * (int64_t)ctx->cu_count;
