@@ -594,6 +594,30 @@ __device__ __forceinline__ void stream_decode_tile(GP g, int t, int64_t& b, int6
 
 typedef stream_args_cptr<GemmArgs> gemm_args_cptr;
 
+// Fragments of one 8-deep k-group for the stream kernel.  A k-contiguous operand: one ds_read_b128
+// per 32-row block (rows block * 32 + fr).  An m- or n-contiguous operand: ONE ds_read_b64 per k
+// for BOTH blocks -- lane fr takes the two neighbours 2 fr, 2 fr + 1 of the wave's 64, i.e. block i
+// holds the rows 2 fr + i (half the LDS instructions of one ds_read_b32 per block and k; the
+// accumulator-to-matrix maps below follow: stream_row / stream_col).
+#define GEMM_LDS_B64(DST, ADDR, OFF) \
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+typedef float gemm_f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool MN_CONTIG>
+__device__ __forceinline__ void stream_read_fragments(float (&f)[2][4], unsigned addr) {
+    if (MN_CONTIG) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            gemm_f32x2 v;
+            GEMM_LDS_B64(v, addr, t * 512);
+            f[0][t] = v[0];
+            f[1][t] = v[1];
+        }
+    } else {
+        dma_read_fragments<false>(f, addr);
+    }
+}
+
 template <bool A_M_CONTIG, bool B_N_CONTIG>
 __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * DMA_STAGE];
@@ -683,9 +707,9 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
     unsigned fa[4], fb[4];
 #pragma unroll
     for (int G = 0; G < 4; ++G) {
-        fa[G] = lbase + (A_M_CONTIG ? (unsigned)((8 * G + 4 * fk) * 512 + (wm * 64 + fr) * 4)
+        fa[G] = lbase + (A_M_CONTIG ? (unsigned)((8 * G + 4 * fk) * 512 + (wm * 64 + 2 * fr) * 4)
                                     : (unsigned)(wm * 64 * 128) + dma_chunk_offset(fr, 2 * G + fk));
-        fb[G] = lbase + 16384 + (B_N_CONTIG ? (unsigned)((8 * G + 4 * fk) * 512 + (wn * 64 + fr) * 4)
+        fb[G] = lbase + 16384 + (B_N_CONTIG ? (unsigned)((8 * G + 4 * fk) * 512 + (wn * 64 + 2 * fr) * 4)
                                             : (unsigned)(wn * 64 * 128) + dma_chunk_offset(fr, 2 * G + fk));
     }
     float oa[2][2][4], ob[2][2][4];
@@ -704,25 +728,33 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
     cc.begin(stream_cold_args<GemmArgs>(), w, tail_u0, tail_cnt);
     bool tile_start = true, whole = false, fast = false;
     int64_t cb = 0, cm0 = 0, cn0 = 0;                     // the tile under `cc`
+    // Where the accumulators live in the wave's 64 x 64 sub-tile.  acc[i][j][r] is MFMA row
+    // rho = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31, of block (i, j); an m-contiguous A
+    // interleaves its two row blocks (row 2 rho + i), a k-contiguous one stacks them (32 i + rho);
+    // the same for B and the columns.  Either way a lane owns, per column, eight runs of four
+    // consecutive rows -- the 16-byte pieces of the stores, the slab and the epilogue factor:
+    //   piece p of column block j: rows lane_m + piece_m(p) .. + 3, from acc[piece_i(p, e)][j][piece_r(p, e)]
+    auto piece_m = [](int p) { return A_M_CONTIG ? 16 * (p >> 1) + 4 * (p & 1) : 32 * (p >> 2) + 8 * (p & 3); };
+    auto piece_i = [](int p, int e) { return A_M_CONTIG ? (e & 1) : (p >> 2); };
+    auto piece_r = [](int p, int e) { return A_M_CONTIG ? 4 * (p >> 1) + 2 * (p & 1) + (e >> 1) : 4 * (p & 3) + e; };
+    const int lane_m = (A_M_CONTIG ? 8 : 4) * (lane >> 5);
+    const int lane_n = (B_N_CONTIG ? 2 : 1) * (lane & 31);
+    constexpr int BLK_N = B_N_CONTIG ? 1 : 32;               // column offset of block j = 1
     // the epilogue factor's registers: one value chain from here on (the asm loads below update them
     // in place), so that no copy of a not-yet-arrived register is ever made where control flow joins
-    gemm_f32x4 ev[2][2][4];
+    gemm_f32x4 ev[2][8];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) ev[i][j][q4] = gemm_f32x4{1.f, 1.f, 1.f, 1.f};
-    // a lane's quad (i, j, r / 4) of the tile: rows m = wm 64 + i 32 + 8 (r / 4) + 4 (lane / 32) .. + 3 of
-    // column n = wn 64 + j 32 + lane % 32
+        for (int p8 = 0; p8 < 8; ++p8) ev[j][p8] = gemm_f32x4{1.f, 1.f, 1.f, 1.f};
 
     issue_tile();
     issue(0);
     __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    dma_read_fragments<A_M_CONTIG>(oa[0], fa[0]);
-    dma_read_fragments<B_N_CONTIG>(ob[0], fb[0]);
+    stream_read_fragments<A_M_CONTIG>(oa[0], fa[0]);
+    stream_read_fragments<B_N_CONTIG>(ob[0], fb[0]);
     if (n_units > 1) issue(1);
     unsigned tog = 0;
     // vector-memory operations younger than the DMAs the next wait is for: the stores of the tile
@@ -744,17 +776,15 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
                 // not track (it would drain the DMA ring at their use): they are older than the DMAs
                 // waited for in the tile's second k-tile (or than the vmcnt(0) before its stores)
                 const int se_n = (int)gc->se_n;
-                const unsigned e_lane = (unsigned)((wn * 64 + (lane & 31)) * se_n + wm * 64 + 4 * (lane >> 5)) * 4u;
+                const unsigned e_lane = (unsigned)((wn * 64 + lane_n) * se_n + wm * 64 + lane_m) * 4u;
                 const float* e_tile = E + cb * gc->se_b + cn0 * se_n + cm0;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const float* base = e_tile + (int64_t)(j * 32) * se_n;
+                    const float* base = e_tile + (int64_t)(j * BLK_N) * se_n;
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4)
-                            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
-                                         : "+v"(ev[i][j][q4]) : "v"(e_lane), "s"(base), "n"((i * 32 + 8 * q4) * 4) : "memory");
+                    for (int p8 = 0; p8 < 8; ++p8)
+                        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+                                     : "+v"(ev[j][p8]) : "v"(e_lane), "s"(base), "n"(piece_m(p8) * 4) : "memory");
                 }
                 young += 16;
             }
@@ -765,8 +795,8 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
             __builtin_amdgcn_s_waitcnt(BSC_LGKMCNT0);
             __builtin_amdgcn_sched_barrier(0);
             if (G < 3) {
-                dma_read_fragments<A_M_CONTIG>(oa[set ^ 1], fa[G + 1] ^ tog);
-                dma_read_fragments<B_N_CONTIG>(ob[set ^ 1], fb[G + 1] ^ tog);
+                stream_read_fragments<A_M_CONTIG>(oa[set ^ 1], fa[G + 1] ^ tog);
+                stream_read_fragments<B_N_CONTIG>(ob[set ^ 1], fb[G + 1] ^ tog);
             } else if (u + 1 < n_units) {
                 if (young == 0) __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
                 else if (young == 16) __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(16));
@@ -774,8 +804,8 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
                 young = 0;
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                dma_read_fragments<A_M_CONTIG>(oa[set ^ 1], fa[0] ^ tog ^ DMA_STAGE);
-                dma_read_fragments<B_N_CONTIG>(ob[set ^ 1], fb[0] ^ tog ^ DMA_STAGE);
+                stream_read_fragments<A_M_CONTIG>(oa[set ^ 1], fa[0] ^ tog ^ DMA_STAGE);
+                stream_read_fragments<B_N_CONTIG>(ob[set ^ 1], fb[0] ^ tog ^ DMA_STAGE);
                 if (u + 2 < n_units) issue(u & 1);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -793,54 +823,50 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
             else young = 0;
             if (!whole) {
                 float* slot = gc->slab + ((int64_t)2 * w + (cc.round > gc->rounds ? 1 : 0)) * (BM * BN);
-                float* p = slot + (wn * 64 + (lane & 31)) * BM + wm * 64 + 4 * (lane >> 5);
+                float* p = slot + (wn * 64 + lane_n) * BM + wm * 64 + lane_m;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int p8 = 0; p8 < 8; ++p8) {
+                        gemm_f32x4 v;
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            gemm_f32x4 v;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q4 + e];
-                            *reinterpret_cast<gemm_f32x4*>(p + j * 32 * BM + i * 32 + 8 * q4) = v;
-                        }
+                        for (int e = 0; e < 4; ++e) v[e] = acc[piece_i(p8, e)][j][piece_r(p8, e)];
+                        *reinterpret_cast<gemm_f32x4*>(p + j * BLK_N * BM + piece_m(p8)) = v;
+                    }
             } else if (fast) {
                 const int sc_n = (int)gc->sc_n, epi_pow = gc->epi_pow, dbg = gc->dbg;
                 const float epi_scale = gc->epi_scale;
                 const bool has_e = gc->E != nullptr;
                 float* c_tile = gc->C + cb * gc->sc_b + cn0 * sc_n + cm0;
-                const unsigned c_lane = (unsigned)((wn * 64 + (lane & 31)) * sc_n + wm * 64 + 4 * (lane >> 5)) * 4u;
+                const unsigned c_lane = (unsigned)((wn * 64 + lane_n) * sc_n + wm * 64 + lane_m) * 4u;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int p8 = 0; p8 < 8; ++p8) {
+                        gemm_f32x4 v;
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            gemm_f32x4 v;
+                        for (int e = 0; e < 4; ++e) v[e] = acc[piece_i(p8, e)][j][piece_r(p8, e)];
+                        if (epi_pow) {
+                            if (epi_pow < 0) {
+                                // v_rcp_f32 and one Newton step (3 instructions; the IEEE division
+                                // sequence is ~10, 640 per tile -- a fifth of a K = 128 tile's MFMA time)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q4 + e];
-                            if (epi_pow) {
-                                if (epi_pow < 0) {
-                                    // v_rcp_f32 and one Newton step (3 instructions; the IEEE division
-                                    // sequence is ~10, 640 per tile -- a fifth of a K = 128 tile's MFMA time)
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
-                                        const float x = v[e], r = __builtin_amdgcn_rcpf(x);
-                                        v[e] = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
-                                    }
+                                for (int e = 0; e < 4; ++e) {
+                                    const float x = v[e], r = __builtin_amdgcn_rcpf(x);
+                                    v[e] = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
                                 }
-                                if (has_e) {
-                                    // (a use the scheduler cannot lift above the vmcnt wait that makes
-                                    // the asm-loaded registers valid)
-                                    asm volatile("" : "+v"(ev[i][j][q4]));
-                                    v *= ev[i][j][q4];
-                                }
-                                v *= epi_scale;
                             }
-                            char* base = reinterpret_cast<char*>(c_tile + (int64_t)(j * 32) * sc_n + i * 32 + 8 * q4);
-                            if (!(dbg & 1)) *reinterpret_cast<gemm_f32x4*>(base + c_lane) = v;
+                            if (has_e) {
+                                // (a use the scheduler cannot lift above the vmcnt wait that makes
+                                // the asm-loaded registers valid)
+                                asm volatile("" : "+v"(ev[j][p8]));
+                                v *= ev[j][p8];
+                            }
+                            v *= epi_scale;
                         }
+                        char* base = reinterpret_cast<char*>(c_tile + (int64_t)(j * BLK_N) * sc_n + piece_m(p8));
+                        if (!(dbg & 1)) *reinterpret_cast<gemm_f32x4*>(base + c_lane) = v;
+                    }
             } else {
                 const int64_t M = gc->M, N = gc->N, sc_m = gc->sc_m, sc_n = gc->sc_n, se_m = gc->se_m, se_n = gc->se_n;
                 const int epi_pow = gc->epi_pow;
@@ -851,11 +877,12 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const int64_t col = cn0 + wn * 64 + j * 32 + (lane & 31);
+                        const int64_t col = cn0 + wn * 64 + (B_N_CONTIG ? 2 * (lane & 31) + j : 32 * j + (lane & 31));
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             if ((r & 3) == 0) asm volatile("" ::: "memory");      // four loads in flight, not sixty-four (registers)
-                            const int64_t row = cm0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            const int rho = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            const int64_t row = cm0 + wm * 64 + (A_M_CONTIG ? 2 * rho + i : 32 * i + rho);
                             if (row < M && col < N) {
                                 float v = acc[i][j][r];
                                 if (epi_pow) {

@@ -478,9 +478,9 @@ class Cfg4(Workload):
         return {"lambda_sum": float(self.model.lam.sum().item())}
 
     def roofline(self, avg_s):
-        return _mfma_roofline("lda_sstats_kernel", 4.0 * self.docs * self.V * self.K,
+        return _mfma_roofline("lda_sstats_stream_kernel", 4.0 * self.docs * self.V * self.K,
                               4.0 * self.docs * self.V, avg_s,
-                              pmc_traffic("lda_sstats_kernel", self.docs == 6250))
+                              pmc_traffic("lda_sstats_stream_kernel", self.docs == 6250))
 
     def cpu_baseline(self, budget_s):
         from oracle import cbuild

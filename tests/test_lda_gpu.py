@@ -171,3 +171,43 @@ def test_lda_driver_with_sparse_counts(ctx):
         b.step()
     ctx.sync()
     npt.assert_allclose(a.lam.cpu().numpy(), b.lam.cpu().numpy(), rtol=3e-5)
+
+
+@pytest.mark.parametrize("docs,V", [(700, 67840), (33, 66000), (1000, 132), (4100, 1028)])
+def test_fused_lda_statistics_persistent_kernel_rounds_and_split_blocks(ctx, docs, V):
+    """K = 128 through lda_sstats_stream_kernel where the 128-column blocks exceed the resident
+    workgroups (a whole round, then left-over blocks split along the documents and added by the
+    fix-up pass), with leading dimensions larger than the extents, a ragged last block and a short
+    last document step -- against the one-block-per-workgroup kernel (BSC_LDA_STREAM=0) on the same
+    operands and against the float64 oracle on a sample of columns."""
+    import os
+    from bayesic_amd.device import Context
+    os.environ["BSC_LDA_STREAM"] = "0"
+    try:
+        plain = Context(0)
+    finally:
+        del os.environ["BSC_LDA_STREAM"]
+    K = 128
+    g = torch.Generator(device=ctx.device).manual_seed(docs + V)
+    ldc, ldth, ldb, ldo = V + 8, K + 4, V + 4, V + 12
+    C = torch.poisson(torch.full((docs, ldc), 0.3, device=ctx.device), generator=g)
+    Th = torch.rand((docs, ldth), generator=g, device=ctx.device) + 0.05
+    Bt = torch.rand((K, ldb), generator=g, device=ctx.device) + 0.05
+    outs = []
+    for c in (ctx, plain):
+        out = torch.full((K, ldo), float("nan"), dtype=torch.float32, device=ctx.device)
+        c.call("bsc_lda_sstats", C, ldc, docs, V, K, Th, ldth, Bt, ldb, out, ldo)
+        c.sync()
+        outs.append(out.cpu().numpy())
+    assert np.isnan(outs[0][:, V:]).all()                         # padding columns untouched
+    # the same arithmetic in the same order per column, but the blocks are cut differently along the
+    # documents: equal to float32 summation error, not bitwise
+    npt.assert_allclose(outs[0][:, :V], outs[1][:, :V], rtol=2e-5, atol=1e-6)
+    cols = np.unique(np.concatenate([np.arange(0, min(V, 300)), np.arange(max(0, V - 300), V),
+                                     np.random.RandomState(1).randint(0, V, 400)]))
+    Cn, Thn, Btn = C.cpu().numpy()[:, cols], Th.cpu().numpy()[:, :K], Bt.cpu().numpy()[:, cols]
+    npt.assert_allclose(outs[0][:, cols], svi.lda_sstats(Cn, Thn, Btn), rtol=3e-5, atol=1e-6)
+    out2 = torch.full((K, ldo), float("nan"), dtype=torch.float32, device=ctx.device)
+    ctx.call("bsc_lda_sstats", C, ldc, docs, V, K, Th, ldth, Bt, ldb, out2, ldo)
+    ctx.sync()
+    npt.assert_array_equal(outs[0][:, :V], out2.cpu().numpy()[:, :V])      # run-to-run identical
