@@ -47,6 +47,7 @@ struct MapArgs {
     int nt_store;     // dense map: streaming stores
     int bcast;        // dense kernels: bit k = operand k is constant along the fast axis (one
                       // scalar load, splat) instead of a 16-byte load
+    int lanes_per_row;  // lane-dense reduce with n_out < 256: n_out / 4 lanes take one row, 64 / that rows per wave load (0: a wave per row)
     int64_t col_chunk;  // map_rows: columns per blockIdx.y (a multiple of 256); short-and-wide
                         // matrices (8 x 1M) are split along the columns as well as the rows
 };
@@ -451,6 +452,79 @@ __global__ __launch_bounds__(256) void map_reduce_lane_dense_f32_kernel(MapArgs 
     }
 }
 
+// ... with fewer than 256 outputs (a [10M x 64] matrix summed over its rows): a wave per row would
+// keep a quarter of its lanes (64 outputs) and move 256 B per load.  Here n_out / 4 lanes take one
+// row and a wave load covers 64 / that many CONSECUTIVE rows (1 KiB of a dense matrix); the
+// sub-rows of a wave and the waves of a block are added in a fixed order at the end.
+template <int N>
+__global__ __launch_bounds__(256) void map_reduce_lane_narrow_f32_kernel(MapArgs a) {
+    __shared__ double red[4][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int L = a.lanes_per_row, R = 64 / L;
+    const int sub = lane / L, o = 4 * (lane - sub * L);
+    const bool active = sub < R;
+    const int split = blockIdx.x;
+    const int64_t r1 = a.n_red;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const float id = a.combine == BSC_OP_MUL ? 1.f : 0.f;
+    if (active) {
+        constexpr int U = 4;
+        const int64_t step = (int64_t)4 * U * R;
+        for (int64_t rb = (int64_t)split * step; rb < r1; rb += (int64_t)a.splits * step) {
+            float4 u[N][U];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const float* base = static_cast<const float*>(a.in[k]) + o * a.keep_strides[k][0];
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int64_t row = rb + (int64_t)(4 * j + wave) * R + sub;
+                    const int64_t r = row < r1 ? row : r1 - 1;
+                    if ((a.bcast >> k) & 1) {
+                        const float sv = static_cast<const float*>(a.in[k])[r * a.red_strides[k][0]];
+                        u[k][j] = make_float4(sv, sv, sv, sv);
+                    } else {
+                        u[k][j] = load4_nt(base + r * a.red_strides[k][0]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                float4 v = make_float4(id, id, id, id);
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    const int op = a.pre_op[k];
+                    const double arg = a.pre_arg[k];
+                    const float x0 = apply_unary<float>(op, u[k][j].x, arg);
+                    const float x1 = apply_unary<float>(op, u[k][j].y, arg);
+                    const float x2 = apply_unary<float>(op, u[k][j].z, arg);
+                    const float x3 = apply_unary<float>(op, u[k][j].w, arg);
+                    if (a.combine == BSC_OP_MUL) { v.x *= x0; v.y *= x1; v.z *= x2; v.w *= x3; }
+                    else { v.x += x0; v.y += x1; v.z += x2; v.w += x3; }
+                }
+                if (rb + (int64_t)(4 * j + wave) * R + sub < r1) {
+                    acc[0] += (double)finish_value<float>(a, v.x);
+                    acc[1] += (double)finish_value<float>(a, v.y);
+                    acc[2] += (double)finish_value<float>(a, v.z);
+                    acc[3] += (double)finish_value<float>(a, v.w);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[wave][lane][c] = acc[c];
+    __syncthreads();
+    if (wave == 0 && lane < L) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            double tot = 0.0;
+            for (int w = 0; w < 4; ++w)
+                for (int s2 = 0; s2 < R; ++s2) tot += red[w][s2 * L + lane][c];
+            if (a.splits > 1) a.partial[(int64_t)split * a.n_out + 4 * lane + c] = tot;
+            else static_cast<float*>(a.out)[(4 * lane + c) * a.out_strides[0]] = (float)tot;
+        }
+    }
+}
+
 // Variant B: the fastest-varying operand axis is a KEPT one.  Lane <-> output, so a
 // wave reads 64 consecutive elements per reduce step; the four waves of a block
 // and `splits` blocks divide the reduce range.
@@ -825,13 +899,15 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
     // split the reduce range until about fused_waves_per_cu waves per CU are in flight
     // (a block is 4 waves: 4 (output, split) jobs in the wave kernels, one output group
     // in the lane kernels)
+    const bool narrow_lane = dense_lane && n_out <= 128;       // several rows per wave load
+    m.lanes_per_row = narrow_lane ? (int)(n_out / 4) : 0;
     const int64_t outs_per_block = lanes_over_outputs ? (dense_lane ? 256 : 64) : 4;
     const int64_t jobs = (n_out + outs_per_block - 1) / outs_per_block;
     int64_t splits = 1;
     const int64_t want_blocks = (int64_t)ctx->cu_count * ctx->fused_waves_per_cu / 4;
     if (jobs < want_blocks) {
         splits = lanes_over_outputs ? want_blocks / jobs : (want_blocks * 4) / n_out;
-        const int64_t max_splits = n_red / (lanes_over_outputs ? 64 : 4096);
+        const int64_t max_splits = n_red / (narrow_lane ? 16 * (64 / m.lanes_per_row) * 4 : lanes_over_outputs ? 64 : 4096);
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
         if (splits > 16384) splits = 16384;
@@ -846,7 +922,15 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
     }
     if (lanes_over_outputs) {
         const int64_t blocks = jobs * splits;
-        if (dense_lane) {
+        if (narrow_lane) {
+#define BSC_NARROW(NV)                                                                            \
+    case NV:                                                                                     \
+        hipLaunchKernelGGL(map_reduce_lane_narrow_f32_kernel<NV>, dim3((unsigned)blocks), dim3(256), \
+                           0, ctx->stream, m);                                                   \
+        break;
+            switch (n_in) { BSC_NARROW(1) BSC_NARROW(2) BSC_NARROW(3) }
+#undef BSC_NARROW
+        } else if (dense_lane) {
 #define BSC_LANE(NV)                                                                             \
     case NV:                                                                                     \
         hipLaunchKernelGGL(map_reduce_lane_dense_f32_kernel<NV>, dim3((unsigned)blocks), dim3(256), \

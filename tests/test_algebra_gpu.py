@@ -294,3 +294,26 @@ def test_gemm_operands_by_lds_dma_all_layouts(ctx, M, N, K, batch):
             ref = 0.5 * E.cpu().numpy().astype(np.float64) / outs[0]
             ok = np.abs(outs[0]) > 1e-2 * bound
             npt.assert_allclose(C.cpu().numpy()[ok], ref[ok], rtol=2e-5)
+
+
+@pytest.mark.parametrize("rows,cols", [(100003, 64), (5000, 4), (70001, 128), (999, 36), (33, 8), (400000, 16)])
+def test_sums_over_the_rows_of_a_narrow_matrix(dev, rows, cols):
+    """sum(A, 0), sum(A * B, 0) and sum(A * w[:, None], 0) with fewer than 256 columns: the reduce
+    kernel that packs several rows into one wave load (map_reduce_lane_narrow_f32_kernel), against
+    float64 numpy; run-to-run identical."""
+    rs = np.random.RandomState(rows + cols)
+    A_ = rs.standard_normal((rows, cols)).astype(np.float32)
+    B_ = rs.standard_normal((rows, cols)).astype(np.float32)
+    w_ = rs.standard_normal(rows).astype(np.float32)
+    A, Bv, w = var("A", 2), var("Bv", 2), var("w", 1)
+    A64, B64, w64 = A_.astype(np.float64), B_.astype(np.float64), w_.astype(np.float64)
+    scale = np.sqrt(rows)
+    for expr, inputs, want in [
+            (sum(A, 0), dict(A=A_), A64.sum(0)),
+            (sum(A * Bv, 0), dict(A=A_, Bv=B_), (A64 * B64).sum(0)),
+            (sum(A * dimshuffle(w, 0, "x"), 0), dict(A=A_, w=w_), (A64 * w64[:, None]).sum(0)),
+            (sum(exp(A * 0.1), 0), dict(A=A_), np.exp(A64 * 0.1).sum(0))]:
+        got = run(dev, expr, **inputs)
+        assert got.shape == (cols,)
+        npt.assert_allclose(got, want, rtol=2e-5, atol=2e-5 * scale)
+        npt.assert_array_equal(got, run(dev, expr, **inputs))
