@@ -618,7 +618,11 @@ __device__ __forceinline__ void stream_read_fragments(float (&f)[2][4], unsigned
     }
 }
 
-template <bool A_M_CONTIG, bool B_N_CONTIG>
+// EDGE: the instantiation for products most of whose tiles are partial (an extent below 128, or a
+// contraction shorter than a k-tile): MFMA blocks that lie wholly outside the matrix and 8-deep
+// k-groups past the end of K are skipped (uniform branches in the k-loop, which the instantiation
+// for large matrices does without -- its few edge tiles multiply their zero padding).
+template <bool A_M_CONTIG, bool B_N_CONTIG, bool EDGE>
 __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * DMA_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -723,11 +727,27 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[set][i][t], ob[set][j][t], acc[i][j], 0, 0, 0);
     };
 
+    // (a tile at the edge of the matrix, or a matrix with an extent below 128: the blocks that lie wholly
+    // outside -- zero operands -- are skipped; C[10M x 64] = X[10M x 16] T[16 x 64] is half outside)
+    auto mfmas_masked = [&](int set, int mask) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (mask & (1 << (2 * i + j))) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[set][i][t], ob[set][j][t], acc[i][j], 0, 0, 0);
+                }
+    };
+
     // ---- the computing side
     StreamCursor cc;
     cc.begin(stream_cold_args<GemmArgs>(), w, tail_u0, tail_cnt);
-    bool tile_start = true, whole = false, fast = false;
+    bool tile_start = true, whole = false, fast = false, interior = false;
     int64_t cb = 0, cm0 = 0, cn0 = 0;                     // the tile under `cc`
+    int m_left = 0, n_left = 0;                           // rows / columns of this wave's 64 x 64 sub-tile inside the matrix
+    int blk_mask = 15;                                    // bit 2 i + j: MFMA block (i, j) of the sub-tile holds anything
     // Where the accumulators live in the wave's 64 x 64 sub-tile.  acc[i][j][r] is MFMA row
     // rho = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31, of block (i, j); an m-contiguous A
     // interleaves its two row blocks (row 2 rho + i), a k-contiguous one stacks them (32 i + rho);
@@ -770,7 +790,22 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
             const float* E = gc->E;
             const bool c_vec = gc->sc_m == 1 && gc->sc_n % 4 == 0 && gc->sc_b % 4 == 0 && (((uintptr_t)gc->C) & 15) == 0 && gc->M % 4 == 0;
             const bool e_vec = !E || (gc->se_m == 1 && gc->se_n % 4 == 0 && gc->se_b % 4 == 0 && (((uintptr_t)E) & 15) == 0);
-            fast = whole && c_vec && e_vec && cm0 + BM <= gc->M && cn0 + BN <= gc->N;
+            interior = cm0 + BM <= gc->M && cn0 + BN <= gc->N;
+            // 16-byte pieces straight from the accumulators: whole tiles; at the edge of the matrix each
+            // piece behind its own in-range test (M % 4 = 0: a piece is wholly inside or outside) -- but
+            // the epilogue factor is prefetched for interior tiles only
+            fast = whole && c_vec && e_vec && (interior || !(gc->epi_pow != 0 && E));
+            {
+                const int64_t ml = gc->M - cm0 - wm * 64, nl = gc->N - cn0 - wn * 64;
+                m_left = (int)(ml < 0 ? 0 : ml > 64 ? 64 : ml);
+                n_left = (int)(nl < 0 ? 0 : nl > 64 ? 64 : nl);
+                blk_mask = 0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if ((A_M_CONTIG ? i : 32 * i) < m_left && (B_N_CONTIG ? j : 32 * j) < n_left) blk_mask |= 1 << (2 * i + j);
+            }
             if (fast && gc->epi_pow != 0 && E) {
                 // the epilogue factor of this tile, 16 x 16 bytes per lane, by loads the compiler does
                 // not track (it would drain the DMA ring at their use): they are older than the DMAs
@@ -789,6 +824,8 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
                 young += 16;
             }
         }
+        // the 8-deep groups of this k-tile that hold anything (a tile's last k-tile may be short)
+        const int k_groups = cc.kt == last_kt ? (k_tail + 7) >> 3 : 4;
 #pragma unroll
         for (int G = 0; G < 4; ++G) {
             const int set = G & 1;
@@ -809,7 +846,8 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
                 if (u + 2 < n_units) issue(u & 1);
             }
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(set);
+            if (!EDGE) mfmas(set);
+            else if (G < k_groups) mfmas_masked(set, blk_mask);
             __builtin_amdgcn_sched_barrier(0);
         }
         tog ^= DMA_STAGE;
@@ -819,7 +857,7 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
             // the epilogue factor is older than the DMAs waited for in this tile's second k-tile; a tile
             // one k-tile long, or the run's last, waits here
             if (gc->n_kt == 1 || u + 1 == n_units) __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
-            if (!whole || fast) young += 16;          // 16 stores per lane below (the guarded path: unknown, wait for all)
+            if (!whole || (fast && interior)) young += 16;    // 16 stores per lane below (edge tiles: fewer, wait for all)
             else young = 0;
             if (!whole) {
                 float* slot = gc->slab + ((int64_t)2 * w + (cc.round > gc->rounds ? 1 : 0)) * (BM * BN);
@@ -865,7 +903,8 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
                             v *= epi_scale;
                         }
                         char* base = reinterpret_cast<char*>(c_tile + (int64_t)(j * BLK_N) * sc_n + piece_m(p8));
-                        if (!(dbg & 1)) *reinterpret_cast<gemm_f32x4*>(base + c_lane) = v;
+                        if (!(dbg & 1) && (interior || (lane_m + piece_m(p8) < m_left && lane_n + j * BLK_N < n_left)))
+                            *reinterpret_cast<gemm_f32x4*>(base + c_lane) = v;
                     }
             } else {
                 const int64_t M = gc->M, N = gc->N, sc_m = gc->sc_m, sc_n = gc->sc_n, se_m = gc->se_m, se_n = gc->se_n;
@@ -1289,8 +1328,17 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
             ctx->slab_rows = 0;
             {
                 bsc_prof_scope prof(ctx);
-#define BSC_GEMM_STREAM(AM, BN_) \
-    hipLaunchKernelGGL((gemm_f32_stream_kernel<AM, BN_>), dim3((unsigned)s.n_wg), dim3(GEMM_BLOCK), 0, ctx->stream, s)
+                // mostly partial tiles?
+                const bool edge = (s.tiles_m == 1 && s.M <= 96) || (s.tiles_n == 1 && s.N <= 96) || K <= 24;
+#define BSC_GEMM_STREAM(AM, BN_)                                                                                          \
+    do {                                                                                                                  \
+        if (edge)                                                                                                         \
+            hipLaunchKernelGGL((gemm_f32_stream_kernel<AM, BN_, true>), dim3((unsigned)s.n_wg), dim3(GEMM_BLOCK), 0,      \
+                               ctx->stream, s);                                                                           \
+        else                                                                                                              \
+            hipLaunchKernelGGL((gemm_f32_stream_kernel<AM, BN_, false>), dim3((unsigned)s.n_wg), dim3(GEMM_BLOCK), 0,     \
+                               ctx->stream, s);                                                                           \
+    } while (0)
                 if (a_m && b_n) BSC_GEMM_STREAM(true, true);
                 else if (a_m) BSC_GEMM_STREAM(true, false);
                 else if (b_n) BSC_GEMM_STREAM(false, true);
