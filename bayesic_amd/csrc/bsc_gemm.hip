@@ -952,36 +952,46 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
 // lies strictly inside tile t; the FIRST such boundary of a tile adds the tile's pieces in k
 // order -- workgroups w-1, w, w+1, ... up to the tile's end -- applies the epilogue and stores.
 // Slab slots are [n][m] like the accumulators: 16 bytes per lane along m.
-__global__ __launch_bounds__(64) void stream_fixup_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256) void stream_fixup_kernel(GemmArgs g) {
+    __shared__ gemm_f32x4 part[3][64];
     const int w = (int)blockIdx.x + 1;
     const int b0 = stream_first_unit(&g, w);
     const int t = b0 / g.n_kt, t_begin = t * g.n_kt, t_end = t_begin + g.n_kt;        // tail tile t
     if (b0 == t_begin || stream_first_unit(&g, w - 1) > t_begin) return;
-    const int e = (blockIdx.y * 64 + threadIdx.x) * 4;           // element of the [128 n][128 m] tile
+    const int quad = threadIdx.x & 63, lane4 = threadIdx.x >> 6;    // 64 element quads x 4 interleaved piece lists
+    const int e = (blockIdx.y * 64 + quad) * 4;                   // element of the [128 n][128 m] tile
     const int n = e >> 7, m = e & 127;
-    gemm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    // the pieces in k order, four loads in flight
-    const float* piece[4];
-    int n_piece = 0;
-    for (int x = w - 1; x < g.n_wg; ++x) {
-        const int x0 = stream_first_unit(&g, x);
-        if (x0 >= t_end) break;
-        if (stream_first_unit(&g, x + 1) == x0) continue;             // a workgroup without tail units
-        piece[n_piece++] = g.slab + ((int64_t)2 * x + (x0 / g.n_kt != t ? 1 : 0)) * (BM * BN) + e;
-        if (n_piece == 4) {
-            gemm_f32x4 p[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) p[i] = *reinterpret_cast<const gemm_f32x4*>(piece[i]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v += p[i];
-            n_piece = 0;
-        }
-    }
-    for (int i = 0; i < n_piece; ++i) v += *reinterpret_cast<const gemm_f32x4*>(piece[i]);
     int64_t b, m0, n0;
     stream_decode_tile(&g, g.rounds * g.n_wg + t, b, m0, n0);
     const int64_t col = n0 + n;
-    if (col >= g.N) return;
+    const bool inside = col < g.N && m0 + m < g.M;              // (elements outside the matrix are not even read)
+    gemm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (inside) {
+        // the pieces in k order: list position p goes to lane p % 4, four loads in flight per lane;
+        // the four lanes' sums are added in lane order below -- a fixed association, run to run
+        const float* piece[4];
+        int n_piece = 0, pos = 0;
+        for (int x = w - 1; x < g.n_wg; ++x) {
+            const int x0 = stream_first_unit(&g, x);
+            if (x0 >= t_end) break;
+            if (stream_first_unit(&g, x + 1) == x0) continue;             // a workgroup without tail units
+            if ((pos++ & 3) != lane4) continue;
+            piece[n_piece++] = g.slab + ((int64_t)2 * x + (x0 / g.n_kt != t ? 1 : 0)) * (BM * BN) + e;
+            if (n_piece == 4) {
+                gemm_f32x4 p[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) p[i] = *reinterpret_cast<const gemm_f32x4*>(piece[i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v += p[i];
+                n_piece = 0;
+            }
+        }
+        for (int i = 0; i < n_piece; ++i) v += *reinterpret_cast<const gemm_f32x4*>(piece[i]);
+    }
+    if (lane4 > 0) part[lane4 - 1][quad] = v;
+    __syncthreads();
+    if (lane4 > 0 || !inside) return;
+    v = ((v + part[0][quad]) + part[1][quad]) + part[2][quad];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int64_t row = m0 + m + q;
@@ -1347,7 +1357,7 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
             }
             BSC_LAUNCH_CHECK();
             if (stream_has_pieces(s)) {
-                hipLaunchKernelGGL(stream_fixup_kernel, dim3((unsigned)(s.n_wg - 1), BM * BN / 256), dim3(64), 0,
+                hipLaunchKernelGGL(stream_fixup_kernel, dim3((unsigned)(s.n_wg - 1), BM * BN / 256), dim3(256), 0,
                                    ctx->stream, s);
                 BSC_LAUNCH_CHECK();
             }
