@@ -83,6 +83,10 @@ SIGNATURES = {
                                        c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
     "bsc_bbvi_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                               c_double, c_double, c_double, c_void_p, c_void_p, c_void_p]),
+    "bsc_bbvi_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                c_double, c_double, c_double, c_void_p, c_void_p, c_int64, c_double,
+                                c_double, c_double, c_double, c_uint64, c_uint32, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p]),
     "bsc_elemwise": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int64), c_void_p,
                              POINTER(c_int64), c_int, POINTER(c_void_p), POINTER(c_int64)]),
     "bsc_convert": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int64), c_void_p,

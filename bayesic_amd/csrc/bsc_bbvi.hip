@@ -834,43 +834,76 @@ __device__ __forceinline__ double score_component(const double* __restrict__ eps
     return i < P ? e * inv_sd : e * e - 1.0;
 }
 
+// A workgroup owns 16 parameters (both score components of each) for all S samples, thread
+// (parameter tid % 16, sample group tid / 16) holds its (at most four) draws in registers: means
+// first, then the centred sums, each added over the 16 groups in a fixed order.  (One thread per
+// component walking all S samples twice -- ten workgroups, 128 dependent loads each -- took 12 us.)
+constexpr int BM_PARAMS = 16;
+
 __global__ __launch_bounds__(BB_BLOCK) void bbvi_moments_kernel(
     const double* __restrict__ lam, const double* __restrict__ eps, const double* __restrict__ f,
     int P, int S, double* __restrict__ cov_part, double* __restrict__ var_part) {
     __shared__ double fs[BB_MAX_S];
-    __shared__ double red[BB_WAVES][2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ double part[BM_PARAMS][16][4];
+    __shared__ double mean[BM_PARAMS][4];
+    __shared__ double cv[BM_PARAMS][2];
+    const int tid = threadIdx.x, pp = tid & 15, sg = tid >> 4;
     if (tid < S) fs[tid] = f[tid];
     __syncthreads();
-    const int i = blockIdx.x * BB_BLOCK + tid;
-    double cov = 0.0, var = 0.0;
-    if (i < 2 * P) {
-        const int p = i < P ? i : i - P;
-        const double inv_sd = exp(-lam[P + p]);
-        double mh = 0.0, mfh = 0.0;
-        for (int s = 0; s < S; ++s) {
-            const double h = score_component(eps, s, P, i, p, inv_sd);
-            mh += h;
-            mfh += fs[s] * h;
-        }
-        mh /= S;
-        mfh /= S;
-        double c = 0.0, v = 0.0;
-        for (int s = 0; s < S; ++s) {
-            const double h = score_component(eps, s, P, i, p, inv_sd);
-            c += (fs[s] * h - mfh) * (h - mh);
-            v += (h - mh) * (h - mh);
-        }
-        cov = c / (S - 1);
-        var = v / (S - 1);
+    const int p = blockIdx.x * BM_PARAMS + pp;
+    double h0[4], h1[4], fv[4];
+    bool on[4];
+    const double inv_sd = p < P ? exp(-lam[P + p]) : 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                    // S <= 64: at most four draws per thread
+        const int s = sg + 16 * k;
+        on[k] = p < P && s < S;
+        const double e = on[k] ? eps[(int64_t)s * P + p] : 0.0;
+        h0[k] = e * inv_sd;
+        h1[k] = e * e - 1.0;
+        fv[k] = on[k] ? fs[s] : 0.0;
     }
-    cov = wave_allsum_f64(cov);
-    var = wave_allsum_f64(var);
-    if (lane == 0) { red[wave][0] = cov; red[wave][1] = var; }
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (on[k]) { a0 += h0[k]; a1 += fv[k] * h0[k]; a2 += h1[k]; a3 += fv[k] * h1[k]; }
+    part[pp][sg][0] = a0; part[pp][sg][1] = a1; part[pp][sg][2] = a2; part[pp][sg][3] = a3;
+    __syncthreads();
+    if (tid < 4 * BM_PARAMS) {                       // (parameter tid / 4, quantity tid % 4): over the groups, in order
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += part[tid >> 2][k][tid & 3];
+        mean[tid >> 2][tid & 3] = t / S;
+    }
+    __syncthreads();
+    const double mh0 = mean[pp][0], mfh0 = mean[pp][1], mh1 = mean[pp][2], mfh1 = mean[pp][3];
+    double c0 = 0.0, v0 = 0.0, c1 = 0.0, v1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (on[k]) {
+            c0 += (fv[k] * h0[k] - mfh0) * (h0[k] - mh0);
+            v0 += (h0[k] - mh0) * (h0[k] - mh0);
+            c1 += (fv[k] * h1[k] - mfh1) * (h1[k] - mh1);
+            v1 += (h1[k] - mh1) * (h1[k] - mh1);
+        }
+    __syncthreads();                                 // `part` is reused
+    part[pp][sg][0] = c0; part[pp][sg][1] = v0; part[pp][sg][2] = c1; part[pp][sg][3] = v1;
+    __syncthreads();
+    if (tid < BM_PARAMS) {                           // one parameter: cov and var of both its components
+        double c = 0.0, v = 0.0;
+        for (int q = 0; q < 2; ++q) {
+            double cq = 0.0, vq = 0.0;
+            for (int k = 0; k < 16; ++k) { cq += part[tid][k][2 * q]; vq += part[tid][k][2 * q + 1]; }
+            c += cq / (S - 1);
+            v += vq / (S - 1);
+        }
+        const bool live = blockIdx.x * BM_PARAMS + tid < P;
+        cv[tid][0] = live ? c : 0.0;
+        cv[tid][1] = live ? v : 0.0;
+    }
     __syncthreads();
     if (tid == 0) {
         double c = 0.0, v = 0.0;
-        for (int k = 0; k < BB_WAVES; ++k) { c += red[k][0]; v += red[k][1]; }
+        for (int k = 0; k < BM_PARAMS; ++k) { c += cv[k][0]; v += cv[k][1]; }
         cov_part[blockIdx.x] = c;
         var_part[blockIdx.x] = v;
     }
@@ -884,9 +917,16 @@ __global__ __launch_bounds__(BB_BLOCK) void bbvi_finish_kernel(
     const int tid = threadIdx.x;
     if (tid < S) fs[tid] = f[tid];
     __syncthreads();
-    double c = 0.0, v = 0.0;                       // every thread: the same fixed-order sums
-    for (int k = 0; k < n_parts; ++k) { c += cov_part[k]; v += var_part[k]; }
-    const double a = c / v;
+    __shared__ double a_sh;                        // as in bbvi_update_kernel
+    if (tid < 64) {
+        double c = 0.0, v = 0.0;
+        for (int k = tid; k < n_parts; k += 64) { c += cov_part[k]; v += var_part[k]; }
+        c = wave_allsum_f64(c);
+        v = wave_allsum_f64(v);
+        if (tid == 0) a_sh = c / v;
+    }
+    __syncthreads();
+    const double a = a_sh;
     if (blockIdx.x == 0 && tid == 0) {
         double fm = 0.0;
         for (int s = 0; s < S; ++s) fm += fs[s];
@@ -900,6 +940,107 @@ __global__ __launch_bounds__(BB_BLOCK) void bbvi_finish_kernel(
     for (int s = 0; s < S; ++s) gsum += (fs[s] - a) * score_component(eps, s, P, i, p, inv_sd);
     grad[i] = gsum / S;
 }
+
+// finish + Adam + the NEXT update's draws in one launch (bsc_bbvi_update): a workgroup owns 16
+// parameters (mu_p, rho_p) for all S samples.
+//   1. thread (parameter pp = tid % 16, sample group sg = tid / 16): its share of
+//      sum_s (f_s - a) h_s for both score components, added over the 16 groups in a fixed order;
+//   2. the 16 threads with sg = 0: gradient, Adam (the arithmetic of adam_ascent_kernel, contraction
+//      off), the new (mu, rho) to LDS;
+//   3. thread (parameter quad tid / 64, sample tid % 64): the Philox draw of bbvi_sample_kernel for the
+//      next step, written over eps (this workgroup's 16 columns, which only it has read) and into
+//      Wz / Bz / zeta.
+// Before: finish, Adam and the sampler were three launches of ~5 us each on a 300 us update.
+constexpr int BU_PARAMS = 16;
+
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(BB_BLOCK) void bbvi_update_kernel(
+    double* __restrict__ lam, double* __restrict__ eps, const double* __restrict__ f, int D, int G, int S,
+    const double* __restrict__ cov_part, const double* __restrict__ var_part, int n_parts,
+    double* __restrict__ m1, double* __restrict__ m2, double lr, double beta1, double beta2, double eps_adam,
+    double corr1, double corr2, uint64_t seed, uint32_t next_step, float* __restrict__ Wz,
+    float* __restrict__ Bz, double* __restrict__ zeta, double* __restrict__ elbo, double* __restrict__ grad) {
+    __shared__ double fs[BB_MAX_S];
+    __shared__ double part[BU_PARAMS][BU_PARAMS][2];
+    __shared__ double fresh[BU_PARAMS][2];
+    const int P = D + G + 1;
+    const int tid = threadIdx.x, pp = tid & 15, sg = tid >> 4;
+    const int p = blockIdx.x * BU_PARAMS + pp;
+    if (tid < S) fs[tid] = f[tid];
+    __syncthreads();
+    // a = sum cov / sum var over the moment kernel's workgroups: lane l of the first wave adds parts
+    // l, l + 64, ..., the wave adds its lanes in a fixed tree -- the same value in every workgroup
+    __shared__ double a_sh;
+    if (tid < 64) {
+        double c = 0.0, v = 0.0;
+        for (int k = tid; k < n_parts; k += 64) { c += cov_part[k]; v += var_part[k]; }
+        c = wave_allsum_f64(c);
+        v = wave_allsum_f64(v);
+        if (tid == 0) a_sh = c / v;
+    }
+    __syncthreads();
+    const double a = a_sh;
+    if (blockIdx.x == 0 && tid == 0) {
+        double fm = 0.0;
+        for (int s = 0; s < S; ++s) fm += fs[s];
+        elbo[0] = fm / S;
+    }
+    double gm = 0.0, gr = 0.0;
+    if (p < P) {
+        const double inv_sd = exp(-lam[P + p]);
+        for (int s = sg; s < S; s += 16) {
+            const double e = eps[(int64_t)s * P + p], wgt = fs[s] - a;
+            gm += wgt * (e * inv_sd);
+            gr += wgt * (e * e - 1.0);
+        }
+    }
+    part[pp][sg][0] = gm;
+    part[pp][sg][1] = gr;
+    __syncthreads();
+    if (sg == 0 && p < P) {
+        double g2[2] = {0.0, 0.0};
+        for (int k = 0; k < 16; ++k) { g2[0] += part[pp][k][0]; g2[1] += part[pp][k][1]; }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t i = (int64_t)h * P + p;
+            const double gi = g2[h] / S;
+            grad[i] = gi;
+            const double am = beta1 * m1[i] + (1.0 - beta1) * gi;
+            const double bm = beta2 * m2[i] + (1.0 - beta2) * gi * gi;
+            m1[i] = am;
+            m2[i] = bm;
+            const double mhat = am / corr1;
+            const double vhat = bm / corr2;
+            const double nv = lam[i] + lr * mhat / (sqrt(vhat) + eps_adam);
+            lam[i] = nv;
+            fresh[pp][h] = nv;
+        }
+    }
+    __syncthreads();
+    // ---- the next step's draws for this workgroup's four parameter quads
+    const int s = tid & 63, quad = blockIdx.x * (BU_PARAMS / 4) + (tid >> 6);
+    if (s >= S || 4 * quad >= P) return;
+    uint32_t cnt[4] = {(uint32_t)quad, (uint32_t)s, 2u, next_step};
+    philox4(cnt, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const double two_m32 = 2.3283064365386963e-10, two_pi = 6.283185307179586476925286766559;
+    const double u0 = ((double)cnt[0] + 0.5) * two_m32, u1 = ((double)cnt[1] + 0.5) * two_m32;
+    const double u2 = ((double)cnt[2] + 0.5) * two_m32, u3 = ((double)cnt[3] + 0.5) * two_m32;
+    const double r0 = sqrt(-2.0 * log(u0)), r1 = sqrt(-2.0 * log(u2));
+    const double t0 = two_pi * u1, t1 = two_pi * u3;
+    const double z4[4] = {r0 * cos(t0), r0 * sin(t0), r1 * cos(t1), r1 * sin(t1)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = 4 * quad + j;
+        if (i >= P) break;
+        eps[(int64_t)s * P + i] = z4[j];
+        const int lp = 4 * (tid >> 6) + j;
+        const double z = fresh[lp][0] + exp(fresh[lp][1]) * z4[j];
+        if (i < D) Wz[(int64_t)s * D + i] = (float)z;
+        else if (i < D + G) Bz[(int64_t)(i - D) * S + s] = (float)z;
+        else zeta[s] = z;
+    }
+}
+#pragma clang fp contract(fast)
 
 }  // namespace
 
@@ -1035,7 +1176,7 @@ int bsc_bbvi_grad(bsc_ctx* ctx, const double* lam, const double* eps, const doub
     BSC_REQUIRE(a0 > 0 && b0 > 0, "bsc_bbvi_grad: a0, b0 must be positive");
     const double log_prior_const = a0 * log(b0) - lgamma(a0);
     const int P = D + G + 1;
-    const int n_parts = (2 * P + BB_BLOCK - 1) / BB_BLOCK;
+    const int n_parts = (P + BM_PARAMS - 1) / BM_PARAMS;
     void* ws = nullptr;
     int rc = bsc_workspace(ctx, (size_t)(BB_MAX_S + 2 * n_parts) * sizeof(double), &ws);
     if (rc != BSC_OK) return rc;
@@ -1049,8 +1190,42 @@ int bsc_bbvi_grad(bsc_ctx* ctx, const double* lam, const double* eps, const doub
     hipLaunchKernelGGL(bbvi_moments_kernel, dim3((unsigned)n_parts), dim3(BB_BLOCK), 0, ctx->stream,
                        lam, eps, f, P, (int)S, cov_part, var_part);
     BSC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bbvi_finish_kernel, dim3((unsigned)n_parts), dim3(BB_BLOCK), 0, ctx->stream,
+    hipLaunchKernelGGL(bbvi_finish_kernel, dim3((unsigned)((2 * P + BB_BLOCK - 1) / BB_BLOCK)), dim3(BB_BLOCK), 0, ctx->stream,
                        lam, eps, f, P, (int)S, cov_part, var_part, n_parts, elbo, grad);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_bbvi_update(bsc_ctx* ctx, double* lam, double* eps, const double* ell, int32_t D, int32_t G, int32_t S,
+                    double scale, double a0, double b0, double* m1, double* m2, int64_t t, double lr,
+                    double beta1, double beta2, double eps_adam, uint64_t seed, uint32_t next_step, float* Wz,
+                    float* Bz, double* zeta, double* elbo, double* grad, double* f_out) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(lam && eps && ell && m1 && m2 && Wz && Bz && zeta && elbo && grad, "bsc_bbvi_update: null pointer");
+    BSC_REQUIRE(D >= 1 && G >= 1 && S >= 2 && S <= BB_MAX_S, "bsc_bbvi_update: D=%d G=%d S=%d (2..%d)", D, G, S,
+                BB_MAX_S);
+    BSC_REQUIRE(a0 > 0 && b0 > 0 && t >= 1, "bsc_bbvi_update: a0, b0 must be positive and t >= 1");
+    const double log_prior_const = a0 * log(b0) - lgamma(a0);
+    const int P = D + G + 1;
+    const int n_parts = (P + BM_PARAMS - 1) / BM_PARAMS;
+    void* ws = nullptr;
+    int rc = bsc_workspace(ctx, (size_t)(BB_MAX_S + 2 * n_parts) * sizeof(double), &ws);
+    if (rc != BSC_OK) return rc;
+    ctx->slab_rows = 0;
+    double* f = (double*)ws;
+    double* cov_part = f + BB_MAX_S;
+    double* var_part = cov_part + n_parts;
+    hipLaunchKernelGGL(bbvi_f_kernel, dim3((unsigned)S), dim3(BB_BLOCK), 0, ctx->stream, (const double*)lam,
+                       (const double*)eps, ell, (int)D, (int)G, scale, a0, b0, log_prior_const, f, f_out);
+    BSC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bbvi_moments_kernel, dim3((unsigned)n_parts), dim3(BB_BLOCK), 0, ctx->stream,
+                       (const double*)lam, (const double*)eps, (const double*)f, P, (int)S, cov_part, var_part);
+    BSC_LAUNCH_CHECK();
+    const double corr1 = 1.0 - pow(beta1, (double)t), corr2 = 1.0 - pow(beta2, (double)t);
+    hipLaunchKernelGGL(bbvi_update_kernel, dim3((unsigned)((P + BU_PARAMS - 1) / BU_PARAMS)), dim3(BB_BLOCK), 0,
+                       ctx->stream, lam, eps, (const double*)f, (int)D, (int)G, (int)S, (const double*)cov_part,
+                       (const double*)var_part, n_parts, m1, m2, lr, beta1, beta2, eps_adam, corr1, corr2, seed,
+                       next_step, Wz, Bz, zeta, elbo, grad);
     BSC_LAUNCH_CHECK();
     return BSC_OK;
 }

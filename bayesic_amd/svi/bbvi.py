@@ -53,17 +53,29 @@ class LogRegBBVI:
         self.f = torch.zeros(S, dtype=f64, device=dev)
         self.elbo = torch.zeros(1, dtype=f64, device=dev)
         self.t = 0
+        self._drawn = False
         self.ctx.reserve((2 * self.ctx.info()["cu_count"] + 8) * 64 * 4)
 
     def step(self):
+        """One update.  The draws of update t are made at the end of update t - 1 (inside
+        ``bsc_bbvi_update``, from the parameters that update has just written), so between two
+        updates ``self.eps`` / ``Wz`` / ``Bz`` hold the NEXT update's noise; assigning to
+        ``self.lam`` from outside must be followed by ``invalidate_draws()``."""
         self.t += 1
         c = self.ctx
-        c.call("bsc_bbvi_sample", self.lam, self.D, self.G, self.S, self.seed, self.t - 1,
-               self.eps, self.Wz, self.Bz, self.zeta)
+        if not self._drawn:
+            c.call("bsc_bbvi_sample", self.lam, self.D, self.G, self.S, self.seed, self.t - 1,
+                   self.eps, self.Wz, self.Bz, self.zeta)
         c.call("bsc_logreg_bbvi_loglik", self.X, self.X.stride(0), self.y, self.g, self.B, self.D,
                self.G, self.Wz, self.Bz, self.S, self.ell)
         self.exchange.all_reduce(self.ell)
-        c.call("bsc_bbvi_grad", self.lam, self.eps, self.ell, self.D, self.G, self.S,
-               self.n_total / self.batch_rows, self.a0, self.b0, self.elbo, self.grad, self.f)
-        c.call("bsc_adam_ascent", self.lam, self.grad, self.m1, self.m2, self.lam.numel(), self.t,
-               self.lr, 0.9, 0.999, 1e-8)
+        # f, control variate, gradient, Adam and the next update's draws: three launches
+        c.call("bsc_bbvi_update", self.lam, self.eps, self.ell, self.D, self.G, self.S,
+               self.n_total / self.batch_rows, self.a0, self.b0, self.m1, self.m2, self.t, self.lr,
+               0.9, 0.999, 1e-8, self.seed, self.t, self.Wz, self.Bz, self.zeta, self.elbo, self.grad,
+               self.f)
+        self._drawn = True
+
+    def invalidate_draws(self):
+        """Call after changing ``lam`` (or ``seed`` / ``t``) by hand: the next update redraws."""
+        self._drawn = False

@@ -323,6 +323,16 @@ int bsc_logreg_bbvi_loglik(bsc_ctx* ctx, const float* X, int64_t ldx, const floa
 int bsc_bbvi_grad(bsc_ctx* ctx, const double* lam, const double* eps, const double* ell, int32_t D,
                   int32_t G, int32_t S, double scale, double a0, double b0, double* elbo,
                   double* grad, double* f_out);
+/* bsc_bbvi_update: everything after the pass in three launches -- bsc_bbvi_grad's f and
+ * control-variate moments, then ONE kernel for the gradient, the Adam ascent step of
+ * bsc_adam_ascent (step count t >= 1, in place on lam, m1, m2) and the draws of the NEXT update
+ * (bsc_bbvi_sample with `next_step`, from the new lam: eps is overwritten, Wz / Bz / zeta
+ * refreshed).  Same results as the three separate calls up to float64 summation order. */
+int bsc_bbvi_update(bsc_ctx* ctx, double* lam, double* eps, const double* ell, int32_t D, int32_t G,
+                    int32_t S, double scale, double a0, double b0, double* m1, double* m2, int64_t t,
+                    double lr, double beta1, double beta2, double eps_adam, uint64_t seed,
+                    uint32_t next_step, float* Wz, float* Bz, double* zeta, double* elbo,
+                    double* grad, double* f_out);
 
 /* ---- executable primitives of the algebra front end -----------------------
  * The five-op IR that Einsum lowering emits plus element-wise nodes:

@@ -130,6 +130,12 @@ class OracleContext:
         grad.copy_(torch.from_numpy(g))
         f_out.copy_(torch.from_numpy(f))
 
+    def bsc_bbvi_update(self, lam, eps, ell, D, G, S, scale, a0, b0, m1, m2, t, lr, b1, b2, eps_adam, seed,
+                        next_step, Wz, Bz, zeta, elbo, grad, f_out):
+        self.bsc_bbvi_grad(lam, eps, ell, D, G, S, scale, a0, b0, elbo, grad, f_out)
+        self.bsc_adam_ascent(lam, grad, m1, m2, lam.numel(), t, lr, b1, b2, eps_adam)
+        self.bsc_bbvi_sample(lam, D, G, S, seed, next_step, eps, Wz, Bz, zeta)
+
     def bsc_adam_ascent(self, lam, grad, m1, m2, n, t, lr, b1, b2, eps):
         new, a, b = svi.adam_ascent(lam.numpy(), grad.numpy(), m1.numpy(), m2.numpy(), t, lr, b1, b2, eps)
         lam.copy_(torch.from_numpy(new))

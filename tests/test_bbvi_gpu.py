@@ -158,3 +158,45 @@ def test_first_generation_kernel_still_agrees(ctx):
     npt.assert_allclose(a, want, rtol=2e-6)
     npt.assert_allclose(b, want, rtol=2e-6)
     old.close()
+
+
+@pytest.mark.parametrize("D,G,S", [(24, 9, 64), (256, 1000, 64), (4, 1, 7), (60, 130, 33)])
+def test_fused_update_equals_grad_adam_and_sample(ctx, D, G, S):
+    """bsc_bbvi_update (gradient + Adam + the next update's draws in one kernel) against the three
+    separate entry points on the same state, and against the oracle's pieces."""
+    P = D + G + 1
+    rs = np.random.RandomState(D + G + S)
+    lam = svi.bbvi_init_lam(P) + 0.05 * rs.standard_normal(2 * P)
+    m1, m2 = 0.01 * rs.standard_normal(2 * P), 0.001 * rs.rand(2 * P)
+    ell = rs.uniform(-900, -700, S)
+    f64 = torch.float64
+    t, lr, seed = 7, 0.01, 4242
+
+    def state():
+        lamd, m1d, m2d = ctx.to_device(lam, f64), ctx.to_device(m1, f64), ctx.to_device(m2, f64)
+        eps, Wz, Bz, zeta = ctx.zeros(S * P, f64), ctx.zeros(S * D), ctx.zeros(G * S), ctx.zeros(S, f64)
+        ctx.call("bsc_bbvi_sample", lamd, D, G, S, seed, t - 1, eps, Wz, Bz, zeta)
+        return lamd, m1d, m2d, eps, Wz, Bz, zeta, ctx.zeros(1, f64), ctx.zeros(2 * P, f64), ctx.zeros(S, f64)
+
+    elld = ctx.to_device(ell, f64)
+    a = state()
+    ctx.call("bsc_bbvi_grad", a[0], a[3], elld, D, G, S, 2.5, 1.3, 0.8, a[7], a[8], a[9])
+    ctx.call("bsc_adam_ascent", a[0], a[8], a[1], a[2], 2 * P, t, lr, 0.9, 0.999, 1e-8)
+    ctx.call("bsc_bbvi_sample", a[0], D, G, S, seed, t, a[3], a[4], a[5], a[6])
+    b = state()
+    ctx.call("bsc_bbvi_update", b[0], b[3], elld, D, G, S, 2.5, 1.3, 0.8, b[1], b[2], t, lr, 0.9, 0.999, 1e-8,
+             seed, t, b[4], b[5], b[6], b[7], b[8], b[9])
+    ctx.sync()
+    names = ["lam", "m1", "m2", "eps", "Wz", "Bz", "zeta", "elbo", "grad", "f"]
+    for name, x, y in zip(names, a, b):
+        x, y = x.cpu().numpy(), y.cpu().numpy()
+        if name in ("Wz", "Bz"):
+            npt.assert_allclose(y, x, rtol=1e-6, atol=1e-7, err_msg=name)
+        elif name == "grad":
+            npt.assert_allclose(y, x, rtol=1e-9, atol=1e-11 * np.abs(x).max(), err_msg=name)
+        else:
+            npt.assert_allclose(y, x, rtol=1e-11, atol=1e-13, err_msg=name)
+    # the next draws are those of the oracle's sampler at the new parameters
+    e_ref, z_ref = svi.bbvi_sample(b[0].cpu().numpy(), P, S, seed, step=t)
+    npt.assert_allclose(b[3].cpu().numpy().reshape(S, P), e_ref, rtol=1e-12, atol=1e-14)
+    npt.assert_allclose(b[6].cpu().numpy(), z_ref[:, P - 1], rtol=1e-11)
