@@ -26,22 +26,34 @@ LIMITS = {
         "map_dense_f32_kernelILi2E": (128, 0),
         "map_reduce_wave_dense_f32_kernelILi2ELi4E": (128, 0),
         "map_reduce_lane_dense_f32_kernelILi2E": (128, 0),
+        "map_reduce_lane_narrow_f32_kernelILi3E": (128, 0),
         "map_reduce_wave_kernelIfLb0E": (128, 0),
         "map_strided_kernelIfLb0E": (96, 0),
     },
     "bsc_lda.hip": {
         "lda_sstats_kernelILi4E": (256, 0),
+        "lda_sstats_stream_kernel": (256, 32),       # (spills at the block boundaries, not in a step)
         "lda_sstats_csc_kernelILi8ELb1E": (96, 0),
     },
     "bsc_gemm.hip": {
         "gemm_f32_mfma_kernelILb1ELb1ELb1E": (256, 0),
         "gemm_f32_mfma_kernelILb0ELb1ELb1E": (256, 0),
+        "gemm_f32_dma_kernel": (144, 0),
+        # two workgroups per CU: <= 256; the few scratch bytes are spills in the guarded edge-tile
+        # store path, outside the k-loop (the loop's own budget is checked in the ISA: DESIGN 12)
+        "gemm_f32_stream_kernel": (256, 64),
+    },
+    "bsc_skinny.hip": {
+        "gemm_skinny_tn_kernel": (128, 0),
+        "gemm_skinny_nt_kernelILi2ELi16E": (192, 0),
     },
     "bsc_mog.hip": {
         "mog_estep_kernel": (256, 0),
     },
     "bsc_bbvi.hip": {
         "logreg_loglik_kernel": (256, 0),
+        "logreg_loglik_dma_kernelILb1ELi4ELi0E": (192, 0),
+        "bbvi_update_kernel": (96, 0),
     },
     "bsc_wouter.hip": {
         # a lambda capturing the prefetch registers once sent them to scratch behind flat
