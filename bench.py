@@ -534,6 +534,11 @@ def run_rank(args):
     if rehearsal:
         local_rank = 0
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # before the HSA runtime starts
+    # the contract is ONE line on stdout: keep the real stdout for it and point fd 1 at stderr for
+    # everything else (gloo announces "[Gloo] Rank 0 is connected ..." on fd 1, RCCL can be chatty too)
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -645,7 +650,8 @@ def run_rank(args):
                 out["cpu_baseline"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     barrier()
     ctx.close()
     if world > 1:
