@@ -27,6 +27,7 @@ struct bsc_ctx {
     int gemm_skinny = 1;              // GEMM: the LDS-DMA kernels of csrc/bsc_skinny.hip for products with one tiny extent (BSC_GEMM_SKINNY=0 turns them off)
     int gemm_dma = 2;                 // GEMM: 2 = persistent stream-K on LDS-DMA operand tiles (gemm_f32_stream_kernel), 1 = one tile per workgroup with LDS-DMA operands (gemm_f32_dma_kernel), 0 = the register-staged kernel (BSC_GEMM_DMA)
     int lda_stream = 1;               // LDA statistic, K = 128: the persistent LDS-DMA kernel (BSC_LDA_STREAM=0: one column block per workgroup, register staging)
+    int gemm_sym = 1;                 // GEMM: X^T X computes the tiles on and above the diagonal only (BSC_GEMM_SYM=0: all of them)
     int gemm_dbg = 0;                 // profiling only (BSC_GEMM_DBG): 1 = the stream kernel drops its whole-tile stores
     int gemm_pipe = 1;                // GEMM: LDS operand reads one k-pair ahead of the MFMAs
     int fused_nt_store = 1;           // dense map: non-temporal stores of the result

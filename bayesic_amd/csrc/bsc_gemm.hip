@@ -53,6 +53,9 @@ struct GemmArgs {
     // strip's width as multiply-and-shift on the scalar unit (q = t m >> sh, exact for t < 2^31)
     unsigned mg_pb, mg_strip, mg_last;
     int sh_pb, sh_strip, sh_last, group_log2;
+    // sym: C = A B with B = A^T (the Gram statistic X^T X): only the tiles on and above the diagonal are
+    // computed (tiles_pb = T (T + 1) / 2 of them), each off-diagonal one stored twice
+    int sym;
     float* slab;       // [2 n_wg][128 n][128 m] partial tiles
 };
 
@@ -576,6 +579,18 @@ __device__ __forceinline__ void stream_decode_tile(GP g, int t, int64_t& b, int6
     const unsigned tiles_pb = (unsigned)g->tiles_pb, group = (unsigned)g->group;
     const unsigned ub = stream_magic_div((unsigned)t, g->mg_pb, g->sh_pb);             // tiles x batch < 2^31 (host)
     const unsigned tt = (unsigned)t - ub * tiles_pb;
+    if (g->sym) {                                   // row-major over the upper triangle of T x T tiles
+        unsigned i = 0, rem = tt, len = (unsigned)g->tiles_m;
+        while (rem >= len) {
+            rem -= len;
+            --len;
+            ++i;
+        }
+        b = ub;
+        m0 = (int64_t)i * BM;
+        n0 = (int64_t)(i + rem) * BN;
+        return;
+    }
     const unsigned strip = group * (unsigned)g->tiles_m;
     const unsigned s = stream_magic_div(tt, g->mg_strip, g->sh_strip), within = tt - s * strip;
     const unsigned left = (unsigned)g->tiles_n - s * group;
@@ -857,7 +872,8 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
             // the epilogue factor is older than the DMAs waited for in this tile's second k-tile; a tile
             // one k-tile long, or the run's last, waits here
             if (gc->n_kt == 1 || u + 1 == n_units) __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
-            if (!whole || (fast && interior)) young += 16;    // 16 stores per lane below (edge tiles: fewer, wait for all)
+            const bool mirror = gc->sym && cm0 != cn0;           // an off-diagonal tile of a symmetric product: stored twice
+            if (!whole || (fast && interior && !mirror)) young += 16;    // 16 stores per lane below (edge / mirrored tiles: another count, wait for all)
             else young = 0;
             if (!whole) {
                 float* slot = gc->slab + ((int64_t)2 * w + (cc.round > gc->rounds ? 1 : 0)) * (BM * BN);
@@ -903,8 +919,15 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
                             v *= epi_scale;
                         }
                         char* base = reinterpret_cast<char*>(c_tile + (int64_t)(j * BLK_N) * sc_n + piece_m(p8));
-                        if (!(dbg & 1) && (interior || (lane_m + piece_m(p8) < m_left && lane_n + j * BLK_N < n_left)))
+                        if (!(dbg & 1) && (interior || (lane_m + piece_m(p8) < m_left && lane_n + j * BLK_N < n_left))) {
                             *reinterpret_cast<gemm_f32x4*>(base + c_lane) = v;
+                            if (mirror) {                // C[n][m] = C[m][n]: the quad's rows become columns
+                                float* mt = gc->C + cb * gc->sc_b + (cm0 + wm * 64 + lane_m + piece_m(p8)) * sc_n +
+                                            (cn0 + wn * 64 + lane_n + j * BLK_N);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) mt[(int64_t)e * sc_n] = v[e];
+                            }
+                        }
                     }
             } else {
                 const int64_t M = gc->M, N = gc->N, sc_m = gc->sc_m, sc_n = gc->sc_n, se_m = gc->se_m, se_n = gc->se_n;
@@ -930,6 +953,7 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
                                     v *= epi_scale;
                                 }
                                 C[row * sc_m + col * sc_n] = v;
+                                if (mirror) C[col * sc_m + row * sc_n] = v;
                             }
                         }
                     }
@@ -999,6 +1023,7 @@ __global__ __launch_bounds__(256) void stream_fixup_kernel(GemmArgs g) {
             float c = v[q];
             if (g.epi_pow) c = gemm_epilogue(g, c, b, row, col);
             g.C[b * g.sc_b + row * g.sc_m + col * g.sc_n] = c;
+            if (g.sym && m0 != n0) g.C[b * g.sc_b + col * g.sc_m + row * g.sc_n] = c;
         }
     }
 }
@@ -1317,6 +1342,10 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
             s.tiles_m = (int)((s.M + BM - 1) / BM);
             s.tiles_n = (int)((s.N + BN - 1) / BN);
             s.tiles_pb = s.tiles_m * s.tiles_n;
+            // X^T X: the same matrix on both sides, transposed -- half the tiles (plus the diagonal)
+            s.sym = ctx->gemm_sym && s.A == s.B && s.M == s.N && s.sa_m == s.sb_n && s.sa_k == s.sb_k && s.sa_b == s.sb_b &&
+                    !(epi.pow && epi.E) && s.tiles_m > 1;
+            if (s.sym) s.tiles_pb = s.tiles_m * (s.tiles_m + 1) / 2;
             s.group = 8;
             s.group_log2 = 3;
             auto magic = [](int64_t d, unsigned& m, int& sh) {       // q = t m >> sh for 0 <= t < 2^31, 1 <= d < 2^31
@@ -1374,7 +1403,7 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
     g.epi_scale = epi.scale; g.epi_pow = epi.pow;
     g.n_kt = 0; g.sk_q = 0; g.sk_r = 0; g.sk_stream = 0; g.n_wg = 0; g.rounds = 0; g.tail_tiles = 0; g.tiles_pb = 0;
     g.group = 1; g.dbg = 0; g.slab = nullptr;
-    g.mg_pb = g.mg_strip = g.mg_last = 0; g.sh_pb = g.sh_strip = g.sh_last = g.group_log2 = 0;
+    g.mg_pb = g.mg_strip = g.mg_last = 0; g.sh_pb = g.sh_strip = g.sh_last = g.group_log2 = 0; g.sym = 0;
     g.tiles_m = (int)((M + BM - 1) / BM);
     g.tiles_n = (int)((N + BN - 1) / BN);
     const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * batch;

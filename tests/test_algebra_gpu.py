@@ -317,3 +317,41 @@ def test_sums_over_the_rows_of_a_narrow_matrix(dev, rows, cols):
         assert got.shape == (cols,)
         npt.assert_allclose(got, want, rtol=2e-5, atol=2e-5 * scale)
         npt.assert_array_equal(got, run(dev, expr, **inputs))
+
+
+@pytest.mark.parametrize("rows,D,batch", [(50000, 384, 1), (4100, 260, 1), (20000, 256, 2), (1000, 640, 1), (333, 132, 3)])
+def test_gram_matrix_computes_the_upper_triangle_of_tiles_once(ctx, rows, D, batch):
+    """dot(X.T, X): the same matrix on both sides -- the GEMM computes the tiles on and above the
+    diagonal and stores each off-diagonal one twice.  Against float64, against the full schedule
+    (BSC_GEMM_SYM=0), exactly symmetric, run-to-run identical; both operand layouts."""
+    import os
+    import torch
+    from bayesic_amd.device import Context
+    os.environ["BSC_GEMM_SYM"] = "0"
+    try:
+        full = Context(0)
+    finally:
+        del os.environ["BSC_GEMM_SYM"]
+    g = torch.Generator(device=ctx.device).manual_seed(rows + D)
+    ld = D + 4
+    X = torch.randn((batch, rows, ld), generator=g, device=ctx.device)
+    X64 = X[:, :, :D].double()
+    want = torch.matmul(X64.transpose(1, 2), X64).cpu().numpy()
+    norm = X64.pow(2).sum(1).sqrt().cpu().numpy()
+    bound = norm[:, :, None] * norm[:, None, :]
+    # X^T X with X row-major (operands m- / n-contiguous), and X X^T with X stored transposed (k-contiguous)
+    Xt = X[:, :, :D].transpose(1, 2).contiguous()                 # [batch, D, rows]
+    for (A, sa, B, sb) in [(X, (rows * ld, 1, ld), X, (rows * ld, ld, 1)),
+                           (Xt, (D * rows, rows, 1), Xt, (D * rows, 1, rows))]:
+        outs = []
+        for c in (ctx, full, ctx):
+            C = torch.full((batch, D, D + 3), float("nan"), device=ctx.device)
+            c.call("bsc_gemm_strided_batched", 0, batch, D, D, rows, A, *sa, B, *sb, C, D * (D + 3), D + 3, 1)
+            c.sync()
+            outs.append(C.cpu().numpy())
+        got = outs[0][:, :, :D].astype(np.float64)
+        assert (np.abs(got - want) <= 1e-5 * bound + 1e-12).all()
+        assert (np.abs(got - outs[1][:, :, :D]) <= 2e-5 * bound + 1e-12).all()
+        npt.assert_array_equal(outs[0][:, :, :D], outs[0][:, :, :D].transpose(0, 2, 1))      # exactly symmetric
+        npt.assert_array_equal(outs[0][:, :, :D], outs[2][:, :, :D])
+        assert np.isnan(outs[0][:, :, D:]).all()
