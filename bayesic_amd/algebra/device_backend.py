@@ -124,9 +124,62 @@ class DeviceBackend(Backend):
         baseline of tools/bench_fusion.py); results are identical up to rounding."""
         self.fuse = bool(fuse)
         self._one = None          # a resident float32 1.0 (broadcast_to of a host scalar)
+        self._keep = None         # buffers made inside an open graph capture
+        self._graphs = {}         # graph_call: key -> recorded hipGraph
         self.ctx = ctx if ctx is not None else default_context()
         if not isinstance(self.ctx, Context):
             raise TypeError("ctx must be a bayesic_amd.device.Context")
+
+    # -- a host-side walk recorded once, replayed as a hipGraph ------------------------------
+    def _kept(self, t):
+        """Every device buffer made while a capture is open is held by the graph (which stores its
+        address, not a reference)."""
+        if self._keep is not None:
+            self._keep.append(t)
+        return t
+
+    def graph_call(self, key, fn, inputs):
+        """``fn()`` issues launches that read the tensors in ``inputs`` (a list; the caller refreshes
+        them in place) and returns a list of device tensors.  The first two calls under a ``key``
+        run eagerly (workspaces and allocator pools reach their final size); the third is recorded
+        into a hipGraph (bsc_capture_begin / _end) and replayed from then on, without the host-side
+        walk of ``fn``, as long as the inputs keep their addresses.  The returned tensors are the
+        graph's own output buffers: consume them before the next call.  Falls back to eager for good
+        when the context is on the null stream or something inside ``fn`` cannot be captured."""
+        entry = self._graphs.get(key)
+        ptrs = tuple(t.data_ptr() for t in inputs)
+        if entry is not None and entry["graph"] is not None:
+            if entry["ptrs"] == ptrs:
+                entry["graph"].launch()
+                return entry["outs"]
+            entry = None                                  # other buffers: start over
+        if entry is None:
+            entry = self._graphs[key] = {"calls": 0, "graph": None, "ptrs": ptrs, "outs": None, "dead": False}
+        entry["calls"] += 1
+        if entry["dead"] or entry["calls"] < 3 or not self.ctx.can_capture or entry["ptrs"] != ptrs:
+            entry["ptrs"] = ptrs
+            return [self._force(o) for o in fn()]
+        self._keep = []
+        self.ctx.capture_begin()
+        try:
+            outs = [self._force(o) for o in fn()]
+        except Exception:
+            self._keep = None
+            try:
+                self.ctx.capture_end()
+            except Exception:
+                pass
+            entry["dead"] = True
+            raise
+        keep, self._keep = self._keep, None
+        try:
+            graph = self.ctx.capture_end(keep + list(outs) + list(inputs))
+        except Exception:
+            entry["dead"] = True                          # not capturable: eager from now on
+            return [self._force(o) for o in fn()]
+        entry["graph"], entry["outs"] = graph, outs
+        graph.launch()                                    # a capture records, it does not run
+        return outs
 
     # -- host <-> device ---------------------------------------------------------
     def from_host(self, array, dtype, ndim):
@@ -146,7 +199,7 @@ class DeviceBackend(Backend):
                 a = a.astype(np.float32)
         # (np.ascontiguousarray would turn a 0-d array into shape (1,))
         a = np.array(a, order="C", copy=True)
-        return torch.from_numpy(a).to(self.ctx.device)
+        return self._kept(torch.from_numpy(a).to(self.ctx.device))
 
     def to_host(self, value):
         value = self._force(value)
@@ -184,7 +237,7 @@ class DeviceBackend(Backend):
         k-th buffer of the previous evaluation of the same expression."""
         shape = tuple(int(n) for n in shape)
         if self._plan is None:
-            return self.ctx.empty(shape, dtype)       # (checks torch's current stream is the context's)
+            return self._kept(self.ctx.empty(shape, dtype))       # (checks torch's current stream is the context's)
         numel = math.prod(shape)
         k = self._cursor
         self._cursor += 1
@@ -192,7 +245,7 @@ class DeviceBackend(Backend):
             buf = self._plan[k]
             if buf is not None and buf.dtype == dtype and buf.numel() == numel:
                 return buf.view(shape)
-        buf = self.ctx.empty((numel,), dtype)
+        buf = self._kept(self.ctx.empty((numel,), dtype))
         if k < len(self._plan):
             self._plan[k] = buf
         else:
@@ -200,7 +253,7 @@ class DeviceBackend(Backend):
         return buf.view(shape)
 
     def _upload_scalar(self, s, dtype, ndim):
-        t = torch.tensor(float(s.value), dtype=dtype, device=self.ctx.device)
+        t = self._kept(torch.tensor(float(s.value), dtype=dtype, device=self.ctx.device))
         return t.reshape((1,) * ndim)
 
     def _convert(self, t, dtype):

@@ -19,6 +19,9 @@ int bsc_fail(int code, const char* fmt, ...) {
 
 int bsc_workspace(bsc_ctx* ctx, size_t bytes, void** out) {
     if (bytes > ctx->workspace_bytes) {
+        if (ctx->capturing)
+            return bsc_fail(BSC_ERR_INVALID, "the workspace would have to grow (%zu > %zu bytes) inside a graph capture: "
+                            "run the same calls once outside the capture first", bytes, ctx->workspace_bytes);
         // Growing is synchronous: earlier launches may still read the old slab.
         BSC_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->workspace) BSC_HIP(hipFree(ctx->workspace));
@@ -159,7 +162,67 @@ int bsc_ctx_profile_read(bsc_ctx* ctx, double* host_total_ms, int64_t* host_laun
 
 int bsc_ctx_sync(bsc_ctx* ctx) {
     BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(!ctx->capturing, "bsc_ctx_sync inside a graph capture");
     BSC_HIP(hipStreamSynchronize(ctx->stream));
+    return BSC_OK;
+}
+
+/* ---- hipGraph capture of a launch sequence ---------------------------------------------------- */
+struct bsc_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+int bsc_capture_begin(bsc_ctx* ctx) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(!ctx->capturing, "bsc_capture_begin: a capture is already open on this context");
+    BSC_REQUIRE(ctx->stream != nullptr, "bsc_capture_begin: the null stream cannot be captured; create the context on a stream");
+    // relaxed: host-side allocator calls of the embedding runtime (torch's caching allocator) stay legal
+    BSC_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+    ctx->capturing = 1;
+    return BSC_OK;
+}
+
+int bsc_capture_end(bsc_ctx* ctx, bsc_graph** out) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(out != nullptr, "bsc_capture_end: out is null");
+    *out = nullptr;
+    BSC_REQUIRE(ctx->capturing, "bsc_capture_end without bsc_capture_begin");
+    ctx->capturing = 0;
+    hipGraph_t graph = nullptr;
+    hipError_t err = hipStreamEndCapture(ctx->stream, &graph);
+    if (err != hipSuccess || graph == nullptr) {
+        (void)hipGetLastError();
+        return bsc_fail(BSC_ERR_HIP, "hipStreamEndCapture: %s (a call inside the capture was not capturable)",
+                        hipGetErrorString(err));
+    }
+    hipGraphExec_t exec = nullptr;
+    err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (err != hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        return bsc_fail(BSC_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(err));
+    }
+    bsc_graph* g = new bsc_graph();
+    g->graph = graph;
+    g->exec = exec;
+    *out = g;
+    return BSC_OK;
+}
+
+int bsc_graph_launch(bsc_ctx* ctx, bsc_graph* g) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(g != nullptr && g->exec != nullptr, "bsc_graph_launch: null graph");
+    BSC_REQUIRE(!ctx->capturing, "bsc_graph_launch inside a graph capture");
+    BSC_HIP(hipGraphLaunch(g->exec, ctx->stream));
+    return BSC_OK;
+}
+
+int bsc_graph_destroy(bsc_graph* g) {
+    if (!g) return BSC_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
     return BSC_OK;
 }
 
@@ -199,6 +262,7 @@ int bsc_free(bsc_ctx* ctx, void* ptr) {
 
 int bsc_h2d(bsc_ctx* ctx, void* dst, const void* host_src, size_t bytes) {
     BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(!ctx->capturing, "bsc_h2d inside a graph capture");
     BSC_HIP(hipMemcpyAsync(dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     BSC_HIP(hipStreamSynchronize(ctx->stream));  // host_src may be pageable
     return BSC_OK;
@@ -206,6 +270,7 @@ int bsc_h2d(bsc_ctx* ctx, void* dst, const void* host_src, size_t bytes) {
 
 int bsc_d2h(bsc_ctx* ctx, void* host_dst, const void* src, size_t bytes) {
     BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(!ctx->capturing, "bsc_d2h inside a graph capture");
     BSC_HIP(hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     BSC_HIP(hipStreamSynchronize(ctx->stream));
     return BSC_OK;

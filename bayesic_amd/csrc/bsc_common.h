@@ -41,6 +41,7 @@ struct bsc_ctx {
     int blr_finish_block = 1024; // threads per workgroup of blr_fused_update_kernel (BSC_BLR_FINISH_BLOCK = 256 | 512 | 1024)
     int blr_nt_loads = 1;        // non-temporal loads of X (read once per pass): +9% measured
     int slab_rows = 0;  // block partials left in `workspace` by bsc_blr_data_pass_partial
+    int capturing = 0;  // between bsc_capture_begin and bsc_capture_end: launches are recorded, not run
     // optional per-kernel timing of the dominant kernel (bsc_ctx_profile)
     int profile = 0;        // 0 = off, n = time every n-th launch of a dominant kernel
     // slot 0: the dominant kernel of an entry point; slot 1: the collective; slot 2: the finish kernel
@@ -83,7 +84,7 @@ struct bsc_prof_scope {
     int slot;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     explicit bsc_prof_scope(bsc_ctx* c, int slot_ = 0) : ctx(c), slot(slot_) {
-        if (ctx->profile <= 0) return;
+        if (ctx->profile <= 0 || ctx->capturing) return;
         if ((ctx->profile_tick[slot]++ % ctx->profile) != 0) return;
         if (!ctx->prof_pool.empty()) {
             ev = ctx->prof_pool.back();

@@ -67,6 +67,21 @@ class Context:
     def sync(self):
         _ffi.check(self.lib.bsc_ctx_sync(self.handle), "bsc_ctx_sync")
 
+    # -- a launch sequence as one hipGraph ------------------------------------
+    @property
+    def can_capture(self):
+        """Stream capture needs a stream of its own (not the null stream torch starts on)."""
+        return self._stream.cuda_stream != 0
+
+    def capture_begin(self):
+        _ffi.check(self.lib.bsc_capture_begin(self.handle), "bsc_capture_begin")
+
+    def capture_end(self, keep=()):
+        """-> Graph.  Raises (and leaves the stream usable) when a call inside was not capturable."""
+        h = ctypes.c_void_p()
+        _ffi.check(self.lib.bsc_capture_end(self.handle, ctypes.byref(h)), "bsc_capture_end")
+        return Graph(self, h, list(keep))
+
     def reserve(self, nbytes):
         _ffi.check(self.lib.bsc_ctx_reserve(self.handle, nbytes), "bsc_ctx_reserve")
 
@@ -161,6 +176,25 @@ class Context:
         """Invoke entry point `name`; torch tensors are passed as device pointers."""
         raw = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
         _ffi.check(getattr(self.lib, name)(self.handle, *raw), name)
+
+
+class Graph:
+    """A captured launch sequence (bsc_capture_begin / bsc_capture_end).  `keep` holds every buffer the
+    recorded launches touch: the graph stores their addresses."""
+
+    def __init__(self, ctx, handle, keep):
+        self.ctx, self.handle, self.keep = ctx, handle, keep
+
+    def launch(self):
+        _ffi.check(self.ctx.lib.bsc_graph_launch(self.ctx.handle, self.handle), "bsc_graph_launch")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.ctx.lib.bsc_graph_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 class Event:

@@ -34,10 +34,17 @@ class ReparamVI(object):
     data        : {input name: array}, uploaded once
     noise       : optional callable step -> eps [S, P] (float64); default: Philox draws on the
                   MI355X backend's device
+    graph       : device backend only.  The evaluation of log p and its gradient is a few dozen short
+                  launches behind a Python walk of the expression (forward, then the tape backwards);
+                  with ``graph=True`` that walk is recorded once into a hipGraph
+                  (``DeviceBackend.graph_call``) and replayed on every later step: the latent draws
+                  are written into fixed device buffers, one graph launch, two results read back.
+                  Needs a context on a stream of its own (``Context.set_stream``); falls back to the
+                  eager walk otherwise.
     """
 
     def __init__(self, log_joint, latents, data, n_samples, seed=0, lr=1e-2, backend=None,
-                 lam0=None, noise=None):
+                 lam0=None, noise=None, graph=False):
         from ..algebra.backend import resolve_backend
         self.backend = resolve_backend(backend)
         if log_joint.ndim != 1:
@@ -66,6 +73,8 @@ class ReparamVI(object):
         self._data = {n: self.backend.from_host(data[n], *types[n]) for n in data if n in types}
         self._noise = noise
         self._eps_dev = None
+        self._graph = bool(graph) and hasattr(self.backend, "graph_call")
+        self._z_dev = None
         self.elbo, self.grad = None, None
 
     def set_data(self, **arrays):
@@ -73,7 +82,7 @@ class ReparamVI(object):
         for name, value in arrays.items():
             if name not in self._types or name in {v.name for v, _ in self.latents}:
                 raise TypeError("%s is not a data input of the log-joint" % name)
-            self._data[name] = self.backend.from_host(value, *self._types[name])
+            self._data[name] = self.backend.from_host(value, *self._types[name])     # (a new buffer: a recorded graph is dropped)
 
     def draw(self, step):
         if self._noise is not None:
@@ -86,8 +95,36 @@ class ReparamVI(object):
         ctx.sync()
         return self._eps_dev.cpu().numpy()
 
+    def _log_joint_and_gradient_graph(self, z):
+        """The same through one recorded hipGraph: fixed input buffers, refreshed in place."""
+        import torch
+        names = [v.name for v, _ in self.latents]
+        if self._z_dev is None:
+            self._z_dev = {v.name: self.backend.from_host(np.zeros((self.S, n), self._types[v.name][0]),
+                                                          *self._types[v.name]) for v, n in self.latents}
+        offset = 0
+        for v, n in self.latents:
+            block = np.ascontiguousarray(z[:, offset:offset + n], dtype=self._types[v.name][0])
+            self._z_dev[v.name].copy_(torch.from_numpy(block))
+            offset += n
+        inputs = dict(self._data)
+        inputs.update(self._z_dev)
+
+        def walk():
+            out, grads = value_and_grad(self.backend, self.log_joint, inputs, names)
+            return [out] + [grads[name] for name in names]
+
+        res = self.backend.graph_call(("reparam", id(self)), walk,
+                                      [self._z_dev[name] for name in names] + list(self._data.values()))
+        f = np.asarray(self.backend.to_host(res[0]), np.float64).reshape(self.S)
+        g = np.concatenate([np.asarray(self.backend.to_host(r), np.float64).reshape(self.S, n)
+                            for r, (_, n) in zip(res[1:], self.latents)], axis=1)
+        return f, g
+
     def log_joint_and_gradient(self, z):
         """(log p(data, z_s) [S], d log p / d z [S, P]) through the executor."""
+        if self._graph:
+            return self._log_joint_and_gradient_graph(z)
         inputs = dict(self._data)
         offset = 0
         for v, n in self.latents:

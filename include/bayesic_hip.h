@@ -51,6 +51,23 @@ int bsc_ctx_set_stream(bsc_ctx* ctx, void* stream);
  * points grow it on demand; call this first when capturing into a graph. */
 int bsc_ctx_reserve(bsc_ctx* ctx, size_t bytes);
 int bsc_ctx_sync(bsc_ctx* ctx);
+
+/* ---- a launch sequence as one hipGraph ------------------------------------------------------
+ * The reference re-walks its expression tree on every evaluation (bayesic/algebra.py:34-40, 60-61,
+ * 767-768); a device update built from a few dozen short launches is then bound by the host walk,
+ * not by the GPU.  Between bsc_capture_begin and bsc_capture_end every entry point called on the
+ * context records its launches into a graph instead of running them (hipStreamBeginCapture on the
+ * context's stream -- which must not be the null stream); bsc_graph_launch replays them in one
+ * submission.  The graph holds the POINTERS the calls were given: the caller keeps every buffer
+ * alive and at the same address, and refreshes inputs by writing into them.  Entry points that
+ * synchronise (bsc_ctx_sync, bsc_d2h, bsc_h2d, a workspace that has to grow) fail inside a capture:
+ * run the sequence once eagerly first.  bsc_capture_end returns an error, and leaves the stream
+ * usable, when something inside could not be captured. */
+typedef struct bsc_graph bsc_graph;
+int bsc_capture_begin(bsc_ctx* ctx);
+int bsc_capture_end(bsc_ctx* ctx, bsc_graph** out);
+int bsc_graph_launch(bsc_ctx* ctx, bsc_graph* g);
+int bsc_graph_destroy(bsc_graph* g);
 /* info[0]=CU count, [1]=wavefront size, [2]=max LDS bytes per workgroup,
  * [3]=clock kHz, [4]=L2 bytes, [5]=gcn arch number (950 for gfx950). */
 int bsc_device_info(bsc_ctx* ctx, int64_t info[8]);

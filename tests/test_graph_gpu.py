@@ -1,0 +1,101 @@
+"""hipGraph capture of a launch sequence through the C ABI (bsc_capture_begin / bsc_capture_end /
+bsc_graph_launch) and its use by the executor (DeviceBackend.graph_call, ReparamVI(graph=True))."""
+import numpy as np
+import numpy.testing as npt
+import pytest
+import torch
+
+from bayesic_amd import _ffi
+from bayesic_amd import algebra as A
+from bayesic_amd.algebra.device_backend import _i64
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def sctx():
+    """A context on a stream of its own (the null stream cannot be captured)."""
+    from bayesic_amd.device import Context
+    prev = torch.cuda.current_stream()
+    c = Context(0)
+    c.set_stream(torch.cuda.Stream(c.device))
+    yield c
+    c.sync()
+    torch.cuda.set_stream(prev)
+    c.close()
+
+
+def test_capture_replays_a_launch_sequence_on_fresh_inputs(sctx):
+    ctx = sctx
+    n, d = 5000, 64
+    g = torch.Generator(device=ctx.device).manual_seed(1)
+    X = torch.randn((n, d), generator=g, device=ctx.device)
+    W = torch.randn((d, 32), generator=g, device=ctx.device)
+    P = torch.empty((n, 32), device=ctx.device)
+    tot = torch.empty(32, device=ctx.device)
+
+    def sequence():
+        ctx.call("bsc_gemm_strided_batched", 0, 1, n, 32, d, X, 0, d, 1, W, 0, 32, 1, P, 0, 32, 1)
+        ctx.call("bsc_sum", 0, 1, _i64([32]), _i64([1]), 1, _i64([n]), _i64([32]), P, tot)
+
+    sequence()                                   # eager once: workspaces reach their size
+    ctx.sync()
+    first = tot.cpu().numpy().copy()
+    ctx.capture_begin()
+    sequence()
+    graph = ctx.capture_end(keep=[X, W, P, tot])
+    tot.zero_()
+    graph.launch()
+    ctx.sync()
+    npt.assert_array_equal(tot.cpu().numpy(), first)            # the same launches: the same bits
+    X.copy_(torch.randn((n, d), generator=g, device=ctx.device))   # new contents, same address
+    graph.launch()
+    ctx.sync()
+    want = (X.double() @ W.double()).sum(0).cpu().numpy()
+    npt.assert_allclose(tot.cpu().numpy(), want, rtol=2e-5, atol=2e-3)
+    # what cannot be captured fails loudly and leaves the stream usable
+    ctx.capture_begin()
+    with pytest.raises(_ffi.BayesicHipError):
+        ctx.sync()
+    ctx.capture_end()
+    sequence()
+    ctx.sync()
+
+
+def test_capture_needs_a_stream_of_its_own(ctx):
+    if ctx.can_capture:
+        pytest.skip("the shared test context is not on the null stream")
+    with pytest.raises(_ffi.BayesicHipError):
+        ctx.capture_begin()
+
+
+def test_reparam_engine_with_its_walk_recorded_as_a_graph(sctx):
+    """ReparamVI(graph=True): the same draws, the same launches in the same order -> the same
+    parameters, bit for bit, as the eager engine over many steps (two eager, one recorded, the rest
+    replayed)."""
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from bayesic_amd.inference import ReparamVI
+    rs = np.random.RandomState(2)
+    N, D, S = 20000, 24, 8
+    Xs = rs.standard_normal((N, D)).astype(np.float32)
+    w_true = rs.standard_normal(D) / 4
+    ys = (Xs @ w_true + 0.5 * rs.standard_normal(N)).astype(np.float32)
+    X, y, W = A.var("X", 2), A.var("y", 1), A.var("W", 2)
+    r = A.dimshuffle(y, "x", 0) - A.dot(W, X.T)
+    lj = A.sum(r * r, axis=1) * (-0.5 / 0.25) + A.sum(W * W, axis=1) * (-0.5)
+    engines = [ReparamVI(lj, [(W, D)], dict(X=Xs, y=ys), n_samples=S, seed=5, backend=DeviceBackend(sctx),
+                         lr=0.02, graph=graph) for graph in (False, True)]
+    for step in range(12):
+        a, b = engines[0].step(), engines[1].step()
+        assert a == b, (step, a, b)
+        npt.assert_array_equal(engines[0].lam, engines[1].lam)
+    entry = engines[1].backend._graphs[("reparam", id(engines[1]))]
+    assert entry["graph"] is not None and not entry["dead"]         # it really was recorded
+    # new data: new buffers, the recorded graph is dropped and a new one made
+    Xs2 = Xs[::-1].copy()
+    for e in engines:
+        e.set_data(X=Xs2)
+    for step in range(5):
+        a, b = engines[0].step(), engines[1].step()
+        assert a == b
+    assert np.isfinite(engines[1].lam).all()

@@ -25,19 +25,22 @@ def main():
     X, y, W = A.var("X", 2), A.var("y", 1), A.var("W", 2)
     r = A.dimshuffle(y, "x", 0) - A.dot(W, X.T)
     lj = A.sum(r * r, axis=1) * (-0.5 / s2) + A.sum(W * W, axis=1) * (-0.5)
-    eng = ReparamVI(lj, [(W, D)], dict(X=Xd.cpu().numpy(), y=yd.cpu().numpy()), n_samples=S, seed=1,
-                    backend=DeviceBackend(ctx), lr=1e-3)
-    for _ in range(5):
-        eng.step()
-    ctx.sync()
-    t0 = time.perf_counter()
-    steps = 20
-    for _ in range(steps):
-        eng.step()
-    ctx.sync()
-    dt = (time.perf_counter() - t0) / steps
-    print("general reparameterisation engine, %dx%d, S=%d: %.2f ms per update (%.1f updates/s); "
-          "the fused config-2 kernels: 0.17 ms" % (N, D, S, dt * 1e3, 1.0 / dt))
+    ctx.set_stream(torch.cuda.Stream(ctx.device))          # a stream of its own: what a graph capture needs
+    data = dict(X=Xd.cpu().numpy(), y=yd.cpu().numpy())
+    for graph in (False, True):
+        eng = ReparamVI(lj, [(W, D)], data, n_samples=S, seed=1, backend=DeviceBackend(ctx), lr=1e-3, graph=graph)
+        for _ in range(5):
+            eng.step()
+        ctx.sync()
+        t0 = time.perf_counter()
+        steps = 20
+        for _ in range(steps):
+            eng.step()
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / steps
+        print("general reparameterisation engine%s, %dx%d, S=%d: %.2f ms per update (%.1f updates/s), elbo %.6e; "
+              "the fused config-2 kernels: 0.17 ms"
+              % (" (walk recorded as a hipGraph)" if graph else "", N, D, S, dt * 1e3, 1.0 / dt, eng.elbo))
 
 
 if __name__ == "__main__":
