@@ -181,6 +181,28 @@ class DeviceBackend(Backend):
         graph.launch()                                    # a capture records, it does not run
         return outs
 
+    def compile(self, expr, bindings=None, graph=False):
+        """As ``Backend.compile``.  ``graph=True``: ``f.device_fn(**device_inputs)`` records its launches
+        once (third call, see ``graph_call``) and replays them while it is called with the same device
+        buffers -- where the reference compiles a Theano function (bayesic/algebra.py:50-58) this
+        records a hipGraph.  The tensor it returns is then the graph's own output buffer, overwritten
+        by the next call.  (``f(**arrays)`` uploads fresh buffers on every call and stays eager.)"""
+        f = Backend.compile(self, expr, bindings)
+        if not graph:
+            return f
+        eager = f.device_fn
+        backend = self
+
+        def device_fn(**device_inputs):
+            names = sorted(device_inputs)
+            tensors = [device_inputs[n] for n in names if isinstance(device_inputs[n], torch.Tensor)]
+            scalars = tuple((n, device_inputs[n].value) for n in names if isinstance(device_inputs[n], HostScalar))
+            return backend.graph_call(("compile", id(expr), scalars), lambda: [eager(**device_inputs)], tensors)[0]
+
+        device_fn.expr = expr            # (keeps id(expr) unique for the life of the function)
+        f.device_fn = device_fn
+        return f
+
     # -- host <-> device ---------------------------------------------------------
     def from_host(self, array, dtype, ndim):
         a = np.asarray(array)

@@ -51,12 +51,14 @@ class Expression(object):
     def _emit(self, backend, *parent_values):
         raise NotImplementedError
 
-    def compile(self, backend=None):
+    def compile(self, backend=None, **options):
         """``f(**{name: array}) -> ndarray`` (bayesic/algebra.py:50-58).  The
         lowered plan is built once here, not on every call; ``f.device_fn`` is
-        the analogue of the reference's ``f.theano_fn`` handle."""
+        the analogue of the reference's ``f.theano_fn`` handle.  ``options`` go to the
+        backend's ``compile`` (the MI355X backend: ``graph=True`` records ``f.device_fn``'s
+        launches as a hipGraph)."""
         from .backend import resolve_backend
-        return resolve_backend(backend).compile(self)
+        return resolve_backend(backend).compile(self, **options)
 
     # -- printing ----------------------------------------------------------
     def __repr__(self):

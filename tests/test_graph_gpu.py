@@ -99,3 +99,34 @@ def test_reparam_engine_with_its_walk_recorded_as_a_graph(sctx):
         a, b = engines[0].step(), engines[1].step()
         assert a == b
     assert np.isfinite(engines[1].lam).all()
+
+
+def test_compiled_expression_with_its_launches_recorded(sctx):
+    """expr.compile(backend, graph=True).device_fn: eager twice, recorded on the third call, replayed
+    afterwards on refreshed inputs; a different buffer or a different scalar input is a new recording."""
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    be = DeviceBackend(sctx)
+    X, w, s = A.var("X", 2), A.var("w", 1), A.var("s", 0)
+    expr = A.sum(A.exp(A.dot(X, w) * s) * A.dot(X, w)) + A.sum(X * X) * 0.5
+    f = expr.compile(be, graph=True)
+    plain = expr.compile(DeviceBackend(sctx))
+    g = torch.Generator(device=sctx.device).manual_seed(3)
+    Xd = torch.randn((30000, 48), generator=g, device=sctx.device) * 0.1
+    wd = torch.randn(48, generator=g, device=sctx.device)
+    sv = be.from_host(np.float32(0.3), "float32", 0)
+    for call in range(6):
+        Xd.copy_(torch.randn((30000, 48), generator=g, device=sctx.device) * 0.1)
+        got = be.to_host(f.device_fn(X=Xd, w=wd, s=sv))
+        want = plain.device_fn(X=Xd, w=wd, s=sv)
+        npt.assert_array_equal(got, plain.backend.to_host(want))
+    entries = [k for k in be._graphs if k[0] == "compile"]
+    assert len(entries) == 1 and be._graphs[entries[0]]["graph"] is not None
+    # another scalar: its value is a kernel argument, so a recording of its own
+    s2 = be.from_host(np.float32(0.1), "float32", 0)
+    for call in range(4):
+        got = be.to_host(f.device_fn(X=Xd, w=wd, s=s2))
+        npt.assert_array_equal(got, plain.backend.to_host(plain.device_fn(X=Xd, w=wd, s=s2)))
+    assert len([k for k in be._graphs if k[0] == "compile"]) == 2
+    x64 = Xd.double().cpu().numpy(); w64 = wd.double().cpu().numpy()
+    ref = (np.exp(x64 @ w64 * 0.1) * (x64 @ w64)).sum() + 0.5 * (x64 * x64).sum()
+    npt.assert_allclose(got, ref, rtol=2e-5)
