@@ -104,6 +104,8 @@ SIGNATURES = {
     "bsc_weighted_outer": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                    c_int64, c_int32, c_int32, c_int32, c_double, c_void_p]),
     "bsc_hbm_read_probe": (c_int, [c_void_p, c_void_p, c_size_t, c_int, POINTER(c_double)]),
+    "bsc_host_alloc": (c_int, [c_size_t, POINTER(c_void_p)]),
+    "bsc_host_free": (c_int, [c_void_p]),
     "bsc_host_register": (c_int, [c_void_p, c_size_t]),
     "bsc_host_unregister": (c_int, [c_void_p]),
     "bsc_loader_create": (c_int, [c_void_p, c_int64, c_int32, c_int32, POINTER(c_void_p)]),

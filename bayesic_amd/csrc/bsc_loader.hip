@@ -12,6 +12,7 @@
 // its own bounce buffer at a fraction of the PCIe rate.
 #include "bsc_common.h"
 
+#include <cstring>
 #include <vector>
 
 struct bsc_loader {
@@ -26,12 +27,42 @@ struct bsc_loader {
         hipEvent_t copied = nullptr;     // recorded on the copy stream after the H2D
         hipEvent_t consumed = nullptr;   // recorded on the compute stream at release
         bool has_consumed = false;
+        // page-locked bounce buffer of this slot for PAGEABLE sources (made on first use).  The runtime
+        // would otherwise lock the caller's pages on the fly and let the copy engine read them; a
+        // pageable source is instead copied here by the host inside bsc_loader_submit, so the device
+        // only ever reads memory this library allocated (or the caller registered), and a pageable
+        // source is free again as soon as submit returns.
+        float* bounce = nullptr;
     };
     std::vector<Slot> slots;
     int64_t submitted = 0, acquired = 0, released = 0;   // monotone counters; slot = counter % n
 };
 
+// page-locked and known to the runtime (hipHostMalloc'ed, or hipHostRegister'ed by the caller)?
+static bool loader_is_page_locked(const void* p) {
+    hipPointerAttribute_t attr;
+    const hipError_t err = hipPointerGetAttributes(&attr, p);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();          // an ordinary malloc'ed pointer: "invalid value", not an error here
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
 extern "C" {
+
+/* page-locked host memory owned by the runtime (hipHostMalloc): the source to stream batches from at the
+ * full PCIe rate without registering memory that malloc owns */
+int bsc_host_alloc(size_t bytes, void** out) {
+    BSC_REQUIRE(out != nullptr && bytes > 0, "bsc_host_alloc: bad arguments");
+    BSC_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return BSC_OK;
+}
+
+int bsc_host_free(void* host_ptr) {
+    if (host_ptr) BSC_HIP(hipHostFree(host_ptr));
+    return BSC_OK;
+}
 
 int bsc_host_register(void* host_ptr, size_t bytes) {
     BSC_REQUIRE(host_ptr != nullptr && bytes > 0, "bsc_host_register: bad arguments");
@@ -84,6 +115,7 @@ int bsc_loader_destroy(bsc_loader* L) {
     for (auto& s : L->slots) {
         (void)hipFree(s.X);
         (void)hipFree(s.y);
+        if (s.bounce) (void)hipHostFree(s.bounce);
         (void)hipEventDestroy(s.copied);
         (void)hipEventDestroy(s.consumed);
     }
@@ -109,6 +141,18 @@ int bsc_loader_submit(bsc_loader* L, const float* host_X, int64_t ldx, const flo
     if (L->submitted >= n) BSC_HIP(hipEventSynchronize(s.copied));
     // the copy may not overtake the kernels that last read this slot
     if (s.has_consumed) BSC_HIP(hipStreamWaitEvent(L->copy_stream, s.consumed, 0));
+    if (!loader_is_page_locked(host_X) || !loader_is_page_locked(host_y)) {
+        // pageable: through the slot's bounce buffer ([rows x D] dense, then y).  The previous copy out
+        // of this buffer has completed: it is the one `copied` was just waited for above (or none yet).
+        if (!s.bounce)
+            BSC_HIP(hipHostMalloc((void**)&s.bounce, (size_t)L->max_rows * (L->D + 1) * sizeof(float), hipHostMallocDefault));
+        for (int64_t r = 0; r < rows; ++r)
+            std::memcpy(s.bounce + r * L->D, host_X + r * ldx, (size_t)L->D * sizeof(float));
+        std::memcpy(s.bounce + rows * L->D, host_y, (size_t)rows * sizeof(float));
+        host_X = s.bounce;
+        host_y = s.bounce + rows * L->D;
+        ldx = L->D;
+    }
     if (ldx == L->D)
         BSC_HIP(hipMemcpyAsync(s.X, host_X, (size_t)rows * L->D * sizeof(float), hipMemcpyHostToDevice,
                                L->copy_stream));

@@ -5,6 +5,7 @@ stream; every compute call goes through the C ABI.  Creating a ``Context``
 without a visible gfx950 GPU raises -- there is no CPU path.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -28,10 +29,13 @@ class Context:
                                            ctypes.byref(handle)), "bsc_ctx_create")
         self.handle = handle
         self.has_comm = False   # an RCCL communicator (comm_init), even of one rank
+        self._graphs = weakref.WeakSet()   # live Graph objects recorded on this context
 
     # -- plumbing ----------------------------------------------------------
     def close(self):
         if getattr(self, "handle", None):
+            for g in list(self._graphs):          # recorded graphs go before the stream they ran on
+                g.destroy()
             self.lib.bsc_ctx_destroy(self.handle)
             self.handle = None
 
@@ -184,15 +188,25 @@ class Graph:
 
     def __init__(self, ctx, handle, keep):
         self.ctx, self.handle, self.keep = ctx, handle, keep
+        ctx._graphs.add(self)
 
     def launch(self):
+        if not self.handle:
+            raise _ffi.BayesicHipError("the graph was destroyed (its context has been closed)")
         _ffi.check(self.ctx.lib.bsc_graph_launch(self.ctx.handle, self.handle), "bsc_graph_launch")
+
+    def destroy(self):
+        """Idempotent.  A graph never outlives its context's stream: Context.close() destroys the
+        graphs recorded on it first (the runtime touches the stream a graph last ran on when the graph
+        is destroyed; left to the garbage collector that happened at some later, unrelated moment)."""
+        if self.handle:
+            handle, self.handle = self.handle, None
+            self.ctx.lib.bsc_graph_destroy(handle)
+            self.keep = []
 
     def __del__(self):
         try:
-            if self.handle:
-                self.ctx.lib.bsc_graph_destroy(self.handle)
-                self.handle = None
+            self.destroy()
         except Exception:
             pass
 

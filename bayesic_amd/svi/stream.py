@@ -13,11 +13,14 @@ kernels only ever see device-resident batches, so the hot path is unchanged.
         model.step()
         loader.release()                            # slot reusable once step t has run
 
-A submitted host batch must stay valid and unchanged until ``n_slots`` further submits have
-returned (the loader keeps a reference that long); sources handed over as raw pointers through
-the C ABI must outlive their copy the same way.  Host arrays should be page-locked: ``MiniBatchLoader.pin(array)`` registers a numpy
-array in place (bsc_host_register); torch tensors made with ``pin_memory=True`` work
-too.  A pageable source is staged by the HIP runtime at a fraction of the PCIe rate.
+Host arrays should be page-locked: ``loader.pinned_empty(shape)`` gives a numpy array in
+hipHostMalloc memory (bsc_host_alloc; valid until ``close()``), torch tensors made with
+``pin_memory=True`` work too, and ``loader.pin(array)`` registers an existing numpy array in place
+(bsc_host_register; unregistered at ``close()`` -- keep the array alive until then).  A page-locked
+batch must stay valid and unchanged until ``n_slots`` further submits have returned (the loader
+keeps a reference that long).  A pageable source is copied by the host, inside ``submit``, into a
+page-locked bounce buffer of the slot -- a fraction of the PCIe rate, but the device never reads
+memory the runtime would have to lock on the fly, and the source is free when submit returns.
 """
 import ctypes
 
@@ -49,6 +52,7 @@ class MiniBatchLoader(object):
         self.handle = h
         self._in_flight = []       # host arrays whose copies may still be running
         self._pinned = []
+        self._host_allocs = []     # hipHostMalloc blocks handed out by pinned_empty
 
     @staticmethod
     def _strides_ok(X, y):
@@ -56,6 +60,16 @@ class MiniBatchLoader(object):
             return X.ndim == 2 and X.strides[1] == 4 and X.strides[0] % 4 == 0 and \
                 y.ndim == 1 and y.strides[0] == 4, X.strides[0] // 4
         return X.dim() == 2 and X.stride(1) == 1 and y.dim() == 1 and y.stride(0) == 1, X.stride(0)
+
+    def pinned_empty(self, shape, dtype=np.float32):
+        """Uninitialised numpy array in page-locked memory owned by the HIP runtime (hipHostMalloc):
+        the source to stream from at the full PCIe rate.  Valid until ``close()``."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = ctypes.c_void_p()
+        _ffi.check(self.ctx.lib.bsc_host_alloc(max(nbytes, 1), ctypes.byref(p)), "bsc_host_alloc")
+        self._host_allocs.append(p)
+        buf = (ctypes.c_char * max(nbytes, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def pin(self, array):
         """Page-lock a numpy array in place for full-rate asynchronous copies."""
@@ -96,6 +110,9 @@ class MiniBatchLoader(object):
                 self.ctx.lib.bsc_host_unregister(a.ctypes.data)
             self._pinned = []
             self._in_flight = []
+            for p in self._host_allocs:
+                self.ctx.lib.bsc_host_free(p)
+            self._host_allocs = []
 
     def __del__(self):
         try:

@@ -22,9 +22,13 @@ def test_batches_arrive_intact_and_in_order(ctx):
     batches = make_batches(5, rows, D)
     batches[3] = (batches[3][0][:1234], batches[3][1][:1234])        # a short batch
     loader = MiniBatchLoader(ctx, rows, D, n_slots=2)
-    for X, y in batches:                                             # page-lock in place
-        loader.pin(X)
-        loader.pin(y)
+    pinned = []
+    for X, y in batches:                                             # page-locked copies (hipHostMalloc)
+        Xp, yp = loader.pinned_empty(X.shape), loader.pinned_empty(y.shape)
+        Xp[...] = X
+        yp[...] = y
+        pinned.append((Xp, yp))
+    batches = pinned
     W = ctx.to_device(np.ones((1, D), np.float32))
     Q = ctx.zeros(1, torch.float64)
     G = ctx.zeros(D, torch.float64)
