@@ -1342,6 +1342,13 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
             s.tiles_m = (int)((s.M + BM - 1) / BM);
             s.tiles_n = (int)((s.N + BN - 1) / BN);
             s.tiles_pb = s.tiles_m * s.tiles_n;
+            // A contraction two to six k-tiles long over many full tiles, nothing folded into the store: what a
+            // tile costs is its 64 KiB of stores, and one tile per workgroup (the hardware's dispatcher dealing
+            // them, LDS-staged 512-byte rows) does that 7 % better than the persistent schedule -- config 4's
+            // dot(Th, Bt), K = 128: 1.45 against 1.57 ms (profiles/r02_ab_gemm_stream_vs_tile_b64.txt)
+            const bool short_k_plain = K > 32 && K <= 6 * BK && !(epi.pow && epi.E) &&
+                                       (int64_t)s.tiles_pb * batch >= 8 * (int64_t)ctx->cu_count && s.M >= 2 * BM && s.N >= 2 * BN;
+            if (!short_k_plain) {
             // X^T X: the same matrix on both sides, transposed -- half the tiles (plus the diagonal)
             s.sym = ctx->gemm_sym && s.A == s.B && s.M == s.N && s.sa_m == s.sb_n && s.sa_k == s.sb_k && s.sa_b == s.sb_b &&
                     !(epi.pow && epi.E) && s.tiles_m > 1;
@@ -1391,6 +1398,7 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
                 BSC_LAUNCH_CHECK();
             }
             return BSC_OK;
+            }   // !short_k_plain
         }
     }
     GemmArgs g;
