@@ -122,6 +122,7 @@ SIGNATURES = {
                                          c_void_p, c_int64, c_int64, c_int64,
                                          c_void_p, c_int64, c_int64, c_int64,
                                          c_void_p, c_int64, c_int64, c_int64]),
+    "bsc_stream_plan": (c_int, [c_int64, c_int32, c_int64, POINTER(c_int32)]),
     "bsc_gemm_epilogue": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64,
                                   c_void_p, c_int64, c_int64, c_int64,
                                   c_void_p, c_int64, c_int64, c_int64,

@@ -1528,6 +1528,17 @@ int bsc_gemm_strided_batched(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, 
                      Epilogue{});
 }
 
+/* The persistent kernels' schedule, host side only (no device needed): how `tiles` tiles of `n_kt` units
+ * are dealt to `slots` resident workgroups.  out = {n_wg, rounds, tail_tiles, sk_stream, sk_q, sk_r}.
+ * Exposed so that the partition can be property-tested without a GPU (tests/test_stream_plan.py). */
+int bsc_stream_plan(int64_t tiles, int32_t n_kt, int64_t slots, int32_t out[6]) {
+    BSC_REQUIRE(out != nullptr && tiles >= 1 && n_kt >= 1 && slots >= 1, "bsc_stream_plan: bad arguments");
+    GemmArgs s{};
+    stream_plan(s, tiles, n_kt, slots);
+    out[0] = s.n_wg; out[1] = s.rounds; out[2] = s.tail_tiles; out[3] = s.sk_stream; out[4] = s.sk_q; out[5] = s.sk_r;
+    return BSC_OK;
+}
+
 int bsc_gemm_epilogue(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t N, int64_t K, const void* A,
                       int64_t sa_b, int64_t sa_m, int64_t sa_k, const void* B, int64_t sb_b, int64_t sb_k,
                       int64_t sb_n, void* C, int64_t sc_b, int64_t sc_m, int64_t sc_n, int power, double scale,

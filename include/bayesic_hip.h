@@ -429,6 +429,11 @@ int bsc_gemm_epilogue(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t
                       int64_t sa_b, int64_t sa_m, int64_t sa_k, const void* B, int64_t sb_b, int64_t sb_k,
                       int64_t sb_n, void* C, int64_t sc_b, int64_t sc_m, int64_t sc_n, int power, double scale,
                       const void* E, int64_t se_b, int64_t se_m, int64_t se_n);
+/* Host-only: the schedule the persistent kernels (GEMM, LDA statistic) use for `tiles` tiles of `n_kt`
+ * units on `slots` resident workgroups; out = {n_wg, rounds, tail_tiles, sk_stream, sk_q, sk_r} --
+ * workgroup w takes tiles w, w + n_wg, ... of `rounds` rounds, then units [u(w), u(w + 1)) of the
+ * tail tiles' unit list, u(w) = sk_stream ? w sk_q + min(w, sk_r) : min(w, tail_tiles) n_kt. */
+int bsc_stream_plan(int64_t tiles, int32_t n_kt, int64_t slots, int32_t out[6]);
 
 /* out[b] = log det A[b] for symmetric positive-definite A[b] (n x n, strides in
  * elements), by float64 Cholesky -- the T.logdet of MultivariateNormal's
