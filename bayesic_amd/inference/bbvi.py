@@ -35,7 +35,7 @@ class ScoreFunctionVI(object):
     """
 
     def __init__(self, log_joint, latents, data, n_samples, seed=0, lr=1e-2, backend=None,
-                 lam0=None):
+                 lam0=None, graph=False):
         from ..algebra.backend import resolve_backend
         from ..algebra.device_backend import DeviceBackend
         self.backend = resolve_backend(backend)
@@ -57,7 +57,11 @@ class ScoreFunctionVI(object):
             self.lam[:] = np.asarray(lam0, np.float64)
         self.m1, self.m2 = np.zeros_like(self.lam), np.zeros_like(self.lam)
         self.t = 0
-        self._f = log_joint.compile(self.backend)
+        # graph=True: the evaluation's launches are recorded once as a hipGraph and replayed
+        # (DeviceBackend.compile(graph=True)); the latent draws then live in fixed device buffers
+        self._graph = bool(graph)
+        self._f = log_joint.compile(self.backend, graph=True) if self._graph else log_joint.compile(self.backend)
+        self._z_dev = None
         types = log_joint.input_types
         latent_names = {v.name for v, _ in self.latents}
         missing = [n for n in types if n not in data and n not in latent_names]
@@ -87,9 +91,17 @@ class ScoreFunctionVI(object):
         """log p(data, z_s) for the rows of z [S, P]; the latents go to the device as float32."""
         inputs = dict(self._data)
         offset = 0
+        if self._graph and self._z_dev is None:
+            self._z_dev = {v.name: self.backend.from_host(np.zeros((self.S, n), np.float32), *self._types[v.name])
+                           for v, n in self.latents}
         for v, n in self.latents:
             block = np.ascontiguousarray(z[:, offset:offset + n], dtype=np.float32)
-            inputs[v.name] = self.backend.from_host(block, *self._types[v.name])
+            if self._graph:
+                import torch
+                self._z_dev[v.name].copy_(torch.from_numpy(block))
+                inputs[v.name] = self._z_dev[v.name]
+            else:
+                inputs[v.name] = self.backend.from_host(block, *self._types[v.name])
             offset += n
         out = self.backend.to_host(self._f.device_fn(**inputs))
         return np.asarray(out, np.float64).reshape(self.S)

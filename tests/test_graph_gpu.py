@@ -130,3 +130,23 @@ def test_compiled_expression_with_its_launches_recorded(sctx):
     x64 = Xd.double().cpu().numpy(); w64 = wd.double().cpu().numpy()
     ref = (np.exp(x64 @ w64 * 0.1) * (x64 @ w64)).sum() + 0.5 * (x64 * x64).sum()
     npt.assert_allclose(got, ref, rtol=2e-5)
+
+
+def test_score_function_engine_with_its_evaluation_recorded(sctx):
+    """ScoreFunctionVI(graph=True) against the eager engine: the same parameters, bit for bit."""
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from bayesic_amd.inference import ScoreFunctionVI
+    rs = np.random.RandomState(4)
+    N, D, S = 5000, 6, 32
+    Xs = rs.standard_normal((N, D)).astype(np.float32)
+    ys = (Xs @ (rs.standard_normal(D) / 3) + 0.5 * rs.standard_normal(N)).astype(np.float32)
+    X, y, W = A.var("X", 2), A.var("y", 1), A.var("W", 2)
+    r = A.dimshuffle(y, "x", 0) - A.dot(W, X.T)
+    lj = A.sum(r * r, axis=1) * (-0.5 / 0.25) + A.sum(W * W, axis=1) * (-0.5)
+    engines = [ScoreFunctionVI(lj, [(W, D)], dict(X=Xs, y=ys), n_samples=S, seed=3, backend=DeviceBackend(sctx),
+                               lr=0.01, graph=graph) for graph in (False, True)]
+    for step in range(8):
+        a, b = engines[0].step(), engines[1].step()
+        assert a == b
+        npt.assert_array_equal(engines[0].lam, engines[1].lam)
+    assert any(e["graph"] is not None for e in engines[1].backend._graphs.values())
