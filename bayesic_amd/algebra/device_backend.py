@@ -138,6 +138,8 @@ class DeviceBackend(Backend):
             self._keep.append(t)
         return t
 
+    _MAX_GRAPHS = 32
+
     def graph_call(self, key, fn, inputs):
         """``fn()`` issues launches that read the tensors in ``inputs`` (a list; the caller refreshes
         them in place) and returns a list of device tensors.  The first two calls under a ``key``
@@ -152,8 +154,15 @@ class DeviceBackend(Backend):
             if entry["ptrs"] == ptrs:
                 entry["graph"].launch()
                 return entry["outs"]
+            entry["graph"].destroy()
+            self._graphs.pop(key, None)
             entry = None                                  # other buffers: start over
         if entry is None:
+            if len(self._graphs) >= self._MAX_GRAPHS:            # (a key that keeps changing -- a scalar input that
+                old = next(iter(self._graphs))                    # varies per call -- must not pile up recordings)
+                dropped = self._graphs.pop(old)
+                if dropped["graph"] is not None:
+                    dropped["graph"].destroy()
             entry = self._graphs[key] = {"calls": 0, "graph": None, "ptrs": ptrs, "outs": None, "dead": False}
         entry["calls"] += 1
         if entry["dead"] or entry["calls"] < 3 or not self.ctx.can_capture or entry["ptrs"] != ptrs:
