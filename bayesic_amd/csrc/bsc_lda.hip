@@ -321,15 +321,19 @@ struct LdaStreamArgs {
     int64_t ldc, ldth, ldb, ldo, docs, V;
     int n_kt, sk_q, sk_r, sk_stream, n_wg, rounds, tail_tiles;   // tiles = 128-column blocks, units = 32-document steps
     int d_tail;        // documents in a block's last step, 1..32
+    int K;             // 32, 64 or 128
 };
 typedef stream_args_cptr<LdaStreamArgs> lda_args_cptr;
 
 #define LDA_LDS_B128(DST, ADDR, OFF) \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+#define LDA_LDS_B64(DST, ADDR, OFF) \
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
 #define LDA_LDS_B32(DST, ADDR, OFF) \
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
 
 typedef float lda_f32x4 __attribute__((ext_vector_type(4)));
+typedef float lda_f32x2 __attribute__((ext_vector_type(2)));
 
 // s_waitcnt lgkmcnt(n) alone (n a compile-time constant after unrolling)
 __device__ __forceinline__ void lda_wait_lgkm(int n) {
@@ -346,9 +350,12 @@ __device__ __forceinline__ void lda_wait_lgkm(int n) {
     }
 }
 
-__global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_stream_kernel(LdaStreamArgs a) {
-    constexpr int KT = 4, K = 128;
-    __shared__ __attribute__((aligned(1024))) char lds[2 * LS_STAGE];
+// KT = K / 32 in {1, 2, 4}: a Th row is RB = 128 KT bytes = CPR = 8 KT chunks; 8 / KT rows per DMA
+// instruction, KT instructions per wave and step; chunk c of row d at position c ^ (d % min(CPR, 16)).
+template <int KT>
+__device__ __forceinline__ void lda_sstats_stream_body(const LdaStreamArgs& a, char* lds) {
+    constexpr int K = 32 * KT, RB = 128 * KT, CPR = 8 * KT, SWZ = (CPR < 16 ? CPR : 16) - 1, RPI = 8 / KT;
+    constexpr int N1 = 4 * KT;                       // phase-1 reads (and 4-MFMA groups) per step
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
@@ -369,11 +376,11 @@ __global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_stream_kernel(LdaStre
     StreamCursor ic;
     ic.begin(stream_cold_args<LdaStreamArgs>(), w, tail_u0, tail_cnt);
     int issued = 0;
-    unsigned vth[4], vc[4];
+    unsigned vth[KT], vc[4];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int row = 2 * (4 * wave + jj) + (lane >> 5);
-        vth[jj] = (unsigned)(row * (int)a.ldth + 4 * ((lane & 31) ^ (row & 15))) * 4u;
+    for (int jj = 0; jj < KT; ++jj) {
+        const int row = RPI * (KT * wave + jj) + lane / CPR;
+        vth[jj] = (unsigned)(row * (int)a.ldth + 4 * ((lane % CPR) ^ (row & SWZ))) * 4u;
     }
     const float *th_ptr, *c_ptr;
     auto issue_tile = [&]() __attribute__((always_inline)) {
@@ -391,19 +398,20 @@ __global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_stream_kernel(LdaStre
     auto issue = [&](int buf) __attribute__((always_inline)) {
         const auto rth = __builtin_amdgcn_make_buffer_rsrc((void*)stream_uniform_ptr(th_ptr), 0, LS_OUTSIDE, 0x00020000);
         const auto rc = __builtin_amdgcn_make_buffer_rsrc((void*)stream_uniform_ptr(c_ptr), 0, LS_OUTSIDE, 0x00020000);
-        char* const dst = lds + buf * LS_STAGE + wave * 4096;
+        char* const dst = lds + buf * LS_STAGE + wave * 4096;            // C tile: 4 KiB per wave at + 16 KiB
+        char* const dth = lds + buf * LS_STAGE + wave * (KT * 1024);      // Th image: KT KiB per wave
         if (__builtin_expect(ic.kt != last_kt || d_tail == DT, 1)) {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rth, (bsc_lds_ptr)(dst + jj * 1024), 16, vth[jj], 0, 0, 0);
+            for (int jj = 0; jj < KT; ++jj)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rth, (bsc_lds_ptr)(dth + jj * 1024), 16, vth[jj], 0, 0, 0);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (bsc_lds_ptr)(dst + 16384 + jj * 1024), 16, vc[jj], 0, 0, 2);
         } else {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const bool in = 2 * (4 * wave + jj) + (lane >> 5) < d_tail;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rth, (bsc_lds_ptr)(dst + jj * 1024), 16, in ? vth[jj] : LS_OUTSIDE, 0, 0, 0);
+            for (int jj = 0; jj < KT; ++jj) {
+                const bool in = RPI * (KT * wave + jj) + lane / CPR < d_tail;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rth, (bsc_lds_ptr)(dth + jj * 1024), 16, in ? vth[jj] : LS_OUTSIDE, 0, 0, 0);
             }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -423,16 +431,19 @@ __global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_stream_kernel(LdaStre
 
     // ---- fragment addresses in buffer 0 (buffer 1: + LS_STAGE as an immediate)
     const unsigned lb = (unsigned)(uintptr_t)(bsc_lds_ptr)lds;
-    unsigned p1[16], p2[8];
+    unsigned p1[N1], p2[8];
 #pragma unroll
-    for (int t4 = 0; t4 < 16; ++t4)        // phase 1: document j, chunk 16 h + t4
-        p1[t4] = lb + (unsigned)(j * 512 + (((16 * h + t4) ^ (j & 15)) * 16));
+    for (int t4 = 0; t4 < N1; ++t4)        // phase 1: document j, chunk N1 h + t4
+        p1[t4] = lb + (unsigned)(j * RB + (((N1 * h + t4) ^ (j & SWZ)) * 16));
+    // phase 2: the KT topics KT j .. of document i + 8 q + 4 h (chunk KT j / 4, byte (4 KT j) % 16 of it),
+    // c2 = i + 4 (q & 1)
 #pragma unroll
-    for (int c2 = 0; c2 < 8; ++c2)         // phase 2: chunk j of document i + 8 q + 4 h, c2 = i + 4 (q & 1)
-        p2[c2] = lb + (unsigned)(4 * h * 512 + ((j ^ (4 * h) ^ ((c2 & 3) | ((c2 >> 2) << 3))) * 16));
+    for (int c2 = 0; c2 < 8; ++c2)
+        p2[c2] = lb + (unsigned)(4 * h * RB + ((((KT * j) >> 2) ^ ((4 * h) & SWZ) ^ (((c2 & 3) | ((c2 >> 2) << 3)) & SWZ)) * 16) +
+                                 ((4 * KT * j) & 15));
     const unsigned pc = lb + 16384 + (unsigned)(4 * h * 512 + (32 * wave + j) * 4);
 
-    float bt[K / 2];      // Bt[64 h + t][v]; at the end of a block: the factor Bt[4 row_r + kt][v] in bt[16 kt + r]
+    float bt[K / 2];      // Bt[(K / 2) h + t][v]; at the end of a block: the factor Bt[KT row_r + kt][v] in bt[16 kt + r]
 #pragma unroll
     for (int t = 0; t < K / 2; ++t) bt[t] = 0.f;
     f32x16 S[KT];
@@ -455,7 +466,7 @@ __global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_stream_kernel(LdaStre
             v_ok = v < gc->V;
             v_lane = (unsigned)(v_ok ? v : gc->V - 1) * 4u;
             whole = cc.kt == 0 && cc.left == gc->n_kt;
-            const unsigned off = v_lane + (unsigned)(64 * h) * (unsigned)gc->ldb * 4u;
+            const unsigned off = v_lane + (unsigned)((K / 2) * h) * (unsigned)gc->ldb * 4u;
             const float* base = gc->Bt;
             const int64_t ldb = gc->ldb;
 #pragma unroll
@@ -475,25 +486,35 @@ __global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_stream_kernel(LdaStre
                 for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
         }
         // slots: 0..15 phase-1 reads (b128); then per q: the four counts (4 x b32), four Th reads (b128)
-        auto slot_size = [](int s) { return s < 16 ? 1 : ((s - 16) % 5 == 0 ? 4 : 1); };
+        constexpr int NS = N1 + 20;                  // slots per step
+        auto slot_size = [](int s) { return s < N1 ? 1 : ((s - N1) % 5 == 0 ? 4 : 1); };
         auto issue_slot = [&](int s) __attribute__((always_inline)) {
             float (&dst)[4] = ring[s % 5];
-            if (s < 16) {
+            if (s < N1) {
                 lda_f32x4 v4;
                 LDA_LDS_B128(v4, p1[s], OFF);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dst[e] = v4[e];
             } else {
-                const int q = (s - 16) / 5, r5 = (s - 16) % 5;
+                const int q = (s - N1) / 5, r5 = (s - N1) % 5;
                 if (r5 == 0) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) LDA_LDS_B32(dst[i], pc, OFF + (i + 8 * q) * 512);
                 } else {
                     const int i = r5 - 1;
-                    lda_f32x4 v4;
-                    LDA_LDS_B128(v4, p2[i + 4 * (q & 1)], OFF + (i + 8 * q) * 512);
+                    if (KT == 4) {
+                        lda_f32x4 v4;
+                        LDA_LDS_B128(v4, p2[i + 4 * (q & 1)], OFF + (i + 8 * q) * RB);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dst[e] = v4[e];
+                        for (int e = 0; e < 4; ++e) dst[e] = v4[e];
+                    } else if (KT == 2) {
+                        lda_f32x2 v2;
+                        LDA_LDS_B64(v2, p2[i + 4 * (q & 1)], OFF + (i + 8 * q) * RB);
+                        dst[0] = v2[0];
+                        dst[1] = v2[1];
+                    } else {
+                        LDA_LDS_B32(dst[0], p2[i + 4 * (q & 1)], OFF + (i + 8 * q) * RB);
+                    }
                 }
             }
         };
@@ -502,21 +523,21 @@ __global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_stream_kernel(LdaStre
         issue_slot(2);
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 36; ++s) {
-            const int after = (s + 1 < 36 ? slot_size(s + 1) : 0) + (s + 2 < 36 ? slot_size(s + 2) : 0);
+        for (int s = 0; s < NS; ++s) {
+            const int after = (s + 1 < NS ? slot_size(s + 1) : 0) + (s + 2 < NS ? slot_size(s + 2) : 0);
             lda_wait_lgkm(after);
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 3 < 36) issue_slot(s + 3);
+            if (s + 3 < NS) issue_slot(s + 3);
             __builtin_amdgcn_sched_barrier(0);
             const float (&f)[4] = ring[s % 5];
-            if (s < 16) {
+            if (s < N1) {
                 // the first MFMA takes the constant 0 as its C operand: no 16 moves to clear P
                 P = __builtin_amdgcn_mfma_f32_32x32x2f32(f[0], bt[4 * s + 0], s == 0 ? zero16 : P, 0, 0, 0);
                 P = __builtin_amdgcn_mfma_f32_32x32x2f32(f[1], bt[4 * s + 1], P, 0, 0, 0);
                 P = __builtin_amdgcn_mfma_f32_32x32x2f32(f[2], bt[4 * s + 2], P, 0, 0, 0);
                 P = __builtin_amdgcn_mfma_f32_32x32x2f32(f[3], bt[4 * s + 3], P, 0, 0, 0);
             } else {
-                const int q = (s - 16) / 5, r5 = (s - 16) % 5;
+                const int q = (s - N1) / 5, r5 = (s - N1) % 5;
                 if (r5 == 0) {
                     // ratio in the result layout; padded documents / columns carry zero counts and P = 0:
                     // the clamp keeps 0 * rcp(0) from becoming NaN (real P are > 0)
@@ -543,12 +564,12 @@ __global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_stream_kernel(LdaStre
             if (whole) {
                 // sstats = Bt * S: the factors Bt[4 row_r + kt][v] into the (now free) bt registers
                 const int64_t ldb = gc->ldb, ldo = gc->ldo;
-                const unsigned off = v_lane + (unsigned)(16 * h) * (unsigned)ldb * 4u;
+                const unsigned off = v_lane + (unsigned)(4 * KT * h) * (unsigned)ldb * 4u;
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float* base = gc->Bt + (int64_t)(4 * ((r & 3) + 8 * (r >> 2)) + kt) * ldb;
+                        const float* base = gc->Bt + (int64_t)(KT * ((r & 3) + 8 * (r >> 2)) + kt) * ldb;
                         asm volatile("global_load_dword %0, %1, %2" : "+v"(bt[16 * kt + r]) : "v"(off), "s"(base) : "memory");
                     }
                 __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
@@ -598,6 +619,18 @@ __global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_stream_kernel(LdaStre
     __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
 }
 
+// (three plain kernels around the one body: hipcc left the host stub of a `template <int KT> __global__`
+// version of this kernel undefined)
+#define LDA_STREAM_KERNEL(NAME, KT_)                                                     \
+    __global__ __launch_bounds__(LDA_BLOCK, 2) void NAME(LdaStreamArgs a) {              \
+        __shared__ __attribute__((aligned(1024))) char lds[2 * LS_STAGE];                \
+        lda_sstats_stream_body<KT_>(a, lds);                                             \
+    }
+LDA_STREAM_KERNEL(lda_sstats_stream_kernel, 4)          // K = 128
+LDA_STREAM_KERNEL(lda_sstats_stream_k64_kernel, 2)
+LDA_STREAM_KERNEL(lda_sstats_stream_k32_kernel, 1)
+#undef LDA_STREAM_KERNEL
+
 // The column blocks that two or more runs share (see stream_fixup_kernel in csrc/bsc_gemm.hip):
 // sstats = Bt * (the pieces in document order).
 __global__ __launch_bounds__(64) void lda_stream_fixup_kernel(LdaStreamArgs g) {
@@ -611,7 +644,7 @@ __global__ __launch_bounds__(64) void lda_stream_fixup_kernel(LdaStreamArgs g) {
         const int x0 = stream_first_unit(&g, x);
         if (x0 >= t_end) break;
         if (stream_first_unit(&g, x + 1) == x0) continue;
-        v += *reinterpret_cast<const lda_f32x4*>(g.slab + ((int64_t)2 * x + (x0 / g.n_kt != t ? 1 : 0)) * (128 * VT) + e);
+        v += *reinterpret_cast<const lda_f32x4*>(g.slab + ((int64_t)2 * x + (x0 / g.n_kt != t ? 1 : 0)) * ((int64_t)g.K * VT) + e);
     }
     const int k = e >> 7;
     const int64_t col = (int64_t)(g.rounds * g.n_wg + t) * VT + (e & 127);
@@ -806,13 +839,13 @@ int bsc_lda_sstats(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int6
     a.fast = a.vec_c && a.vec_th && (32 * ldc + VT) * 4 < ((int64_t)1 << 31) &&
              (32 * ldth + K) * 4 < ((int64_t)1 << 31);
     const int64_t n_vt = (V + VT - 1) / VT;
-    if (K == 128 && ctx->lda_stream && docs > 0 && a.vec_c && a.vec_th && V % 4 == 0 &&
+    if ((K == 128 || K == 64 || K == 32) && ctx->lda_stream && docs > 0 && a.vec_c && a.vec_th && V % 4 == 0 &&
         (31 * ldc + VT) * 4 < ((int64_t)1 << 31) && (31 * ldth + K) * 4 < ((int64_t)1 << 31) &&
         (K * ldb + V) * 4 < ((int64_t)1 << 32) && V * 4 < ((int64_t)1 << 32) && n_vt < ((int64_t)1 << 24) &&
         (docs + DT - 1) / DT < ((int64_t)1 << 22)) {
         LdaStreamArgs g{};
         g.C = C; g.Th = Th; g.Bt = Bt; g.out = sstats;
-        g.ldc = ldc; g.ldth = ldth; g.ldb = ldb; g.ldo = ldo; g.docs = docs; g.V = V;
+        g.ldc = ldc; g.ldth = ldth; g.ldb = ldb; g.ldo = ldo; g.docs = docs; g.V = V; g.K = K;
         const int n_kt = (int)((docs + DT - 1) / DT);
         g.d_tail = (int)(docs - (int64_t)(n_kt - 1) * DT);
         stream_plan(g, n_vt, n_kt, 2 * (int64_t)ctx->cu_count);
@@ -823,7 +856,10 @@ int bsc_lda_sstats(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int6
         g.slab = (float*)ws;
         {
             bsc_prof_scope prof(ctx);
-            hipLaunchKernelGGL(lda_sstats_stream_kernel, dim3((unsigned)g.n_wg), dim3(LDA_BLOCK), 0, ctx->stream, g);
+            const dim3 grid((unsigned)g.n_wg), block(LDA_BLOCK);
+            if (K == 128) hipLaunchKernelGGL(lda_sstats_stream_kernel, grid, block, 0, ctx->stream, g);
+            else if (K == 64) hipLaunchKernelGGL(lda_sstats_stream_k64_kernel, grid, block, 0, ctx->stream, g);
+            else hipLaunchKernelGGL(lda_sstats_stream_k32_kernel, grid, block, 0, ctx->stream, g);
         }
         BSC_LAUNCH_CHECK();
         if (stream_has_pieces(g)) {

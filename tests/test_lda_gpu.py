@@ -173,9 +173,11 @@ def test_lda_driver_with_sparse_counts(ctx):
     npt.assert_allclose(a.lam.cpu().numpy(), b.lam.cpu().numpy(), rtol=3e-5)
 
 
-@pytest.mark.parametrize("docs,V", [(700, 67840), (33, 66000), (1000, 132), (4100, 1028)])
-def test_fused_lda_statistics_persistent_kernel_rounds_and_split_blocks(ctx, docs, V):
-    """K = 128 through lda_sstats_stream_kernel where the 128-column blocks exceed the resident
+@pytest.mark.parametrize("docs,V,K", [(700, 67840, 128), (33, 66000, 128), (1000, 132, 128), (4100, 1028, 128),
+                                      (700, 67840, 64), (4100, 1028, 64), (45, 260, 64),
+                                      (700, 67840, 32), (4100, 1028, 32), (33, 132, 32)])
+def test_fused_lda_statistics_persistent_kernel_rounds_and_split_blocks(ctx, docs, V, K):
+    """K = 128, 64, 32 through lda_sstats_stream_kernel where the 128-column blocks exceed the resident
     workgroups (a whole round, then left-over blocks split along the documents and added by the
     fix-up pass), with leading dimensions larger than the extents, a ragged last block and a short
     last document step -- against the one-block-per-workgroup kernel (BSC_LDA_STREAM=0) on the same
@@ -187,8 +189,7 @@ def test_fused_lda_statistics_persistent_kernel_rounds_and_split_blocks(ctx, doc
         plain = Context(0)
     finally:
         del os.environ["BSC_LDA_STREAM"]
-    K = 128
-    g = torch.Generator(device=ctx.device).manual_seed(docs + V)
+    g = torch.Generator(device=ctx.device).manual_seed(docs + V + K)
     ldc, ldth, ldb, ldo = V + 8, K + 4, V + 4, V + 12
     C = torch.poisson(torch.full((docs, ldc), 0.3, device=ctx.device), generator=g)
     Th = torch.rand((docs, ldth), generator=g, device=ctx.device) + 0.05
