@@ -213,6 +213,52 @@ __global__ __launch_bounds__(256) void softmax_rows_small_kernel(const float* __
     }
 }
 
+// cols % 4 == 0, 16-byte aligned rows, cols <= 256: a lane takes four consecutive columns, a row
+// occupies L = 2^ceil(log2(cols / 4)) lanes, a wave load covers 64 / L rows (1 KiB of a dense matrix
+// at cols = 64, where one lane per column moved 256 B per load and shuffled 12 times per row); two
+// row groups in flight per wave.
+template <int L>
+__global__ __launch_bounds__(256) void softmax_rows_vec4_kernel(const float* __restrict__ in, int64_t rows,
+                                                                int cols, int64_t ld_in, float* __restrict__ out,
+                                                                int64_t ld_out, float* __restrict__ lse) {
+    constexpr int RPW = 64 / L;
+    const int lane = threadIdx.x & 63;
+    const int c = 4 * (lane % L), sub = lane / L;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    for (int64_t r0 = wave * 2 * RPW; r0 < rows; r0 += n_waves * 2 * RPW) {
+        float4 x[2];
+        bool live[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t r = r0 + u * RPW + sub;
+            live[u] = r < rows && c < cols;
+            x[u] = live[u] ? *reinterpret_cast<const float4*>(in + r * ld_in + c)
+                           : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t r = r0 + u * RPW + sub;
+            float4 v = make_float4(x[u].x * LOG2E, x[u].y * LOG2E, x[u].z * LOG2E, x[u].w * LOG2E);
+            float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+#pragma unroll
+            for (int off = 1; off < L; off <<= 1) m = fmaxf(m, __shfl_xor(m, off));
+            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live[u])
+                e = make_float4(__builtin_amdgcn_exp2f(v.x - m), __builtin_amdgcn_exp2f(v.y - m),
+                                __builtin_amdgcn_exp2f(v.z - m), __builtin_amdgcn_exp2f(v.w - m));
+            float z = (e.x + e.y) + (e.z + e.w);
+#pragma unroll
+            for (int off = 1; off < L; off <<= 1) z += __shfl_xor(z, off);
+            const float rz = __builtin_amdgcn_rcpf(z), inv = rz * (2.0f - z * rz);
+            if (live[u])
+                *reinterpret_cast<float4*>(out + r * ld_out + c) = make_float4(e.x * inv, e.y * inv, e.z * inv, e.w * inv);
+            if (lse && r < rows && c == 0) lse[r] = (m + __builtin_amdgcn_logf(z)) * LN2;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void softmax_rows_wide_kernel(const float* __restrict__ in, int64_t rows, int cols,
                                                                 int64_t ld_in, float* __restrict__ out,
                                                                 int64_t ld_out, float* __restrict__ lse) {
@@ -286,6 +332,20 @@ int bsc_softmax_rows(bsc_ctx* ctx, const float* in, int64_t rows, int64_t cols, 
     if (blocks > 16 * (int64_t)ctx->cu_count) blocks = 16 * (int64_t)ctx->cu_count;
 #define BSC_SM(P) hipLaunchKernelGGL(softmax_rows_small_kernel<P>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, \
                                      in, rows, (int)cols, ld_in, out, ld_out, lse)
+    const bool vec4 = cols % 4 == 0 && cols >= 8 && cols <= 256 && ld_in % 4 == 0 && ld_out % 4 == 0 &&
+                      (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    if (vec4) {
+        const int l = cols <= 8 ? 2 : cols <= 16 ? 4 : cols <= 32 ? 8 : cols <= 64 ? 16 : cols <= 128 ? 32 : 64;
+        int64_t vb = (rows + 8 * (64 / l) - 1) / (8 * (64 / l));
+        if (vb > 16 * (int64_t)ctx->cu_count) vb = 16 * (int64_t)ctx->cu_count;
+#define BSC_SM4(L_) hipLaunchKernelGGL(softmax_rows_vec4_kernel<L_>, dim3((unsigned)vb), dim3(256), 0, ctx->stream, \
+                                       in, rows, (int)cols, ld_in, out, ld_out, lse)
+        if (l == 2) BSC_SM4(2); else if (l == 4) BSC_SM4(4); else if (l == 8) BSC_SM4(8); else if (l == 16) BSC_SM4(16);
+        else if (l == 32) BSC_SM4(32); else BSC_SM4(64);
+#undef BSC_SM4
+        BSC_LAUNCH_CHECK();
+        return BSC_OK;
+    }
     if (cols > 64)
         hipLaunchKernelGGL(softmax_rows_wide_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, in, rows,
                            (int)cols, ld_in, out, ld_out, lse);

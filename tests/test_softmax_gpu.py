@@ -9,7 +9,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("rows,cols", [(1, 1), (7, 3), (1000, 64), (4099, 17), (333, 2), (50, 65), (9, 1000),
-                                       (20000, 16), (5, 1024), (0, 8)])
+                                       (20000, 16), (5, 1024), (0, 8),
+                                       # the 16-bytes-per-lane kernel: every lane count, ragged row groups
+                                       (100003, 64), (7, 8), (4099, 12), (333, 28), (1001, 100), (50, 256), (13, 132)])
 def test_softmax_rows_matches_numpy(ctx, rows, cols):
     rs = np.random.RandomState(rows + cols)
     x = (rs.standard_normal((rows, cols)) * 6.0).astype(np.float32)
