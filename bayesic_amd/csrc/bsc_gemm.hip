@@ -56,6 +56,12 @@ struct GemmArgs {
     // sym: C = A B with B = A^T (the Gram statistic X^T X): only the tiles on and above the diagonal are
     // computed (tiles_pb = T (T + 1) / 2 of them), each off-diagonal one stored twice
     int sym;
+    // ksplit (EDGE instantiation, one tile, extents <= 64): the four waves share the tile's ONE 64 x 64
+    // sub-tile and take one 8-deep k-group of every k-tile each -- C[64 x 16] = R^T X over 10M rows is a
+    // quarter of one wave's work per k-tile instead of all of it; each wave's partial goes to the slab
+    // as a piece of its own (slot 4 (2 w + which) + wave)
+    int ksplit;
+    int fix_lanes;     // stream_fixup_kernel: piece lists per element quad (4 or 64)
     float* slab;       // [2 n_wg][128 n][128 m] partial tiles
 };
 
@@ -642,7 +648,8 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
     __shared__ __attribute__((aligned(1024))) char lds[2 * DMA_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const bool ksplit = EDGE && g.ksplit;
+    const int wm = ksplit ? 0 : wave >> 1, wn = ksplit ? 0 : wave & 1;     // (ksplit: every wave on sub-tile (0, 0))
     int w = blockIdx.x;
     int n_units, tail_u0, tail_cnt;
     {
@@ -801,7 +808,7 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
             tile_start = false;
             const gemm_args_cptr gc = stream_cold_args<GemmArgs>();
             stream_decode_tile(gc, cc.t, cb, cm0, cn0);
-            whole = cc.kt == 0 && cc.left == gc->n_kt;
+            whole = cc.kt == 0 && cc.left == gc->n_kt && !ksplit;      // (ksplit: every wave holds a partial)
             const float* E = gc->E;
             const bool c_vec = gc->sc_m == 1 && gc->sc_n % 4 == 0 && gc->sc_b % 4 == 0 && (((uintptr_t)gc->C) & 15) == 0 && gc->M % 4 == 0;
             const bool e_vec = !E || (gc->se_m == 1 && gc->se_n % 4 == 0 && gc->se_b % 4 == 0 && (((uintptr_t)E) & 15) == 0);
@@ -862,7 +869,7 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
             }
             __builtin_amdgcn_sched_barrier(0);
             if (!EDGE) mfmas(set);
-            else if (G < k_groups) mfmas_masked(set, blk_mask);
+            else if (G < k_groups && (!ksplit || G == wave)) mfmas_masked(set, blk_mask);
             __builtin_amdgcn_sched_barrier(0);
         }
         tog ^= DMA_STAGE;
@@ -876,7 +883,8 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
             if (!whole || (fast && interior && !mirror)) young += 16;    // 16 stores per lane below (edge / mirrored tiles: another count, wait for all)
             else young = 0;
             if (!whole) {
-                float* slot = gc->slab + ((int64_t)2 * w + (cc.round > gc->rounds ? 1 : 0)) * (BM * BN);
+                const int64_t piece = (int64_t)2 * w + (cc.round > gc->rounds ? 1 : 0);
+                float* slot = gc->slab + (ksplit ? 4 * piece + wave : piece) * (BM * BN);
                 float* p = slot + (wn * 64 + lane_n) * BM + wm * 64 + lane_m;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -972,18 +980,26 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
     __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
 }
 
-// The tiles that two or more runs share: boundary w (the first unit of workgroup w, 1 <= w < n_wg)
-// lies strictly inside tile t; the FIRST such boundary of a tile adds the tile's pieces in k
-// order -- workgroups w-1, w, w+1, ... up to the tile's end -- applies the epilogue and stores.
-// Slab slots are [n][m] like the accumulators: 16 bytes per lane along m.
+// The tiles that two or more runs share.  One block column per TAIL tile: the tile is split when its
+// first and last unit belong to different workgroups; its pieces -- workgroups owner(first unit) ..
+// owner(last unit), in that order -- are added, the epilogue applied, the result stored.  Slab slots
+// are [n][m] like the accumulators: 16 bytes per lane along m.
+__device__ __forceinline__ int stream_owner(const GemmArgs& g, int u) {          // (sk_stream only)
+    const int big = g.sk_r * (g.sk_q + 1);                   // units held by the sk_r workgroups with one more
+    return u < big ? u / (g.sk_q + 1) : g.sk_r + (u - big) / g.sk_q;
+}
+
 __global__ __launch_bounds__(256) void stream_fixup_kernel(GemmArgs g) {
-    __shared__ gemm_f32x4 part[3][64];
-    const int w = (int)blockIdx.x + 1;
-    const int b0 = stream_first_unit(&g, w);
-    const int t = b0 / g.n_kt, t_begin = t * g.n_kt, t_end = t_begin + g.n_kt;        // tail tile t
-    if (b0 == t_begin || stream_first_unit(&g, w - 1) > t_begin) return;
-    const int quad = threadIdx.x & 63, lane4 = threadIdx.x >> 6;    // 64 element quads x 4 interleaved piece lists
-    const int e = (blockIdx.y * 64 + quad) * 4;                   // element of the [128 n][128 m] tile
+    // PL piece lists per element quad (4, or 64 when a tile was cut into hundreds of pieces): list
+    // position p goes to lane p % PL, each lane adds its pieces in order with four loads in flight, the
+    // lanes' sums are added in lane order -- a fixed association, run to run
+    __shared__ gemm_f32x4 part[256];
+    const int PL = g.fix_lanes, QB = 256 / PL;                   // quads per block
+    const int t = (int)blockIdx.x, t_begin = t * g.n_kt, t_end = t_begin + g.n_kt;    // tail tile t
+    const int x_first = stream_owner(g, t_begin), x_last = stream_owner(g, t_end - 1);
+    if (x_first == x_last) return;                               // one workgroup had all of it: stored there
+    const int quad = threadIdx.x % QB, lane4 = threadIdx.x / QB;
+    const int e = (blockIdx.y * QB + quad) * 4;                   // element of the [128 n][128 m] tile
     const int n = e >> 7, m = e & 127;
     int64_t b, m0, n0;
     stream_decode_tile(&g, g.rounds * g.n_wg + t, b, m0, n0);
@@ -991,31 +1007,30 @@ __global__ __launch_bounds__(256) void stream_fixup_kernel(GemmArgs g) {
     const bool inside = col < g.N && m0 + m < g.M;              // (elements outside the matrix are not even read)
     gemm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (inside) {
-        // the pieces in k order: list position p goes to lane p % 4, four loads in flight per lane;
-        // the four lanes' sums are added in lane order below -- a fixed association, run to run
+        // workgroup x's piece of this tile: its first tail tile -> slot 0, a later one -> slot 1
+        const int subs = g.ksplit ? 4 : 1;                        // (ksplit: a workgroup left four pieces, one per wave)
+        const int n_pieces = (x_last - x_first + 1) * subs;
         const float* piece[4];
-        int n_piece = 0, pos = 0;
-        for (int x = w - 1; x < g.n_wg; ++x) {
-            const int x0 = stream_first_unit(&g, x);
-            if (x0 >= t_end) break;
-            if (stream_first_unit(&g, x + 1) == x0) continue;             // a workgroup without tail units
-            if ((pos++ & 3) != lane4) continue;
-            piece[n_piece++] = g.slab + ((int64_t)2 * x + (x0 / g.n_kt != t ? 1 : 0)) * (BM * BN) + e;
+        int n_piece = 0;
+        for (int p = lane4; p < n_pieces; p += PL) {
+            const int x = x_first + p / subs, sub = p - (p / subs) * subs;
+            const int64_t base = (int64_t)2 * x + (stream_first_unit(&g, x) / g.n_kt != t ? 1 : 0);
+            piece[n_piece++] = g.slab + (g.ksplit ? 4 * base + sub : base) * (BM * BN) + e;
             if (n_piece == 4) {
-                gemm_f32x4 p[4];
+                gemm_f32x4 q4[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) p[i] = *reinterpret_cast<const gemm_f32x4*>(piece[i]);
+                for (int i = 0; i < 4; ++i) q4[i] = *reinterpret_cast<const gemm_f32x4*>(piece[i]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v += p[i];
+                for (int i = 0; i < 4; ++i) v += q4[i];
                 n_piece = 0;
             }
         }
         for (int i = 0; i < n_piece; ++i) v += *reinterpret_cast<const gemm_f32x4*>(piece[i]);
     }
-    if (lane4 > 0) part[lane4 - 1][quad] = v;
+    part[lane4 * QB + quad] = v;
     __syncthreads();
     if (lane4 > 0 || !inside) return;
-    v = ((v + part[0][quad]) + part[1][quad]) + part[2][quad];
+    for (int l = 1; l < PL; ++l) v += part[l * QB + quad];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int64_t row = m0 + m + q;
@@ -1350,6 +1365,8 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
                                        (int64_t)s.tiles_pb * batch >= 8 * (int64_t)ctx->cu_count && s.M >= 2 * BM && s.N >= 2 * BN;
             if (!short_k_plain) {
             // X^T X: the same matrix on both sides, transposed -- half the tiles (plus the diagonal)
+            s.ksplit = 0;
+            s.fix_lanes = 4;
             s.sym = ctx->gemm_sym && s.A == s.B && s.M == s.N && s.sa_m == s.sb_n && s.sa_k == s.sb_k && s.sa_b == s.sb_b &&
                     !(epi.pow && epi.E) && s.tiles_m > 1;
             if (s.sym) s.tiles_pb = s.tiles_m * (s.tiles_m + 1) / 2;
@@ -1367,8 +1384,12 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
             s.n_kt = (int)((K + BK - 1) / BK);
             s.dbg = ctx->gemm_dbg;
             stream_plan(s, (int64_t)s.tiles_pb * batch, s.n_kt, 2 * (int64_t)ctx->cu_count);
+            // one tile with both extents within a wave's 64 x 64 and a long contraction, split along it: the
+            // four waves of a workgroup split the k-groups (EDGE instantiation)
+            s.ksplit = s.sk_stream && s.tiles_pb * batch == 1 && s.M <= 64 && s.N <= 64 && s.n_wg > 1 && s.rounds == 0 &&
+                       K % 32 == 0;
             void* ws = nullptr;
-            int rc = bsc_workspace(ctx, (size_t)2 * s.n_wg * BM * BN * sizeof(float), &ws);
+            int rc = bsc_workspace(ctx, (size_t)(s.ksplit ? 8 : 2) * s.n_wg * BM * BN * sizeof(float), &ws);
             if (rc != BSC_OK) return rc;
             s.slab = (float*)ws;
             ctx->slab_rows = 0;
@@ -1393,7 +1414,9 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
             }
             BSC_LAUNCH_CHECK();
             if (stream_has_pieces(s)) {
-                hipLaunchKernelGGL(stream_fixup_kernel, dim3((unsigned)(s.n_wg - 1), BM * BN / 256), dim3(256), 0,
+                // pieces per split tile: about n_wg / tail_tiles (x 4 with ksplit)
+                s.fix_lanes = (int64_t)s.n_wg * (s.ksplit ? 4 : 1) >= 64 * (int64_t)s.tail_tiles ? 64 : 4;
+                hipLaunchKernelGGL(stream_fixup_kernel, dim3((unsigned)s.tail_tiles, BM * BN / 4 / (256 / s.fix_lanes)), dim3(256), 0,
                                    ctx->stream, s);
                 BSC_LAUNCH_CHECK();
             }
@@ -1411,7 +1434,7 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
     g.epi_scale = epi.scale; g.epi_pow = epi.pow;
     g.n_kt = 0; g.sk_q = 0; g.sk_r = 0; g.sk_stream = 0; g.n_wg = 0; g.rounds = 0; g.tail_tiles = 0; g.tiles_pb = 0;
     g.group = 1; g.dbg = 0; g.slab = nullptr;
-    g.mg_pb = g.mg_strip = g.mg_last = 0; g.sh_pb = g.sh_strip = g.sh_last = g.group_log2 = 0; g.sym = 0;
+    g.mg_pb = g.mg_strip = g.mg_last = 0; g.sh_pb = g.sh_strip = g.sh_last = g.group_log2 = 0; g.sym = 0; g.ksplit = 0; g.fix_lanes = 4;
     g.tiles_m = (int)((M + BM - 1) / BM);
     g.tiles_n = (int)((N + BN - 1) / BN);
     const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * batch;

@@ -250,7 +250,9 @@ def test_skinny_products_long_contraction_tn(dev, M, D, K):
 
 
 @pytest.mark.parametrize("M,N,K,batch", [(128, 128, 32, 1), (132, 260, 1004, 1), (130, 257, 1000, 1), (256, 384, 36, 1),
-                                          (100, 516, 8, 3), (4, 8, 4, 2), (640, 132, 4100, 1), (257, 129, 20, 1)])
+                                          (100, 516, 8, 3), (4, 8, 4, 2), (640, 132, 4100, 1), (257, 129, 20, 1),
+                                          # one small tile, long contraction: the waves split the k-groups
+                                          (64, 16, 96000, 1), (60, 64, 32768, 1), (8, 4, 40000, 1)])
 def test_gemm_operands_by_lds_dma_all_layouts(ctx, M, N, K, batch):
     """bsc_gemm_strided_batched in the four operand layouts (each operand contiguous along its
     free axis or along k): the LDS-DMA kernel (gemm_f32_dma_kernel) wherever 16-byte pieces fall
