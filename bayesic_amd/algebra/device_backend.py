@@ -125,6 +125,9 @@ class DeviceBackend(Backend):
         self.fuse = bool(fuse)
         self._one = None          # a resident float32 1.0 (broadcast_to of a host scalar)
         self._keep = None         # buffers made inside an open graph capture
+        self._const = set()       # storages the caller promised not to change (mark_constant)
+        self._const_cache = {}    # element-wise values of constants only: computed once, LRU by bytes
+        self._const_bytes = 0
         self._graphs = {}         # graph_call: key -> recorded hipGraph
         self.ctx = ctx if ctx is not None else default_context()
         if not isinstance(self.ctx, Context):
@@ -189,6 +192,22 @@ class DeviceBackend(Backend):
         entry["graph"], entry["outs"] = graph, outs
         graph.launch()                                    # a capture records, it does not run
         return outs
+
+    _CONST_CACHE_BYTES = 8 << 30
+
+    def mark_constant(self, *tensors):
+        """A promise that these device tensors (a model's data) are not written while they stay marked:
+        an element-wise value of constants only -- ``X * X`` in every message of a Gaussian model --
+        is then computed once and kept (up to _CONST_CACHE_BYTES, least recently used first out)
+        instead of being recomputed by every evaluation that contains it."""
+        for t in tensors:
+            if isinstance(t, torch.Tensor):
+                self._const.add(t.untyped_storage().data_ptr())
+
+    def forget_constants(self):
+        self._const.clear()
+        self._const_cache.clear()
+        self._const_bytes = 0
 
     def compile(self, expr, bindings=None, graph=False):
         """As ``Backend.compile``.  ``graph=True``: ``f.device_fn(**device_inputs)`` records its launches
@@ -374,7 +393,29 @@ class DeviceBackend(Backend):
         shape = lazy.shape
         terms = lazy.terms
         out = None
-        if not red and rank > 1:
+        ckey = None
+        if self._const and not red and self._keep is None and \
+                all(t.untyped_storage().data_ptr() in self._const for t, _, _ in terms):
+            ckey = (lazy.combine, tuple((t.data_ptr(), tuple(t.shape), tuple(t.stride()), op, float(arg))
+                                        for t, op, arg in terms),
+                    float(lazy.scale), float(lazy.shift), lazy.post, tuple(shape), lazy.dtype)
+            hit = self._const_cache.pop(ckey, None)
+            if hit is not None:
+                self._const_cache[ckey] = hit            # most recently used last
+                return hit
+        if ckey is not None:
+            # kept across evaluations: not a buffer of the per-expression memory plan
+            nbytes = math.prod(shape) * (8 if lazy.dtype == torch.float64 else 4)
+            while self._const_cache and self._const_bytes + nbytes > self._CONST_CACHE_BYTES:
+                old_key = next(iter(self._const_cache))
+                old = self._const_cache.pop(old_key)
+                self._const_bytes -= old.numel() * old.element_size()
+                self._const.discard(old.untyped_storage().data_ptr())
+            if nbytes <= self._CONST_CACHE_BYTES:
+                out = self.ctx.empty([shape[a] for a in keep], lazy.dtype)
+            else:
+                ckey = None
+        if out is None and not red and rank > 1:
             # Pure map: lay the result out the way its biggest operand lies in memory (a
             # transposed view stays a transposed view) so that reads and writes both stream;
             # a row-major result of a column-major operand is an uncoalesced transpose.
@@ -407,6 +448,10 @@ class DeviceBackend(Backend):
                       _i64(keep_strides), _i64(red_strides), pre_ops, pre_args, float(lazy.scale),
                       float(lazy.shift), _OPS[post_op], float(post_arg), _ffi.ptr(out),
                       _i64(out.stride()))
+        if ckey is not None:
+            self._const_cache[ckey] = out
+            self._const_bytes += out.numel() * out.element_size()
+            self._const.add(out.untyped_storage().data_ptr())      # a value of constants is a constant
         return out
 
     def _force(self, v):

@@ -432,6 +432,10 @@ class MeanFieldVMP(object):
                 node.bind(self.backend)
         self._data = {name: self.backend.from_host(value, *types[name])
                       for name, value in data.items() if name in types}
+        if hasattr(self.backend, "mark_constant"):
+            # the data never changes between updates: element-wise values of data alone (x^2 in every
+            # message of a Gaussian model) are computed once by the device executor, not per message
+            self.backend.mark_constant(*self._data.values())
         carried = {self._carrier(t) for n in self.nodes for t in n.statistics} - {None}
         missing = [n for n in types
                    if n not in self._data and n not in carried and n not in self._by_name]
@@ -487,6 +491,9 @@ class MeanFieldVMP(object):
             if name not in self._types:
                 raise TypeError("%s is not an input of the log-joint" % name)
             self._data[name] = self.backend.from_host(value, *self._types[name])
+        if hasattr(self.backend, "mark_constant"):
+            self.backend.forget_constants()
+            self.backend.mark_constant(*self._data.values())
         if self._elbo_fns is not None:
             self._elbo_data = dict(self._data)
 

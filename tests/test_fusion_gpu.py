@@ -363,3 +363,38 @@ def test_narrow_rows_with_several_row_vector_operands(dev, R, C):
     e2 = P * row(a) * row(b) * Q
     npt.assert_allclose(e2.compile(dev)(P=P_, Q=Q_, a=a_, b=b_), P_.astype(np.float64) * a_ * b_ * Q_, rtol=2e-5,
                         atol=1e-6)
+
+
+def test_values_of_constant_data_are_computed_once(ctx):
+    """DeviceBackend.mark_constant: an element-wise value of marked inputs only (x * x feeding a
+    contraction) is launched once and reused by later evaluations -- of this and of other expressions --
+    until forget_constants(); unmarked operands are recomputed as before."""
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    be = DeviceBackend(ctx)
+    rs = np.random.RandomState(5)
+    X_ = rs.standard_normal((3000, 12)).astype(np.float32)
+    R_ = rs.rand(3000, 7).astype(np.float32)
+    T_ = rs.rand(7, 12).astype(np.float32)
+    X, R, Tm = var("X", 2), var("R", 2), var("Tm", 2)
+    stat = dot(R.T, X * X)                      # sum_n r_nk x_nd^2
+    logit = dot(X * X, Tm.T)                    # another expression with the same constant sub-value
+    Xd, Rd, Td = (be.from_host(a, "float32", 2) for a in (X_, R_, T_))
+    f, h = stat.compile(be).device_fn, logit.compile(be).device_fn
+    with Counting(ctx) as c:
+        a0 = be.to_host(f(R=Rd, X=Xd))
+    assert c.count("bsc_map_reduce") == 1       # unmarked: x * x is a launch of every evaluation
+    be.mark_constant(Xd)
+    with Counting(ctx) as c:
+        a1 = be.to_host(f(R=Rd, X=Xd))
+        a2 = be.to_host(f(R=Rd, X=Xd))
+        b1 = be.to_host(h(X=Xd, Tm=Td))
+    assert c.count("bsc_map_reduce") == 1       # once for all three
+    npt.assert_array_equal(a0, a1)
+    npt.assert_array_equal(a1, a2)
+    x64 = X_.astype(np.float64)
+    npt.assert_allclose(a1, R_.astype(np.float64).T @ (x64 * x64), rtol=2e-5)
+    npt.assert_allclose(b1, (x64 * x64) @ T_.astype(np.float64).T, rtol=2e-5)
+    be.forget_constants()
+    with Counting(ctx) as c:
+        be.to_host(f(R=Rd, X=Xd))
+    assert c.count("bsc_map_reduce") == 1
