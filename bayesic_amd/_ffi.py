@@ -58,6 +58,10 @@ SIGNATURES = {
                                   c_void_p, c_int32, c_void_p, c_void_p]),
     "bsc_blr_data_pass_partial": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32,
                                           c_void_p, c_int32]),
+    "bsc_blr_data_pass_sweep": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32,
+                                        c_void_p, c_int32, c_void_p, c_void_p, c_int32]),
+    "bsc_blr_data_pass_partial_sweep": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                                c_int32, c_void_p, c_int32, c_int32]),
     "bsc_blr_fused_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,
                                      c_double, c_double, c_double, c_int64, c_double, c_double,

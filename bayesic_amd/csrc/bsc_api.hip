@@ -74,6 +74,7 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
         ctx->blr_finish_block = (v == 256 || v == 512) ? v : 1024;
     }
     if (const char* e = getenv("BSC_BLR_PK")) ctx->blr_pk = atoi(e) != 0;
+    if (const char* e = getenv("BSC_BLR_KEEP")) ctx->blr_keep = atoi(e);
     if (const char* e = getenv("BSC_FUSED_MAP_BLOCKS_PER_CU")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 64) ctx->fused_map_blocks_per_cu = v;

@@ -293,11 +293,11 @@ struct MTile {
     float4 yv;     // y[row0 + 4 kq .. + 3]: the rows of this lane's MFMA result registers
 };
 
-template <bool NT>
-__device__ __forceinline__ void load_mtile(MTile& t, const float* __restrict__ X, int64_t ldx,
-                                           const float* __restrict__ y, int64_t row0, int64_t B,
-                                           int lane) {
-    const int64_t rem = B - row0;
+template <int AUX>
+__device__ __forceinline__ void load_mtile_policy(MTile& t, const float* __restrict__ X, int64_t ldx,
+                                                  const float* __restrict__ y, int64_t row0, int64_t B,
+                                                  int lane) {
+    const int64_t rem = row0 < 0 ? 0 : B - row0;   // a window before row 0 is as empty as one past B
     uint64_t xbytes = 0, ybytes = 0;
     if (rem > 0) {
         xbytes = ((uint64_t)(rem - 1) * (uint64_t)ldx + (uint64_t)GCOLS) * 4u;
@@ -312,7 +312,7 @@ __device__ __forceinline__ void load_mtile(MTile& t, const float* __restrict__ X
     const int row_bytes = (int)(ldx * 4);
 #pragma unroll
     for (int r = 0; r < MT_ROWS; ++r) {
-        auto v = __builtin_amdgcn_raw_buffer_load_b128(xs, lane_off, r * row_bytes, NT ? 2 : 0);
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(xs, lane_off, r * row_bytes, AUX);
         t.x[r] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
                              __uint_as_float(v[3]));
     }
@@ -321,10 +321,85 @@ __device__ __forceinline__ void load_mtile(MTile& t, const float* __restrict__ X
                        __uint_as_float(v[3]));
 }
 
+// One iteration of a wave: the tile in `t` goes to LDS and `t` takes the tile at next_row0 with
+// the cache policy STREAM (non-temporal) or not (allocating); then forward, residuals, backward.
+template <int AUX, bool PK>
+__device__ __forceinline__ void mfma_tile_step(MTile& t, float* __restrict__ tl, float* __restrict__ rb,
+                                               const float (&wreg)[GCOLS / 4], float4 (&acc)[SG],
+                                               float& qacc, const float* __restrict__ X, int64_t ldx,
+                                               const float* __restrict__ y, int64_t next_row0,
+                                               int64_t B, int lane) {
+    const int i16 = lane & 15, kq = lane >> 4;
+    const bool live = i16 < SG;                 // lanes whose MFMA column is a sample
+    // the tile to LDS, then its registers take the next tile (unconditional prefetch:
+    // tiles outside the mini-batch read zeros without touching memory)
+#pragma unroll
+    for (int r = 0; r < MT_ROWS; ++r)
+        *reinterpret_cast<float4*>(tl + r * MT_RS + 4 * lane) = t.x[r];
+    const float4 yv = t.yv;
+    load_mtile_policy<AUX>(t, X, ldx, y, next_row0, B, lane);
+    wave_lds_sync();
+
+    // forward on the MFMA pipe; two accumulators so that no MFMA waits on its predecessor
+    mfma_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+    const float* arow = tl + i16 * MT_RS + 64 * kq;
+#pragma unroll
+    for (int j = 0; j < GCOLS / 16; j += 2) {
+        const float4 a0 = *reinterpret_cast<const float4*>(arow + 4 * j);
+        const float4 a1 = *reinterpret_cast<const float4*>(arow + 4 * j + 4);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wreg[4 * j + 0], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wreg[4 * j + 4], d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wreg[4 * j + 1], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wreg[4 * j + 5], d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wreg[4 * j + 2], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wreg[4 * j + 6], d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wreg[4 * j + 3], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wreg[4 * j + 7], d1, 0, 0, 0);
+    }
+    // result register reg of lane (i16, kq) = dot(row 4 kq + reg, sample i16)
+    if (live) {
+        const float r0 = yv.x - (d0[0] + d1[0]), r1 = yv.y - (d0[1] + d1[1]);
+        const float r2 = yv.z - (d0[2] + d1[2]), r3 = yv.w - (d0[3] + d1[3]);
+        qacc = fmaf(r0, r0, qacc); qacc = fmaf(r1, r1, qacc);
+        qacc = fmaf(r2, r2, qacc); qacc = fmaf(r3, r3, qacc);
+        float* dst = rb + (4 * kq) * SG + i16;
+        dst[0] = r0; dst[SG] = r1; dst[2 * SG] = r2; dst[3 * SG] = r3;
+    }
+    wave_lds_sync();
+
+    // backward on the VALU: rows from LDS (row-major again), residuals by broadcast
+#pragma unroll
+    for (int r = 0; r < MT_ROWS; ++r) {
+        if ((r & 3) == 0 && r) asm volatile("" ::: "memory");   // four rows of reads in flight
+        const float4 x4 = *reinterpret_cast<const float4*>(tl + r * MT_RS + 4 * lane);
+        const float4 c0 = *reinterpret_cast<const float4*>(rb + r * SG);
+        const float4 c1 = *reinterpret_cast<const float4*>(rb + r * SG + 4);
+        if (PK) {
+            axpy4_pk(acc[0], c0.x, x4); axpy4_pk(acc[1], c0.y, x4);
+            axpy4_pk(acc[2], c0.z, x4); axpy4_pk(acc[3], c0.w, x4);
+            axpy4_pk(acc[4], c1.x, x4); axpy4_pk(acc[5], c1.y, x4);
+            axpy4_pk(acc[6], c1.z, x4); axpy4_pk(acc[7], c1.w, x4);
+        } else {
+            axpy4(acc[0], c0.x, x4); axpy4(acc[1], c0.y, x4);
+            axpy4(acc[2], c0.z, x4); axpy4(acc[3], c0.w, x4);
+            axpy4(acc[4], c1.x, x4); axpy4(acc[5], c1.y, x4);
+            axpy4(acc[6], c1.z, x4); axpy4(acc[7], c1.w, x4);
+        }
+    }
+    wave_lds_sync();   // the next iteration overwrites the tile
+}
+
+// Sweep order.  Iteration k of every wave reads one contiguous WINDOW of gridDim.x * 4 tiles (33 MB at
+// 1M x 256 on 505 workgroups); `rev` walks the windows from the end of the mini-batch to its start.
+// The last `keep` windows of a sweep are read with the allocating cache policy, everything before them
+// non-temporal: they are then still in the 256 MiB Infinity Cache when the NEXT sweep over the same
+// mini-batch -- run in the other direction -- starts with exactly those windows.  The policy changes
+// once per sweep, so the loop is split in two straight-line bodies rather than branching per tile
+// (a per-tile branch around the loads cost 6 us of the 164).
 template <bool NT, bool PK>
 __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_mfma_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ y, int64_t B,
-    const float* __restrict__ W, int S, float* __restrict__ slab, int n_iter) {
+    const float* __restrict__ W, int S, float* __restrict__ slab, int n_iter, int rev, int keep) {
     constexpr int LDS_FLOATS = PASS_WAVES * (MT_WAVE_LDS > SLAB_STRIDE ? MT_WAVE_LDS : SLAB_STRIDE);
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     const int tid = threadIdx.x;
@@ -351,70 +426,25 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_mfma_kernel(
 #pragma unroll
     for (int s = 0; s < SG; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     float qacc = 0.f;
-    const bool live = i16 < SG;                 // lanes whose MFMA column is a sample
+    const bool live = i16 < SG;
 
-    const int64_t stride = (int64_t)gridDim.x * PASS_WAVES;
-    int64_t tile = (int64_t)blockIdx.x * PASS_WAVES + wave;
+    const int64_t stride0 = (int64_t)gridDim.x * PASS_WAVES;
+    const int64_t stride = rev ? -stride0 : stride0;
+    int64_t tile = (int64_t)blockIdx.x * PASS_WAVES + wave + (rev ? (int64_t)(n_iter - 1) * stride0 : 0);
+    if (!NT) keep = n_iter;                    // every load allocating
+    const int n_stream = n_iter - keep > 0 ? n_iter - keep : 0;   // windows read non-temporal
     MTile t;
-    load_mtile<NT>(t, X, ldx, y, tile * MT_ROWS, B, lane);
-    for (int k = 0; k < n_iter; ++k) {
-        // the tile to LDS, then its registers take the next tile (unconditional prefetch:
-        // tiles past the end read zeros without touching memory)
-#pragma unroll
-        for (int r = 0; r < MT_ROWS; ++r)
-            *reinterpret_cast<float4*>(tl + r * MT_RS + 4 * lane) = t.x[r];
-        const float4 yv = t.yv;
+    if (n_stream > 0) load_mtile_policy<2>(t, X, ldx, y, n_iter > 0 ? tile * MT_ROWS : B, B, lane);
+    else load_mtile_policy<0>(t, X, ldx, y, n_iter > 0 ? tile * MT_ROWS : B, B, lane);
+    int k = 0;
+    for (; k + 1 < n_stream; ++k) {            // this window and the next one streamed
         tile += stride;
-        load_mtile<NT>(t, X, ldx, y, tile * MT_ROWS, B, lane);
-        wave_lds_sync();
-
-        // forward on the MFMA pipe; two accumulators so that no MFMA waits on its predecessor
-        mfma_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-        const float* arow = tl + i16 * MT_RS + 64 * kq;
-#pragma unroll
-        for (int j = 0; j < GCOLS / 16; j += 2) {
-            const float4 a0 = *reinterpret_cast<const float4*>(arow + 4 * j);
-            const float4 a1 = *reinterpret_cast<const float4*>(arow + 4 * j + 4);
-            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wreg[4 * j + 0], d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wreg[4 * j + 4], d1, 0, 0, 0);
-            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wreg[4 * j + 1], d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wreg[4 * j + 5], d1, 0, 0, 0);
-            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wreg[4 * j + 2], d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wreg[4 * j + 6], d1, 0, 0, 0);
-            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wreg[4 * j + 3], d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wreg[4 * j + 7], d1, 0, 0, 0);
-        }
-        // result register reg of lane (i16, kq) = dot(row 4 kq + reg, sample i16)
-        if (live) {
-            const float r0 = yv.x - (d0[0] + d1[0]), r1 = yv.y - (d0[1] + d1[1]);
-            const float r2 = yv.z - (d0[2] + d1[2]), r3 = yv.w - (d0[3] + d1[3]);
-            qacc = fmaf(r0, r0, qacc); qacc = fmaf(r1, r1, qacc);
-            qacc = fmaf(r2, r2, qacc); qacc = fmaf(r3, r3, qacc);
-            float* dst = rb + (4 * kq) * SG + i16;
-            dst[0] = r0; dst[SG] = r1; dst[2 * SG] = r2; dst[3 * SG] = r3;
-        }
-        wave_lds_sync();
-
-        // backward on the VALU: rows from LDS (row-major again), residuals by broadcast
-#pragma unroll
-        for (int r = 0; r < MT_ROWS; ++r) {
-            if ((r & 3) == 0 && r) asm volatile("" ::: "memory");   // four rows of reads in flight
-            const float4 x4 = *reinterpret_cast<const float4*>(tl + r * MT_RS + 4 * lane);
-            const float4 c0 = *reinterpret_cast<const float4*>(rb + r * SG);
-            const float4 c1 = *reinterpret_cast<const float4*>(rb + r * SG + 4);
-            if (PK) {
-                axpy4_pk(acc[0], c0.x, x4); axpy4_pk(acc[1], c0.y, x4);
-                axpy4_pk(acc[2], c0.z, x4); axpy4_pk(acc[3], c0.w, x4);
-                axpy4_pk(acc[4], c1.x, x4); axpy4_pk(acc[5], c1.y, x4);
-                axpy4_pk(acc[6], c1.z, x4); axpy4_pk(acc[7], c1.w, x4);
-            } else {
-                axpy4(acc[0], c0.x, x4); axpy4(acc[1], c0.y, x4);
-                axpy4(acc[2], c0.z, x4); axpy4(acc[3], c0.w, x4);
-                axpy4(acc[4], c1.x, x4); axpy4(acc[5], c1.y, x4);
-                axpy4(acc[6], c1.z, x4); axpy4(acc[7], c1.w, x4);
-            }
-        }
-        wave_lds_sync();   // the next iteration overwrites the tile
+        mfma_tile_step<2, PK>(t, tl, rb, wreg, acc, qacc, X, ldx, y, tile * MT_ROWS, B, lane);
+    }
+    for (; k < n_iter; ++k) {                  // the next window is kept (or is the empty one after the last)
+        tile += stride;
+        mfma_tile_step<0, PK>(t, tl, rb, wreg, acc, qacc, X, ldx, y,
+                                  k + 1 < n_iter ? tile * MT_ROWS : B, B, lane);
     }
 
     // block reduction through LDS, fixed order over waves (same slab layout as above)
@@ -1073,15 +1103,31 @@ void launch_pass_rows(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y,
                            0, ctx->stream, X, ldx, y, B, D, W, sg, slab, g.n_iter);
 }
 
+// Windows (one per iteration: n_blocks * 4 tiles of 16 rows) that fit the Infinity Cache.
+int keep_windows(const bsc_ctx* ctx, int64_t ldx, PassGrid g) {
+    if (ctx->blr_keep >= 0) return ctx->blr_keep < g.n_iter ? ctx->blr_keep : g.n_iter;
+    const double window = (double)g.n_blocks * PASS_WAVES * MT_ROWS * (double)ldx * 4.0;
+    // MI355X_MICROARCH.md: Infinity Cache 256 MiB; y, the slab and the draws live there too, and
+    // tools/ab_pass.py sweep measures 6-8 windows of 33 MB best, 9-10 worse: aim at 7/8 of it
+    const double cache = 224.0 * 1024.0 * 1024.0;
+    int k = window > 0 ? (int)(cache / window + 0.5) : 0;
+    return k < g.n_iter ? k : g.n_iter;
+}
+
+// sweep: BSC_SWEEP_STREAM (0) forward, every load non-temporal; BSC_SWEEP_FORWARD_KEEP (1) forward,
+// BSC_SWEEP_BACKWARD_KEEP (2) backward, the windows read last left in the Infinity Cache.  The 4-
+// and 8-row kernels (D != 256) always stream forward.
 void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B, int D,
-                 const float* W, int sg, PassGrid g, float* slab) {
+                 const float* W, int sg, PassGrid g, float* slab, int sweep) {
     bsc_prof_scope prof(ctx);  // times the pass kernel alone
     const bool nt = ctx->blr_nt_loads != 0;
     const int rows = pass_rows(ctx, D, y);
     if (rows == 16) {
+        const int rev = sweep == BSC_SWEEP_BACKWARD_KEEP ? 1 : 0;
+        const int keep = sweep == BSC_SWEEP_STREAM ? 0 : keep_windows(ctx, ldx, g);
 #define BSC_PASS_MFMA(NT_, PK_)                                                                    \
     hipLaunchKernelGGL((blr_pass_mfma_kernel<NT_, PK_>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0,   \
-                       ctx->stream, X, ldx, y, B, W, sg, slab, g.n_iter)
+                       ctx->stream, X, ldx, y, B, W, sg, slab, g.n_iter, rev, keep)
         if (nt && ctx->blr_pk) BSC_PASS_MFMA(true, true);
         else if (nt) BSC_PASS_MFMA(true, false);
         else if (ctx->blr_pk) BSC_PASS_MFMA(false, true);
@@ -1094,6 +1140,46 @@ void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int6
         if (nt) launch_pass_rows<4, true>(ctx, X, ldx, y, B, D, W, sg, g, slab);
         else launch_pass_rows<4, false>(ctx, X, ldx, y, B, D, W, sg, g, slab);
     }
+}
+
+int data_pass_impl(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B, int32_t D,
+                   const float* W, int32_t S, double* Q, double* G, int sweep) {
+    int rc = check_pass_args(X, ldx, y, B, D, W, S, FIN_MAX_S);
+    if (rc != BSC_OK) return rc;
+    BSC_REQUIRE(Q && G, "bsc_blr_data_pass: null output");
+    BSC_REQUIRE(sweep >= 0 && sweep <= 2, "bsc_blr_data_pass: sweep=%d (0, 1 or 2)", sweep);
+    const PassGrid g = pass_grid(ctx, B, pass_rows(ctx, D, y));
+    void* ws = nullptr;
+    rc = bsc_workspace(ctx, (size_t)g.n_blocks * SLAB_STRIDE * sizeof(float), &ws);
+    if (rc != BSC_OK) return rc;
+    float* slab = (float*)ws;
+    ctx->slab_rows = 0;  // the slab is consumed here
+    for (int s0 = 0; s0 < S; s0 += SG) {
+        const int sg = (S - s0 < SG) ? (S - s0) : SG;
+        launch_pass(ctx, X, ldx, y, B, (int)D, W + (int64_t)s0 * D, sg, g, slab, sweep);
+        BSC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(blr_slab_reduce_kernel, dim3((SLAB_STRIDE + BSC_WAVE - 1) / BSC_WAVE),
+                           dim3(RED_BLOCK), 0, ctx->stream, slab, g.n_blocks, (int)D, (int)S, s0,
+                           Q, G);
+        BSC_LAUNCH_CHECK();
+        if (sweep != BSC_SWEEP_STREAM) sweep = 3 - sweep;   // the next sample group walks back
+    }
+    return BSC_OK;
+}
+
+int data_pass_partial_impl(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B,
+                           int32_t D, const float* W, int32_t S, int sweep) {
+    int rc = check_pass_args(X, ldx, y, B, D, W, S, SG);
+    if (rc != BSC_OK) return rc;
+    BSC_REQUIRE(sweep >= 0 && sweep <= 2, "bsc_blr_data_pass_partial: sweep=%d (0, 1 or 2)", sweep);
+    const PassGrid g = pass_grid(ctx, B, pass_rows(ctx, D, y));
+    void* ws = nullptr;
+    rc = bsc_workspace(ctx, (size_t)g.n_blocks * SLAB_STRIDE * sizeof(float), &ws);
+    if (rc != BSC_OK) return rc;
+    launch_pass(ctx, X, ldx, y, B, (int)D, W, (int)S, g, (float*)ws, sweep);
+    BSC_LAUNCH_CHECK();
+    ctx->slab_rows = g.n_blocks;
+    return BSC_OK;
 }
 
 }  // namespace
@@ -1136,40 +1222,27 @@ int bsc_blr_noise(bsc_ctx* ctx, int32_t D, int32_t S, uint64_t seed, uint32_t st
 int bsc_blr_data_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B,
                       int32_t D, const float* W, int32_t S, double* Q, double* G) {
     BSC_CHECK_CTX(ctx);
-    int rc = check_pass_args(X, ldx, y, B, D, W, S, FIN_MAX_S);
-    if (rc != BSC_OK) return rc;
-    BSC_REQUIRE(Q && G, "bsc_blr_data_pass: null output");
-    const PassGrid g = pass_grid(ctx, B, pass_rows(ctx, D, y));
-    void* ws = nullptr;
-    rc = bsc_workspace(ctx, (size_t)g.n_blocks * SLAB_STRIDE * sizeof(float), &ws);
-    if (rc != BSC_OK) return rc;
-    float* slab = (float*)ws;
-    ctx->slab_rows = 0;  // the slab is consumed here
-    for (int s0 = 0; s0 < S; s0 += SG) {
-        const int sg = (S - s0 < SG) ? (S - s0) : SG;
-        launch_pass(ctx, X, ldx, y, B, (int)D, W + (int64_t)s0 * D, sg, g, slab);
-        BSC_LAUNCH_CHECK();
-        hipLaunchKernelGGL(blr_slab_reduce_kernel, dim3((SLAB_STRIDE + BSC_WAVE - 1) / BSC_WAVE),
-                           dim3(RED_BLOCK), 0, ctx->stream, slab, g.n_blocks, (int)D, (int)S, s0,
-                           Q, G);
-        BSC_LAUNCH_CHECK();
-    }
-    return BSC_OK;
+    return data_pass_impl(ctx, X, ldx, y, B, D, W, S, Q, G, BSC_SWEEP_STREAM);
+}
+
+int bsc_blr_data_pass_sweep(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B,
+                            int32_t D, const float* W, int32_t S, double* Q, double* G,
+                            int32_t sweep) {
+    BSC_CHECK_CTX(ctx);
+    return data_pass_impl(ctx, X, ldx, y, B, D, W, S, Q, G, sweep);
 }
 
 int bsc_blr_data_pass_partial(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y,
                               int64_t B, int32_t D, const float* W, int32_t S) {
     BSC_CHECK_CTX(ctx);
-    int rc = check_pass_args(X, ldx, y, B, D, W, S, SG);
-    if (rc != BSC_OK) return rc;
-    const PassGrid g = pass_grid(ctx, B, pass_rows(ctx, D, y));
-    void* ws = nullptr;
-    rc = bsc_workspace(ctx, (size_t)g.n_blocks * SLAB_STRIDE * sizeof(float), &ws);
-    if (rc != BSC_OK) return rc;
-    launch_pass(ctx, X, ldx, y, B, (int)D, W, (int)S, g, (float*)ws);
-    BSC_LAUNCH_CHECK();
-    ctx->slab_rows = g.n_blocks;
-    return BSC_OK;
+    return data_pass_partial_impl(ctx, X, ldx, y, B, D, W, S, BSC_SWEEP_STREAM);
+}
+
+int bsc_blr_data_pass_partial_sweep(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y,
+                                    int64_t B, int32_t D, const float* W, int32_t S,
+                                    int32_t sweep) {
+    BSC_CHECK_CTX(ctx);
+    return data_pass_partial_impl(ctx, X, ldx, y, B, D, W, S, sweep);
 }
 
 int bsc_blr_elbo_grad(bsc_ctx* ctx, const double* lam, const double* eps, const float* W,

@@ -9,6 +9,11 @@ bayesic/distribution/base.py:47-69.
 Model:  y_n ~ N(x_n.w, s2),  w | s2 ~ N(0, s2 I),  s2 ~ InvGamma(alpha0, beta0)
 q:      w ~ N(m, diag e^{2 rho}),  log s2 ~ N(a, e^{2b});  lam = [m, rho, a, b].
 
+``sweep="alternate"`` (default): the passes over a resident mini-batch alternate their direction
+so that each starts in the rows the previous one left in the Infinity Cache (158 instead of 164 us
+at 1M x 256; a shard below 256 MiB is read from the cache entirely).  ``sweep="stream"`` always walks
+forward with non-temporal loads.
+
 One update is two launches on one GPU -- the streaming data pass and a fused
 finish (float64 reduction of the pass partials, ELBO + pathwise gradient, Adam
 step, next step's Philox draws) -- with lam and the draws double-buffered.
@@ -34,6 +39,9 @@ import torch
 from ..device import default_context
 from .exchange import Exchange
 
+# include/bayesic_hip.h: BSC_SWEEP_*
+SWEEP_STREAM, SWEEP_FORWARD_KEEP, SWEEP_BACKWARD_KEEP = 0, 1, 2
+
 
 class BLRReparamSVI:
     NOISE_BLOCK = 32
@@ -41,7 +49,8 @@ class BLRReparamSVI:
     VIRTUAL_SHARDS = 8
 
     def __init__(self, X, y, n_total=None, n_samples=8, seed=1234, lr=1e-2, alpha0=1.0,
-                 beta0=1.0, ctx=None, group=None, lam0=None, fused=True, reproducible=False):
+                 beta0=1.0, ctx=None, group=None, lam0=None, fused=True, reproducible=False,
+                 sweep="alternate"):
         self.ctx = ctx or default_context()
         dev = self.ctx.device
         self.X = X if isinstance(X, torch.Tensor) else self.ctx.to_device(X, torch.float32)
@@ -66,6 +75,15 @@ class BLRReparamSVI:
         self.n_total = float(n_total) if n_total is not None else self.batch_rows
         self.fused = bool(fused)
         self.reproducible = bool(reproducible)
+        if sweep not in ("alternate", "stream"):
+            raise ValueError("sweep must be 'alternate' or 'stream'")
+        # "alternate": successive passes over the SAME resident mini-batch walk it forward, then
+        # backward, ..., each leaving the rows it read last in the 256 MiB Infinity Cache for the
+        # pass that starts there (include/bayesic_hip.h, bsc_blr_data_pass_sweep).  A batch that
+        # has just been swapped in (set_batch) is streamed on its first pass.
+        self.sweep = sweep
+        self._sweep_next = SWEEP_FORWARD_KEEP
+        self._fresh_batch = False
         if self.reproducible:
             V = self.VIRTUAL_SHARDS
             total = int(round(self.batch_rows))
@@ -119,12 +137,29 @@ class BLRReparamSVI:
                 raise ValueError("batch must be float32 X [rows, %d] row-major and y [rows]" % self.D)
             self.X, self.y = X, y
             self._Xarg, self._yarg, self._ldx, self.B = X, y, X.stride(0), X.shape[0]
+            self._fresh_batch = True
         else:
             if rows is None:
                 raise ValueError("raw device pointers need `rows`")
             self.X = self.y = None
             self._Xarg, self._yarg = int(X), int(y)
             self._ldx, self.B = int(ldx if ldx is not None else self.D), int(rows)
+            self._fresh_batch = True
+
+    def _take_sweep(self):
+        """Sweep order of the pass about to be issued (and book-keeping for the one after)."""
+        if self.sweep != "alternate" or self.reproducible:
+            return SWEEP_STREAM
+        if self._fresh_batch:
+            # nothing of this batch is cached and it may never be read again: stream it; if it IS
+            # read again, that pass walks back from the end
+            self._fresh_batch = False
+            self._sweep_next = SWEEP_BACKWARD_KEEP
+            return SWEEP_STREAM
+        code = self._sweep_next
+        if ((self.S + 7) // 8) & 1:         # an odd number of sample groups ends at the other side
+            self._sweep_next = 3 - code
+        return code
 
     # -- current views ---------------------------------------------------------
     @property
@@ -168,8 +203,8 @@ class BLRReparamSVI:
     def data_pass(self):
         if self.reproducible:
             return self._data_pass_by_shard()
-        self.ctx.call("bsc_blr_data_pass", self._Xarg, self._ldx, self._yarg, self.B,
-                      self.D, self.W, self.S, self.Q, self.G)
+        self.ctx.call("bsc_blr_data_pass_sweep", self._Xarg, self._ldx, self._yarg, self.B,
+                      self.D, self.W, self.S, self.Q, self.G, self._take_sweep())
 
     def _data_pass_by_shard(self):
         """One pass per virtual shard this rank holds, each into its own row of the [V, n] buffer
@@ -215,8 +250,8 @@ class BLRReparamSVI:
         if not self._drawn:
             self.sample(self.t)  # Philox step index == number of completed updates
         if self.fused and self.world == 1 and not self.exchange.rccl and self.S <= 8 and not self.reproducible:
-            self.ctx.call("bsc_blr_data_pass_partial", self._Xarg, self._ldx,
-                          self._yarg, self.B, self.D, self.W, self.S)
+            self.ctx.call("bsc_blr_data_pass_partial_sweep", self._Xarg, self._ldx,
+                          self._yarg, self.B, self.D, self.W, self.S, self._take_sweep())
             self._finish(None)
         else:
             self.data_pass()

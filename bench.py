@@ -57,6 +57,10 @@ def parse_args(argv=None):
     ap.add_argument("--reproducible", action="store_true",
                     help="cfg2: the bit-reproducible mode (one pass per virtual shard, block-sparse "
                          "all-reduce, ordered add): identical results on 1, 2, 4 and 8 GPUs")
+    ap.add_argument("--sweep", default="alternate", choices=["alternate", "stream"],
+                    help="cfg2: alternate = successive passes over the resident mini-batch walk it "
+                         "forward / backward so each starts in the rows the Infinity Cache still holds "
+                         "(the driver's default); stream = always forward, non-temporal")
     ap.add_argument("--rccl-world1", action="store_true",
                     help="N=1 with a one-rank RCCL communicator: the collective is really enqueued")
     ap.add_argument("--no-kernel-timing", action="store_true",
@@ -196,18 +200,24 @@ class Cfg2(Workload):
         self.X, self.y, self.rows, self.D, self.S = X, y, rows, D, S
         self.n_total = float(global_rows)       # the resident global batch is the data set
         self.model = BLRReparamSVI(X, y, n_total=self.n_total, n_samples=S, seed=1234, lr=1e-3, ctx=ctx,
-                                   fused=not args.unfused, reproducible=args.reproducible)
+                                   fused=not args.unfused, reproducible=args.reproducible,
+                                   sweep=args.sweep)
         self.units_per_step = global_rows / 1e6 if args.scaling == "strong" else world * rows / 1e6
         self.describe = ("cfg2: Bayesian linear regression (Normal-InverseGamma), %dx%d f32 mini-batch %s, "
                          "reparam-trick ELBO, S=%d, Adam"
                          % (rows, D, "per GPU" if args.scaling == "weak" else
                             "block of a global %d-row batch" % global_rows, S))
         self.config = {"rows_per_gpu": rows, "global_rows": global_rows, "dim": D, "mc_samples": S,
-                       "reproducible": bool(args.reproducible)}
+                       "reproducible": bool(args.reproducible), "sweep": args.sweep}
 
     def spin(self):
-        self.ctx.call("bsc_blr_data_pass_partial", self.X, self.X.stride(0), self.y, self.rows, self.D,
-                      self.model.W, min(self.S, 8))
+        # the same launch the update loop makes, in the same sweep order (alternating directions
+        # over the resident batch unless --sweep stream)
+        code = 0
+        if self.model.sweep == "alternate" and not self.model.reproducible:
+            code = self._spin_sweep = 3 - getattr(self, "_spin_sweep", 2)
+        self.ctx.call("bsc_blr_data_pass_partial_sweep", self.X, self.X.stride(0), self.y, self.rows,
+                      self.D, self.model.W, min(self.S, 8), code)
 
     def step(self):
         self.model.step()

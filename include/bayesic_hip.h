@@ -202,6 +202,26 @@ int bsc_blr_data_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y,
 int bsc_blr_data_pass_partial(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y,
                               int64_t B, int32_t D, const float* W, int32_t S);
 
+/* The same two passes with the SWEEP ORDER chosen by the caller -- for a mini-batch that is
+ * read again by the next pass (the following update of a resident batch; the next group of 8
+ * draws when S > 8).  MI355X keeps the last ~256 MiB it has read in the Infinity Cache unless a
+ * load says otherwise, so passes that alternate BSC_SWEEP_FORWARD_KEEP / BSC_SWEEP_BACKWARD_KEEP
+ * start in the rows the previous pass ended with: 0.25 of a 1M x 256 mini-batch is then served
+ * on-die (164 -> 158 us per pass), all of a shard below 256 MiB.  BSC_SWEEP_STREAM is what the
+ * plain entry points do: forward, every load non-temporal, nothing left behind -- right for a batch
+ * that is read once.  The statistics are the same sums taken in another order (float32 block
+ * partials, so the last bits differ between orders; each order is deterministic).  When S > 8 the
+ * sample groups alternate, starting from `sweep`.  D == 256 only; other widths always stream. */
+#define BSC_SWEEP_STREAM 0
+#define BSC_SWEEP_FORWARD_KEEP 1
+#define BSC_SWEEP_BACKWARD_KEEP 2
+int bsc_blr_data_pass_sweep(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y,
+                            int64_t B, int32_t D, const float* W, int32_t S,
+                            double* Q, double* G, int32_t sweep);
+int bsc_blr_data_pass_partial_sweep(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y,
+                                    int64_t B, int32_t D, const float* W, int32_t S,
+                                    int32_t sweep);
+
 /* Monte-Carlo ELBO and pathwise gradient from the (all-reduced) pass outputs.
  * batch_rows = global mini-batch rows, scale = N_total / batch_rows.
  * Writes elbo[1], grad[2D+2] (float64). */

@@ -59,6 +59,14 @@ class OracleContext:
     def bsc_blr_data_pass_partial(self, X, ldx, y, B, D, W, S):
         self._pending = svi.blr_data_pass(X.numpy(), y.numpy(), W.numpy().reshape(S, D))
 
+    def bsc_blr_data_pass_sweep(self, X, ldx, y, B, D, W, S, Q, G, sweep):
+        assert sweep in (0, 1, 2)       # the order of the rows does not change the sums
+        self.bsc_blr_data_pass(X, ldx, y, B, D, W, S, Q, G)
+
+    def bsc_blr_data_pass_partial_sweep(self, X, ldx, y, B, D, W, S, sweep):
+        assert sweep in (0, 1, 2)
+        self.bsc_blr_data_pass_partial(X, ldx, y, B, D, W, S)
+
     def bsc_blr_fused_update(self, stats, lam_in, lam_out, m1, m2, eps, W, xi, D, S, batch_rows,
                              scale, alpha0, beta0, t, lr, b1, b2, adam_eps, seed, next_step,
                              eps_n, eps_ready, W_n, xi_n, elbo, grad):

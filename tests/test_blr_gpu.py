@@ -358,3 +358,102 @@ def test_noise_ring_wraps_and_matches_per_step_sampling(ctx):
             ctx.sync()
             np.testing.assert_allclose(model.elbo.item(), elbo, rtol=1e-6)
             np.testing.assert_allclose(model.lam.cpu().numpy(), lam, atol=5e-4)
+
+
+# ---- sweep order (bsc_blr_data_pass_sweep / _partial_sweep; include/bayesic_hip.h) ----------------
+def _pass_sweep(ctx, Xd, yd, Wd, sweep, B=None):
+    from bayesic_amd._ffi import ptr
+    S, D = Wd.shape
+    B = Xd.shape[0] if B is None else B
+    Q = ctx.zeros(S, torch.float64)
+    G = ctx.zeros((S, D), torch.float64)
+    ctx.call("bsc_blr_data_pass_sweep", ptr(Xd), Xd.stride(0) if Xd.shape[0] else D, ptr(yd), B, D,
+             ptr(Wd), S, ptr(Q), ptr(G), sweep)
+    ctx.sync()
+    return Q.cpu().numpy(), G.cpu().numpy()
+
+
+@pytest.mark.parametrize("B,S", [
+    (0, 8),               # nothing to sweep
+    (5, 8),               # one partial tile: one window
+    (16, 3),
+    (4099, 8),            # one window, ragged
+    (130_003, 8),         # five windows on 256 CUs, the last one ragged
+    (70_000, 20),         # S > 8: three sample groups walk forward, back, forward
+])
+def test_sweep_orders_agree_with_the_oracle_and_are_deterministic(ctx, B, S):
+    """Every sweep order computes the same sums (float32 block partials in another order: the
+    oracle tolerance of the streaming pass holds for each), and each order repeats bit for bit."""
+    rng = np.random.RandomState(B + S)
+    D = 256
+    X = rng.standard_normal((B, D)).astype(np.float32)
+    y = rng.standard_normal(B).astype(np.float32)
+    W = (rng.standard_normal((S, D)) / 16).astype(np.float32)
+    Xd, yd, Wd = ctx.to_device(X), ctx.to_device(y), ctx.to_device(W)
+    Qr, Gr = svi.blr_data_pass_chunked(X, y, W) if B else (np.zeros(S), np.zeros((S, D)))
+    colnorm = np.sqrt((X.astype(np.float64) ** 2).sum(axis=0))[None, :]
+    bound = np.sqrt(Qr)[:, None] * colnorm
+    for sweep in (0, 1, 2):
+        Q, G = _pass_sweep(ctx, Xd, yd, Wd, sweep)
+        np.testing.assert_allclose(Q, Qr, rtol=2e-5, atol=2e-5)
+        assert (np.abs(G - Gr) <= 2e-5 * bound + 1e-12).all(), "sweep %d" % sweep
+        Q2, G2 = _pass_sweep(ctx, Xd, yd, Wd, sweep)
+        assert np.array_equal(Q, Q2) and np.array_equal(G, G2), "sweep %d is not deterministic" % sweep
+    # streaming forward and keeping forward read the rows in the same order: same bits for the
+    # first sample group (the second group of a keeping sweep walks back)
+    Q0, G0 = _pass_sweep(ctx, Xd, yd, Wd, 0)
+    Q1, G1 = _pass_sweep(ctx, Xd, yd, Wd, 1)
+    assert np.array_equal(Q0[:8], Q1[:8]) and np.array_equal(G0[:8], G1[:8])
+
+
+@pytest.mark.parametrize("keep", ["0", "1", "3", "100"])
+def test_sweep_keep_window_counts(keep, monkeypatch):
+    """BSC_BLR_KEEP = windows a keeping sweep reads with the allocating policy: 0 (none), fewer
+    than the sweep has, and more than it has all give the streaming pass's bits (forward) and the
+    oracle's sums (backward)."""
+    from bayesic_amd.device import Context
+    monkeypatch.setenv("BSC_BLR_KEEP", keep)
+    ctx = Context(0)
+    rng = np.random.RandomState(int(keep))
+    B, D, S = 100_001, 256, 8
+    X = rng.standard_normal((B, D)).astype(np.float32)
+    y = rng.standard_normal(B).astype(np.float32)
+    W = (rng.standard_normal((S, D)) / 16).astype(np.float32)
+    Xd, yd, Wd = ctx.to_device(X), ctx.to_device(y), ctx.to_device(W)
+    Q0, G0 = _pass_sweep(ctx, Xd, yd, Wd, 0)
+    Q1, G1 = _pass_sweep(ctx, Xd, yd, Wd, 1)
+    Q2, G2 = _pass_sweep(ctx, Xd, yd, Wd, 2)
+    assert np.array_equal(Q0, Q1) and np.array_equal(G0, G1)
+    np.testing.assert_allclose(Q2, Q0, rtol=1e-5)
+    np.testing.assert_allclose(G2, G0, rtol=1e-4, atol=1e-3 * np.abs(G0).max())
+
+
+def test_sweep_rejects_unknown_order(ctx):
+    from bayesic_amd._ffi import BayesicHipError
+    X = ctx.zeros((16, 256), torch.float32)
+    y = ctx.zeros(16, torch.float32)
+    W = ctx.zeros((8, 256), torch.float32)
+    with pytest.raises(BayesicHipError, match="sweep"):
+        _pass_sweep(ctx, X, y, W, 3)
+
+
+def test_alternating_driver_tracks_the_streaming_driver(ctx):
+    """BLRReparamSVI(sweep="alternate") -- the default -- and sweep="stream" run the same updates;
+    they differ by the float32 summation order of every second pass only."""
+    from bayesic_amd.svi.blr import BLRReparamSVI
+    X, y, _ = svi.make_cfg2(50_000, 256)
+    a = BLRReparamSVI(X, y, n_samples=8, seed=7, lr=0.01, ctx=ctx)
+    b = BLRReparamSVI(X, y, n_samples=8, seed=7, lr=0.01, ctx=ctx, sweep="stream")
+    assert a.sweep == "alternate"
+    codes = []
+    for _ in range(6):
+        codes.append(a._sweep_next)
+        a.step()
+        b.step()
+    ctx.sync()
+    assert codes == [1, 2, 1, 2, 1, 2]
+    np.testing.assert_allclose(a.elbo.item(), b.elbo.item(), rtol=1e-6)
+    np.testing.assert_allclose(a.lam.cpu().numpy(), b.lam.cpu().numpy(), atol=1e-5)
+    # a freshly swapped-in batch is streamed once, then walked back
+    a.set_batch(a.X, a.y)
+    assert a._take_sweep() == 0 and a._take_sweep() == 2 and a._take_sweep() == 1

@@ -33,6 +33,18 @@ def main():
     pk_mode = "pk" in sys.argv
     if pk_mode:
         variants = [(16, 0, 1), (16, 1000, 1)]      # second entry: BSC_BLR_PK=1 (cap field reused as a tag)
+    sweep_mode = "sweep" in sys.argv
+    if sweep_mode:
+        # (alternate?, BSC_BLR_KEEP): passes that alternate BSC_SWEEP_FORWARD_KEEP / BACKWARD_KEEP with
+        # `keep` trailing windows left in the Infinity Cache (-1 = the library's own choice) against
+        # the plain streaming pass
+        ctxs = {}
+        for alt, keep in [(0, 0), (1, -1), (1, 6), (1, 7), (1, 8), (1, 9), (1, 10)]:
+            os.environ["BSC_BLR_KEEP"] = str(keep)
+            os.environ["BSC_BLR_TILE_ROWS"] = "16"
+            ctxs[(alt, keep)] = Context(0)
+            ctxs[(alt, keep)].reserve(16 << 20)
+        variants = []
     for rows, wps, nt in variants:
         os.environ["BSC_BLR_PK"] = "1" if (pk_mode and wps == 1000) else "0"
         if pk_mode:
@@ -43,20 +55,32 @@ def main():
         ctxs[(rows, wps, nt)] = Context(0)
         ctxs[(rows, wps, nt)].reserve(16 << 20)
     res = {k: [] for k in ctxs}
-    for rows, c in ctxs.items():     # warm-up
-        for _ in range(5):
+    def launch(key, c, i):
+        if sweep_mode and key[0]:
+            c.call("bsc_blr_data_pass_partial_sweep", ptr(X), D, ptr(y), B, D, ptr(W), S, 1 + (i & 1))
+        else:
             c.call("bsc_blr_data_pass_partial", ptr(X), D, ptr(y), B, D, ptr(W), S)
+
+    for rows, c in ctxs.items():     # warm-up
+        for i in range(5):
+            launch(rows, c, i)
         c.sync()
     for r in range(rounds):
         for rows, c in ctxs.items():
             c.profile(True)
-            for _ in range(per):
-                c.call("bsc_blr_data_pass_partial", ptr(X), D, ptr(y), B, D, ptr(W), S)
+            for i in range(per):
+                launch(rows, c, i)
             ms, n = c.profile_read()
             c.profile(False)
             res[rows].append(ms / n * 1e3)
     bytes_ = 4.0 * B * D + 4.0 * B
     print("pure-read probe on this box: %.0f GB/s" % next(iter(ctxs.values())).read_probe(X))
+    if sweep_mode:
+        for key in ctxs:
+            a = np.array(res[key])
+            print("alternate=%d keep=%d  per-launch us: median %.1f  min %.1f  max %.1f  -> %.0f GB/s (median)"
+                  % (key + (np.median(a), a.min(), a.max(), bytes_ / np.median(a) / 1e3)))
+        return
     for key in ctxs:
         a = np.array(res[key])
         print("rows=%d waves/SIMD cap=%d nt=%d  per-launch us: median %.1f  min %.1f  max %.1f  -> %.0f GB/s (median)"

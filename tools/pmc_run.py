@@ -27,6 +27,17 @@ def main():
         X = torch.randn((N, D), generator=g, device=dev)
         y = torch.randn(N, generator=g, device=dev)
         W = torch.randn((S, D), generator=g, device=dev) / 16
+        # as the driver issues it: passes over the resident batch alternate their direction
+        turn = [0]
+
+        def fn():
+            turn[0] += 1
+            ctx.call("bsc_blr_data_pass_partial_sweep", X, D, y, N, D, W, S, 1 + (turn[0] & 1))
+    elif which == "cfg2stream":
+        N, D, S = 1_000_000, 256, 8
+        X = torch.randn((N, D), generator=g, device=dev)
+        y = torch.randn(N, generator=g, device=dev)
+        W = torch.randn((S, D), generator=g, device=dev) / 16
         fn = lambda: ctx.call("bsc_blr_data_pass_partial", X, D, y, N, D, W, S)
     elif which == "cfg3":
         N, D, K = 10_000_000, 16, 64
