@@ -468,6 +468,172 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_mfma_kernel(
     }
 }
 
+// ---- both contractions on the MFMA pipe (D == 256) ------------------------------------------
+//
+// With every load served from the caches blr_pass_mfma_kernel still takes ~150 us per 1M x 256
+// pass (tools/ab_pass.py floor): 64 v_mfma_f32_16x16x4 (half of each idle: S = 8 of 16 columns)
+// plus 256 v_pk_fma_f32 per 16-row tile keep a SIMD busy about as long as HBM takes to deliver the
+// tile, so a faster memory schedule alone cannot show.  Here the backward rank-1 updates
+// G[s, :] += r[n, s] x[n, :] run on v_mfma_f32_4x4x1_16B_f32 -- sixteen independent 4 x 4 outer
+// products per instruction, no idle half: block b = lane / 4 owns columns 16 b .. 16 b + 15, the A
+// operand is the residual r[n][4 sb + lane % 4] (the same in every block), the B operand component
+// q of the row as the lane holds it (column 4 lane + q), and the result register i of accumulator
+// (sb, q) is G[4 sb + i][4 lane + q] -- the accumulators the VALU variant keeps, so the epilogue and
+// the slab are unchanged.  128 MFMAs of 8 cycles replace 256 packed FMAs of 8 cycles and leave the
+// VALU with the sixteen residuals.
+//
+// Schedule (`Sched`): the windows (one per iteration: gridDim.x * 4 tiles) are walked forward,
+// backward, or ROTATED: workgroup group g = blockIdx >> rot_shift starts at window g % n_iter and
+// wraps around.  Windows [0, keep) -- the head of the mini-batch -- are read with the allocating
+// policy and stay in the 256 MiB Infinity Cache from pass to pass, all others non-temporal; with the
+// rotation a fraction keep / n_iter of the workgroups is in the cached zone at any moment, so cache
+// hits and HBM reads overlap for the whole pass instead of taking turns.
+struct Sched {
+    int n_iter, mode, keep, phi;
+    int64_t stride0, slot, B;
+    __device__ __forceinline__ int window(int p) const {
+        if (mode == 2) { const int w = p + phi; return w >= n_iter ? w - n_iter : w; }
+        if (mode == 4) return 0;          // measurement only: every position re-reads window 0
+        return mode == 1 ? n_iter - 1 - p : p;
+    }
+    // allocating policy for the window at position p?  (p = n_iter: the empty prefetch after the last)
+    __device__ __forceinline__ bool kept(int p) const {
+        if (p >= n_iter) return true;
+        return mode == 2 ? window(p) < keep : p >= n_iter - keep;
+    }
+    __device__ __forceinline__ int64_t row0(int p) const {
+        return p < n_iter ? ((int64_t)window(p) * stride0 + slot) * MT_ROWS : B;
+    }
+};
+
+template <bool NT>
+__global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_mx_kernel(
+    const float* __restrict__ X, int64_t ldx, const float* __restrict__ y, int64_t B,
+    const float* __restrict__ W, int S, float* __restrict__ slab, int n_iter, int mode, int keep,
+    int rot_shift) {
+    constexpr int LDS_FLOATS = PASS_WAVES * (MT_WAVE_LDS > SLAB_STRIDE ? MT_WAVE_LDS : SLAB_STRIDE);
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    float* tl = lds + wave * MT_WAVE_LDS;      // this wave's tile
+    float* rb = tl + MT_ROWS * MT_RS;          // residuals [sample][row]
+
+    float wreg[GCOLS / 4];                     // forward B operand, as in blr_pass_mfma_kernel
+#pragma unroll
+    for (int j = 0; j < GCOLS / 16; ++j) {
+        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i16 < S) w4 = *reinterpret_cast<const float4*>(W + (int64_t)i16 * GCOLS + 64 * kq + 4 * j);
+        wreg[4 * j + 0] = w4.x; wreg[4 * j + 1] = w4.y;
+        wreg[4 * j + 2] = w4.z; wreg[4 * j + 3] = w4.w;
+    }
+    mfma_f32x4 acc[2][4];                      // [sample group][column component]: register i = sample 4 sb + i
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[sb][q] = mfma_f32x4{0.f, 0.f, 0.f, 0.f};
+    float qacc = 0.f;
+    const bool live = i16 < SG;                // lanes whose forward MFMA column is a sample
+
+    Sched sc;
+    sc.n_iter = n_iter; sc.mode = mode; sc.keep = NT ? keep : n_iter;
+    sc.stride0 = (int64_t)gridDim.x * PASS_WAVES;
+    sc.slot = (int64_t)blockIdx.x * PASS_WAVES + wave;
+    sc.B = B;
+    sc.phi = (mode == 2 && n_iter > 0) ? (int)((blockIdx.x >> rot_shift) % (unsigned)n_iter) : 0;
+
+    MTile t;
+    if (sc.kept(0)) load_mtile_policy<0>(t, X, ldx, y, sc.row0(0), B, lane);
+    else load_mtile_policy<2>(t, X, ldx, y, sc.row0(0), B, lane);
+    for (int p = 0; p < n_iter; ++p) {
+        // the tile to LDS, its registers take the next window's tile (tiles outside the mini-batch
+        // read zeros without touching memory)
+#pragma unroll
+        for (int r = 0; r < MT_ROWS; ++r)
+            *reinterpret_cast<float4*>(tl + r * MT_RS + 4 * lane) = t.x[r];
+        const float4 yv = t.yv;
+        const int64_t next0 = sc.row0(p + 1);
+        if (sc.kept(p + 1)) load_mtile_policy<0>(t, X, ldx, y, next0, B, lane);
+        else load_mtile_policy<2>(t, X, ldx, y, next0, B, lane);
+        wave_lds_sync();
+
+        // forward on v_mfma_f32_16x16x4_f32 (two accumulators, no MFMA waits on its predecessor)
+        mfma_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = tl + i16 * MT_RS + 64 * kq;
+#pragma unroll
+        for (int j = 0; j < GCOLS / 16; j += 2) {
+            const float4 a0 = *reinterpret_cast<const float4*>(arow + 4 * j);
+            const float4 a1 = *reinterpret_cast<const float4*>(arow + 4 * j + 4);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wreg[4 * j + 0], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wreg[4 * j + 4], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wreg[4 * j + 1], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wreg[4 * j + 5], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wreg[4 * j + 2], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wreg[4 * j + 6], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wreg[4 * j + 3], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wreg[4 * j + 7], d1, 0, 0, 0);
+        }
+        // result register reg of lane (i16, kq) = dot(row 4 kq + reg, sample i16); the residuals go
+        // to rb[sample][row]: one 16-byte store per live lane
+        if (live) {
+            const float r0 = yv.x - (d0[0] + d1[0]), r1 = yv.y - (d0[1] + d1[1]);
+            const float r2 = yv.z - (d0[2] + d1[2]), r3 = yv.w - (d0[3] + d1[3]);
+            qacc = fmaf(r0, r0, qacc); qacc = fmaf(r1, r1, qacc);
+            qacc = fmaf(r2, r2, qacc); qacc = fmaf(r3, r3, qacc);
+            *reinterpret_cast<float4*>(rb + i16 * MT_ROWS + 4 * kq) = make_float4(r0, r1, r2, r3);
+        }
+        wave_lds_sync();
+
+        // backward on v_mfma_f32_4x4x1_16B_f32: per row 2 sample groups x 4 column components
+#pragma unroll
+        for (int g = 0; g < MT_ROWS / 4; ++g) {
+            if (g) asm volatile("" ::: "memory");   // four rows of reads in flight
+            // A operands of rows 4 g .. 4 g + 3: r[row][4 sb + lane % 4] (broadcast reads)
+            const float4 ra0 = *reinterpret_cast<const float4*>(rb + (lane & 3) * MT_ROWS + 4 * g);
+            const float4 ra1 = *reinterpret_cast<const float4*>(rb + (4 + (lane & 3)) * MT_ROWS + 4 * g);
+            const float a0[4] = {ra0.x, ra0.y, ra0.z, ra0.w};
+            const float a1[4] = {ra1.x, ra1.y, ra1.z, ra1.w};
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float4 x4 = *reinterpret_cast<const float4*>(tl + (4 * g + rr) * MT_RS + 4 * lane);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[rr], x4.x, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[rr], x4.x, acc[1][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[rr], x4.y, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[rr], x4.y, acc[1][1], 0, 0, 0);
+                acc[0][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[rr], x4.z, acc[0][2], 0, 0, 0);
+                acc[1][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[rr], x4.z, acc[1][2], 0, 0, 0);
+                acc[0][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[rr], x4.w, acc[0][3], 0, 0, 0);
+                acc[1][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[rr], x4.w, acc[1][3], 0, 0, 0);
+            }
+        }
+        wave_lds_sync();   // the next iteration overwrites the tile
+    }
+
+    // block reduction through LDS, fixed order over waves (slab layout of the other pass kernels)
+    __syncthreads();
+    float* ep = lds + wave * SLAB_STRIDE;
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(ep + (4 * sb + i) * GCOLS + 4 * lane) =
+                make_float4(acc[sb][0][i], acc[sb][1][i], acc[sb][2][i], acc[sb][3][i]);
+    float qv = live ? qacc : 0.f;
+    qv += __shfl_xor(qv, 16);
+    qv += __shfl_xor(qv, 32);
+    if (lane < SG) ep[SLAB_G + lane] = qv;
+    __syncthreads();
+    float* out = slab + (int64_t)blockIdx.x * SLAB_STRIDE;
+    for (int i = tid; i < SLAB_STRIDE; i += PASS_BLOCK) {
+        const int src = i < SLAB_G ? (i & 7) * GCOLS + (i >> 3) : i;
+        float v = lds[src];
+#pragma unroll
+        for (int k = 1; k < PASS_WAVES; ++k) v += lds[k * SLAB_STRIDE + src];
+        out[i] = v;
+    }
+}
+
 // float64 sum of p[b * SLAB_STRIDE] over slab rows b = first, first+step, ...
 // Loads are issued in batches of 16 before any add: the partials were written by
 // another kernel, so every load is a MALL/HBM round trip (~0.4 us) and a
@@ -1128,7 +1294,19 @@ void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int6
 #define BSC_PASS_MFMA(NT_, PK_)                                                                    \
     hipLaunchKernelGGL((blr_pass_mfma_kernel<NT_, PK_>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0,   \
                        ctx->stream, X, ldx, y, B, W, sg, slab, g.n_iter, rev, keep)
-        if (nt && ctx->blr_pk) BSC_PASS_MFMA(true, true);
+        if (ctx->blr_mx) {
+            // both contractions on the MFMA pipe; a keeping sweep becomes the rotated cached-zone
+            // schedule unless BSC_BLR_MX = 2 (same sweep orders as the other kernel)
+            int mode = rev, rot = 0;
+            if (sweep != BSC_SWEEP_STREAM && ctx->blr_mx == 1) { mode = 2; rot = ctx->blr_rot; }
+            if (ctx->blr_mx == 4) mode = 4;
+            if (nt)
+                hipLaunchKernelGGL((blr_pass_mx_kernel<true>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0,
+                                   ctx->stream, X, ldx, y, B, W, sg, slab, g.n_iter, mode, keep, rot);
+            else
+                hipLaunchKernelGGL((blr_pass_mx_kernel<false>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0,
+                                   ctx->stream, X, ldx, y, B, W, sg, slab, g.n_iter, mode, keep, rot);
+        } else if (nt && ctx->blr_pk) BSC_PASS_MFMA(true, true);
         else if (nt) BSC_PASS_MFMA(true, false);
         else if (ctx->blr_pk) BSC_PASS_MFMA(false, true);
         else BSC_PASS_MFMA(false, false);

@@ -457,3 +457,30 @@ def test_alternating_driver_tracks_the_streaming_driver(ctx):
     # a freshly swapped-in batch is streamed once, then walked back
     a.set_batch(a.X, a.y)
     assert a._take_sweep() == 0 and a._take_sweep() == 2 and a._take_sweep() == 1
+
+
+@pytest.mark.parametrize("mx", ["1", "2"])
+def test_all_mfma_pass_variant_matches_oracle(mx, monkeypatch):
+    """BSC_BLR_MX selects blr_pass_mx_kernel (backward rank-1 updates on v_mfma_f32_4x4x1; 1 = with the
+    rotated cached-zone schedule for keeping sweeps, 2 = plain sweep orders).  Not the default (DESIGN.md
+    section 12: same speed at the read ceiling) but kept selectable, so it is held to the same tolerance."""
+    from bayesic_amd.device import Context
+    monkeypatch.setenv("BSC_BLR_MX", mx)
+    monkeypatch.setenv("BSC_BLR_KEEP", "2")
+    ctx = Context(0)
+    for B, S in [(0, 8), (5, 8), (4099, 3), (130_003, 8), (70_000, 20)]:
+        rng = np.random.RandomState(B + S)
+        D = 256
+        X = rng.standard_normal((B, D)).astype(np.float32)
+        y = rng.standard_normal(B).astype(np.float32)
+        W = (rng.standard_normal((S, D)) / 16).astype(np.float32)
+        Xd, yd, Wd = ctx.to_device(X), ctx.to_device(y), ctx.to_device(W)
+        Qr, Gr = svi.blr_data_pass_chunked(X, y, W) if B else (np.zeros(S), np.zeros((S, D)))
+        colnorm = np.sqrt((X.astype(np.float64) ** 2).sum(axis=0))[None, :]
+        bound = np.sqrt(Qr)[:, None] * colnorm
+        for sweep in (0, 1, 2):
+            Q, G = _pass_sweep(ctx, Xd, yd, Wd, sweep)
+            np.testing.assert_allclose(Q, Qr, rtol=2e-5, atol=2e-5)
+            assert (np.abs(G - Gr) <= 2e-5 * bound + 1e-12).all(), "B=%d sweep %d" % (B, sweep)
+            Q2, G2 = _pass_sweep(ctx, Xd, yd, Wd, sweep)
+            assert np.array_equal(Q, Q2) and np.array_equal(G, G2)

@@ -39,8 +39,15 @@ def main():
         # `keep` trailing windows left in the Infinity Cache (-1 = the library's own choice) against
         # the plain streaming pass
         ctxs = {}
-        for alt, keep in [(0, 0), (1, -1), (1, 6), (1, 7), (1, 8), (1, 9), (1, 10)]:
+        # alt >= 10: fixed cached zone of `keep` windows + rotated schedule, rotation unit 2^(alt-10) workgroups
+        # (alt, keep): alt 0 = streaming pass, 1 = alternating keeping sweeps; + 10 * BSC_BLR_MX
+        # (10/11: blr_pass_mx_kernel with the rotated cached zone; 20/21: that kernel, plain sweeps);
+        # + 100 * BSC_BLR_ROT
+        # BSC_BLR_MX = 4: every position re-reads window 0 (cache hits only: the kernel's compute floor)
+        for alt, keep in [(0, 0), (1, -1), (20, 0), (21, -1), (211, 7), (40, 0), (41, 33)]:
             os.environ["BSC_BLR_KEEP"] = str(keep)
+            os.environ["BSC_BLR_MX"] = str((alt % 100) // 10)
+            os.environ["BSC_BLR_ROT"] = str(alt // 100)
             os.environ["BSC_BLR_TILE_ROWS"] = "16"
             ctxs[(alt, keep)] = Context(0)
             ctxs[(alt, keep)].reserve(16 << 20)
@@ -56,7 +63,7 @@ def main():
         ctxs[(rows, wps, nt)].reserve(16 << 20)
     res = {k: [] for k in ctxs}
     def launch(key, c, i):
-        if sweep_mode and key[0]:
+        if sweep_mode and key[0] % 10:
             c.call("bsc_blr_data_pass_partial_sweep", ptr(X), D, ptr(y), B, D, ptr(W), S, 1 + (i & 1))
         else:
             c.call("bsc_blr_data_pass_partial", ptr(X), D, ptr(y), B, D, ptr(W), S)
