@@ -76,6 +76,7 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
     if (const char* e = getenv("BSC_BLR_PK")) ctx->blr_pk = atoi(e) != 0;
     if (const char* e = getenv("BSC_BLR_KEEP")) ctx->blr_keep = atoi(e);
     if (const char* e = getenv("BSC_BLR_MX")) ctx->blr_mx = atoi(e);
+    if (const char* e = getenv("BSC_BLR_WIDE")) ctx->blr_wide = atoi(e) != 0;
     if (const char* e = getenv("BSC_BLR_ROT")) ctx->blr_rot = atoi(e) & 15;
     if (const char* e = getenv("BSC_FUSED_MAP_BLOCKS_PER_CU")) {
         const int v = atoi(e);

@@ -506,18 +506,26 @@ struct Sched {
     }
 };
 
-template <bool NT>
+constexpr int MX_WAVE_LDS = MT_ROWS * MT_RS + MT_ROWS * 16;   // tile + residuals of up to 16 draws
+
+// NSB = sample groups of four per pass: 2 (S <= 8) or 4 (S <= 16: the forward MFMA's sixteen columns
+// all carry a draw -- the second eight cost the forward nothing --, the backward doubles; one pass
+// over X for 16 draws instead of two, bsc_blr_data_pass with S > 8).  The block partials of draws
+// 8 .. 15 go to a second slab behind the first (slab + gridDim.x rows).
+template <bool NT, int NSB>
 __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_mx_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ y, int64_t B,
     const float* __restrict__ W, int S, float* __restrict__ slab, int n_iter, int mode, int keep,
     int rot_shift) {
-    constexpr int LDS_FLOATS = PASS_WAVES * (MT_WAVE_LDS > SLAB_STRIDE ? MT_WAVE_LDS : SLAB_STRIDE);
+    constexpr int NS = 4 * NSB;                 // draws per pass
+    constexpr int NH = NSB / 2;                 // slabs (one per eight draws)
+    constexpr int LDS_FLOATS = PASS_WAVES * (MX_WAVE_LDS > NH * SLAB_STRIDE ? MX_WAVE_LDS : NH * SLAB_STRIDE);
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
-    float* tl = lds + wave * MT_WAVE_LDS;      // this wave's tile
+    float* tl = lds + wave * MX_WAVE_LDS;      // this wave's tile
     float* rb = tl + MT_ROWS * MT_RS;          // residuals [sample][row]
 
     float wreg[GCOLS / 4];                     // forward B operand, as in blr_pass_mfma_kernel
@@ -528,13 +536,13 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_mx_kernel(
         wreg[4 * j + 0] = w4.x; wreg[4 * j + 1] = w4.y;
         wreg[4 * j + 2] = w4.z; wreg[4 * j + 3] = w4.w;
     }
-    mfma_f32x4 acc[2][4];                      // [sample group][column component]: register i = sample 4 sb + i
+    mfma_f32x4 acc[NSB][4];                    // [sample group][column component]: register i = sample 4 sb + i
 #pragma unroll
-    for (int sb = 0; sb < 2; ++sb)
+    for (int sb = 0; sb < NSB; ++sb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[sb][q] = mfma_f32x4{0.f, 0.f, 0.f, 0.f};
     float qacc = 0.f;
-    const bool live = i16 < SG;                // lanes whose forward MFMA column is a sample
+    const bool live = i16 < NS;                // lanes whose forward MFMA column is a sample
 
     Sched sc;
     sc.n_iter = n_iter; sc.mode = mode; sc.keep = NT ? keep : n_iter;
@@ -590,47 +598,48 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_mx_kernel(
         for (int g = 0; g < MT_ROWS / 4; ++g) {
             if (g) asm volatile("" ::: "memory");   // four rows of reads in flight
             // A operands of rows 4 g .. 4 g + 3: r[row][4 sb + lane % 4] (broadcast reads)
-            const float4 ra0 = *reinterpret_cast<const float4*>(rb + (lane & 3) * MT_ROWS + 4 * g);
-            const float4 ra1 = *reinterpret_cast<const float4*>(rb + (4 + (lane & 3)) * MT_ROWS + 4 * g);
-            const float a0[4] = {ra0.x, ra0.y, ra0.z, ra0.w};
-            const float a1[4] = {ra1.x, ra1.y, ra1.z, ra1.w};
+            float4 ra[NSB];
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb)
+                ra[sb] = *reinterpret_cast<const float4*>(rb + (4 * sb + (lane & 3)) * MT_ROWS + 4 * g);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const float4 x4 = *reinterpret_cast<const float4*>(tl + (4 * g + rr) * MT_RS + 4 * lane);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[rr], x4.x, acc[0][0], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[rr], x4.x, acc[1][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[rr], x4.y, acc[0][1], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[rr], x4.y, acc[1][1], 0, 0, 0);
-                acc[0][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[rr], x4.z, acc[0][2], 0, 0, 0);
-                acc[1][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[rr], x4.z, acc[1][2], 0, 0, 0);
-                acc[0][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[rr], x4.w, acc[0][3], 0, 0, 0);
-                acc[1][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[rr], x4.w, acc[1][3], 0, 0, 0);
+#pragma unroll
+                for (int sb = 0; sb < NSB; ++sb) {
+                    const float a = rr == 0 ? ra[sb].x : rr == 1 ? ra[sb].y : rr == 2 ? ra[sb].z : ra[sb].w;
+                    acc[sb][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, x4.x, acc[sb][0], 0, 0, 0);
+                    acc[sb][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, x4.y, acc[sb][1], 0, 0, 0);
+                    acc[sb][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, x4.z, acc[sb][2], 0, 0, 0);
+                    acc[sb][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, x4.w, acc[sb][3], 0, 0, 0);
+                }
             }
         }
         wave_lds_sync();   // the next iteration overwrites the tile
     }
 
-    // block reduction through LDS, fixed order over waves (slab layout of the other pass kernels)
+    // block reduction through LDS, fixed order over waves (slab layout of the other pass kernels,
+    // one slab per eight draws)
     __syncthreads();
-    float* ep = lds + wave * SLAB_STRIDE;
+    float* ep = lds + wave * (NH * SLAB_STRIDE);
 #pragma unroll
-    for (int sb = 0; sb < 2; ++sb)
+    for (int sb = 0; sb < NSB; ++sb)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(ep + (4 * sb + i) * GCOLS + 4 * lane) =
+            *reinterpret_cast<float4*>(ep + (sb >> 1) * SLAB_STRIDE + (4 * (sb & 1) + i) * GCOLS + 4 * lane) =
                 make_float4(acc[sb][0][i], acc[sb][1][i], acc[sb][2][i], acc[sb][3][i]);
-    float qv = live ? qacc : 0.f;
+    float qv = live ? qacc : 0.f;              // lane (i16, kq): rows 4 kq .. of draw i16
     qv += __shfl_xor(qv, 16);
     qv += __shfl_xor(qv, 32);
-    if (lane < SG) ep[SLAB_G + lane] = qv;
+    if (lane < NS) ep[(lane >> 3) * SLAB_STRIDE + SLAB_G + (lane & 7)] = qv;
     __syncthreads();
-    float* out = slab + (int64_t)blockIdx.x * SLAB_STRIDE;
-    for (int i = tid; i < SLAB_STRIDE; i += PASS_BLOCK) {
-        const int src = i < SLAB_G ? (i & 7) * GCOLS + (i >> 3) : i;
+    for (int i = tid; i < NH * SLAB_STRIDE; i += PASS_BLOCK) {
+        const int h = i / SLAB_STRIDE, ii = i - h * SLAB_STRIDE;
+        const int src = h * SLAB_STRIDE + (ii < SLAB_G ? (ii & 7) * GCOLS + (ii >> 3) : ii);
         float v = lds[src];
 #pragma unroll
-        for (int k = 1; k < PASS_WAVES; ++k) v += lds[k * SLAB_STRIDE + src];
-        out[i] = v;
+        for (int k = 1; k < PASS_WAVES; ++k) v += lds[k * (NH * SLAB_STRIDE) + src];
+        slab[((int64_t)h * gridDim.x + blockIdx.x) * SLAB_STRIDE + ii] = v;
     }
 }
 
@@ -1284,7 +1293,7 @@ int keep_windows(const bsc_ctx* ctx, int64_t ldx, PassGrid g) {
 // BSC_SWEEP_BACKWARD_KEEP (2) backward, the windows read last left in the Infinity Cache.  The 4-
 // and 8-row kernels (D != 256) always stream forward.
 void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B, int D,
-                 const float* W, int sg, PassGrid g, float* slab, int sweep) {
+                 const float* W, int sg, PassGrid g, float* slab, int sweep, bool wide = false) {
     bsc_prof_scope prof(ctx);  // times the pass kernel alone
     const bool nt = ctx->blr_nt_loads != 0;
     const int rows = pass_rows(ctx, D, y);
@@ -1294,18 +1303,20 @@ void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int6
 #define BSC_PASS_MFMA(NT_, PK_)                                                                    \
     hipLaunchKernelGGL((blr_pass_mfma_kernel<NT_, PK_>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0,   \
                        ctx->stream, X, ldx, y, B, W, sg, slab, g.n_iter, rev, keep)
-        if (ctx->blr_mx) {
-            // both contractions on the MFMA pipe; a keeping sweep becomes the rotated cached-zone
-            // schedule unless BSC_BLR_MX = 2 (same sweep orders as the other kernel)
+        if (ctx->blr_mx || wide) {
+            // both contractions on the MFMA pipe; BSC_BLR_MX = 1 turns a keeping sweep into the rotated
+            // cached-zone schedule, 4 re-reads window 0 at every position (the compute floor)
             int mode = rev, rot = 0;
             if (sweep != BSC_SWEEP_STREAM && ctx->blr_mx == 1) { mode = 2; rot = ctx->blr_rot; }
             if (ctx->blr_mx == 4) mode = 4;
-            if (nt)
-                hipLaunchKernelGGL((blr_pass_mx_kernel<true>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0,
-                                   ctx->stream, X, ldx, y, B, W, sg, slab, g.n_iter, mode, keep, rot);
-            else
-                hipLaunchKernelGGL((blr_pass_mx_kernel<false>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0,
-                                   ctx->stream, X, ldx, y, B, W, sg, slab, g.n_iter, mode, keep, rot);
+#define BSC_PASS_MX(NT_, NSB_)                                                                     \
+    hipLaunchKernelGGL((blr_pass_mx_kernel<NT_, NSB_>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0,    \
+                       ctx->stream, X, ldx, y, B, W, sg, slab, g.n_iter, mode, keep, rot)
+            if (wide && nt) BSC_PASS_MX(true, 4);
+            else if (wide) BSC_PASS_MX(false, 4);
+            else if (nt) BSC_PASS_MX(true, 2);
+            else BSC_PASS_MX(false, 2);
+#undef BSC_PASS_MX
         } else if (nt && ctx->blr_pk) BSC_PASS_MFMA(true, true);
         else if (nt) BSC_PASS_MFMA(true, false);
         else if (ctx->blr_pk) BSC_PASS_MFMA(false, true);
@@ -1328,18 +1339,29 @@ int data_pass_impl(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, in
     BSC_REQUIRE(sweep >= 0 && sweep <= 2, "bsc_blr_data_pass: sweep=%d (0, 1 or 2)", sweep);
     const PassGrid g = pass_grid(ctx, B, pass_rows(ctx, D, y));
     void* ws = nullptr;
-    rc = bsc_workspace(ctx, (size_t)g.n_blocks * SLAB_STRIDE * sizeof(float), &ws);
+    rc = bsc_workspace(ctx, (size_t)2 * g.n_blocks * SLAB_STRIDE * sizeof(float), &ws);
     if (rc != BSC_OK) return rc;
     float* slab = (float*)ws;
     ctx->slab_rows = 0;  // the slab is consumed here
-    for (int s0 = 0; s0 < S; s0 += SG) {
-        const int sg = (S - s0 < SG) ? (S - s0) : SG;
-        launch_pass(ctx, X, ldx, y, B, (int)D, W + (int64_t)s0 * D, sg, g, slab, sweep);
+    const dim3 rgrid((SLAB_STRIDE + BSC_WAVE - 1) / BSC_WAVE);
+    const bool wide_ok = pass_rows(ctx, D, y) == 16 && ctx->blr_wide;
+    for (int s0 = 0; s0 < S;) {
+        // nine or more draws left: sixteen per pass (blr_pass_mx_kernel<., 4>), two slabs
+        const bool wide = wide_ok && S - s0 > SG;
+        const int cap = wide ? 2 * SG : SG;
+        const int sg = (S - s0 < cap) ? (S - s0) : cap;
+        launch_pass(ctx, X, ldx, y, B, (int)D, W + (int64_t)s0 * D, sg, g, slab, sweep, wide);
         BSC_LAUNCH_CHECK();
-        hipLaunchKernelGGL(blr_slab_reduce_kernel, dim3((SLAB_STRIDE + BSC_WAVE - 1) / BSC_WAVE),
-                           dim3(RED_BLOCK), 0, ctx->stream, slab, g.n_blocks, (int)D, (int)S, s0,
-                           Q, G);
+        hipLaunchKernelGGL(blr_slab_reduce_kernel, rgrid, dim3(RED_BLOCK), 0, ctx->stream, slab,
+                           g.n_blocks, (int)D, (int)S, s0, Q, G);
         BSC_LAUNCH_CHECK();
+        if (sg > SG) {
+            hipLaunchKernelGGL(blr_slab_reduce_kernel, rgrid, dim3(RED_BLOCK), 0, ctx->stream,
+                               slab + (int64_t)g.n_blocks * SLAB_STRIDE, g.n_blocks, (int)D, (int)S,
+                               s0 + SG, Q, G);
+            BSC_LAUNCH_CHECK();
+        }
+        s0 += sg;
         if (sweep != BSC_SWEEP_STREAM) sweep = 3 - sweep;   // the next sample group walks back
     }
     return BSC_OK;

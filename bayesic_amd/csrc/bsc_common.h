@@ -42,6 +42,7 @@ struct bsc_ctx {
     int blr_nt_loads = 1;        // non-temporal loads of X (read once per pass): +9% measured
     int blr_keep = -1;           // windows a keeping sweep leaves in the Infinity Cache (BSC_BLR_KEEP; -1 = what fits 256 MiB)
     int blr_mx = 0;              // BSC_BLR_MX: 1 = blr_pass_mx_kernel (backward on 4x4x1 MFMA) with the rotated cached-zone schedule, 2 = that kernel with the plain sweep orders
+    int blr_wide = 1;            // BSC_BLR_WIDE: S > 8 runs sixteen draws per pass (blr_pass_mx_kernel<., 4>); 0 = eight per pass
     int blr_rot = 2;             // BSC_BLR_ROT: workgroups per rotation group = 2^rot
     int slab_rows = 0;  // block partials left in `workspace` by bsc_blr_data_pass_partial
     int capturing = 0;  // between bsc_capture_begin and bsc_capture_end: launches are recorded, not run

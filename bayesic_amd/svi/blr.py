@@ -157,9 +157,23 @@ class BLRReparamSVI:
             self._sweep_next = SWEEP_BACKWARD_KEEP
             return SWEEP_STREAM
         code = self._sweep_next
-        if ((self.S + 7) // 8) & 1:         # an odd number of sample groups ends at the other side
+        if self._passes_per_update() & 1:   # an odd number of passes ends at the other side
             self._sweep_next = 3 - code
         return code
+
+    def _passes_per_update(self):
+        """Launches of the pass kernel per update, as bsc_blr_data_pass issues them: eight draws per
+        pass, or sixteen while more than eight are left (D = 256, BSC_BLR_WIDE not 0)."""
+        import os
+        if self.S <= 8:
+            return 1
+        if self.D == 256 and os.environ.get("BSC_BLR_WIDE", "1") != "0":
+            n, left = 0, self.S
+            while left > 0:
+                left -= 16 if left > 8 else 8
+                n += 1
+            return n
+        return (self.S + 7) // 8
 
     # -- current views ---------------------------------------------------------
     @property

@@ -190,7 +190,9 @@ int bsc_blr_noise(bsc_ctx* ctx, int32_t D, int32_t S, uint64_t seed, uint32_t st
  *      Q[s]   = sum_n r[n,s]^2            (float64 out)
  *      G[s,d] = sum_n r[n,s] X[n,d]       (float64 out, [S,D])
  * Requires D % 4 == 0, D <= 256, 1 <= S <= 64, X 16-byte aligned, ldx % 4 == 0.
- * Deterministic: fixed partition, fixed-order float64 finish. */
+ * Deterministic: fixed partition, fixed-order float64 finish.
+ * S > 8: X is read once per SIXTEEN draws at D == 256 (both contractions on the MFMA pipe:
+ * 1M x 256, S = 16 in 202-232 us, S = 64 in 751-775 us), once per eight otherwise. */
 int bsc_blr_data_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y,
                       int64_t B, int32_t D, const float* W, int32_t S,
                       double* Q, double* G);

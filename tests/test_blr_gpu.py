@@ -58,6 +58,10 @@ def _check_pass(ctx, X, y, W, tol=2e-5):
     (2050, 4, 2),         # minimum D
     (777, 252, 5),
     (300, 128, 16),       # S > 8: two sample groups
+    (2000, 256, 9),       # D = 256, S > 8: sixteen draws per pass (blr_pass_mx_kernel<., 4>), one used in the second slab
+    (4099, 256, 16),      # both slabs full
+    (1003, 256, 20),      # a 16-draw pass, then a 4-draw pass
+    (40_000, 256, 64),    # four 16-draw passes over several windows
     (100, 32, 64),        # S = 64 (config-5 sample count)
 ])
 def test_data_pass_matches_oracle(ctx, B, D, S):
@@ -484,3 +488,27 @@ def test_all_mfma_pass_variant_matches_oracle(mx, monkeypatch):
             assert (np.abs(G - Gr) <= 2e-5 * bound + 1e-12).all(), "B=%d sweep %d" % (B, sweep)
             Q2, G2 = _pass_sweep(ctx, Xd, yd, Wd, sweep)
             assert np.array_equal(Q, Q2) and np.array_equal(G, G2)
+
+
+def test_sixteen_draws_per_pass_equals_eight_per_pass(monkeypatch):
+    """S > 8 at D = 256 runs sixteen draws per pass by default (BSC_BLR_WIDE=1); eight per pass
+    (BSC_BLR_WIDE=0) reads X twice as often and must agree to the float32 summation order."""
+    from bayesic_amd.device import Context
+    rng = np.random.RandomState(16)
+    B, D, S = 90_001, 256, 24
+    X = rng.standard_normal((B, D)).astype(np.float32)
+    y = rng.standard_normal(B).astype(np.float32)
+    W = (rng.standard_normal((S, D)) / 16).astype(np.float32)
+    out = {}
+    for wide in ("1", "0"):
+        monkeypatch.setenv("BSC_BLR_WIDE", wide)
+        ctx = Context(0)
+        Xd, yd, Wd = ctx.to_device(X), ctx.to_device(y), ctx.to_device(W)
+        out[wide] = [_pass_sweep(ctx, Xd, yd, Wd, sweep) for sweep in (0, 1, 2)]
+        again = _pass_sweep(ctx, Xd, yd, Wd, 1)
+        assert np.array_equal(again[0], out[wide][1][0]) and np.array_equal(again[1], out[wide][1][1])
+    Qr, Gr = svi.blr_data_pass_chunked(X, y, W)
+    for (Qa, Ga), (Qb, Gb) in zip(out["1"], out["0"]):
+        np.testing.assert_allclose(Qa, Qb, rtol=1e-5)
+        np.testing.assert_allclose(Qa, Qr, rtol=2e-5)
+        np.testing.assert_allclose(Ga, Gb, rtol=1e-4, atol=2e-4 * np.abs(Gr).max())

@@ -33,6 +33,34 @@ def main():
     pk_mode = "pk" in sys.argv
     if pk_mode:
         variants = [(16, 0, 1), (16, 1000, 1)]      # second entry: BSC_BLR_PK=1 (cap field reused as a tag)
+    if "wide" in sys.argv:
+        # S > 8: sixteen draws per pass (BSC_BLR_WIDE=1, default) against eight per pass
+        res = {}
+        for S_ in (16, 64):
+            Ww = torch.randn((S_, D), generator=g, device=dev) / 16
+            Q = torch.zeros(S_, dtype=torch.float64, device=dev)
+            G = torch.zeros((S_, D), dtype=torch.float64, device=dev)
+            for wide in ("1", "0"):
+                os.environ["BSC_BLR_WIDE"] = wide
+                c = Context(0)
+                c.reserve(32 << 20)
+                for alt in (0, 1):
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    times = []
+                    for rep in range(rounds + 2):
+                        torch.cuda.synchronize()
+                        ev0.record(torch.cuda.current_stream())
+                        for i in range(per):
+                            c.call("bsc_blr_data_pass_sweep", ptr(X), D, ptr(y), B, D, ptr(Ww), S_, ptr(Q), ptr(G),
+                                   (1 + (i & 1)) if alt else 0)
+                        ev1.record(torch.cuda.current_stream())
+                        torch.cuda.synchronize()
+                        if rep >= 2:
+                            times.append(ev0.elapsed_time(ev1) / per * 1e3)
+                    print("S=%d draws per pass=%s sweeps=%s: %.1f us per bsc_blr_data_pass (median of %d bursts of %d)"
+                          % (S_, "16" if wide == "1" else "8", "alternate" if alt else "stream",
+                             float(np.median(times)), rounds, per))
+        return
     sweep_mode = "sweep" in sys.argv
     if sweep_mode:
         # (alternate?, BSC_BLR_KEEP): passes that alternate BSC_SWEEP_FORWARD_KEEP / BACKWARD_KEEP with
