@@ -200,7 +200,7 @@ class Cfg2(Workload):
         self.X, self.y, self.rows, self.D, self.S = X, y, rows, D, S
         self.n_total = float(global_rows)       # the resident global batch is the data set
         self.model = BLRReparamSVI(X, y, n_total=self.n_total, n_samples=S, seed=1234, lr=1e-3, ctx=ctx,
-                                   fused=not args.unfused, reproducible=args.reproducible,
+                                   group=args.exchange_group, fused=not args.unfused, reproducible=args.reproducible,
                                    sweep=args.sweep)
         self.units_per_step = global_rows / 1e6 if args.scaling == "strong" else world * rows / 1e6
         self.describe = ("cfg2: Bayesian linear regression (Normal-InverseGamma), %dx%d f32 mini-batch %s, "
@@ -321,7 +321,8 @@ class Cfg3(Workload):
         eta_init = mog_mod.init_eta(_normal_f32(np, 5, (2000, D)) +
                                     centres[np.random.RandomState(4).randint(K, size=2000)], K, D, seed=2)
         self.n_total = float(global_rows)
-        self.model = mog_mod.MoGNatGradSVI(self.X, K, eta0, eta_init, n_total=self.n_total, ctx=ctx)
+        self.model = mog_mod.MoGNatGradSVI(self.X, K, eta0, eta_init, n_total=self.n_total, ctx=ctx,
+                                           group=args.exchange_group)
         self.model.expected_params()
         self.units_per_step = 1.0 if args.scaling == "strong" else float(world)
         self.describe = ("cfg3: mixture of Gaussians K=%d, %dx%d f32 mini-batch %s, discrete latent "
@@ -394,7 +395,7 @@ class Cfg5(Workload):
         self.rows, self.D, self.G, self.S = rows, D, G, S
         self.n_total = float(global_rows)
         self.model = LogRegBBVI(self.X, self.y, self.g, G, n_total=self.n_total, n_samples=S, seed=1234,
-                                lr=1e-3, ctx=ctx)
+                                lr=1e-3, ctx=ctx, group=args.exchange_group)
         self.units_per_step = global_rows / 1e6 if args.scaling == "strong" else world * rows / 1e6
         self.describe = ("cfg5: hierarchical logistic regression, %dx%d f32 mini-batch %s, G=%d groups, "
                          "BBVI score-function gradient with control variate, S=%d, Adam"
@@ -470,7 +471,8 @@ class Cfg4(Workload):
         gamma = torch.rand((docs, K), generator=g, device=dev) + 0.5
         lam = torch.rand((K, V), generator=gp, device=dev) + 0.5      # replicated: same on every rank
         self.docs, self.V, self.K = docs, V, K
-        self.model = LDAFixedGammaSVI(C, gamma, lam, docs_total=float(global_docs), ctx=ctx)
+        self.model = LDAFixedGammaSVI(C, gamma, lam, docs_total=float(global_docs), ctx=ctx,
+                                      group=args.exchange_group)
         self.units_per_step = 1.0 if args.scaling == "strong" else float(world)
         self.describe = ("cfg4: LDA-style Dirichlet-Multinomial, %d docs x %d vocab f32 dense counts %s, "
                          "K=%d, fixed-gamma local step + natural-gradient step (all-reduce of %d x %d f32)"
@@ -561,8 +563,27 @@ def run_rank(args):
     from bayesic_amd.svi.exchange import init_comm
 
     ctx = Context(local_rank)
+    args.exchange_group = None
+    exchange_note = None
     if world > 1 and not rehearsal:
-        init_comm(ctx)
+        # the product route: an RCCL communicator held by the context (bsc_comm_init_rank).  Should
+        # that fail on ANY rank (it has only ever run at world size 1: gpurun boxes have one GPU), all
+        # ranks agree over the host channel to exchange through torch.distributed's own RCCL process
+        # group instead -- same library, same xGMI links, two stream hops more -- and the line says so.
+        err = None
+        try:
+            init_comm(ctx)
+        except Exception as e:      # noqa: BLE001 -- reported, not swallowed
+            err = "%s: %s" % (type(e).__name__, e)
+            sys.stderr.write("bench.py rank %d: bsc_comm_init_rank failed (%s)\n" % (rank, err))
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32)
+        dist.all_reduce(flag)                                   # gloo, host tensor
+        if int(flag.item()) > 0:
+            if ctx.has_comm:
+                ctx.comm_destroy()
+            args.exchange_group = dist.new_group(backend="nccl")
+            exchange_note = ("torch.distributed RCCL process group (fallback: bsc_comm_init_rank failed on "
+                             "%d rank(s)%s)" % (int(flag.item()), "; this rank: " + err if err else ""))
     elif world == 1 and args.rccl_world1:
         ctx.comm_init(ctx.comm_unique_id(), 0, 1)
     wl = WORKLOADS[args.config](args, ctx, torch, rank, world)
@@ -649,6 +670,7 @@ def run_rank(args):
             "rccl_ranks": info["world"] if ctx.has_comm else 0,
             "rccl_version": info["rccl_version"] if ctx.has_comm else None,
             "exchange": ("rccl via bsc_allreduce_sum on the ctx stream" if ctx.has_comm else
+                         exchange_note if exchange_note else
                          ("gloo (rehearsal: all ranks on one GPU)" if world > 1 else "none (one rank)")),
             "spin_up_launches": spin_launches,
         }
