@@ -126,6 +126,7 @@ class DeviceBackend(Backend):
         self._one = None          # a resident float32 1.0 (broadcast_to of a host scalar)
         self._keep = None         # buffers made inside an open graph capture
         self._const = set()       # storages the caller promised not to change (mark_constant)
+        self._const_ptrs = set()  # single tensors under the same promise (mark_constant_tensor)
         self._const_cache = {}    # element-wise values of constants only: computed once, LRU by bytes
         self._const_bytes = 0
         self._graphs = {}         # graph_call: key -> recorded hipGraph
@@ -204,10 +205,44 @@ class DeviceBackend(Backend):
             if isinstance(t, torch.Tensor):
                 self._const.add(t.untyped_storage().data_ptr())
 
+    def mark_constant_tensor(self, *tensors):
+        """The same promise for tensors that may share their storage with others (an intermediate
+        the executor allocated from its arena, such as a mixture's responsibilities): only a tensor
+        starting at exactly this address counts, not its storage's other tenants."""
+        for t in tensors:
+            if isinstance(t, torch.Tensor):
+                self._const_ptrs.add(t.data_ptr())
+
+    def _is_const(self, t):
+        return t.untyped_storage().data_ptr() in self._const or t.data_ptr() in self._const_ptrs
+
     def forget_constants(self):
         self._const.clear()
+        self._const_ptrs.clear()
         self._const_cache.clear()
         self._const_bytes = 0
+
+    def unmark_constant(self, *tensors):
+        """The caller is about to change or release these tensors: cached values computed from them
+        are dropped and they are no longer constants (call BEFORE the storage can be reused)."""
+        for t in tensors:
+            if not isinstance(t, torch.Tensor):
+                continue
+            ptr = t.data_ptr()
+            if ptr in self._const_ptrs:
+                self._const_ptrs.discard(ptr)
+            else:
+                self._const.discard(t.untyped_storage().data_ptr())
+            for key in [k for k in self._const_cache if self._key_mentions(k, ptr)]:
+                old = self._const_cache.pop(key)
+                self._const_bytes -= old.numel() * old.element_size()
+                self._const.discard(old.untyped_storage().data_ptr())
+
+    @staticmethod
+    def _key_mentions(key, ptr):
+        if key and key[0] == "sum":
+            return key[1] == ptr
+        return any(term[0] == ptr for term in key[1])
 
     def compile(self, expr, bindings=None, graph=False):
         """As ``Backend.compile``.  ``graph=True``: ``f.device_fn(**device_inputs)`` records its launches
@@ -394,8 +429,8 @@ class DeviceBackend(Backend):
         terms = lazy.terms
         out = None
         ckey = None
-        if self._const and not red and self._keep is None and \
-                all(t.untyped_storage().data_ptr() in self._const for t, _, _ in terms):
+        if (self._const or self._const_ptrs) and not red and self._keep is None and \
+                all(self._is_const(t) for t, _, _ in terms):
             ckey = (lazy.combine, tuple((t.data_ptr(), tuple(t.shape), tuple(t.stride()), op, float(arg))
                                         for t, op, arg in terms),
                     float(lazy.scale), float(lazy.shift), lazy.post, tuple(shape), lazy.dtype)
@@ -600,10 +635,24 @@ class DeviceBackend(Backend):
             return self._launch(x, axes)
         axes = [a % x.dim() for a in axes]
         keep = [a for a in range(x.dim()) if a not in axes]
-        out = self._empty([x.shape[a] for a in keep], x.dtype)
+        ckey = None
+        if (self._const or self._const_ptrs) and self._keep is None and self._is_const(x):
+            # a sum of a constant (the column sums of a mixture's responsibilities occur in the
+            # messages of three factors): computed once while its operand stays marked
+            ckey = ("sum", x.data_ptr(), tuple(x.shape), tuple(x.stride()), tuple(axes), x.dtype)
+            hit = self._const_cache.pop(ckey, None)
+            if hit is not None:
+                self._const_cache[ckey] = hit
+                return hit
+        out_shape = [x.shape[a] for a in keep]
+        small = math.prod(out_shape) * x.element_size() <= (1 << 20)
+        out = self.ctx.empty(out_shape, x.dtype) if (ckey is not None and small) else self._empty(out_shape, x.dtype)
         self.ctx.call("bsc_sum", _DT[x.dtype], len(keep), _i64(x.shape[a] for a in keep),
                       _i64(x.stride(a) for a in keep), len(axes), _i64(x.shape[a] for a in axes),
                       _i64(x.stride(a) for a in axes), _ffi.ptr(x), _ffi.ptr(out))
+        if ckey is not None and small:
+            self._const_cache[ckey] = out
+            self._const_bytes += out.numel() * out.element_size()
         return out
 
     @staticmethod

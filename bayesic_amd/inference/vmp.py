@@ -290,11 +290,20 @@ class CategoricalNode(LatentNode):
         self._backend = backend
         if self.eta[0] is not None and isinstance(self.eta[0], np.ndarray):
             self.eta = [backend.from_host(self.eta[0].astype(np.float32), "float32", len(self._shape))]
+        self._drop_cache() if self._cache is not None else None
+        self._cache = None
+
+    def _drop_cache(self):
+        # the responsibilities are marked constant while they stand (the executor then computes a
+        # reduction that several messages share -- their column sums -- once); un-mark before the
+        # buffer can be reused
+        if self._cache is not None and hasattr(self._backend, "unmark_constant"):
+            self._backend.unmark_constant(self._cache[0])
         self._cache = None
 
     def set_eta(self, j, value):
         self.eta[j] = value
-        self._cache = None
+        self._drop_cache()
 
     def expectations_backend(self):
         b = self._backend
@@ -306,6 +315,8 @@ class CategoricalNode(LatentNode):
                 self._cache = (b.materialize(r), lse)
             else:
                 self._cache = b.softmax_rows(self.eta[0])
+            if hasattr(b, "mark_constant_tensor"):
+                b.mark_constant_tensor(self._cache[0])
         return [self._cache[0]]
 
     def expectations(self):
