@@ -536,6 +536,8 @@ class DeviceBackend(Backend):
         gemms = [a for a in rest if isinstance(a, LazyGemm)]
         if gemms:
             fused = self._fold_into_gemm(rest, host) if (mul and self.fuse and len(gemms) == 1) else None
+            if fused is None and not mul and self.fuse and len(gemms) >= 2:
+                fused = self._concat_products(rest, host)
             if fused is not None:
                 return fused
             rest = [self._force(a) if isinstance(a, LazyGemm) else a for a in rest]
@@ -571,6 +573,84 @@ class DeviceBackend(Backend):
         out = Lazy(op_name, terms, shape, dtype, scale=coef if mul else 1.0,
                    shift=0.0 if mul else coef)
         return out if self.fuse else self._launch(out)
+
+    def _map_into(self, out_view, shape, operands, scale=1.0, shift=0.0):
+        """out_view[...] = scale * sum(operands) + shift for float32 operands given as (tensor, strides)
+        over `shape`: one bsc_map_reduce launch writing through the view's strides."""
+        n = len(operands)
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in operands])
+        strides = []
+        for _, st in operands:
+            strides += list(st)
+        pre_ops = (ctypes.c_int32 * n)(*([_OPS["copy"]] * n))
+        pre_args = (ctypes.c_double * n)(*([0.0] * n))
+        self.ctx.call("bsc_map_reduce", _DT[torch.float32], _OPS["add"], len(shape), _i64(shape), 0,
+                      _i64([]), n, ptrs, _i64(strides), _i64([]), pre_ops, pre_args, float(scale),
+                      float(shift), _OPS["copy"], 0.0, _ffi.ptr(out_view), _i64(out_view.stride()))
+
+    def _concat_products(self, rest, host):
+        """sum_i s_i dot(X_i, Y_i) + row vectors + scalars  ->  ONE product dot([X_1 | X_2 | .. | 1],
+        [s_1 Y_1 ; s_2 Y_2 ; .. ; bias]) when every X_i is a CONSTANT with contiguous rows (a model's
+        data and cached element-wise values of it: the logits of an exponential-family mixture are
+        sum_j T_j(x) . eta_j + c).  The wide left operand is built once and kept with the constants;
+        the stacked right operand is a few small launches per evaluation.  Saves one [M, N] result per
+        product and the n-ary add over them.  None when the addends do not have that form."""
+        gemms = [a for a in rest if isinstance(a, LazyGemm)]
+        others = [a for a in rest if not isinstance(a, LazyGemm)]
+        g0 = gemms[0]
+        if len(g0.shape) != 2 or g0.dtype != torch.float32:
+            return None
+        m, n = g0.shape
+        for g in gemms:
+            xb, gm, gn, k, x, sxb, sxm, sxk, y, syb, syk, syn = g.gemm
+            if g.power != 1 or g.E is not None or xb != 1 or (gm, gn) != (m, n) or g.dtype != torch.float32 \
+                    or sxk != 1 or sxm < k or not self._is_const(x) or self._keep is not None:
+                return None
+        rows = []
+        for a in others:                    # only bias-like addends: [1, n] (or [n]) float32
+            if isinstance(a, Lazy):
+                if tuple(a.shape) not in ((1, n), (n,)):
+                    return None
+                a = self._force(a)
+            if not isinstance(a, torch.Tensor) or a.dtype != torch.float32 or tuple(a.shape) not in ((1, n), (n,)):
+                return None
+            rows.append((a, [0, a.stride(-1)]))
+        bias = bool(rows) or any(h != 0.0 for h in host)
+        ks = [g.gemm[3] for g in gemms]
+        ktot = sum(ks) + (1 if bias else 0)
+        kp = (ktot + 3) // 4 * 4
+        if kp > 1024 or m * kp * 4 > self._CONST_CACHE_BYTES // 2:
+            return None
+        ckey = ("kcat", tuple((g.gemm[4].data_ptr(), g.gemm[3], g.gemm[6]) for g in gemms), bias, m, kp)
+        xcat = self._const_cache.pop(ckey, None)
+        if xcat is None:
+            if self._one is None:
+                self._one = self.from_host(np.ones(1, np.float32), "float32", 1)
+            xcat = self.ctx.empty((m, kp), torch.float32)
+            self.ctx.call("bsc_memset", xcat, 0, xcat.numel() * 4)
+            off = 0
+            for g in gemms:
+                k, x, sxm = g.gemm[3], g.gemm[4], g.gemm[6]
+                self._map_into(xcat[:, off:off + k], [m, k], [(x, [sxm, 1])])
+                off += k
+            if bias:
+                self._map_into(xcat[:, off:off + 1], [m, 1], [(self._one, [0, 0])])
+            self._const_bytes += xcat.numel() * 4
+            self._const.add(xcat.untyped_storage().data_ptr())
+        self._const_cache[ckey] = xcat
+        ycat = self._empty((kp, n), torch.float32)
+        self.ctx.call("bsc_memset", ycat, 0, ycat.numel() * 4)
+        off = 0
+        for g in gemms:
+            k, y, syk, syn = g.gemm[3], g.gemm[8], g.gemm[10], g.gemm[11]
+            self._map_into(ycat[off:off + k, :], [k, n], [(y, [syk, syn])], scale=g.scale)
+            off += k
+        if bias:
+            if rows:
+                self._map_into(ycat[off:off + 1, :], [1, n], rows, shift=float(sum(host)))
+            else:
+                self._map_into(ycat[off:off + 1, :], [1, n], [(self._one, [0, 0])], scale=float(sum(host)))
+        return LazyGemm((1, m, n, kp, xcat, 0, kp, 1, ycat, 0, n, 1), (m, n), torch.float32)
 
     def _fold_into_gemm(self, rest, host):
         """scale * dot ** power * E as ONE launch when the product has exactly one other operand,

@@ -398,3 +398,49 @@ def test_values_of_constant_data_are_computed_once(ctx):
     with Counting(ctx) as c:
         be.to_host(f(R=Rd, X=Xd))
     assert c.count("bsc_map_reduce") == 1
+
+
+@pytest.mark.parametrize("n_rows,d,k", [(3000, 12, 7), (4097, 16, 64), (5, 3, 2)])
+def test_sums_of_products_over_constant_rows_become_one_product(ctx, n_rows, d, k):
+    """sum_i s_i dot(X_i, Y_i) + row vectors + a scalar with every X_i CONSTANT (a model's data and
+    cached element-wise values of it: the logits of an exponential-family mixture) is ONE product over
+    the concatenated contraction [X_1 | X_2 | 1] . [s_1 Y_1 ; s_2 Y_2 ; bias] -- the wide left operand
+    built once, no [M, N] intermediate per product and no n-ary add over them.  With unmarked data the
+    expression runs as before; both agree with float64."""
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    be = DeviceBackend(ctx)
+    rs = np.random.RandomState(n_rows)
+    X_ = rs.standard_normal((n_rows, d)).astype(np.float32)
+    A_ = rs.standard_normal((k, d)).astype(np.float32)
+    B_ = rs.rand(k, d).astype(np.float32)
+    c_ = rs.standard_normal(k).astype(np.float32)
+    e_ = rs.standard_normal(k).astype(np.float32)
+    X, Am, Bm, cv, ev = var("X", 2), var("Am", 2), var("Bm", 2), var("cv", 1), var("ev", 1)
+    logits = dot(X, Am.T) + dot(X * X, Bm.T) * (-0.5) + dimshuffle(cv, "x", 0) * 0.5 \
+        + dimshuffle(ev, "x", 0) + 0.25
+    f = logits.compile(be).device_fn
+    Xd, Ad, Bd = (be.from_host(a, "float32", 2) for a in (X_, A_, B_))
+    cd, ed = (be.from_host(a, "float32", 1) for a in (c_, e_))
+    x64 = X_.astype(np.float64)
+    want = x64 @ A_.astype(np.float64).T - 0.5 * (x64 * x64) @ B_.astype(np.float64).T \
+        + 0.5 * c_[None, :] + e_[None, :] + 0.25
+    tol = dict(rtol=2e-5, atol=2e-5 * np.abs(want).max())
+    with Counting(ctx) as c:
+        plain = be.to_host(f(X=Xd, Am=Ad, Bm=Bd, cv=cd, ev=ed))
+    assert c.count("bsc_gemm_strided_batched") + c.count("bsc_gemm_epilogue") == 2
+    npt.assert_allclose(plain, want, **tol)
+    be.mark_constant(Xd)
+    be.to_host(f(X=Xd, Am=Ad, Bm=Bd, cv=cd, ev=ed))          # builds [X | X^2 | 1] once
+    with Counting(ctx) as c:
+        fused = be.to_host(f(X=Xd, Am=Ad, Bm=Bd, cv=cd, ev=ed))
+    assert c.count("bsc_gemm_strided_batched") + c.count("bsc_gemm_epilogue") == 1
+    npt.assert_allclose(fused, want, **tol)
+    # other right-hand sides reuse the wide operand; the result follows them
+    A2 = be.from_host((2.0 * A_).astype(np.float32), "float32", 2)
+    again = be.to_host(f(X=Xd, Am=A2, Bm=Bd, cv=cd, ev=ed))
+    npt.assert_allclose(again, want + x64 @ A_.astype(np.float64).T, **tol)
+    be.forget_constants()
+    with Counting(ctx) as c:
+        back = be.to_host(f(X=Xd, Am=Ad, Bm=Bd, cv=cd, ev=ed))
+    assert c.count("bsc_gemm_strided_batched") + c.count("bsc_gemm_epilogue") == 2
+    npt.assert_allclose(back, want, **tol)

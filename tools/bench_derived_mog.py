@@ -21,7 +21,8 @@ from bayesic_amd.svi import mog as mog_mod
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+    nums = [a for a in sys.argv[1:] if a.isdigit()]
+    n = int(nums[0]) if nums else 10_000_000
     D, K = 16, 64
     ctx = Context(0)
     rs = np.random.RandomState(3)
@@ -44,6 +45,18 @@ def main():
         ctx.sync()
         print("%-34s %9.3f ms per update (%d rows, K = %d, D = %d)" % (name, (time.perf_counter() - t0) / reps * 1e3, n, K, D),
               flush=True)
+        if "--steps" in sys.argv:          # each update on its own: is a slow run slow in every update?
+            each = []
+            for _ in range(8):
+                t1 = time.perf_counter()
+                step()
+                ctx.sync()
+                each.append((time.perf_counter() - t1) * 1e3)
+            print("    single updates (ms): " + " ".join("%.2f" % v for v in each), flush=True)
+            import torch
+            st = torch.cuda.memory_stats()
+            print("    torch allocator: %d device mallocs, %d frees, %.1f GB reserved"
+                  % (st["num_device_alloc"], st["num_device_free"], st["reserved_bytes.all.current"] / 1e9))
     got, want = derived.eta_fused_layout(), fused.eta.cpu().numpy()
     scale = np.maximum(np.abs(want), 1.0)
     print("max relative difference of the natural parameters after 13 updates: %.2e" % np.abs((got - want) / scale).max())
