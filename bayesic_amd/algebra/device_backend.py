@@ -127,6 +127,7 @@ class DeviceBackend(Backend):
         self._keep = None         # buffers made inside an open graph capture
         self._const = set()       # storages the caller promised not to change (mark_constant)
         self._const_ptrs = set()  # single tensors under the same promise (mark_constant_tensor)
+        self._wide = {}           # (ptr, columns, row stride) of a constituent -> (key of its wide operand, column offset)
         self._const_cache = {}    # element-wise values of constants only: computed once, LRU by bytes
         self._const_bytes = 0
         self._graphs = {}         # graph_call: key -> recorded hipGraph
@@ -220,6 +221,7 @@ class DeviceBackend(Backend):
         self._const.clear()
         self._const_ptrs.clear()
         self._const_cache.clear()
+        self._wide.clear()
         self._const_bytes = 0
 
     def unmark_constant(self, *tensors):
@@ -240,7 +242,7 @@ class DeviceBackend(Backend):
 
     @staticmethod
     def _key_mentions(key, ptr):
-        if key and key[0] == "sum":
+        if key and key[0] in ("sum", "kprod"):
             return key[1] == ptr
         return any(term[0] == ptr for term in key[1])
 
@@ -627,6 +629,8 @@ class DeviceBackend(Backend):
             if self._one is None:
                 self._one = self.from_host(np.ones(1, np.float32), "float32", 1)
             xcat = self.ctx.empty((m, kp), torch.float32)
+            for stale in [key for key in self._const_cache if key[0] == "kprod" and key[5] == xcat.data_ptr()]:
+                self._const_bytes -= self._const_cache.pop(stale).numel() * 4     # products with a former tenant
             self.ctx.call("bsc_memset", xcat, 0, xcat.numel() * 4)
             off = 0
             for g in gemms:
@@ -638,6 +642,12 @@ class DeviceBackend(Backend):
             self._const_bytes += xcat.numel() * 4
             self._const.add(xcat.untyped_storage().data_ptr())
         self._const_cache[ckey] = xcat
+        off = 0
+        for g in gemms:
+            self._wide[(g.gemm[4].data_ptr(), g.gemm[3], g.gemm[6])] = (ckey, off)
+            off += g.gemm[3]
+        if bias:
+            self._wide[("ones", m)] = (ckey, off)
         ycat = self._empty((kp, n), torch.float32)
         self.ctx.call("bsc_memset", ycat, 0, ycat.numel() * 4)
         off = 0
@@ -651,6 +661,35 @@ class DeviceBackend(Backend):
             else:
                 self._map_into(ycat[off:off + 1, :], [1, n], [(self._one, [0, 0])], scale=float(sum(host)))
         return LazyGemm((1, m, n, kp, xcat, 0, kp, 1, ycat, 0, n, 1), (m, n), torch.float32)
+
+    def _product_with_wide(self, x, m, k, sxm, sxk, part):
+        """dot(x^T-like [m, k], Y) where Y [k, n] is a constituent of a cached wide operand
+        [Y_1 | Y_2 | .. | 1] (see _concat_products) and x is a constant: the product with the WHOLE wide
+        operand is computed once, kept while x stays marked, and every constituent's product -- and,
+        through the ones column, the sums of x over the contracted axis -- is a column block of it.
+        The responsibility-weighted statistics of a mixture (R^T X, R^T X^2, sum_n R) are then one pass
+        over R instead of three.  `part` = (ptr, columns, row stride) of Y, or ("ones", k)."""
+        if part is None or not self._is_const(x):
+            return None
+        entry = self._wide.get(part)
+        if entry is None:
+            return None
+        wkey, off = entry
+        xcat = self._const_cache.get(wkey)
+        if xcat is None or xcat.shape[0] != k:
+            self._wide.pop(part, None)
+            return None
+        kp = xcat.shape[1]
+        pkey = ("kprod", x.data_ptr(), m, sxm, sxk, xcat.data_ptr())
+        prod = self._const_cache.pop(pkey, None)
+        if prod is None:
+            prod = self.ctx.empty((m, kp), torch.float32)
+            self.ctx.call("bsc_gemm_strided_batched", _DT[torch.float32], 1, m, kp, k,
+                          _ffi.ptr(x), 0, sxm, sxk, _ffi.ptr(xcat), 0, kp, 1, _ffi.ptr(prod), m * kp, kp, 1)
+            self._const_bytes += prod.numel() * 4
+        self._const_cache[pkey] = prod
+        width = 1 if part[0] == "ones" else part[1]
+        return prod[:, off:off + width]
 
     def _fold_into_gemm(self, rest, host):
         """scale * dot ** power * E as ONE launch when the product has exactly one other operand,
@@ -716,6 +755,12 @@ class DeviceBackend(Backend):
         axes = [a % x.dim() for a in axes]
         keep = [a for a in range(x.dim()) if a not in axes]
         ckey = None
+        if self._wide and self._keep is None and x.dim() == 2 and axes == [0] and x.dtype == torch.float32 \
+                and ("ones", x.shape[0]) in self._wide and self._is_const(x):
+            col = self._product_with_wide(x, x.shape[1], x.shape[0], x.stride(1), x.stride(0),
+                                          ("ones", x.shape[0]))
+            if col is not None:
+                return col.reshape(x.shape[1])
         if (self._const or self._const_ptrs) and self._keep is None and self._is_const(x):
             # a sum of a constant (the column sums of a mixture's responsibilities occur in the
             # messages of three factors): computed once while its operand stays marked
@@ -931,6 +976,11 @@ class DeviceBackend(Backend):
         if k != k2 or xb != yb:
             raise ValueError("tensordot: contracted / batch extents differ (%d vs %d, %d vs %d)"
                              % (k, k2, xb, yb))
+        if self.fuse and dtype == torch.float32 and len(out_shape) == 2 and xb == 1 and self._wide and \
+                self._keep is None:
+            part = self._product_with_wide(x, m, k, sxm, sxk, (y.data_ptr(), n, syk) if syn == 1 else None)
+            if part is not None:
+                return part
         if self.fuse and dtype == torch.float32 and len(out_shape) == 2 and xb == 1 and m > 1 and n > 1 \
                 and k > 0 and self._plan is not None:
             # deferred: a _mul / pow(., -1) consumer folds into the store (inside evaluate() only --

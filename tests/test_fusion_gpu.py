@@ -444,3 +444,54 @@ def test_sums_of_products_over_constant_rows_become_one_product(ctx, n_rows, d, 
         back = be.to_host(f(X=Xd, Am=Ad, Bm=Bd, cv=cd, ev=ed))
     assert c.count("bsc_gemm_strided_batched") + c.count("bsc_gemm_epilogue") == 2
     npt.assert_allclose(back, want, **tol)
+
+
+def test_statistics_against_the_wide_operand_are_one_pass(ctx):
+    """Once [X | X^2 | 1] exists (previous test), the products of a CONSTANT R with its constituents --
+    dot(R.T, X), dot(R.T, X * X) -- and the column sums of R are column blocks of ONE product
+    dot(R.T, [X | X^2 | 1]), computed once while R stays marked: the responsibility-weighted statistics
+    of a mixture in one pass over R instead of three."""
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    be = DeviceBackend(ctx)
+    rs = np.random.RandomState(11)
+    n_rows, d, k = 5003, 16, 24
+    X_ = rs.standard_normal((n_rows, d)).astype(np.float32)
+    A_ = rs.standard_normal((k, d)).astype(np.float32)
+    B_ = rs.rand(k, d).astype(np.float32)
+    c_ = rs.standard_normal(k).astype(np.float32)
+    R_ = rs.rand(n_rows, k).astype(np.float32)
+    X, Am, Bm, cv, R = var("X", 2), var("Am", 2), var("Bm", 2), var("cv", 1), var("R", 2)
+    logits = (dot(X, Am.T) + dot(X * X, Bm.T) * (-0.5) + dimshuffle(cv, "x", 0)).compile(be).device_fn
+    s1 = dot(R.T, X).compile(be).device_fn
+    s2 = (dot(R.T, X * X) * (-0.5)).compile(be).device_fn
+    s0 = sum(R, axis=0).compile(be).device_fn
+    Xd, Ad, Bd, Rd = (be.from_host(a, "float32", 2) for a in (X_, A_, B_, R_))
+    cd = be.from_host(c_, "float32", 1)
+    be.mark_constant(Xd)
+    be.to_host(logits(X=Xd, Am=Ad, Bm=Bd, cv=cd))            # builds the wide operand
+    x64, r64 = X_.astype(np.float64), R_.astype(np.float64)
+
+    def check(r64):
+        with Counting(ctx) as c:
+            a = be.to_host(s1(R=Rd, X=Xd))
+            b = be.to_host(s2(R=Rd, X=Xd))
+            z = be.to_host(s0(R=Rd))
+        npt.assert_allclose(a, r64.T @ x64, rtol=2e-5, atol=1e-3)
+        npt.assert_allclose(b, -0.5 * (r64.T @ (x64 * x64)), rtol=2e-5, atol=1e-3)
+        npt.assert_allclose(z, r64.sum(axis=0), rtol=2e-5)
+        return c.count("bsc_gemm_strided_batched") + c.count("bsc_gemm_epilogue"), c.count("bsc_sum")
+
+    gemms, sums = check(r64)
+    assert gemms == 2 and sums == 1                          # R not marked: as before
+    be.mark_constant_tensor(Rd)
+    gemms, sums = check(r64)
+    assert gemms == 1 and sums == 0                          # one product serves all three
+    gemms, sums = check(r64)
+    assert gemms == 0 and sums == 0                          # and is kept while R stands
+    # R changes: un-mark first (what CategoricalNode.set_eta does), then the statistics follow
+    be.unmark_constant(Rd)
+    R2 = (R_ * 0.5 + 0.125).astype(np.float32)
+    Rd.copy_(be.from_host(R2, "float32", 2))
+    be.mark_constant_tensor(Rd)
+    gemms, sums = check(R2.astype(np.float64))
+    assert gemms == 1 and sums == 0
