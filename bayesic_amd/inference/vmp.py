@@ -488,9 +488,12 @@ class MeanFieldVMP(object):
             needed = {k: v for k, v in inputs.items()}
             value = f.device_fn(**needed)
             if node.resident:       # a data-sized message stays where it was computed
-                out.append(self.backend.materialize(value))
-            else:
-                out.append(np.asarray(self.backend.to_host(value), np.float64))
+                value = self.backend.materialize(value)
+            out.append(value)
+        if not node.resident:
+            # read back only after EVERY statistic's launches are queued: a read-back waits for the
+            # device, and the walk of the next expression would otherwise run beside an idle GPU
+            out = [None if v is None else np.asarray(self.backend.to_host(v), np.float64) for v in out]
         return out
 
     def set_data(self, **arrays):
