@@ -196,7 +196,10 @@ class Einsum(Expression):
 
     def __hash__(self):
         """Insensitive to factor order and sum-index numbering: a sum index is
-        described by where it occurs (bayesic/algebra.py:1001-1034)."""
+        described by where it occurs (bayesic/algebra.py:1001-1034).  Computed once per object."""
+        cached = self.__dict__.get("_hash_value")
+        if cached is not None:
+            return cached
         occurrences = defaultdict(Counter)
         for factor, indices in self.factors_and_indices:
             for axis, index in enumerate(indices):
@@ -206,7 +209,8 @@ class Einsum(Expression):
         described = Counter(
             (factor, tuple(i if i[0] == OUT else (SUM, signature[i]) for i in indices))
             for factor, indices in self.factors_and_indices)
-        return hash(frozenset(described.items()))
+        value = self.__dict__["_hash_value"] = hash(frozenset(described.items()))
+        return value
 
     @staticmethod
     def _factor_axes_for_indices(indices_for_factors):

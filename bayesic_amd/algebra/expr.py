@@ -82,7 +82,12 @@ class Expression(object):
         return not self.__eq__(other)
 
     def __hash__(self):
-        return hash(self._equality_by())
+        # expressions are immutable once built; the executor looks every node of a tree up in the
+        # bindings of each evaluation, so the structural hash is computed once per object
+        h = self.__dict__.get("_hash_value")
+        if h is None:
+            h = self.__dict__["_hash_value"] = hash(self._equality_by())
+        return h
 
 
 class var(Expression):
