@@ -469,9 +469,18 @@ class MeanFieldVMP(object):
                 for k, (t, e) in enumerate(zip(m.statistics, m.expectations_backend())):
                     values[self._carrier(t) or "_E_%s_%d" % (m.var.name, k)] = e
                 continue
-            for k, (t, e) in enumerate(zip(m.statistics, m.expectations())):
-                name = self._carrier(t) or "_E_%s_%d" % (m.var.name, k)
-                values[name] = self.backend.from_host(np.asarray(e, np.float64), "float32", t.ndim)
+            # the expectations of a host-side node change only when its natural parameters are
+            # replaced (update() assigns new arrays): their device copies are kept until then, instead
+            # of being computed and uploaded again for every message that reads them
+            cache = self.__dict__.setdefault("_expectation_cache", {})
+            held = cache.get(m.var.name)
+            if held is None or len(held[0]) != len(m.eta) or any(a is not b for a, b in zip(held[0], m.eta)):
+                uploaded = {}
+                for k, (t, e) in enumerate(zip(m.statistics, m.expectations())):
+                    name = self._carrier(t) or "_E_%s_%d" % (m.var.name, k)
+                    uploaded[name] = self.backend.from_host(np.asarray(e, np.float64), "float32", t.ndim)
+                held = cache[m.var.name] = (list(m.eta), uploaded)
+            values.update(held[1])
         return values
 
     def message(self, name):
