@@ -236,9 +236,23 @@ class DeviceBackend(Backend):
             else:
                 self._const.discard(t.untyped_storage().data_ptr())
             for key in [k for k in self._const_cache if self._key_mentions(k, ptr)]:
-                old = self._const_cache.pop(key)
-                self._const_bytes -= old.numel() * old.element_size()
-                self._const.discard(old.untyped_storage().data_ptr())
+                self._evict(key)
+
+    def _evict(self, key):
+        """Drop one cached value and everything computed FROM it (a wide operand built from a cached
+        element-wise value, products with that wide operand): once its buffer is released another
+        tensor may get the address the dependants are keyed by."""
+        old = self._const_cache.pop(key, None)
+        if old is None:
+            return
+        self._const_bytes -= old.numel() * old.element_size()
+        self._const.discard(old.untyped_storage().data_ptr())
+        ptr = old.data_ptr()
+        for part in [p for p, (wkey, _) in self._wide.items() if wkey == key or p[0] == ptr]:
+            self._wide.pop(part, None)
+        for dep in [k for k in self._const_cache
+                    if self._key_mentions(k, ptr) or (k[0] == "kprod" and k[5] == ptr)]:
+            self._evict(dep)
 
     @staticmethod
     def _key_mentions(key, ptr):
@@ -444,10 +458,7 @@ class DeviceBackend(Backend):
             # kept across evaluations: not a buffer of the per-expression memory plan
             nbytes = math.prod(shape) * (8 if lazy.dtype == torch.float64 else 4)
             while self._const_cache and self._const_bytes + nbytes > self._CONST_CACHE_BYTES:
-                old_key = next(iter(self._const_cache))
-                old = self._const_cache.pop(old_key)
-                self._const_bytes -= old.numel() * old.element_size()
-                self._const.discard(old.untyped_storage().data_ptr())
+                self._evict(next(iter(self._const_cache)))
             if nbytes <= self._CONST_CACHE_BYTES:
                 out = self.ctx.empty([shape[a] for a in keep], lazy.dtype)
             else:
@@ -630,7 +641,7 @@ class DeviceBackend(Backend):
                 self._one = self.from_host(np.ones(1, np.float32), "float32", 1)
             xcat = self.ctx.empty((m, kp), torch.float32)
             for stale in [key for key in self._const_cache if key[0] == "kprod" and key[5] == xcat.data_ptr()]:
-                self._const_bytes -= self._const_cache.pop(stale).numel() * 4     # products with a former tenant
+                self._evict(stale)                                                # products with a former tenant
             self.ctx.call("bsc_memset", xcat, 0, xcat.numel() * 4)
             off = 0
             for g in gemms:
@@ -978,7 +989,10 @@ class DeviceBackend(Backend):
                              % (k, k2, xb, yb))
         if self.fuse and dtype == torch.float32 and len(out_shape) == 2 and xb == 1 and self._wide and \
                 self._keep is None:
-            part = self._product_with_wide(x, m, k, sxm, sxk, (y.data_ptr(), n, syk) if syn == 1 else None)
+            # (y must still be the constant the wide operand was built from: a cached value that has
+            # been evicted may have handed its address to something else)
+            part = self._product_with_wide(x, m, k, sxm, sxk,
+                                           (y.data_ptr(), n, syk) if (syn == 1 and self._is_const(y)) else None)
             if part is not None:
                 return part
         if self.fuse and dtype == torch.float32 and len(out_shape) == 2 and xb == 1 and m > 1 and n > 1 \

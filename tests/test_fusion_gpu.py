@@ -495,3 +495,35 @@ def test_statistics_against_the_wide_operand_are_one_pass(ctx):
     be.mark_constant_tensor(Rd)
     gemms, sums = check(R2.astype(np.float64))
     assert gemms == 1 and sums == 0
+
+
+def test_dropping_a_constant_drops_what_was_built_from_it(ctx):
+    """unmark_constant(X) removes the cached X * X, the wide operand [X | X^2 | 1] built from both and
+    the products with it; the same expressions then run on the plain route and still agree."""
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    be = DeviceBackend(ctx)
+    rs = np.random.RandomState(12)
+    n_rows, d, k = 2000, 8, 5
+    X_ = rs.standard_normal((n_rows, d)).astype(np.float32)
+    A_ = rs.standard_normal((k, d)).astype(np.float32)
+    R_ = rs.rand(n_rows, k).astype(np.float32)
+    X, Am, R = var("X", 2), var("Am", 2), var("R", 2)
+    logits = (dot(X, Am.T) + dot(X * X, Am.T) * 0.5).compile(be).device_fn
+    stat = dot(R.T, X * X).compile(be).device_fn
+    Xd, Ad, Rd = (be.from_host(a, "float32", 2) for a in (X_, A_, R_))
+    be.mark_constant(Xd)
+    be.mark_constant_tensor(Rd)
+    x64 = X_.astype(np.float64)
+    want_l = x64 @ A_.T.astype(np.float64) + 0.5 * (x64 * x64) @ A_.T.astype(np.float64)
+    want_s = R_.astype(np.float64).T @ (x64 * x64)
+    for _ in range(2):
+        npt.assert_allclose(be.to_host(logits(X=Xd, Am=Ad)), want_l, rtol=2e-5, atol=1e-4)
+        npt.assert_allclose(be.to_host(stat(R=Rd, X=Xd)), want_s, rtol=2e-5, atol=1e-3)
+    assert be._wide and any(key[0] == "kcat" for key in be._const_cache)
+    be.unmark_constant(Xd)
+    assert not be._wide and not be._const_cache            # X * X, the wide operand, the products: gone
+    X2 = (X_ * 2).astype(np.float32)
+    Xd.copy_(be.from_host(X2, "float32", 2))                # X may change now
+    npt.assert_allclose(be.to_host(logits(X=Xd, Am=Ad)), 2 * (x64 @ A_.T.astype(np.float64))
+                        + 2.0 * (x64 * x64) @ A_.T.astype(np.float64), rtol=2e-5, atol=1e-4)
+    npt.assert_allclose(be.to_host(stat(R=Rd, X=Xd)), 4 * want_s, rtol=2e-5, atol=1e-3)
