@@ -79,6 +79,8 @@ SIGNATURES = {
     "bsc_natgrad_update_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_float,
                                        c_float]),
     "bsc_softmax_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "bsc_gemm_softmax_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64,
+                                      c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
     "bsc_suffstats_normal": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "bsc_mog_estep": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p,
                               c_void_p, c_void_p, c_void_p]),

@@ -631,7 +631,7 @@ class DeviceBackend(Backend):
         bias = bool(rows) or any(h != 0.0 for h in host)
         ks = [g.gemm[3] for g in gemms]
         ktot = sum(ks) + (1 if bias else 0)
-        kp = (ktot + 3) // 4 * 4
+        kp = (ktot + 7) // 8 * 8          # (a multiple of 8: bsc_gemm_softmax_rows pairs column s with K/2 + s)
         if kp > 1024 or m * kp * 4 > self._CONST_CACHE_BYTES // 2:
             return None
         ckey = ("kcat", tuple((g.gemm[4].data_ptr(), g.gemm[3], g.gemm[6]) for g in gemms), bias, m, kp)
@@ -813,6 +813,45 @@ class DeviceBackend(Backend):
     def diagonal(self, x, axis1, axis2):
         x = self._force(x)
         return torch.diagonal(x, 0, axis1, axis2)     # view; the diagonal axis goes last
+
+    def evaluate_softmax_rows(self, expr, inputs, bindings=None):
+        """softmax over the last axis of the value of ``expr`` (a resident Categorical node's update).
+        Returns (R, lse, cross, logits): when the value is a tall-skinny product nothing else reads --
+        the logits of a mixture, after _concat_products one product [X | X^2 | 1] . coefficients --
+        ONE launch (bsc_gemm_softmax_rows) produces R, lse and cross = sum_c R * logits, and
+        ``logits`` is None: they never reach memory.  Otherwise the logits are evaluated as usual and
+        returned with their softmax (cross is then None)."""
+        entry = self._plans.get(id(expr))
+        if entry is None or entry[0] is not expr:
+            if len(self._plans) >= self._MAX_PLANS:
+                self._plans.pop(next(iter(self._plans)))
+            entry = self._plans[id(expr)] = [expr, []]
+        self._plan, self._cursor = entry[1], 0
+        logits = None
+        try:
+            root = Backend.evaluate(self, expr, inputs, bindings)
+            g = root if isinstance(root, LazyGemm) else None
+            if g is not None and self._keep is None:
+                xb, m, n, k, x, sxb, sxm, sxk, y, syb, syk, syn = g.gemm
+                if g.power == 1 and g.E is None and g.scale == 1.0 and xb == 1 and sxk == 1 and k % 8 == 0 \
+                        and k <= 64 and n <= 64 and n % 4 == 0 and sxm % 4 == 0 and x.data_ptr() % 16 == 0 \
+                        and g.dtype == torch.float32 and len(g.shape) == 2:
+                    R = self.ctx.empty((m, n), torch.float32)
+                    lse = self.ctx.empty((m,), torch.float32)
+                    cross = self.ctx.empty((m,), torch.float32)
+                    self.ctx.call("bsc_gemm_softmax_rows", _ffi.ptr(x), sxm, m, k, _ffi.ptr(y), syk, syn, n,
+                                  _ffi.ptr(R), n, _ffi.ptr(lse), _ffi.ptr(cross))
+                    return R, lse, cross, None
+            logits = self._force(root)
+        finally:
+            plan, self._plan = self._plan, None
+        if isinstance(logits, torch.Tensor):
+            where = logits.untyped_storage().data_ptr()
+            for k_, buf in enumerate(plan):
+                if buf is not None and buf.untyped_storage().data_ptr() == where:
+                    plan[k_] = None
+        R, lse = self.softmax_rows(logits)
+        return R, lse, None, logits
 
     def softmax_rows(self, x):
         x = self._force(x)

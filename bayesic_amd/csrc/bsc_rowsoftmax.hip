@@ -1,0 +1,221 @@
+// Row softmax of a tall-skinny product: R = softmax_rows(A . B), lse, sum_c R * (A . B).
+//
+// The local step of a mixture with exponential-family components (README.md:43: the discrete
+// latent's factor; bayesic/distribution/base.py:47-69 for the likelihood split): the logits of row
+// n are features(x_n) . coefficients -- a [rows, K] x [K, N] product with K, N <= 64 and millions of
+// rows -- and only their softmax is wanted.  As two launches (the executor's _tensordot, then
+// bsc_softmax_rows) the [rows, N] logits are written, read and written again; here a wave owns
+// 32-row tiles, forms their logits with v_mfma_f32_32x32x2_f32 (the forward half of
+// csrc/bsc_mog.hip's E-step: A(B^T in registers) * B(row features: lane = row), so that lane
+// (row, half) holds 32 of the row's N logits), takes the softmax in-lane plus ONE permlane32 swap,
+// and writes the responsibilities through wave-private LDS as whole rows.  HBM-bound: A once,
+// R once.
+//
+// k-steps pair column s with column K/2 + s: the lower half-wave contracts the first half of a
+// row, the upper half-wave the second half, so every lane loads exactly the K/2 contiguous floats
+// it multiplies (K % 8 == 0).
+#include "bsc_common.h"
+
+namespace {
+
+constexpr int RS_T = 32;                 // rows per tile
+constexpr int RS_N = 64;                 // columns of the result (padded)
+constexpr int RS_KH = 32;                // k-steps (K / 2) at most
+constexpr int RS_BLOCK = 256;
+constexpr int RS_WAVES = RS_BLOCK / BSC_WAVE;
+constexpr int RS_STRIDE = RS_N + 4;      // LDS row stride of the staged tile [row][column]
+
+typedef float rs_f32x16 __attribute__((ext_vector_type(16)));
+typedef float rs_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int rs_drow(int q, int lane) {  // C/D row of accumulator register q
+    return (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+}
+
+__device__ __forceinline__ float rs_swap32_max(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+__device__ __forceinline__ float rs_swap32_sum(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+struct RsRow {
+    float x[RS_KH];
+};
+
+// lane (row = l & 31, half = l >> 5) loads columns half * K/2 .. + K/2 - 1 of its row; rows past the
+// end read 0 through the descriptor
+__device__ __forceinline__ void rs_load(RsRow& t, const float* __restrict__ A, int64_t lda, int64_t row0,
+                                        int64_t rows, int K, int lane) {
+    const int64_t rem = rows - row0;
+    uint64_t bytes = 0;
+    if (rem > 0) bytes = ((uint64_t)(rem - 1) * (uint64_t)lda + (uint64_t)K) * 4u;
+    const unsigned rec = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes;
+    const int64_t safe0 = rem > 0 ? row0 : 0;
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(A + safe0 * lda), 0, rec, 0x00020000);
+    const int kh = K >> 1;
+    const int off = (lane & 31) * (int)(lda * 4) + (lane >> 5) * kh * 4;
+#pragma unroll
+    for (int c4 = 0; c4 < RS_KH / 4; ++c4) {
+        if (4 * c4 < kh) {                 // wave-uniform
+            auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16 * c4, 0, 2);   // nt: read once
+            t.x[4 * c4 + 0] = __uint_as_float(v[0]);
+            t.x[4 * c4 + 1] = __uint_as_float(v[1]);
+            t.x[4 * c4 + 2] = __uint_as_float(v[2]);
+            t.x[4 * c4 + 3] = __uint_as_float(v[3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(RS_BLOCK, 2) void gemm_softmax_rows_kernel(
+    const float* __restrict__ A, int64_t lda, int64_t rows, int K, const float* __restrict__ B,
+    int64_t ldbk, int64_t ldbn, int N, float* __restrict__ R, int64_t ldr, float* __restrict__ lse,
+    float* __restrict__ cross, int n_iter) {
+    __shared__ __attribute__((aligned(16))) float lds[RS_WAVES * RS_T * RS_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    float* rt = lds + wave * (RS_T * RS_STRIDE);
+    const int kh = K >> 1;
+
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    // A operand of the MFMA: B[k = half * K/2 + s][column 32 cb + l31], in log2 units
+    float wreg[2][RS_KH];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int col = 32 * cb + l31;
+#pragma unroll
+        for (int s = 0; s < RS_KH; ++s) {
+            float v = 0.f;
+            if (s < kh && col < N) v = B[(int64_t)(half * kh + s) * ldbk + (int64_t)col * ldbn] * LOG2E;
+            wreg[cb][s] = v;
+        }
+    }
+
+    const int64_t stride = (int64_t)gridDim.x * RS_WAVES;
+    int64_t tile = (int64_t)blockIdx.x * RS_WAVES + wave;
+    RsRow xa, xb;
+#pragma unroll
+    for (int s = 0; s < RS_KH; ++s) { xa.x[s] = 0.f; xb.x[s] = 0.f; }
+    rs_load(xa, A, lda, tile * RS_T, rows, K, lane);
+    auto one_tile = [&](const RsRow& cur, RsRow& nxt) {
+        rs_load(nxt, A, lda, (tile + stride) * RS_T, rows, K, lane);   // unconditional prefetch
+        const int64_t row0 = tile * RS_T;
+        rs_f32x16 logit[2];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { logit[0][q] = 0.f; logit[1][q] = 0.f; }
+#pragma unroll
+        for (int c4 = 0; c4 < RS_KH / 4; ++c4) {
+            if (4 * c4 < kh) {             // wave-uniform: whole groups of four k-steps
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int s = 4 * c4 + j;
+                    logit[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[0][s], cur.x[s], logit[0], 0, 0, 0);
+                    logit[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[1][s], cur.x[s], logit[1], 0, 0, 0);
+                }
+            }
+        }
+        if (N < RS_N) {                    // padded columns take no part in the softmax
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (32 * cb + rs_drow(q, lane) >= N) logit[cb][q] = -1.0e30f;
+        }
+        // softmax over the row's columns: 32 in this lane, 32 in lane ^ 32
+        const bool valid = row0 + l31 < rows;
+        float m = -3.0e38f;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) m = fmaxf(m, logit[cb][q]);
+        m = rs_swap32_max(m);
+        const rs_f32x2 m2 = {m, m};
+        rs_f32x2 ssum2 = {0.f, 0.f}, csum2 = {0.f, 0.f};
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {
+                const rs_f32x2 d = rs_f32x2{logit[cb][q], logit[cb][q + 1]} - m2;
+                const rs_f32x2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+                logit[cb][q] = e[0];
+                logit[cb][q + 1] = e[1];
+                ssum2 += e;
+                // (d = -1e30 on a padded column: e = 0 and 0 * -1e30 = -0)
+                csum2 = __builtin_elementwise_fma(e, d, csum2);
+            }
+        const float ssum = rs_swap32_sum(ssum2[0] + ssum2[1]);
+        const float csum = rs_swap32_sum(csum2[0] + csum2[1]);
+        const float inv = 1.0f / ssum;
+        if (valid && half == 0) {
+            // natural-log units: logit = LN2 * log2-logit
+            lse[row0 + l31] = LN2 * (m + __builtin_amdgcn_logf(ssum));
+            if (cross) cross[row0 + l31] = LN2 * (csum * inv + m);
+        }
+        // responsibilities -> LDS as [row][column] (registers 4g .. 4g+3 are 4 consecutive columns)
+        const rs_f32x2 inv2 = {inv, inv};
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const rs_f32x2 a = rs_f32x2{logit[cb][4 * gq], logit[cb][4 * gq + 1]} * inv2;
+                const rs_f32x2 b = rs_f32x2{logit[cb][4 * gq + 2], logit[cb][4 * gq + 3]} * inv2;
+                *reinterpret_cast<float4*>(rt + l31 * RS_STRIDE + 32 * cb + 8 * gq + 4 * half) =
+                    make_float4(a[0], a[1], b[0], b[1]);
+            }
+        wave_lds_sync();
+        // whole rows out: N / 4 sixteen-byte pieces per row, consecutive lanes consecutive pieces
+        const int n4 = N >> 2;
+        for (int c = lane; c < RS_T * n4; c += BSC_WAVE) {
+            const int r = c / n4, p = c - r * n4;
+            if (row0 + r < rows) {
+                const float4 v = *reinterpret_cast<const float4*>(rt + r * RS_STRIDE + 4 * p);
+                *reinterpret_cast<float4*>(R + (row0 + r) * ldr + 4 * p) = v;
+            }
+        }
+        wave_lds_sync();   // the next tile overwrites rt
+        tile += stride;
+    };
+    for (int it = 0; it < n_iter; it += 2) {   // n_iter is even (host): the row buffers alternate
+        one_tile(xa, xb);
+        one_tile(xb, xa);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bsc_gemm_softmax_rows(bsc_ctx* ctx, const float* A, int64_t lda, int64_t rows, int32_t K,
+                          const float* B, int64_t ldbk, int64_t ldbn, int32_t N, float* R, int64_t ldr,
+                          float* lse, float* cross) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(rows >= 0 && K > 0 && N > 0, "bsc_gemm_softmax_rows: rows=%lld K=%d N=%d",
+                (long long)rows, K, N);
+    BSC_REQUIRE((A && R && lse) || rows == 0, "bsc_gemm_softmax_rows: null pointer");
+    BSC_REQUIRE(B != nullptr, "bsc_gemm_softmax_rows: B is null");
+    if (K > 2 * RS_KH || K % 8 != 0 || N > RS_N || N % 4 != 0)
+        return bsc_fail(BSC_ERR_UNSUPPORTED,
+                        "bsc_gemm_softmax_rows: K=%d (<= 64, multiple of 8) N=%d (<= 64, multiple of 4)", K, N);
+    BSC_REQUIRE(lda >= K && lda % 4 == 0 && lda < ((int64_t)1 << 26) && ldr >= N && ldr % 4 == 0,
+                "bsc_gemm_softmax_rows: lda=%lld ldr=%lld", (long long)lda, (long long)ldr);
+    BSC_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)R) & 15) == 0,
+                "bsc_gemm_softmax_rows: A and R must be 16-byte aligned");
+    if (rows == 0) return BSC_OK;
+    const int64_t n_tiles = (rows + RS_T - 1) / RS_T;
+    const int64_t max_waves = (int64_t)2 * 4 * ctx->cu_count;          // two waves per SIMD
+    int64_t n_iter = (n_tiles + max_waves - 1) / max_waves;
+    n_iter += n_iter & 1;                                                // the row buffers alternate
+    const int64_t waves = (n_tiles + n_iter - 1) / n_iter;
+    const int64_t blocks = (waves + RS_WAVES - 1) / RS_WAVES;
+    bsc_prof_scope prof(ctx);
+    hipLaunchKernelGGL(gemm_softmax_rows_kernel, dim3((unsigned)blocks), dim3(RS_BLOCK), 0, ctx->stream, A, lda,
+                       rows, (int)K, B, ldbk, ldbn, (int)N, R, ldr, lse, cross, (int)n_iter);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+}  // extern "C"

@@ -272,6 +272,7 @@ class CategoricalNode(LatentNode):
         self.resident = bool(resident)
         self._backend = None
         self._cache = None          # (E[z], log-sum-exp) of the current eta, on the backend
+        self._cross = None          # sum_c E[z] * eta per row when eta itself was not stored (set_softmax)
         if log_prob is None:
             if not self.resident or shape is None:
                 raise ValueError("log_prob=None needs resident=True and the shape (N, K)")
@@ -293,6 +294,19 @@ class CategoricalNode(LatentNode):
         self._drop_cache() if self._cache is not None else None
         self._cache = None
 
+    FUSED = "logits not materialised"     # eta[0] of a node whose softmax was taken inside the product
+
+    def set_softmax(self, r, lse, cross):
+        """The node's update when the backend took the softmax inside the logits' product
+        (DeviceBackend.evaluate_softmax_rows): responsibilities, log-sum-exp and sum_c r * logits per
+        row -- everything expectations and entropy need; the logits themselves were never stored."""
+        self._drop_cache()
+        self.eta[0] = self.FUSED
+        self._cache = (r, lse)
+        self._cross = cross
+        if hasattr(self._backend, "mark_constant_tensor"):
+            self._backend.mark_constant_tensor(r)
+
     def _drop_cache(self):
         # the responsibilities are marked constant while they stand (the executor then computes a
         # reduction that several messages share -- their column sums -- once); un-mark before the
@@ -300,6 +314,7 @@ class CategoricalNode(LatentNode):
         if self._cache is not None and hasattr(self._backend, "unmark_constant"):
             self._backend.unmark_constant(self._cache[0])
         self._cache = None
+        self._cross = None
 
     def set_eta(self, j, value):
         self.eta[j] = value
@@ -335,7 +350,10 @@ class CategoricalNode(LatentNode):
                 return float(np.prod(self._shape[:-1]) * math.log(self._shape[-1]))
             lse = self._cache[1]
             total = b.to_host(b.sum(lse, list(range(len(self._shape) - 1))))
-            cross = b.to_host(b.sum(b.mul(r, self.eta[0]), list(range(len(self._shape)))))
+            if self._cross is not None:
+                cross = b.to_host(b.sum(self._cross, list(range(len(self._shape) - 1))))
+            else:
+                cross = b.to_host(b.sum(b.mul(r, self.eta[0]), list(range(len(self._shape)))))
             return float(np.asarray(total, np.float64) - np.asarray(cross, np.float64))
         r = self.expectations()[0]
         return float(-np.sum(np.where(r > 0.0, r * np.log(np.where(r > 0.0, r, 1.0)), 0.0)))
@@ -406,6 +424,7 @@ class MeanFieldVMP(object):
     def __init__(self, log_joint, nodes, data, backend=None):
         from ..algebra.backend import resolve_backend
         self.backend = resolve_backend(backend)
+        self.fuse_softmax = True    # (False: a resident Categorical node's logits are always materialised)
         self._log_joint = list(log_joint) if isinstance(log_joint, (list, tuple)) else [log_joint]
         self._elbo_fns = None
         self.nodes = list(nodes)
@@ -548,6 +567,24 @@ class MeanFieldVMP(object):
         SVI), a LOCAL latent -- one factor per datum, like a mixture's assignments -- is updated
         with 1 / (N / B): its own terms are not replicated."""
         node = self._by_name[name]
+        if node.resident and rho == 1.0 and message_scale == 1.0 and isinstance(node, CategoricalNode) and \
+                self.fuse_softmax and hasattr(self.backend, "evaluate_softmax_rows") and \
+                len(self._messages[name]) == 1 and self._messages[name][0] is not None and \
+                len(node._shape) == 2:
+            # a resident Categorical node replaced outright: its logits are only wanted through their
+            # softmax, which the backend may take inside the product that forms them
+            c, _, bound = self._messages[name][0]
+            inputs = dict(self._data)
+            inputs.update(self._expectation_inputs(node))
+            r, lse, cross, logits = self.backend.evaluate_softmax_rows(c, inputs, bound)
+            if logits is None:
+                node.set_softmax(r, lse, cross)
+            else:
+                node.set_eta(0, logits)
+                node._cache = (r, lse)
+                if hasattr(self.backend, "mark_constant_tensor"):
+                    self.backend.mark_constant_tensor(r)
+            return node
         message = self.message(name)
         if node.resident:
             b = self.backend

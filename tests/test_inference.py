@@ -903,3 +903,48 @@ def test_derived_diagonal_mixture_on_device_100k_rows(ctx):
     assert (np.abs(got - eta) <= 1e-3 * scale).all(), np.abs((got - eta) / scale).max()
     import torch
     assert isinstance(model.z.eta[0], torch.Tensor) and model.z.eta[0].is_cuda       # never left the device
+
+
+@pytest.mark.gpu
+def test_softmax_inside_the_logits_product_is_the_same_update(ctx):
+    """With N / B = 1 a resident Categorical node's update takes its softmax INSIDE the product that
+    forms the logits (DeviceBackend.evaluate_softmax_rows -> bsc_gemm_softmax_rows: the logits are
+    never stored).  Same responsibilities, same global updates, same bound as the route that
+    materialises them (MeanFieldVMP.fuse_softmax = False)."""
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from bayesic_amd.inference.mixture import DiagonalMixtureVMP
+    from oracle import svi
+    n, d, k = 30_011, 16, 64
+    X, _, _ = svi.make_cfg3(n, d, k)
+    eta = svi.mog_init_eta(X[:500], k, d, seed=2)
+    alpha, m, kappa, a, b = svi.mog_unpack(eta, k, d)
+    models = []
+    for fuse in (True, False):
+        model = DiagonalMixtureVMP(X, k, n_total=float(n), init=(alpha, m, kappa, a, b),
+                                   backend=DeviceBackend(ctx), dtype="float32")
+        model.vmp.fuse_softmax = fuse
+        calls = []
+        real = ctx.call
+
+        def spy(name, *args, _calls=calls, _real=real):
+            _calls.append(name)
+            return _real(name, *args)
+
+        ctx.call = spy
+        try:
+            for t in range(1, 4):
+                model.step((t + 1.0) ** -0.6)
+        finally:
+            ctx.call = real
+        models.append((model, calls))
+    (fused, fused_calls), (plain, plain_calls) = models
+    assert fused_calls.count("bsc_gemm_softmax_rows") == 3 and fused_calls.count("bsc_softmax_rows") == 0
+    assert plain_calls.count("bsc_gemm_softmax_rows") == 0 and plain_calls.count("bsc_softmax_rows") == 3
+    assert fused.z.eta[0] is fused.z.FUSED
+    # (float32 responsibilities from two different summation orders, three damped updates on)
+    npt.assert_allclose(fused.eta_fused_layout(), plain.eta_fused_layout(), rtol=1e-3, atol=1e-3)
+    rf = fused.vmp.backend.to_host(fused.z.expectations_backend()[0])
+    rp = plain.vmp.backend.to_host(plain.z.expectations_backend()[0])
+    npt.assert_allclose(rf, rp, rtol=1e-3, atol=1e-5)
+    npt.assert_allclose(fused.z.entropy(), plain.z.entropy(), rtol=1e-4)
+    npt.assert_allclose(fused.vmp.elbo(), plain.vmp.elbo(), rtol=1e-5)

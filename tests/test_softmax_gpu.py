@@ -43,3 +43,52 @@ def test_softmax_rows_strided_and_limits(ctx):
     assert float(out[:, 20:].abs().max()) == 0.0
     with pytest.raises(BayesicHipError, match="1024"):
         ctx.call("bsc_softmax_rows", x, 1, 2000, 2000, out, 2000, 0)
+
+
+# ---- bsc_gemm_softmax_rows: the softmax taken inside the tall-skinny product ---------------------
+@pytest.mark.parametrize("rows,K,N,lda,transposed_b", [
+    (1, 8, 4, 8, False), (33, 16, 64, 16, False), (4099, 40, 64, 40, True), (1000, 64, 60, 68, False),
+    (70_001, 40, 64, 40, False), (257, 24, 12, 24, True),
+])
+def test_gemm_softmax_rows_matches_numpy(ctx, rows, K, N, lda, transposed_b):
+    """R = softmax_rows(A . B), lse and cross = sum_c R * (A . B) in one pass; float32 products and
+    sums against float64 numpy: rtol 2e-5 on the responsibilities' scale, 1e-5 * |logit| on lse / cross."""
+    import torch
+    rs = np.random.RandomState(rows + K + N)
+    A_ = np.zeros((rows, lda), np.float32)
+    A_[:, :K] = rs.standard_normal((rows, K))
+    B_ = (rs.standard_normal((K, N)) * 1.5).astype(np.float32)
+    Ad = ctx.to_device(A_)
+    Bd = ctx.to_device(np.ascontiguousarray(B_.T)) if transposed_b else ctx.to_device(B_)
+    ldbk, ldbn = (1, K) if transposed_b else (N, 1)
+    R = ctx.zeros((rows, N), torch.float32)
+    lse = ctx.zeros(rows, torch.float32)
+    cross = ctx.zeros(rows, torch.float32)
+    ctx.call("bsc_gemm_softmax_rows", Ad, lda, rows, K, Bd, ldbk, ldbn, N, R, N, lse, cross)
+    ctx.sync()
+    logits = A_[:, :K].astype(np.float64) @ B_.astype(np.float64)
+    m = logits.max(axis=1, keepdims=True)
+    e = np.exp(logits - m)
+    want = e / e.sum(axis=1, keepdims=True)
+    scale = np.abs(logits).max() + 1.0
+    np.testing.assert_allclose(R.cpu().numpy(), want, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(lse.cpu().numpy(), (m + np.log(e.sum(axis=1, keepdims=True)))[:, 0],
+                               rtol=0, atol=1e-5 * scale)
+    np.testing.assert_allclose(cross.cpu().numpy(), (want * logits).sum(axis=1), rtol=0, atol=2e-5 * scale)
+    # rows sum to one; a null `cross` is allowed
+    np.testing.assert_allclose(R.cpu().numpy().sum(axis=1), 1.0, rtol=1e-5)
+    ctx.call("bsc_gemm_softmax_rows", Ad, lda, rows, K, Bd, ldbk, ldbn, N, R, N, lse, None)
+    ctx.sync()
+
+
+def test_gemm_softmax_rows_envelope(ctx):
+    import torch
+    from bayesic_amd._ffi import BayesicHipError
+    A = ctx.zeros((8, 72), torch.float32)
+    B = ctx.zeros((72, 64), torch.float32)
+    R = ctx.zeros((8, 64), torch.float32)
+    lse = ctx.zeros(8, torch.float32)
+    for K, N in ((72, 64), (12, 64), (16, 6)):
+        with pytest.raises(BayesicHipError, match="bsc_gemm_softmax_rows"):
+            ctx.call("bsc_gemm_softmax_rows", A, 72, 8, K, B, 64, 1, N, R, 64, lse, None)
+    ctx.call("bsc_gemm_softmax_rows", A, 72, 0, 16, B, 64, 1, 64, R, 64, lse, None)     # no rows: nothing to do
