@@ -42,13 +42,15 @@ __device__ __forceinline__ float rs_swap32_sum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+template <int KHT>
 struct RsRow {
-    float x[RS_KH];
+    float x[KHT];
 };
 
 // lane (row = l & 31, half = l >> 5) loads columns half * K/2 .. + K/2 - 1 of its row; rows past the
 // end read 0 through the descriptor
-__device__ __forceinline__ void rs_load(RsRow& t, const float* __restrict__ A, int64_t lda, int64_t row0,
+template <int KHT>
+__device__ __forceinline__ void rs_load(RsRow<KHT>& t, const float* __restrict__ A, int64_t lda, int64_t row0,
                                         int64_t rows, int K, int lane) {
     const int64_t rem = rows - row0;
     uint64_t bytes = 0;
@@ -59,17 +61,19 @@ __device__ __forceinline__ void rs_load(RsRow& t, const float* __restrict__ A, i
     const int kh = K >> 1;
     const int off = (lane & 31) * (int)(lda * 4) + (lane >> 5) * kh * 4;
 #pragma unroll
-    for (int c4 = 0; c4 < RS_KH / 4; ++c4) {
-        if (4 * c4 < kh) {                 // wave-uniform
-            auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16 * c4, 0, 2);   // nt: read once
-            t.x[4 * c4 + 0] = __uint_as_float(v[0]);
-            t.x[4 * c4 + 1] = __uint_as_float(v[1]);
-            t.x[4 * c4 + 2] = __uint_as_float(v[2]);
-            t.x[4 * c4 + 3] = __uint_as_float(v[3]);
-        }
+    for (int c4 = 0; c4 < KHT / 4; ++c4) {  // unconditional: a load inside a branch makes hipcc wait with vmcnt(0)
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16 * c4, 0, 2);   // nt: read once
+        t.x[4 * c4 + 0] = __uint_as_float(v[0]);
+        t.x[4 * c4 + 1] = __uint_as_float(v[1]);
+        t.x[4 * c4 + 2] = __uint_as_float(v[2]);
+        t.x[4 * c4 + 3] = __uint_as_float(v[3]);
     }
 }
 
+// KHT = K / 2 exactly: one instantiation per K = 8, 16, .. 64, so that neither the loads nor the MFMAs
+// sit inside a branch (hipcc answers a conditional load with s_waitcnt vmcnt(0) before every use --
+// the prefetch was waited for the moment it was issued, 1.18 ms instead of 0.8 at 10M x 40 -> 64).
+template <int KHT>
 __global__ __launch_bounds__(RS_BLOCK, 2) void gemm_softmax_rows_kernel(
     const float* __restrict__ A, int64_t lda, int64_t rows, int K, const float* __restrict__ B,
     int64_t ldbk, int64_t ldbn, int N, float* __restrict__ R, int64_t ldr, float* __restrict__ lse,
@@ -83,12 +87,12 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void gemm_softmax_rows_kernel(
 
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
     // A operand of the MFMA: B[k = half * K/2 + s][column 32 cb + l31], in log2 units
-    float wreg[2][RS_KH];
+    float wreg[2][KHT];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         const int col = 32 * cb + l31;
 #pragma unroll
-        for (int s = 0; s < RS_KH; ++s) {
+        for (int s = 0; s < KHT; ++s) {
             float v = 0.f;
             if (s < kh && col < N) v = B[(int64_t)(half * kh + s) * ldbk + (int64_t)col * ldbn] * LOG2E;
             wreg[cb][s] = v;
@@ -97,26 +101,23 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void gemm_softmax_rows_kernel(
 
     const int64_t stride = (int64_t)gridDim.x * RS_WAVES;
     int64_t tile = (int64_t)blockIdx.x * RS_WAVES + wave;
-    RsRow xa, xb;
+    // Three row buffers in rotation: the tile being multiplied and the next TWO in flight -- with one
+    // tile (5 KB per wave at K = 40) in flight the kernel sat at 3.7 TB/s, bound by memory latency.
+    RsRow<KHT> xa, xb, xc;
 #pragma unroll
-    for (int s = 0; s < RS_KH; ++s) { xa.x[s] = 0.f; xb.x[s] = 0.f; }
+    for (int s = 0; s < KHT; ++s) { xa.x[s] = 0.f; xb.x[s] = 0.f; xc.x[s] = 0.f; }
     rs_load(xa, A, lda, tile * RS_T, rows, K, lane);
-    auto one_tile = [&](const RsRow& cur, RsRow& nxt) {
-        rs_load(nxt, A, lda, (tile + stride) * RS_T, rows, K, lane);   // unconditional prefetch
+    rs_load(xb, A, lda, (tile + stride) * RS_T, rows, K, lane);
+    auto one_tile = [&](const RsRow<KHT>& cur, RsRow<KHT>& nxt) {
+        rs_load(nxt, A, lda, (tile + 2 * stride) * RS_T, rows, K, lane);   // unconditional prefetch
         const int64_t row0 = tile * RS_T;
         rs_f32x16 logit[2];
 #pragma unroll
         for (int q = 0; q < 16; ++q) { logit[0][q] = 0.f; logit[1][q] = 0.f; }
 #pragma unroll
-        for (int c4 = 0; c4 < RS_KH / 4; ++c4) {
-            if (4 * c4 < kh) {             // wave-uniform: whole groups of four k-steps
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int s = 4 * c4 + j;
-                    logit[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[0][s], cur.x[s], logit[0], 0, 0, 0);
-                    logit[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[1][s], cur.x[s], logit[1], 0, 0, 0);
-                }
-            }
+        for (int s = 0; s < KHT; ++s) {
+            logit[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[0][s], cur.x[s], logit[0], 0, 0, 0);
+            logit[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[1][s], cur.x[s], logit[1], 0, 0, 0);
         }
         if (N < RS_N) {                    // padded columns take no part in the softmax
 #pragma unroll
@@ -126,7 +127,10 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void gemm_softmax_rows_kernel(
                     if (32 * cb + rs_drow(q, lane) >= N) logit[cb][q] = -1.0e30f;
         }
         // softmax over the row's columns: 32 in this lane, 32 in lane ^ 32
-        const bool valid = row0 + l31 < rows;
+        // rows of this tile that exist (0 .. 32): everything below is 32-bit
+        const int64_t left = rows - row0;
+        const int n_valid = left >= RS_T ? RS_T : (left > 0 ? (int)left : 0);
+        const bool valid = l31 < n_valid;
         float m = -3.0e38f;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
@@ -152,8 +156,12 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void gemm_softmax_rows_kernel(
         const float inv = 1.0f / ssum;
         if (valid && half == 0) {
             // natural-log units: logit = LN2 * log2-logit
-            lse[row0 + l31] = LN2 * (m + __builtin_amdgcn_logf(ssum));
-            if (cross) cross[row0 + l31] = LN2 * (csum * inv + m);
+            float* lse_t = lse + row0;         // (uniform base, 32-bit lane offset)
+            lse_t[l31] = LN2 * (m + __builtin_amdgcn_logf(ssum));
+            if (cross) {
+                float* cross_t = cross + row0;
+                cross_t[l31] = LN2 * (csum * inv + m);
+            }
         }
         // responsibilities -> LDS as [row][column] (registers 4g .. 4g+3 are 4 consecutive columns)
         const rs_f32x2 inv2 = {inv, inv};
@@ -167,21 +175,29 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void gemm_softmax_rows_kernel(
                     make_float4(a[0], a[1], b[0], b[1]);
             }
         wave_lds_sync();
-        // whole rows out: N / 4 sixteen-byte pieces per row, consecutive lanes consecutive pieces
-        const int n4 = N >> 2;
-        for (int c = lane; c < RS_T * n4; c += BSC_WAVE) {
-            const int r = c / n4, p = c - r * n4;
-            if (row0 + r < rows) {
-                const float4 v = *reinterpret_cast<const float4*>(rt + r * RS_STRIDE + 4 * p);
-                *reinterpret_cast<float4*>(R + (row0 + r) * ldr + 4 * p) = v;
+        // whole rows out: a quarter-wave per row (lane & 15 = sixteen-byte piece, lane >> 4 = row of
+        // the group of four), eight groups per tile; no division, 32-bit offsets from the tile's base
+        {
+            float* Rt = R + row0 * ldr;
+            const int p = lane & 15, rq = lane >> 4;
+            const int ld = (int)ldr;
+            const bool piece = 4 * p < N;
+#pragma unroll
+            for (int it = 0; it < RS_T / 4; ++it) {
+                const int r = 4 * it + rq;
+                if (piece && r < n_valid) {
+                    const float4 v = *reinterpret_cast<const float4*>(rt + r * RS_STRIDE + 4 * p);
+                    *reinterpret_cast<float4*>(Rt + r * ld + 4 * p) = v;
+                }
             }
         }
         wave_lds_sync();   // the next tile overwrites rt
         tile += stride;
     };
-    for (int it = 0; it < n_iter; it += 2) {   // n_iter is even (host): the row buffers alternate
-        one_tile(xa, xb);
+    for (int it = 0; it < n_iter; it += 3) {   // n_iter is a multiple of 3 (host): the buffers rotate
+        one_tile(xa, xc);
         one_tile(xb, xa);
+        one_tile(xc, xb);
     }
 }
 
@@ -208,12 +224,24 @@ int bsc_gemm_softmax_rows(bsc_ctx* ctx, const float* A, int64_t lda, int64_t row
     const int64_t n_tiles = (rows + RS_T - 1) / RS_T;
     const int64_t max_waves = (int64_t)2 * 4 * ctx->cu_count;          // two waves per SIMD
     int64_t n_iter = (n_tiles + max_waves - 1) / max_waves;
-    n_iter += n_iter & 1;                                                // the row buffers alternate
+    n_iter = (n_iter + 2) / 3 * 3;                                       // the three row buffers rotate
     const int64_t waves = (n_tiles + n_iter - 1) / n_iter;
     const int64_t blocks = (waves + RS_WAVES - 1) / RS_WAVES;
     bsc_prof_scope prof(ctx);
-    hipLaunchKernelGGL(gemm_softmax_rows_kernel, dim3((unsigned)blocks), dim3(RS_BLOCK), 0, ctx->stream, A, lda,
-                       rows, (int)K, B, ldbk, ldbn, (int)N, R, ldr, lse, cross, (int)n_iter);
+#define BSC_RS(KHT_)                                                                                       \
+    hipLaunchKernelGGL(gemm_softmax_rows_kernel<KHT_>, dim3((unsigned)blocks), dim3(RS_BLOCK), 0, ctx->stream, \
+                       A, lda, rows, (int)K, B, ldbk, ldbn, (int)N, R, ldr, lse, cross, (int)n_iter)
+    switch (K / 2) {
+        case 4: BSC_RS(4); break;
+        case 8: BSC_RS(8); break;
+        case 12: BSC_RS(12); break;
+        case 16: BSC_RS(16); break;
+        case 20: BSC_RS(20); break;
+        case 24: BSC_RS(24); break;
+        case 28: BSC_RS(28); break;
+        default: BSC_RS(32); break;
+    }
+#undef BSC_RS
     BSC_LAUNCH_CHECK();
     return BSC_OK;
 }

@@ -26,6 +26,7 @@ KERNELS = {
     "cfg2": ("blr_pass_mfma_kernel", "bsc_blr.hip", 4.0 * 1_000_000 * 256 + 4.0 * 1_000_000),
     "cfg2stream": ("blr_pass_mfma_kernel", "bsc_blr.hip", 4.0 * 1_000_000 * 256 + 4.0 * 1_000_000),
     "cfg3": ("mog_estep_kernel", "bsc_mog.hip", 4.0 * 10_000_000 * 16),
+    "rowsoftmax": ("gemm_softmax_rows_kernel", "bsc_rowsoftmax.hip", 4.0 * 10_000_000 * (40 + 64 + 2)),
     "cfg4": ("lda_sstats_stream_kernel", "bsc_lda.hip", 4.0 * 6250 * 100_000),
     "cfg5": ("logreg_loglik_dma_kernel", "bsc_bbvi.hip", 4.0 * 1_000_000 * 256 + 8.0 * 1_000_000),
     "wouter": ("weighted_outer_kernel", "bsc_wouter.hip", 4.0 * 10_000_000 * (64 + 16)),

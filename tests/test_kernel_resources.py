@@ -24,6 +24,11 @@ LIMITS = {
         "blr_pass_kernelILb1ELi8ELb1E": (256, 0),
         "blr_fused_update_kernel": (128, 0),
     },
+    "bsc_rowsoftmax.hip": {
+        "gemm_softmax_rows_kernelILi20E": (256, 0),     # K = 40 (the derived mixture): 2 waves/SIMD, no scratch
+        "gemm_softmax_rows_kernelILi8E": (256, 0),
+        "gemm_softmax_rows_kernelILi32E": (256, 0),     # K = 64
+    },
     "bsc_fused.hip": {
         "map_dense_f32_kernelILi2E": (128, 0),
         "map_reduce_wave_dense_f32_kernelILi2ELi4E": (128, 0),

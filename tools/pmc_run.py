@@ -2,7 +2,7 @@
 passes (tools/pmc_collect.sh).  Inputs are random device tensors (counters do not depend on the
 values); the call is the same C-ABI entry point bench.py / the drivers use.
 
-    python3 tools/pmc_run.py cfg2|cfg3|cfg4|cfg5|wouter|gram|skinny|lda1|lda1e|lda2|sq4096nt|sq4096tn [reps]
+    python3 tools/pmc_run.py cfg2|cfg3|cfg4|cfg5|rowsoftmax|wouter|gram|skinny|lda1|lda1e|lda2|sq4096nt|sq4096tn [reps]
 """
 import os
 import sys
@@ -39,6 +39,15 @@ def main():
         y = torch.randn(N, generator=g, device=dev)
         W = torch.randn((S, D), generator=g, device=dev) / 16
         fn = lambda: ctx.call("bsc_blr_data_pass_partial", X, D, y, N, D, W, S)
+    elif which == "rowsoftmax":
+        # the derived mixture's local step: softmax_rows([X | X^2 | 1 | 0..] . coefficients), 10M x 40 -> 64
+        N, K, C = 10_000_000, 40, 64
+        A = torch.randn((N, K), generator=g, device=dev)
+        B = torch.randn((K, C), generator=g, device=dev) * 0.3
+        R = torch.empty((N, C), device=dev)
+        lse = torch.empty(N, device=dev)
+        cross = torch.empty(N, device=dev)
+        fn = lambda: ctx.call("bsc_gemm_softmax_rows", A, K, N, K, B, C, 1, C, R, C, lse, cross)
     elif which == "cfg3":
         N, D, K = 10_000_000, 16, 64
         X = torch.randn((N, D), generator=g, device=dev) * 3
