@@ -234,7 +234,7 @@ class Cfg2(Workload):
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(kernel, self.rows == 1_000_000 and self.D == 256),
                 "algorithmic_bytes_per_launch": algo,
-                "launches_per_step": (self.S + 7) // 8}
+                "launches_per_step": self.model._passes_per_update()}
 
     def cpu_baseline(self, budget_s):
         """Three legs on this host, each bounded to ~budget_s: (a) numpy float32/BLAS executing the
