@@ -80,7 +80,7 @@ SIGNATURES = {
                                        c_float]),
     "bsc_softmax_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "bsc_gemm_softmax_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64,
-                                      c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
+                                      c_int64, c_int32, c_float, c_void_p, c_int64, c_void_p, c_void_p]),
     "bsc_suffstats_normal": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "bsc_mog_estep": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p,
                               c_void_p, c_void_p, c_void_p]),

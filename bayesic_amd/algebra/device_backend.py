@@ -814,8 +814,8 @@ class DeviceBackend(Backend):
         x = self._force(x)
         return torch.diagonal(x, 0, axis1, axis2)     # view; the diagonal axis goes last
 
-    def evaluate_softmax_rows(self, expr, inputs, bindings=None):
-        """softmax over the last axis of the value of ``expr`` (a resident Categorical node's update).
+    def evaluate_softmax_rows(self, expr, inputs, bindings=None, scale=1.0):
+        """softmax over the last axis of ``scale`` times the value of ``expr`` (a resident Categorical node's update).
         Returns (R, lse, cross, logits): when the value is a tall-skinny product nothing else reads --
         the logits of a mixture, after _concat_products one product [X | X^2 | 1] . coefficients --
         ONE launch (bsc_gemm_softmax_rows) produces R, lse and cross = sum_c R * logits, and
@@ -833,15 +833,17 @@ class DeviceBackend(Backend):
             g = root if isinstance(root, LazyGemm) else None
             if g is not None and self._keep is None:
                 xb, m, n, k, x, sxb, sxm, sxk, y, syb, syk, syn = g.gemm
-                if g.power == 1 and g.E is None and g.scale == 1.0 and xb == 1 and sxk == 1 and k % 8 == 0 \
+                if g.power == 1 and g.E is None and xb == 1 and sxk == 1 and k % 8 == 0 \
                         and k <= 64 and n <= 64 and n % 4 == 0 and sxm % 4 == 0 and x.data_ptr() % 16 == 0 \
                         and g.dtype == torch.float32 and len(g.shape) == 2:
                     R = self.ctx.empty((m, n), torch.float32)
                     lse = self.ctx.empty((m,), torch.float32)
                     cross = self.ctx.empty((m,), torch.float32)
                     self.ctx.call("bsc_gemm_softmax_rows", _ffi.ptr(x), sxm, m, k, _ffi.ptr(y), syk, syn, n,
-                                  _ffi.ptr(R), n, _ffi.ptr(lse), _ffi.ptr(cross))
+                                  float(g.scale) * float(scale), _ffi.ptr(R), n, _ffi.ptr(lse), _ffi.ptr(cross))
                     return R, lse, cross, None
+            if float(scale) != 1.0:
+                root = self._combine("mul", [root, HostScalar(float(scale))])
             logits = self._force(root)
         finally:
             plan, self._plan = self._plan, None

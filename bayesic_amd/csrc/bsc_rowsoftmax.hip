@@ -1,4 +1,4 @@
-// Row softmax of a tall-skinny product: R = softmax_rows(A . B), lse, sum_c R * (A . B).
+// Row softmax of a tall-skinny product: R = softmax_rows(alpha A . B), lse, sum_c R * (alpha A . B).
 //
 // The local step of a mixture with exponential-family components (README.md:43: the discrete
 // latent's factor; bayesic/distribution/base.py:47-69 for the likelihood split): the logits of row
@@ -76,8 +76,8 @@ __device__ __forceinline__ void rs_load(RsRow<KHT>& t, const float* __restrict__
 template <int KHT>
 __global__ __launch_bounds__(RS_BLOCK, 2) void gemm_softmax_rows_kernel(
     const float* __restrict__ A, int64_t lda, int64_t rows, int K, const float* __restrict__ B,
-    int64_t ldbk, int64_t ldbn, int N, float* __restrict__ R, int64_t ldr, float* __restrict__ lse,
-    float* __restrict__ cross, int n_iter) {
+    int64_t ldbk, int64_t ldbn, int N, float alpha, float* __restrict__ R, int64_t ldr,
+    float* __restrict__ lse, float* __restrict__ cross, int n_iter) {
     __shared__ __attribute__((aligned(16))) float lds[RS_WAVES * RS_T * RS_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void gemm_softmax_rows_kernel(
     const int kh = K >> 1;
 
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-    // A operand of the MFMA: B[k = half * K/2 + s][column 32 cb + l31], in log2 units
+    // A operand of the MFMA: alpha * B[k = half * K/2 + s][column 32 cb + l31], in log2 units
     float wreg[2][KHT];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void gemm_softmax_rows_kernel(
 #pragma unroll
         for (int s = 0; s < KHT; ++s) {
             float v = 0.f;
-            if (s < kh && col < N) v = B[(int64_t)(half * kh + s) * ldbk + (int64_t)col * ldbn] * LOG2E;
+            if (s < kh && col < N) v = B[(int64_t)(half * kh + s) * ldbk + (int64_t)col * ldbn] * (alpha * LOG2E);
             wreg[cb][s] = v;
         }
     }
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void gemm_softmax_rows_kernel(
 extern "C" {
 
 int bsc_gemm_softmax_rows(bsc_ctx* ctx, const float* A, int64_t lda, int64_t rows, int32_t K,
-                          const float* B, int64_t ldbk, int64_t ldbn, int32_t N, float* R, int64_t ldr,
-                          float* lse, float* cross) {
+                          const float* B, int64_t ldbk, int64_t ldbn, int32_t N, float alpha, float* R,
+                          int64_t ldr, float* lse, float* cross) {
     BSC_CHECK_CTX(ctx);
     BSC_REQUIRE(rows >= 0 && K > 0 && N > 0, "bsc_gemm_softmax_rows: rows=%lld K=%d N=%d",
                 (long long)rows, K, N);
@@ -230,7 +230,7 @@ int bsc_gemm_softmax_rows(bsc_ctx* ctx, const float* A, int64_t lda, int64_t row
     bsc_prof_scope prof(ctx);
 #define BSC_RS(KHT_)                                                                                       \
     hipLaunchKernelGGL(gemm_softmax_rows_kernel<KHT_>, dim3((unsigned)blocks), dim3(RS_BLOCK), 0, ctx->stream, \
-                       A, lda, rows, (int)K, B, ldbk, ldbn, (int)N, R, ldr, lse, cross, (int)n_iter)
+                       A, lda, rows, (int)K, B, ldbk, ldbn, (int)N, alpha, R, ldr, lse, cross, (int)n_iter)
     switch (K / 2) {
         case 4: BSC_RS(4); break;
         case 8: BSC_RS(8); break;

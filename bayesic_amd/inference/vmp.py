@@ -567,7 +567,7 @@ class MeanFieldVMP(object):
         SVI), a LOCAL latent -- one factor per datum, like a mixture's assignments -- is updated
         with 1 / (N / B): its own terms are not replicated."""
         node = self._by_name[name]
-        if node.resident and rho == 1.0 and message_scale == 1.0 and isinstance(node, CategoricalNode) and \
+        if node.resident and rho == 1.0 and isinstance(node, CategoricalNode) and \
                 self.fuse_softmax and hasattr(self.backend, "evaluate_softmax_rows") and \
                 len(self._messages[name]) == 1 and self._messages[name][0] is not None and \
                 len(node._shape) == 2:
@@ -576,7 +576,7 @@ class MeanFieldVMP(object):
             c, _, bound = self._messages[name][0]
             inputs = dict(self._data)
             inputs.update(self._expectation_inputs(node))
-            r, lse, cross, logits = self.backend.evaluate_softmax_rows(c, inputs, bound)
+            r, lse, cross, logits = self.backend.evaluate_softmax_rows(c, inputs, bound, scale=message_scale)
             if logits is None:
                 node.set_softmax(r, lse, cross)
             else:

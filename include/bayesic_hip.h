@@ -282,17 +282,17 @@ int bsc_softmax_rows(bsc_ctx* ctx, const float* in, int64_t rows, int64_t cols, 
                      int64_t ld_out, float* lse);
 
 /* The same expectation when the logits are a tall-skinny product that nothing else needs:
- *   R = softmax_rows(A . B),  lse[r] = log sum_c exp (A . B)[r, c],  cross[r] = sum_c R[r, c] (A . B)[r, c]
+ *   L = alpha * A . B,  R = softmax_rows(L),  lse[r] = log sum_c exp L[r, c],  cross[r] = sum_c R[r, c] L[r, c]
  * with A [rows, K] (unit column stride, rows lda apart), B [K, N] (strides ldbk, ldbn), R [rows, N]
  * (rows ldr apart) -- features(x_n) . coefficients of a mixture with exponential-family components
- * (README.md:43).  One pass: A is read once and R written once; the logits never reach memory (as two
+ * (README.md:43; alpha = the 1 / (N / B) of a local latent under mini-batch scaling, README.md:69-79).  One pass: A is read once and R written once; the logits never reach memory (as two
  * launches they are written, read and written again).  `cross` (may be NULL) is what the factor's
  * entropy sum_r (lse[r] - cross[r]) needs in place of the logits.  float32; K <= 64 and a multiple of
  * 8, N <= 64 and a multiple of 4, A and R 16-byte aligned, lda % 4 == ldr % 4 == 0; anything else is
  * BSC_ERR_UNSUPPORTED (callers then take bsc_gemm_strided_batched + bsc_softmax_rows). */
 int bsc_gemm_softmax_rows(bsc_ctx* ctx, const float* A, int64_t lda, int64_t rows, int32_t K,
-                          const float* B, int64_t ldbk, int64_t ldbn, int32_t N, float* R, int64_t ldr,
-                          float* lse, float* cross);
+                          const float* B, int64_t ldbk, int64_t ldbn, int32_t N, float alpha, float* R,
+                          int64_t ldr, float* lse, float* cross);
 
 /* Fixed-gamma local step of the LDA-style Dirichlet-Multinomial model (BASELINE
  * config 4): sstats[k,v] = Bt[k,v] * sum_d Th[d,k] C[d,v] / (sum_k' Th[d,k'] Bt[k',v]),

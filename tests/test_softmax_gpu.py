@@ -64,9 +64,10 @@ def test_gemm_softmax_rows_matches_numpy(ctx, rows, K, N, lda, transposed_b):
     R = ctx.zeros((rows, N), torch.float32)
     lse = ctx.zeros(rows, torch.float32)
     cross = ctx.zeros(rows, torch.float32)
-    ctx.call("bsc_gemm_softmax_rows", Ad, lda, rows, K, Bd, ldbk, ldbn, N, R, N, lse, cross)
+    alpha = 1.0 if rows % 2 else 0.375           # (the multiplier of a local latent under mini-batch scaling)
+    ctx.call("bsc_gemm_softmax_rows", Ad, lda, rows, K, Bd, ldbk, ldbn, N, alpha, R, N, lse, cross)
     ctx.sync()
-    logits = A_[:, :K].astype(np.float64) @ B_.astype(np.float64)
+    logits = alpha * (A_[:, :K].astype(np.float64) @ B_.astype(np.float64))
     m = logits.max(axis=1, keepdims=True)
     e = np.exp(logits - m)
     want = e / e.sum(axis=1, keepdims=True)
@@ -77,7 +78,7 @@ def test_gemm_softmax_rows_matches_numpy(ctx, rows, K, N, lda, transposed_b):
     np.testing.assert_allclose(cross.cpu().numpy(), (want * logits).sum(axis=1), rtol=0, atol=2e-5 * scale)
     # rows sum to one; a null `cross` is allowed
     np.testing.assert_allclose(R.cpu().numpy().sum(axis=1), 1.0, rtol=1e-5)
-    ctx.call("bsc_gemm_softmax_rows", Ad, lda, rows, K, Bd, ldbk, ldbn, N, R, N, lse, None)
+    ctx.call("bsc_gemm_softmax_rows", Ad, lda, rows, K, Bd, ldbk, ldbn, N, alpha, R, N, lse, None)
     ctx.sync()
 
 
@@ -90,5 +91,5 @@ def test_gemm_softmax_rows_envelope(ctx):
     lse = ctx.zeros(8, torch.float32)
     for K, N in ((72, 64), (12, 64), (16, 6)):
         with pytest.raises(BayesicHipError, match="bsc_gemm_softmax_rows"):
-            ctx.call("bsc_gemm_softmax_rows", A, 72, 8, K, B, 64, 1, N, R, 64, lse, None)
-    ctx.call("bsc_gemm_softmax_rows", A, 72, 0, 16, B, 64, 1, 64, R, 64, lse, None)     # no rows: nothing to do
+            ctx.call("bsc_gemm_softmax_rows", A, 72, 8, K, B, 64, 1, N, 1.0, R, 64, lse, None)
+    ctx.call("bsc_gemm_softmax_rows", A, 72, 0, 16, B, 64, 1, 64, 1.0, R, 64, lse, None)     # no rows: nothing to do

@@ -47,7 +47,7 @@ def main():
         R = torch.empty((N, C), device=dev)
         lse = torch.empty(N, device=dev)
         cross = torch.empty(N, device=dev)
-        fn = lambda: ctx.call("bsc_gemm_softmax_rows", A, K, N, K, B, C, 1, C, R, C, lse, cross)
+        fn = lambda: ctx.call("bsc_gemm_softmax_rows", A, K, N, K, B, C, 1, C, 1.0, R, C, lse, cross)
     elif which == "cfg3":
         N, D, K = 10_000_000, 16, 64
         X = torch.randn((N, D), generator=g, device=dev) * 3
