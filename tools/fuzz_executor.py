@@ -1,4 +1,9 @@
-"""Longer run of the generator of tests/test_fuzz_gpu.py: python tools/fuzz_executor.py [seeds] [max_steps]"""
+"""Longer run of the generator of tests/test_fuzz_gpu.py: python tools/fuzz_executor.py [seeds] [max_steps]
+
+FUZZ_CONSTANTS=1: every input is uploaded once and MARKED CONSTANT, and each tree is evaluated twice on
+the device -- the second time through whatever the executor cached of it (element-wise values of
+constants, sums of constants, wide operands of concatenated products and the products with them) --
+both against the float64 oracle."""
 import builtins
 import os
 import sys
@@ -22,6 +27,17 @@ def main():
         for n in list(F.SHAPES):
             F.SHAPES[n] = tuple(d * scale_dims for d in F.SHAPES[n])
     dev = DeviceBackend(Context(0))
+    constants = os.environ.get("FUZZ_CONSTANTS", "0") == "1"
+    resident = {}
+    if constants:
+        import torch
+        for name, value in F.inputs().items():
+            arr = np.asarray(value)
+            resident[name] = (dev.from_host(arr.astype(np.float32), "float32", arr.ndim), arr)
+        for t, _ in resident.values():
+            if isinstance(t, torch.Tensor):
+                dev.mark_constant(t)
+                dev.mark_constant_tensor(t)
     bad = ran = 0
     for seed in range(1000, 1000 + seeds):
         made = F.Grower(seed).grow(2 + seed % max_steps)
@@ -33,7 +49,20 @@ def main():
             want = np.asarray(expr.compile(NumpyBackend(np.float64))(**vals), np.float64)
             if not np.isfinite(want).all():
                 continue
-            got = np.asarray(expr.compile(dev)(**vals), np.float64)
+            if constants:
+                f = expr.compile(dev).device_fn
+                dvals = {n: resident[n][0] for n in vals}
+                first = np.asarray(dev.to_host(f(**dvals)), np.float64)
+                got = np.asarray(dev.to_host(f(**dvals)), np.float64)
+                if first.shape != got.shape or not np.allclose(first, got, rtol=1e-5, atol=1e-6 * (1 + np.abs(want).max())):
+                    bad += 1
+                    print("CACHED != FIRST seed %d: %r" % (seed, expr), flush=True)
+                if got.ndim == 0 and want.ndim > 0:
+                    got = got.reshape((1,) * want.ndim)
+                if got.shape != want.shape:
+                    got = np.broadcast_to(got, want.shape)
+            else:
+                got = np.asarray(expr.compile(dev)(**vals), np.float64)
             ran += 1
             scale = builtins.max(float(np.abs(want).max()) if want.size else 0.0, 1e-3)
             err = float(np.abs(got - want).max()) if want.size else 0.0
