@@ -106,6 +106,13 @@ class MoGNatGradSVI:
             self._s1 = A.dot(Rv.T, Xv).compile(be).device_fn
             self._s2 = A.dot(Rv.T, Xv * Xv).compile(be).device_fn
             self._lse_sum = A.sum(A.var("l", 1)).compile(be).device_fn
+            # the mini-batch does not change between updates: the executor then keeps X * X, runs the
+            # logits as ONE product [X | X^2 | 1] . [B | A | c]^T and -- with the responsibilities marked
+            # while they stand -- the three statistics as one product against the same wide operand
+            import os
+            self._constants = os.environ.get("BSC_MOG_EXECUTOR_CONSTANTS", "1") != "0"   # (0: for A/B runs)
+            if self._constants:
+                be.mark_constant(self.X)
 
     def expected_params(self):
         self.ctx.call("bsc_mog_expected_params", self.eta, self.K, self.D, self.Wmat,
@@ -119,6 +126,8 @@ class MoGNatGradSVI:
         be, D = self.backend, self.D
         logits = self._logits(X=self.X, B=self.Wmat[:, :D], A=self.Wmat[:, D:], c=self.c)
         R, lse = be.softmax_rows(logits)
+        if self._constants:
+            be.mark_constant_tensor(R)
         stats = self.stats.view(self.K, 1 + 2 * D)
         f64 = torch.float64
         # (dtype conversion through bsc_convert; the slice copies are device-to-device plumbing)
@@ -126,6 +135,8 @@ class MoGNatGradSVI:
         stats[:, 1:1 + D].copy_(be._convert(be.materialize(self._s1(R=R, X=self.X)), f64))
         stats[:, 1 + D:].copy_(be._convert(be.materialize(self._s2(R=R, X=self.X)), f64))
         self.lse.copy_(be._convert(be.materialize(self._lse_sum(l=lse)).reshape(1), f64))
+        if self._constants:
+            be.unmark_constant(R)       # before the buffer can be reused
 
     def step(self, rho=None):
         """One SVI update; rho defaults to the Robbins-Monro schedule (t+1)^-0.6."""
