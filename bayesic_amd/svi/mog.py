@@ -101,7 +101,7 @@ class MoGNatGradSVI:
             from ..algebra.device_backend import DeviceBackend
             self.backend = be = DeviceBackend(self.ctx)
             Xv, Bv, Av, cv, Rv = A.var("X", 2), A.var("B", 2), A.var("A", 2), A.var("c", 1), A.var("R", 2)
-            self._logits = (A.dot(Xv, Bv.T) + A.dot(Xv * Xv, Av.T) + A.dimshuffle(cv, "x", 0)).compile(be).device_fn
+            self._logits_expr = A.dot(Xv, Bv.T) + A.dot(Xv * Xv, Av.T) + A.dimshuffle(cv, "x", 0)
             self._s0 = A.sum(Rv, axis=0).compile(be).device_fn
             self._s1 = A.dot(Rv.T, Xv).compile(be).device_fn
             self._s2 = A.dot(Rv.T, Xv * Xv).compile(be).device_fn
@@ -124,8 +124,10 @@ class MoGNatGradSVI:
                           self.Wmat, self.c, self.stats, self.lse)
             return
         be, D = self.backend, self.D
-        logits = self._logits(X=self.X, B=self.Wmat[:, :D], A=self.Wmat[:, D:], c=self.c)
-        R, lse = be.softmax_rows(logits)
+        # (K <= 64 and 2 D + 1 <= 64 with a constant mini-batch: the softmax is taken inside the one
+        # product that forms the logits -- bsc_gemm_softmax_rows; otherwise product, then bsc_softmax_rows)
+        R, lse, _, _ = be.evaluate_softmax_rows(
+            self._logits_expr, dict(X=self.X, B=self.Wmat[:, :D], A=self.Wmat[:, D:], c=self.c))
         if self._constants:
             be.mark_constant_tensor(R)
         stats = self.stats.view(self.K, 1 + 2 * D)

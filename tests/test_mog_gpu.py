@@ -121,7 +121,7 @@ def test_unsupported_sizes_fail_loudly(ctx):
         ctx.call("bsc_mog_estep", ptr(X), 17, 8, 17, 4, ptr(W), ptr(c), ptr(stats), ptr(lse))
 
 
-@pytest.mark.parametrize("K,D", [(100, 24), (8, 16), (65, 4), (200, 40)])
+@pytest.mark.parametrize("K,D", [(100, 24), (8, 16), (65, 4), (200, 40), (64, 24), (32, 20)])
 def test_executor_route_beyond_one_tile_matches_oracle(ctx, K, D):
     """K > 64 or D > 16 (outside the fused kernel's MFMA tile): the same local step through the
     algebra executor -- GEMMs, one fused add, bsc_softmax_rows, three contractions -- against the
