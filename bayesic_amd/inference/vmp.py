@@ -412,6 +412,88 @@ class NotConjugateMessage(ValueError):
     pass
 
 
+class _ResidentGlobal(object):
+    """Mixin for a parameter-sized factor whose natural parameters and expectations live on the
+    backend (``resident=True`` in DiagonalMixtureVMP): no message is read back and no expectation
+    uploaded per update, so an update issues its launches without a single host synchronisation and
+    the Python walk of the next message runs while the device works on the previous one.  float32 on
+    the device backend (the host-side nodes keep float64)."""
+    resident = True
+
+    def bind(self, backend):
+        self._backend = backend
+        self._shape = tuple(np.broadcast_shapes(*[np.shape(e) for e in self.eta]))
+        # (float64 handed over: a float64 backend keeps it, the device backend stores float32)
+        self.eta = [backend.from_host(np.ascontiguousarray(np.broadcast_to(np.asarray(e, np.float64), self._shape)),
+                                      "float32", len(self._shape))
+                    for e in self.eta]
+        self._exp = None
+
+    def set_eta(self, j, value):
+        b = self._backend
+        value = b.materialize(value)
+        if tuple(np.shape(value)) != self._shape:
+            # a coefficient that does not depend on one of the statistic's axes comes back with that
+            # axis broadcast (extent 1): sum_d LT_kd inside a term gives c_kd = c_k
+            value = b.materialize(b.elemwise("add", b.broadcast_to(value, self._shape), b.constant(0.0)))
+        self.eta[j] = value
+        self._exp = None
+
+    def host_eta(self):
+        return [np.asarray(self._backend.to_host(e), np.float64).reshape(self._shape) for e in self.eta]
+
+    def expectations(self):
+        return [np.asarray(self._backend.to_host(e), np.float64) for e in self.expectations_backend()]
+
+    def entropy(self):
+        return self.host_copy().entropy()
+
+
+class ResidentDirichletNode(_ResidentGlobal, DirichletNode):
+    def expectations_backend(self):
+        if self._exp is None:
+            b = self._backend
+            alpha = b.elemwise("add", self.eta[0], b.constant(1.0))
+            last = len(self._shape) - 1
+            total = b.sum(alpha, [last])
+            axes = list(range(last)) + ["x"]
+            psi_total = b.dimshuffle(b.elemwise("digamma", total), axes)
+            self._exp = [b.materialize(b.elemwise("add", b.elemwise("digamma", alpha),
+                                                  b.mul(b.constant(-1.0), psi_total)))]
+        return self._exp
+
+    def host_copy(self):
+        return DirichletNode(self.var, alpha=self.host_eta()[0] + 1.0)
+
+
+class ResidentNormalGammaNode(_ResidentGlobal, NormalGammaNode):
+    def expectations_backend(self):
+        """(E[tau mu], E[tau mu^2], E[log tau], E[tau]) from eta = (kappa m, -kappa / 2, a - 1/2,
+        -b - kappa m^2 / 2), element-wise on the backend."""
+        if self._exp is None:
+            b = self._backend
+            e1, e2, e3, e4 = self.eta
+            c = b.constant
+            inv = lambda x: b.elemwise("pow", x, c(-1.0))
+            kappa = b.materialize(b.mul(c(-2.0), e2))
+            m = b.materialize(b.mul(e1, inv(kappa)))
+            a = b.materialize(b.elemwise("add", e3, c(0.5)))
+            rate = b.materialize(b.elemwise("add", b.mul(c(-1.0), e4), b.mul(c(-0.5), kappa, m, m)))
+            a_over_b = b.materialize(b.mul(a, inv(rate)))
+            self._exp = [b.materialize(b.mul(m, a_over_b)),
+                         b.materialize(b.elemwise("add", inv(kappa), b.mul(m, m, a_over_b))),
+                         b.materialize(b.elemwise("add", b.elemwise("digamma", a),
+                                                  b.mul(c(-1.0), b.elemwise("log", rate)))),
+                         a_over_b]
+        return self._exp
+
+    def host_copy(self):
+        e1, e2, e3, e4 = self.host_eta()
+        kappa = -2.0 * e2
+        m = e1 / kappa
+        return NormalGammaNode(*self._vars, m=m, kappa=kappa, a=e3 + 0.5, b=-e4 - 0.5 * kappa * m * m)
+
+
 class MeanFieldVMP(object):
     """Coordinate-ascent mean field on a conjugate-exponential log-joint.
 

@@ -859,7 +859,7 @@ def test_elbo_sees_data_that_occurs_only_in_latent_free_terms_and_untouched_stat
 
 # ---- config 3's model, updates derived: resident assignments, NormalGamma factors ---------------
 
-def _cfg3_derived_and_oracle(backend, dtype, n, d, k, steps, resident=True):
+def _cfg3_derived_and_oracle(backend, dtype, n, d, k, steps, resident=True, resident_globals=None):
     from bayesic_amd.inference.mixture import DiagonalMixtureVMP
     from oracle import svi
     X, _, _ = svi.make_cfg3(n, d, k)
@@ -867,7 +867,8 @@ def _cfg3_derived_and_oracle(backend, dtype, n, d, k, steps, resident=True):
     eta = svi.mog_init_eta(X[:500], k, d, seed=2)
     alpha, m, kappa, a, b = svi.mog_unpack(eta, k, d)
     model = DiagonalMixtureVMP(X if dtype == "float32" else X.astype(np.float64), k, n_total=10.0 * n,
-                               init=(alpha, m, kappa, a, b), backend=backend, dtype=dtype, resident=resident)
+                               init=(alpha, m, kappa, a, b), backend=backend, dtype=dtype, resident=resident,
+                               resident_globals=resident_globals)
     for t in range(1, steps + 1):
         rho = (t + 1.0) ** -0.6
         model.step(rho)
@@ -889,6 +890,29 @@ def test_derived_diagonal_mixture_equals_the_config3_svi_step():
     # resident and host-side assignments are the same update
     host, _ = _cfg3_derived_and_oracle(B64, "float64", 3000, 5, 4, steps=3, resident=False)
     npt.assert_allclose(model.eta_fused_layout(), host.eta_fused_layout(), rtol=1e-9)
+
+
+def test_derived_mixture_with_resident_global_factors():
+    """resident_globals=True: the Dirichlet and NormalGamma factors keep their natural parameters and
+    expectations on the backend (digamma, log, reciprocals as element-wise backend ops), so an update
+    reads nothing back.  Same updates as the host-side factors (float64 backend) and as the oracle."""
+    model, eta = _cfg3_derived_and_oracle(B64, "float64", 3000, 5, 4, steps=3, resident_globals=True)
+    npt.assert_allclose(model.eta_fused_layout(), eta, rtol=2e-5, atol=1e-6)
+    host, _ = _cfg3_derived_and_oracle(B64, "float64", 3000, 5, 4, steps=3, resident_globals=False)
+    assert not host.resident_globals and model.resident_globals
+    npt.assert_allclose(model.eta_fused_layout(), host.eta_fused_layout(), rtol=1e-6, atol=1e-9)
+    npt.assert_allclose(model.vmp.elbo(), host.vmp.elbo(), rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_derived_mixture_with_resident_global_factors_on_device(ctx):
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    model, eta = _cfg3_derived_and_oracle(DeviceBackend(ctx), "float32", 100_000, 16, 64, steps=2,
+                                          resident_globals=True)
+    got = model.eta_fused_layout()
+    scale = np.maximum(np.abs(eta), 1.0)
+    assert (np.abs(got - eta) <= 1e-3 * scale).all(), np.abs((got - eta) / scale).max()
+    assert np.isfinite(model.vmp.elbo())
 
 
 @pytest.mark.gpu

@@ -33,7 +33,8 @@ def main():
     eta = mog_mod.init_eta(X[:2000], K, D, seed=2)
     alpha, m, kappa, a, b = mog_mod.unpack(eta, K, D)
     fused = mog_mod.MoGNatGradSVI(ctx.to_device(X), K, eta0, eta, n_total=float(n), ctx=ctx)
-    derived = DiagonalMixtureVMP(X, K, n_total=float(n), init=(alpha, m, kappa, a, b), backend=DeviceBackend(ctx))
+    derived = DiagonalMixtureVMP(X, K, n_total=float(n), init=(alpha, m, kappa, a, b), backend=DeviceBackend(ctx),
+                                 resident_globals="--host-globals" not in sys.argv)
     for name, step in (("fused (svi/mog.py)", fused.step), ("derived (inference/mixture.py)", derived.step)):
         for _ in range(3):
             step()
