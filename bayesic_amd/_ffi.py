@@ -62,6 +62,7 @@ SIGNATURES = {
                                         c_void_p, c_int32, c_void_p, c_void_p, c_int32]),
     "bsc_blr_data_pass_partial_sweep": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                                 c_int32, c_void_p, c_int32, c_int32]),
+    "bsc_blr_pass_count": (c_int, [c_void_p, c_void_p, c_int32, c_int32, POINTER(c_int32)]),
     "bsc_blr_fused_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,
                                      c_double, c_double, c_double, c_int64, c_double, c_double,
@@ -87,6 +88,10 @@ SIGNATURES = {
     "bsc_mog_expected_params": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "bsc_mog_natgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,
                                 c_double]),
+    "bsc_mog_expected_params_bound": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+                                              c_void_p]),
+    "bsc_mog_natgrad_elbo": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,
+                                     c_double, c_void_p, c_void_p, c_void_p]),
     "bsc_bbvi_sample": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_uint64, c_uint32,
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "bsc_logreg_bbvi_loglik": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
@@ -107,6 +112,14 @@ SIGNATURES = {
                                c_int64, c_void_p, c_int64, c_void_p, c_int64]),
     "bsc_lda_sstats_csc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32,
                                    c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
+    "bsc_lda_sstats_bound": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p,
+                                     c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "bsc_lda_sstats_csc_bound": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32,
+                                         c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "bsc_dirichlet_expectation_bound": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_double,
+                                                c_void_p, c_void_p]),
+    "bsc_natgrad_update_f32_elbo": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_float, c_float,
+                                            c_void_p, c_void_p, c_void_p, c_void_p]),
     "bsc_weighted_outer": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                    c_int64, c_int32, c_int32, c_int32, c_double, c_void_p]),
     "bsc_hbm_read_probe": (c_int, [c_void_p, c_void_p, c_size_t, c_int, POINTER(c_double)]),

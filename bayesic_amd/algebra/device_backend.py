@@ -39,6 +39,7 @@ import numpy as np
 import torch
 
 from .. import _ffi
+from .._ffi import BayesicHipError
 from ..device import Context, default_context
 from .backend import Backend
 
@@ -125,8 +126,13 @@ class DeviceBackend(Backend):
         self.fuse = bool(fuse)
         self._one = None          # a resident float32 1.0 (broadcast_to of a host scalar)
         self._keep = None         # buffers made inside an open graph capture
-        self._const = set()       # storages the caller promised not to change (mark_constant)
-        self._const_ptrs = set()  # single tensors under the same promise (mark_constant_tensor)
+        # storages the caller promised not to change (mark_constant): storage address -> the tensor.  The
+        # strong reference is what makes an ADDRESS a valid identity: while a tensor is marked its block
+        # cannot go back to the allocator, so no other tensor can turn up at the address the cached values
+        # are keyed by (a freed model's data once handed its address -- and its cached X * X -- to the next
+        # model's upload).  Unmarking evicts every value computed from the tensor before releasing it.
+        self._const = {}
+        self._const_ptrs = {}     # single tensors under the same promise (mark_constant_tensor): address -> tensor
         self._wide = {}           # (ptr, columns, row stride) of a constituent -> (key of its wide operand, column offset)
         self._const_cache = {}    # element-wise values of constants only: computed once, LRU by bytes
         self._const_bytes = 0
@@ -152,13 +158,27 @@ class DeviceBackend(Backend):
         into a hipGraph (bsc_capture_begin / _end) and replayed from then on, without the host-side
         walk of ``fn``, as long as the inputs keep their addresses.  The returned tensors are the
         graph's own output buffers: consume them before the next call.  Falls back to eager for good
-        when the context is on the null stream or something inside ``fn`` cannot be captured."""
+        when the context is on the null stream or something inside ``fn`` cannot be captured (the call
+        in which the capture failed is re-run eagerly: a capture records, it does not execute).
+
+        What a recording holds on to: its inputs, its outputs and EVERY device buffer the walk touched while
+        it was recorded -- the capture runs with the per-expression memory plans switched off, so all
+        intermediates are fresh allocations owned by the graph (a plan's buffers may be evicted, resized or
+        rewritten by an eager evaluation at any later time).  The context's workspace is checked by
+        bsc_graph_launch itself; a graph it refuses as stale is recorded again."""
         entry = self._graphs.get(key)
         ptrs = tuple(t.data_ptr() for t in inputs)
         if entry is not None and entry["graph"] is not None:
             if entry["ptrs"] == ptrs:
-                entry["graph"].launch()
-                return entry["outs"]
+                try:
+                    entry["graph"].launch()
+                    return entry["outs"]
+                except BayesicHipError as e:
+                    if "stale graph" not in str(e):
+                        raise
+                    entry["graph"].destroy()
+                    entry.update(graph=None, outs=None, calls=2)      # the next call records again
+                    return [self._force(o) for o in fn()]
             entry["graph"].destroy()
             self._graphs.pop(key, None)
             entry = None                                  # other buffers: start over
@@ -173,7 +193,7 @@ class DeviceBackend(Backend):
         if entry["dead"] or entry["calls"] < 3 or not self.ctx.can_capture or entry["ptrs"] != ptrs:
             entry["ptrs"] = ptrs
             return [self._force(o) for o in fn()]
-        self._keep = []
+        self._keep = []                   # (evaluate() then allocates every intermediate afresh: _plan_for)
         self.ctx.capture_begin()
         try:
             outs = [self._force(o) for o in fn()]
@@ -184,7 +204,9 @@ class DeviceBackend(Backend):
             except Exception:
                 pass
             entry["dead"] = True
-            raise
+            # nothing ran (a capture records): give the caller this call's result by the eager walk; only
+            # if that fails too is the error the caller's
+            return [self._force(o) for o in fn()]
         keep, self._keep = self._keep, None
         try:
             graph = self.ctx.capture_end(keep + list(outs) + list(inputs))
@@ -204,7 +226,7 @@ class DeviceBackend(Backend):
         instead of being recomputed by every evaluation that contains it."""
         for t in tensors:
             if isinstance(t, torch.Tensor):
-                self._const.add(t.untyped_storage().data_ptr())
+                self._const[t.untyped_storage().data_ptr()] = t
 
     def mark_constant_tensor(self, *tensors):
         """The same promise for tensors that may share their storage with others (an intermediate
@@ -212,7 +234,7 @@ class DeviceBackend(Backend):
         starting at exactly this address counts, not its storage's other tenants."""
         for t in tensors:
             if isinstance(t, torch.Tensor):
-                self._const_ptrs.add(t.data_ptr())
+                self._const_ptrs[t.data_ptr()] = t
 
     def _is_const(self, t):
         return t.untyped_storage().data_ptr() in self._const or t.data_ptr() in self._const_ptrs
@@ -231,12 +253,12 @@ class DeviceBackend(Backend):
             if not isinstance(t, torch.Tensor):
                 continue
             ptr = t.data_ptr()
-            if ptr in self._const_ptrs:
-                self._const_ptrs.discard(ptr)
-            else:
-                self._const.discard(t.untyped_storage().data_ptr())
             for key in [k for k in self._const_cache if self._key_mentions(k, ptr)]:
-                self._evict(key)
+                self._evict(key)        # (while the tensor is still held: nothing can have taken its address)
+            if ptr in self._const_ptrs:
+                self._const_ptrs.pop(ptr, None)
+            else:
+                self._const.pop(t.untyped_storage().data_ptr(), None)
 
     def _evict(self, key):
         """Drop one cached value and everything computed FROM it (a wide operand built from a cached
@@ -246,7 +268,7 @@ class DeviceBackend(Backend):
         if old is None:
             return
         self._const_bytes -= old.numel() * old.element_size()
-        self._const.discard(old.untyped_storage().data_ptr())
+        self._const.pop(old.untyped_storage().data_ptr(), None)
         ptr = old.data_ptr()
         for part in [p for p, (wkey, _) in self._wide.items() if wkey == key or p[0] == ptr]:
             self._wide.pop(part, None)
@@ -499,7 +521,7 @@ class DeviceBackend(Backend):
         if ckey is not None:
             self._const_cache[ckey] = out
             self._const_bytes += out.numel() * out.element_size()
-            self._const.add(out.untyped_storage().data_ptr())      # a value of constants is a constant
+            self._const[out.untyped_storage().data_ptr()] = out      # a value of constants is a constant
         return out
 
     def _force(self, v):
@@ -651,7 +673,7 @@ class DeviceBackend(Backend):
             if bias:
                 self._map_into(xcat[:, off:off + 1], [m, 1], [(self._one, [0, 0])])
             self._const_bytes += xcat.numel() * 4
-            self._const.add(xcat.untyped_storage().data_ptr())
+            self._const[xcat.untyped_storage().data_ptr()] = xcat
         self._const_cache[ckey] = xcat
         off = 0
         for g in gemms:
@@ -721,13 +743,22 @@ class DeviceBackend(Backend):
                 return None
         return LazyGemm(g.gemm, g.shape, g.dtype, power=g.power, scale=g.scale * math.prod(host), E=E)
 
-    def evaluate(self, expr, inputs, bindings=None):
+    def _plan_for(self, expr):
+        """The buffers the previous evaluation of ``expr`` left behind -- or, while a graph is being
+        recorded, an empty throw-away plan: the recorded launches keep the ADDRESSES of their
+        intermediates, so those must belong to the graph (``_kept``), not to a plan that a later eager
+        evaluation rewrites, resizes or evicts."""
+        if self._keep is not None:
+            return []
         entry = self._plans.get(id(expr))
         if entry is None or entry[0] is not expr:
             if len(self._plans) >= self._MAX_PLANS:
                 self._plans.pop(next(iter(self._plans)))
             entry = self._plans[id(expr)] = [expr, []]
-        self._plan, self._cursor = entry[1], 0
+        return entry[1]
+
+    def evaluate(self, expr, inputs, bindings=None):
+        self._plan, self._cursor = self._plan_for(expr), 0
         try:
             out = self._force(Backend.evaluate(self, expr, inputs, bindings))
         finally:
@@ -821,12 +852,7 @@ class DeviceBackend(Backend):
         ONE launch (bsc_gemm_softmax_rows) produces R, lse and cross = sum_c R * logits, and
         ``logits`` is None: they never reach memory.  Otherwise the logits are evaluated as usual and
         returned with their softmax (cross is then None)."""
-        entry = self._plans.get(id(expr))
-        if entry is None or entry[0] is not expr:
-            if len(self._plans) >= self._MAX_PLANS:
-                self._plans.pop(next(iter(self._plans)))
-            entry = self._plans[id(expr)] = [expr, []]
-        self._plan, self._cursor = entry[1], 0
+        self._plan, self._cursor = self._plan_for(expr), 0
         logits = None
         try:
             root = Backend.evaluate(self, expr, inputs, bindings)

@@ -103,6 +103,23 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
         const int v = atoi(e);
         if (v >= 1 && v <= 8) ctx->wo_wg_per_cu = v;
     }
+    // BSC_BLR_MX=4, BSC_GEMM_DBG and BSC_BBVI_DBG select profiling-only builds whose RESULTS ARE WRONG
+    // (deletion builds: a kernel without its stores, a pass that re-reads one window ...).  They exist
+    // for tools/ab_*.py; a process gets them only by also saying BSC_PROFILING_BUILDS=1, and then loudly.
+    if (ctx->blr_mx == 4 || ctx->gemm_dbg != 0 || ctx->bbvi_dbg != 0) {
+        const char* allow = getenv("BSC_PROFILING_BUILDS");
+        if (!allow || atoi(allow) != 1) {
+            const int mx = ctx->blr_mx, gd = ctx->gemm_dbg, bd = ctx->bbvi_dbg;
+            delete ctx;
+            return bsc_fail(BSC_ERR_INVALID,
+                            "bsc_ctx_create: BSC_BLR_MX=%d / BSC_GEMM_DBG=%d / BSC_BBVI_DBG=%d select profiling-only "
+                            "kernels that compute WRONG results; set BSC_PROFILING_BUILDS=1 as well if that is "
+                            "what you want", mx, gd, bd);
+        }
+        fprintf(stderr, "libbayesic_hip: WARNING -- profiling-only kernels selected (BSC_BLR_MX=%d BSC_GEMM_DBG=%d "
+                        "BSC_BBVI_DBG=%d): results of this context are WRONG by construction\n",
+                ctx->blr_mx, ctx->gemm_dbg, ctx->bbvi_dbg);
+    }
     *out = ctx;
     return BSC_OK;
 }
@@ -175,6 +192,11 @@ int bsc_ctx_sync(bsc_ctx* ctx) {
 struct bsc_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    // the recorded kernels carry the ADDRESS of the context's workspace (stream-K slabs, block partials):
+    // a later eager call that grows the workspace frees it, and a replay would write into freed memory.
+    // bsc_graph_launch refuses a graph whose workspace is no longer the context's.
+    void* workspace = nullptr;
+    size_t workspace_bytes = 0;
 };
 
 int bsc_capture_begin(bsc_ctx* ctx) {
@@ -210,6 +232,8 @@ int bsc_capture_end(bsc_ctx* ctx, bsc_graph** out) {
     bsc_graph* g = new bsc_graph();
     g->graph = graph;
     g->exec = exec;
+    g->workspace = ctx->workspace;
+    g->workspace_bytes = ctx->workspace_bytes;
     *out = g;
     return BSC_OK;
 }
@@ -218,6 +242,10 @@ int bsc_graph_launch(bsc_ctx* ctx, bsc_graph* g) {
     BSC_CHECK_CTX(ctx);
     BSC_REQUIRE(g != nullptr && g->exec != nullptr, "bsc_graph_launch: null graph");
     BSC_REQUIRE(!ctx->capturing, "bsc_graph_launch inside a graph capture");
+    if (g->workspace != ctx->workspace || g->workspace_bytes != ctx->workspace_bytes)
+        return bsc_fail(BSC_ERR_INVALID, "bsc_graph_launch: stale graph -- the context's workspace was re-allocated "
+                        "(%zu -> %zu bytes) after this graph was recorded; record it again", g->workspace_bytes,
+                        ctx->workspace_bytes);
     BSC_HIP(hipGraphLaunch(g->exec, ctx->stream));
     return BSC_OK;
 }

@@ -1386,6 +1386,19 @@ int data_pass_partial_impl(bsc_ctx* ctx, const float* X, int64_t ldx, const floa
 
 extern "C" {
 
+int bsc_blr_pass_count(bsc_ctx* ctx, const float* y, int32_t D, int32_t S, int32_t* count) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(count && S >= 1 && D >= 1, "bsc_blr_pass_count: bad arguments");
+    const bool wide_ok = pass_rows(ctx, D, y) == 16 && ctx->blr_wide;
+    int n = 0;
+    for (int s0 = 0; s0 < S; ++n) {
+        const int cap = (wide_ok && S - s0 > SG) ? 2 * SG : SG;
+        s0 += (S - s0 < cap) ? (S - s0) : cap;
+    }
+    *count = n;
+    return BSC_OK;
+}
+
 int bsc_philox_normal(bsc_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t step,
                       int32_t n_samples, int32_t n_params, double* eps) {
     BSC_CHECK_CTX(ctx);

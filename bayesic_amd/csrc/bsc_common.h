@@ -81,6 +81,21 @@ __device__ inline double bsc_digamma_f64(double x) {
                           (1.0 / 240.0 - inv2 * (5.0 / 660.0 - inv2 * (691.0 / 32760.0))))));
     return acc + log(x) - 0.5 * inv - series;
 }
+
+// lnGamma in float64 by the same route: lnGamma(x) = lnGamma(x + n) - log prod_{i<n} (x + i), x + n >= 8,
+// Stirling's series there (next term 1 / (156 y^13) < 2e-14 at y = 8).  x > 0.
+__device__ inline double bsc_lgamma_f64(double x) {
+#pragma clang fp contract(off)
+    double P = 1.0;
+    while (x < 8.0) {
+        P *= x;
+        x += 1.0;
+    }
+    const double inv = 1.0 / x, inv2 = inv * inv;
+    const double series = inv * (1.0 / 12.0 - inv2 * (1.0 / 360.0 - inv2 * (1.0 / 1260.0 - inv2 *
+                          (1.0 / 1680.0 - inv2 * (1.0 / 1188.0 - inv2 * (691.0 / 360360.0))))));
+    return (x - 0.5) * log(x) - x + 0.91893853320467274178032973640562 + series - log(P);
+}
 #endif
 
 struct bsc_prof_scope {

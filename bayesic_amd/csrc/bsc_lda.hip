@@ -45,7 +45,21 @@ struct LdaArgs {
     int splits;
     int vec_c, vec_th;        // 16-byte global loads allowed
     int fast;                 // interior steps may use uniform-base + 32-bit-lane-offset loads
+    float* ll_slab;           // BOUND: per-wave partial of sum_dv C log2(phinorm), [gridDim.y][gridDim.x][4]
 };
+
+// The words' part of the evidence lower bound (README.md:30-37; Hoffman, Blei, Bach 2010 eq. 7 with the
+// per-word assignments at their optimum): sum_dv C_dv log(phinorm_dv).  phinorm exists only in the registers
+// of these kernels, so the sum is taken there -- one v_log_f32 and one fma per element next to the v_rcp_f32
+// of the ratio, per-lane float32 partials, one float per wave at the end, added in float64 in a fixed order
+// (lda_ll_reduce_kernel).  Padded documents / columns carry zero counts and contribute 0 * log2(1e-30) = -0.
+__global__ __launch_bounds__(64) void lda_ll_reduce_kernel(const float* __restrict__ slab, int64_t n, double mult,
+                                                           double* __restrict__ out) {
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 64) acc += (double)slab[i];
+    acc = wave_allsum_f64(acc);
+    if (threadIdx.x == 0) out[0] = mult * acc;
+}
 
 // global -> registers for one step: Th tile [32][K] and C tile [32][128]
 template <int KT>
@@ -147,7 +161,7 @@ __device__ __forceinline__ void stage_store(const Staged<KT>& st, float* th, flo
 // phase 2: col = v, contraction over the 32 documents two at a time: step r pairs the
 //   documents row_r + 4h -- exactly what register r of P holds -- and i = topic with the
 //   interleaved map k = KT * i + kt, so one b128 read of Th[d][KT*i ..] feeds the KT tiles.
-template <int KT>
+template <int KT, bool BOUND>
 __global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_kernel(LdaArgs a) {
     constexpr int K = 32 * KT;
     __shared__ __attribute__((aligned(16))) float th_s[2][DT * TH_LD];
@@ -173,6 +187,7 @@ __global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_kernel(LdaArgs a) {
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
+    float ll = 0.f;
 
     const bool fast = (KT == 1 || KT == 2 || KT == 4) && a.fast && v_base + VT <= a.V;   // uniform
     Staged<KT> st;
@@ -233,7 +248,9 @@ __global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_kernel(LdaArgs a) {
                 // padded documents / columns were staged as zero counts; their P is 0 (Th or Bt
                 // is 0 there), so the clamp alone keeps 0 * rcp(0) from becoming NaN -- one
                 // v_max instead of a compare and a select per element (real P are > 0)
-                P[r] = c[i] * __builtin_amdgcn_rcpf(fmaxf(P[r], 1.0e-30f));
+                const float pc = fmaxf(P[r], 1.0e-30f);
+                if constexpr (BOUND) ll = __builtin_fmaf(c[i], __builtin_amdgcn_logf(pc), ll);
+                P[r] = c[i] * __builtin_amdgcn_rcpf(pc);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -262,6 +279,10 @@ __global__ __launch_bounds__(LDA_BLOCK, 2) void lda_sstats_kernel(LdaArgs a) {
         cur ^= 1;
     }
 
+    if constexpr (BOUND) {
+        const float t = wave_allsum(ll);
+        if (lane == 0) a.ll_slab[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave] = t;
+    }
     // ---- epilogue: S[kt] register r is topic k = KT * row_r + kt, column v --------------
     if (!v_ok) return;
 #pragma unroll
@@ -322,6 +343,7 @@ struct LdaStreamArgs {
     int n_kt, sk_q, sk_r, sk_stream, n_wg, rounds, tail_tiles;   // tiles = 128-column blocks, units = 32-document steps
     int d_tail;        // documents in a block's last step, 1..32
     int K;             // 32, 64 or 128
+    float* ll_slab;    // BOUND: [n_wg][4] per-wave partials of sum_dv C log2(phinorm)
 };
 typedef stream_args_cptr<LdaStreamArgs> lda_args_cptr;
 
@@ -352,7 +374,7 @@ __device__ __forceinline__ void lda_wait_lgkm(int n) {
 
 // KT = K / 32 in {1, 2, 4}: a Th row is RB = 128 KT bytes = CPR = 8 KT chunks; 8 / KT rows per DMA
 // instruction, KT instructions per wave and step; chunk c of row d at position c ^ (d % min(CPR, 16)).
-template <int KT>
+template <int KT, bool BOUND>
 __device__ __forceinline__ void lda_sstats_stream_body(const LdaStreamArgs& a, char* lds) {
     constexpr int K = 32 * KT, RB = 128 * KT, CPR = 8 * KT, SWZ = (CPR < 16 ? CPR : 16) - 1, RPI = 8 / KT;
     constexpr int N1 = 4 * KT;                       // phase-1 reads (and 4-MFMA groups) per step
@@ -368,7 +390,11 @@ __device__ __forceinline__ void lda_sstats_stream_body(const LdaStreamArgs& a, c
         tail_cnt = stream_first_unit(gc, w + 1) - tail_u0;
         n_units = gc->rounds * gc->n_kt + tail_cnt;
     }
-    if (n_units == 0) return;
+    if (n_units == 0) {
+        if (BOUND && lane == 0) a.ll_slab[blockIdx.x * 4 + wave] = 0.f;
+        return;
+    }
+    float ll = 0.f;
     const int64_t step_th = 32 * a.ldth, step_c = 32 * a.ldc;
     const int last_kt = a.n_kt - 1, d_tail = a.d_tail;
 
@@ -547,7 +573,9 @@ __device__ __forceinline__ void lda_sstats_stream_body(const LdaStreamArgs& a, c
                         // max as integers: one v_max_i32 (a float max quiets its input first -- a second
                         // instruction); the same result for every non-NaN P
                         const int pi = __float_as_int(P[4 * q + i]), lo = __float_as_int(1.0e-30f);
-                        P[4 * q + i] = f[i] * __builtin_amdgcn_rcpf(__int_as_float(pi > lo ? pi : lo));
+                        const float pc = __int_as_float(pi > lo ? pi : lo);
+                        if constexpr (BOUND) ll = __builtin_fmaf(f[i], __builtin_amdgcn_logf(pc), ll);
+                        P[4 * q + i] = f[i] * __builtin_amdgcn_rcpf(pc);
                     }
                 } else {
                     const int i = r5 - 1;
@@ -617,18 +645,25 @@ __device__ __forceinline__ void lda_sstats_stream_body(const LdaStreamArgs& a, c
         if (u + 1 < n_units) step_body(std::integral_constant<int, 1>{}, u + 1);
     }
     __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+    if constexpr (BOUND) {
+        const float t = wave_allsum(ll);
+        if (lane == 0) stream_cold_args<LdaStreamArgs>()->ll_slab[blockIdx.x * 4 + wave] = t;
+    }
 }
 
 // (three plain kernels around the one body: hipcc left the host stub of a `template <int KT> __global__`
 // version of this kernel undefined)
-#define LDA_STREAM_KERNEL(NAME, KT_)                                                     \
+#define LDA_STREAM_KERNEL(NAME, KT_, BOUND_)                                             \
     __global__ __launch_bounds__(LDA_BLOCK, 2) void NAME(LdaStreamArgs a) {              \
         __shared__ __attribute__((aligned(1024))) char lds[2 * LS_STAGE];                \
-        lda_sstats_stream_body<KT_>(a, lds);                                             \
+        lda_sstats_stream_body<KT_, BOUND_>(a, lds);                                     \
     }
-LDA_STREAM_KERNEL(lda_sstats_stream_kernel, 4)          // K = 128
-LDA_STREAM_KERNEL(lda_sstats_stream_k64_kernel, 2)
-LDA_STREAM_KERNEL(lda_sstats_stream_k32_kernel, 1)
+LDA_STREAM_KERNEL(lda_sstats_stream_kernel, 4, false)          // K = 128
+LDA_STREAM_KERNEL(lda_sstats_stream_k64_kernel, 2, false)
+LDA_STREAM_KERNEL(lda_sstats_stream_k32_kernel, 1, false)
+LDA_STREAM_KERNEL(lda_sstats_stream_bound_kernel, 4, true)    // ... + sum_dv C log2(phinorm)
+LDA_STREAM_KERNEL(lda_sstats_stream_k64_bound_kernel, 2, true)
+LDA_STREAM_KERNEL(lda_sstats_stream_k32_bound_kernel, 1, true)
 #undef LDA_STREAM_KERNEL
 
 // The column blocks that two or more runs share (see stream_fixup_kernel in csrc/bsc_gemm.hip):
@@ -678,9 +713,10 @@ struct LdaCscArgs {
     int64_t ldth, ldb, ldo, docs, V;
     int vec_th;
     int fast;   // docs * ldth * 4 < 2^31 and 16-byte Th rows: gathers go through buffer descriptors
+    float* ll_slab;   // BOUND: [grid][4] per-wave partials of 16 * sum_nz C log2(phinorm) (every lane of a group adds it)
 };
 
-template <int KPL, bool FAST>   // topics per lane; K = 16 * KPL
+template <int KPL, bool FAST, bool BOUND>   // topics per lane; K = 16 * KPL
 __global__ __launch_bounds__(LDA_BLOCK) void lda_sstats_csc_kernel(LdaCscArgs a) {
     constexpr int K = 16 * KPL;
     __shared__ float tile[K * CSC_LD];
@@ -695,6 +731,7 @@ __global__ __launch_bounds__(LDA_BLOCK) void lda_sstats_csc_kernel(LdaCscArgs a)
     }
     __syncthreads();
 
+    float ll = 0.f;
     for (int w = 0; w < CSC_WORDS / 4; ++w) {
         const int c = 16 * wave + w;
         const int64_t v = v_base + c;
@@ -750,7 +787,9 @@ __global__ __launch_bounds__(LDA_BLOCK) void lda_sstats_csc_kernel(LdaCscArgs a)
 #pragma unroll
                     for (int i = 0; i < KPL; ++i) p += th[u][i] * bt[i];
                     p = row16_allsum(p);
-                    const float r = cnt[u] * __builtin_amdgcn_rcpf(fmaxf(p, 1.0e-30f));
+                    const float pc = fmaxf(p, 1.0e-30f);
+                    if constexpr (BOUND) ll = __builtin_fmaf(cnt[u], __builtin_amdgcn_logf(pc), ll);
+                    const float r = cnt[u] * __builtin_amdgcn_rcpf(pc);
 #pragma unroll
                     for (int i = 0; i < KPL; ++i) acc[i] += th[u][i] * r;
                 }
@@ -786,6 +825,7 @@ __global__ __launch_bounds__(LDA_BLOCK) void lda_sstats_csc_kernel(LdaCscArgs a)
                 for (int i = 0; i < KPL; ++i) p += th[u][i] * bt[i];
                 p = row16_allsum(p);
                 const float r = cnt[u] != 0.f ? cnt[u] / p : 0.f;
+                if constexpr (BOUND) ll += cnt[u] != 0.f ? cnt[u] * __builtin_amdgcn_logf(p) : 0.f;
 #pragma unroll
                 for (int i = 0; i < KPL; ++i) acc[i] += th[u][i] * r;
             }
@@ -802,6 +842,10 @@ __global__ __launch_bounds__(LDA_BLOCK) void lda_sstats_csc_kernel(LdaCscArgs a)
             for (int i = 0; i < KPL; ++i) tile[(gl * KPL + i) * CSC_LD + c] = acc[i] * bt[i];
         }
     }
+    if constexpr (BOUND) {
+        const float t = wave_allsum(ll);
+        if (lane == 0) a.ll_slab[(int64_t)blockIdx.x * 4 + wave] = t;
+    }
     __syncthreads();
     for (int i = tid; i < K * CSC_WORDS; i += LDA_BLOCK) {
         const int k = i / CSC_WORDS, c = i % CSC_WORDS;
@@ -811,23 +855,29 @@ __global__ __launch_bounds__(LDA_BLOCK) void lda_sstats_csc_kernel(LdaCscArgs a)
 
 template <int KT>
 void launch_lda(bsc_ctx* ctx, const LdaArgs& a, dim3 grid) {
-    hipLaunchKernelGGL(lda_sstats_kernel<KT>, grid, dim3(LDA_BLOCK), 0, ctx->stream, a);
+    if (a.ll_slab) hipLaunchKernelGGL((lda_sstats_kernel<KT, true>), grid, dim3(LDA_BLOCK), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((lda_sstats_kernel<KT, false>), grid, dim3(LDA_BLOCK), 0, ctx->stream, a);
 }
+
+constexpr double LN2 = 0.69314718055994530941723212145818;
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int bsc_lda_sstats(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int64_t V, int32_t K,
-                   const float* Th, int64_t ldth, const float* Bt, int64_t ldb, float* sstats,
-                   int64_t ldo) {
+int lda_sstats_impl(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int64_t V, int32_t K,
+                    const float* Th, int64_t ldth, const float* Bt, int64_t ldb, float* sstats,
+                    int64_t ldo, double* ll) {
     BSC_CHECK_CTX(ctx);
     BSC_REQUIRE(docs >= 0 && V >= 0 && K > 0, "bsc_lda_sstats: bad extents");
     if (K % 32 != 0 || K > 128)
         return bsc_fail(BSC_ERR_UNSUPPORTED,
                         "bsc_lda_sstats: K must be 32, 64, 96 or 128 (got %d); use the algebra "
                         "executor for other topic counts", K);
-    if (V == 0) return BSC_OK;
+    if (V == 0) {
+        if (ll) BSC_HIP(hipMemsetAsync(ll, 0, sizeof(double), ctx->stream));
+        return BSC_OK;
+    }
     BSC_REQUIRE(Bt && sstats && (docs == 0 || (C && Th)), "bsc_lda_sstats: null pointer");
     BSC_REQUIRE(ldc >= V && ldth >= K && ldb >= V && ldo >= V, "bsc_lda_sstats: leading dimension");
     LdaArgs a{};
@@ -850,18 +900,31 @@ int bsc_lda_sstats(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int6
         g.d_tail = (int)(docs - (int64_t)(n_kt - 1) * DT);
         stream_plan(g, n_vt, n_kt, 2 * (int64_t)ctx->cu_count);
         void* ws = nullptr;
-        int rc = bsc_workspace(ctx, (size_t)2 * g.n_wg * K * VT * sizeof(float), &ws);
+        const size_t slab_floats = (size_t)2 * g.n_wg * K * VT;
+        int rc = bsc_workspace(ctx, (slab_floats + (size_t)4 * g.n_wg) * sizeof(float), &ws);
         if (rc != BSC_OK) return rc;
         ctx->slab_rows = 0;
         g.slab = (float*)ws;
+        g.ll_slab = ll ? (float*)ws + slab_floats : nullptr;
         {
             bsc_prof_scope prof(ctx);
             const dim3 grid((unsigned)g.n_wg), block(LDA_BLOCK);
-            if (K == 128) hipLaunchKernelGGL(lda_sstats_stream_kernel, grid, block, 0, ctx->stream, g);
-            else if (K == 64) hipLaunchKernelGGL(lda_sstats_stream_k64_kernel, grid, block, 0, ctx->stream, g);
-            else hipLaunchKernelGGL(lda_sstats_stream_k32_kernel, grid, block, 0, ctx->stream, g);
+            if (ll) {
+                if (K == 128) hipLaunchKernelGGL(lda_sstats_stream_bound_kernel, grid, block, 0, ctx->stream, g);
+                else if (K == 64) hipLaunchKernelGGL(lda_sstats_stream_k64_bound_kernel, grid, block, 0, ctx->stream, g);
+                else hipLaunchKernelGGL(lda_sstats_stream_k32_bound_kernel, grid, block, 0, ctx->stream, g);
+            } else {
+                if (K == 128) hipLaunchKernelGGL(lda_sstats_stream_kernel, grid, block, 0, ctx->stream, g);
+                else if (K == 64) hipLaunchKernelGGL(lda_sstats_stream_k64_kernel, grid, block, 0, ctx->stream, g);
+                else hipLaunchKernelGGL(lda_sstats_stream_k32_kernel, grid, block, 0, ctx->stream, g);
+            }
         }
         BSC_LAUNCH_CHECK();
+        if (ll) {
+            hipLaunchKernelGGL(lda_ll_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, (const float*)g.ll_slab,
+                               (int64_t)4 * g.n_wg, LN2, ll);
+            BSC_LAUNCH_CHECK();
+        }
         if (stream_has_pieces(g)) {
             hipLaunchKernelGGL(lda_stream_fixup_kernel, dim3((unsigned)(g.n_wg - 1), K * VT / 256), dim3(64), 0,
                                ctx->stream, g);
@@ -888,16 +951,16 @@ int bsc_lda_sstats(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int6
     a.docs_per_split = ((steps + best - 1) / best) * DT;
     if (a.docs_per_split == 0) a.docs_per_split = DT;
     float* partial = nullptr;
-    if (best > 1) {
+    const size_t partial_floats = best > 1 ? (size_t)best * K * V : 0, ll_floats = ll ? (size_t)4 * n_vt * best : 0;
+    if (partial_floats + ll_floats) {
         void* ws = nullptr;
-        int rc = bsc_workspace(ctx, (size_t)best * K * V * sizeof(float), &ws);
+        int rc = bsc_workspace(ctx, (partial_floats + ll_floats) * sizeof(float), &ws);
         if (rc != BSC_OK) return rc;
         ctx->slab_rows = 0;
-        partial = (float*)ws;
-        a.out = partial;
-    } else {
-        a.out = sstats;
+        if (ll) a.ll_slab = (float*)ws + partial_floats;
+        if (best > 1) partial = (float*)ws;
     }
+    a.out = best > 1 ? partial : sstats;
     const dim3 grid((unsigned)n_vt, (unsigned)best);
     {
         bsc_prof_scope prof(ctx);  // times the fused kernel alone
@@ -917,18 +980,64 @@ int bsc_lda_sstats(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int6
                            partial, best, (int64_t)K, V, Bt, ldb, sstats, ldo);
         BSC_LAUNCH_CHECK();
     }
+    if (ll) {
+        hipLaunchKernelGGL(lda_ll_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, (const float*)a.ll_slab,
+                           (int64_t)ll_floats, LN2, ll);
+        BSC_LAUNCH_CHECK();
+    }
     return BSC_OK;
+}
+
+int lda_sstats_csc_impl(bsc_ctx* ctx, const int64_t* colptr, const int32_t* rowidx, const float* vals,
+                        int64_t docs, int64_t V, int32_t K, const float* Th, int64_t ldth,
+                        const float* Bt, int64_t ldb, float* sstats, int64_t ldo, double* ll);
+
+}  // namespace
+
+extern "C" {
+
+int bsc_lda_sstats(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int64_t V, int32_t K,
+                   const float* Th, int64_t ldth, const float* Bt, int64_t ldb, float* sstats,
+                   int64_t ldo) {
+    return lda_sstats_impl(ctx, C, ldc, docs, V, K, Th, ldth, Bt, ldb, sstats, ldo, nullptr);
+}
+
+int bsc_lda_sstats_bound(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int64_t V, int32_t K,
+                         const float* Th, int64_t ldth, const float* Bt, int64_t ldb, float* sstats,
+                         int64_t ldo, double* ll) {
+    if (!ll) return bsc_fail(BSC_ERR_INVALID, "bsc_lda_sstats_bound: ll is NULL");
+    return lda_sstats_impl(ctx, C, ldc, docs, V, K, Th, ldth, Bt, ldb, sstats, ldo, ll);
 }
 
 int bsc_lda_sstats_csc(bsc_ctx* ctx, const int64_t* colptr, const int32_t* rowidx, const float* vals,
                        int64_t docs, int64_t V, int32_t K, const float* Th, int64_t ldth,
                        const float* Bt, int64_t ldb, float* sstats, int64_t ldo) {
+    return lda_sstats_csc_impl(ctx, colptr, rowidx, vals, docs, V, K, Th, ldth, Bt, ldb, sstats, ldo, nullptr);
+}
+
+int bsc_lda_sstats_csc_bound(bsc_ctx* ctx, const int64_t* colptr, const int32_t* rowidx, const float* vals,
+                             int64_t docs, int64_t V, int32_t K, const float* Th, int64_t ldth,
+                             const float* Bt, int64_t ldb, float* sstats, int64_t ldo, double* ll) {
+    if (!ll) return bsc_fail(BSC_ERR_INVALID, "bsc_lda_sstats_csc_bound: ll is NULL");
+    return lda_sstats_csc_impl(ctx, colptr, rowidx, vals, docs, V, K, Th, ldth, Bt, ldb, sstats, ldo, ll);
+}
+
+}  // extern "C"
+
+namespace {
+
+int lda_sstats_csc_impl(bsc_ctx* ctx, const int64_t* colptr, const int32_t* rowidx, const float* vals,
+                        int64_t docs, int64_t V, int32_t K, const float* Th, int64_t ldth,
+                        const float* Bt, int64_t ldb, float* sstats, int64_t ldo, double* ll) {
     BSC_CHECK_CTX(ctx);
     BSC_REQUIRE(docs >= 0 && V >= 0 && K > 0, "bsc_lda_sstats_csc: bad extents");
     if (K % 32 != 0 || K > 128)
         return bsc_fail(BSC_ERR_UNSUPPORTED,
                         "bsc_lda_sstats_csc: K must be 32, 64, 96 or 128 (got %d)", K);
-    if (V == 0) return BSC_OK;
+    if (V == 0) {
+        if (ll) BSC_HIP(hipMemsetAsync(ll, 0, sizeof(double), ctx->stream));
+        return BSC_OK;
+    }
     BSC_REQUIRE(colptr && Bt && sstats, "bsc_lda_sstats_csc: null pointer");
     BSC_REQUIRE(ldth >= K && ldb >= V && ldo >= V, "bsc_lda_sstats_csc: leading dimension");
     LdaCscArgs a{};
@@ -938,23 +1047,42 @@ int bsc_lda_sstats_csc(bsc_ctx* ctx, const int64_t* colptr, const int32_t* rowid
     a.vec_th = (ldth % 4 == 0) && (((uintptr_t)Th) & 15) == 0;
     a.fast = a.vec_th && docs > 0 && docs * ldth * 4 < ((int64_t)1 << 31) && ctx->csc_fast;
     const dim3 grid((unsigned)((V + CSC_WORDS - 1) / CSC_WORDS));
+    if (ll) {
+        void* ws = nullptr;
+        int rc = bsc_workspace(ctx, (size_t)4 * grid.x * sizeof(float), &ws);
+        if (rc != BSC_OK) return rc;
+        ctx->slab_rows = 0;
+        a.ll_slab = (float*)ws;
+    }
     {
         bsc_prof_scope prof(ctx);
         switch (K / 32) {
+#define BSC_CSC1(KPL, F)                                                                               \
+    do {                                                                                               \
+        if (ll) hipLaunchKernelGGL((lda_sstats_csc_kernel<KPL, F, true>), grid, dim3(LDA_BLOCK), 0, ctx->stream, a);   \
+        else hipLaunchKernelGGL((lda_sstats_csc_kernel<KPL, F, false>), grid, dim3(LDA_BLOCK), 0, ctx->stream, a);     \
+    } while (0)
 #define BSC_CSC(KPL)                                                                                   \
     do {                                                                                               \
-        if (a.fast) hipLaunchKernelGGL((lda_sstats_csc_kernel<KPL, true>), grid, dim3(LDA_BLOCK), 0, ctx->stream, a);  \
-        else hipLaunchKernelGGL((lda_sstats_csc_kernel<KPL, false>), grid, dim3(LDA_BLOCK), 0, ctx->stream, a);        \
+        if (a.fast) BSC_CSC1(KPL, true);                                                               \
+        else BSC_CSC1(KPL, false);                                                                     \
     } while (0)
             case 1: BSC_CSC(2); break;
             case 2: BSC_CSC(4); break;
             case 3: BSC_CSC(6); break;
             default: BSC_CSC(8); break;
 #undef BSC_CSC
+#undef BSC_CSC1
         }
     }
     BSC_LAUNCH_CHECK();
+    if (ll) {
+        // every lane of a 16-lane group added the group's term: 1/16 of the wave sums
+        hipLaunchKernelGGL(lda_ll_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, (const float*)a.ll_slab,
+                           (int64_t)4 * grid.x, LN2 / 16.0, ll);
+        BSC_LAUNCH_CHECK();
+    }
     return BSC_OK;
 }
 
-}  // extern "C"
+}  // namespace

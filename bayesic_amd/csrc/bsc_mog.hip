@@ -313,18 +313,37 @@ __device__ __forceinline__ double digamma_f64(double x) { return bsc_digamma_f64
 // 16 lanes per component, one column each (float64 digamma / log / divisions per column: a
 // thread per component walking its D columns took 15 us); a component's terms are then added
 // in a fixed butterfly order inside its 16-lane group.
+//
+// With eta0 (the prior's natural parameters, same layout) the kernel also forms the global part of
+// the evidence lower bound (README.md:30-37; factor decomposition of bayesic/distribution/base.py:47-69),
+//     bound = E_q[log p(pi, mu, tau)] - E_q[log q(pi, mu, tau)]
+//           = sum over factors of  <eta0 - eta, E_q[T]> - A(eta0) + A(eta),
+// from the very digamma / log values the logit coefficients need (oracle.svi.mog_global_bound):
+// Dirichlet  T = log pi_k,  A = sum lnGamma(alpha_k) - lnGamma(sum alpha);
+// NormalGamma T = (tau mu, -tau mu^2/2, log(tau)/2, -tau/2), A = lnGamma(a) - a log b - log(kappa)/2 + log(2 pi)/2.
+// Fixed-order sums: 16-lane butterfly per component, components in index order by one thread.
 __global__ __launch_bounds__(1024) void mog_expected_params_kernel(const double* __restrict__ eta,
+                                                                   const double* __restrict__ eta0,
                                                                    int K, int D,
                                                                    float* __restrict__ Wmat,
-                                                                   float* __restrict__ cvec) {
-    __shared__ double alpha_sum;
+                                                                   float* __restrict__ cvec,
+                                                                   double* __restrict__ bound) {
+    __shared__ double alpha_sum, alpha0_sum;
+    __shared__ double comp_bound[1024];
     const int dl = threadIdx.x & 15;
     const double LOG_2PI = 1.8378770664093454835606594728112;
     if (threadIdx.x < 64) {   // one wave: the Dirichlet's total, fixed order
-        double a = 0.0;
-        for (int j = threadIdx.x; j < K; j += 64) a += eta[j] + 1.0;
+        double a = 0.0, a0 = 0.0;
+        for (int j = threadIdx.x; j < K; j += 64) {
+            a += eta[j] + 1.0;
+            if (eta0) a0 += eta0[j] + 1.0;
+        }
         const double tot = wave_allsum_f64(a);
-        if (threadIdx.x == 0) alpha_sum = tot;
+        const double tot0 = wave_allsum_f64(a0);
+        if (threadIdx.x == 0) {
+            alpha_sum = tot;
+            alpha0_sum = tot0;
+        }
     }
     __syncthreads();
     const int64_t KD = (int64_t)K * D;
@@ -332,33 +351,63 @@ __global__ __launch_bounds__(1024) void mog_expected_params_kernel(const double*
     // four 16-lane groups only up to the tail, so the shuffles below stay inside a group)
     for (int k0 = 0; k0 < K; k0 += 64) {
         const int k = k0 + (threadIdx.x >> 4);
-        double c = 0.0;
+        double c = 0.0, gb = 0.0;
         if (k < K) {
             for (int d = dl; d < D; d += 16) {
                 const int64_t i = (int64_t)k * D + d;
+                const double e1 = eta[K + i], e3 = eta[K + 2 * KD + i], e4 = eta[K + 3 * KD + i];
                 const double kappa = eta[K + KD + i];
-                const double m = eta[K + i] / kappa;
-                const double a = 0.5 * (eta[K + 2 * KD + i] + 1.0);
-                const double b = 0.5 * (eta[K + 3 * KD + i] - kappa * m * m);
+                const double m = e1 / kappa;
+                const double a = 0.5 * (e3 + 1.0);
+                const double b = 0.5 * (e4 - kappa * m * m);
                 const double T = a / b;
-                c += 0.5 * (digamma_f64(a) - log(b)) - 0.5 * LOG_2PI - 0.5 * T * m * m - 0.5 / kappa;
+                const double elog_tau = digamma_f64(a) - log(b);
+                c += 0.5 * elog_tau - 0.5 * LOG_2PI - 0.5 * T * m * m - 0.5 / kappa;
                 Wmat[(int64_t)k * 2 * D + d] = (float)(T * m);
                 Wmat[(int64_t)k * 2 * D + D + d] = (float)(-0.5 * T);
+                if (eta0) {
+                    const double p1 = eta0[K + i], kappa0 = eta0[K + KD + i], p3 = eta0[K + 2 * KD + i],
+                                 p4 = eta0[K + 3 * KD + i];
+                    const double m0 = p1 / kappa0, a0 = 0.5 * (p3 + 1.0), b0 = 0.5 * (p4 - kappa0 * m0 * m0);
+                    gb += (p1 - e1) * (T * m) + (kappa0 - kappa) * (-0.5 * (1.0 / kappa + m * m * T)) +
+                          (p3 - e3) * (0.5 * elog_tau) + (p4 - e4) * (-0.5 * T) +
+                          (lgamma(a) - a * log(b) - 0.5 * log(kappa)) -
+                          (lgamma(a0) - a0 * log(b0) - 0.5 * log(kappa0));
+                }
             }
         }
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) c += __shfl_xor(c, off);
-        if (k < K && dl == 0)
-            cvec[k] = (float)(c + digamma_f64(eta[k] + 1.0) - digamma_f64(alpha_sum));
+        for (int off = 8; off > 0; off >>= 1) {
+            c += __shfl_xor(c, off);
+            gb += __shfl_xor(gb, off);
+        }
+        if (k < K && dl == 0) {
+            const double elog_pi = digamma_f64(eta[k] + 1.0) - digamma_f64(alpha_sum);
+            cvec[k] = (float)(c + elog_pi);
+            if (eta0)
+                comp_bound[k] = gb + (eta0[k] - eta[k]) * elog_pi + lgamma(eta[k] + 1.0) - lgamma(eta0[k] + 1.0);
+        }
+    }
+    if (eta0 && bound) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = lgamma(alpha0_sum) - lgamma(alpha_sum);
+            for (int k = 0; k < K; ++k) tot += comp_bound[k];
+            bound[0] = tot;
+        }
     }
 }
 
 // eta <- (1-rho) eta + rho (eta0 + scale * message(stats)), stats = [K][R | Sx | Sxx]
+// With `elbo`: elbo[0] = scale * lse[0] + bound[0] -- the mini-batch estimate of the evidence lower
+// bound AT the natural parameters the statistics were taken with (before this step moves them).
 __global__ void mog_natgrad_kernel(double* __restrict__ eta, const double* __restrict__ eta0,
                                    const double* __restrict__ stats, int K, int D, double scale,
-                                   double rho) {
+                                   double rho, const double* __restrict__ lse,
+                                   const double* __restrict__ bound, double* __restrict__ elbo) {
     const int64_t KD = (int64_t)K * D;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && elbo) elbo[0] = scale * lse[0] + bound[0];
     if (i >= K + 4 * KD) return;
     double msg;
     if (i < K) {
@@ -383,8 +432,21 @@ int bsc_mog_expected_params(bsc_ctx* ctx, const double* eta, int32_t K, int32_t 
     BSC_CHECK_CTX(ctx);
     BSC_REQUIRE(eta && Wmat && c, "bsc_mog_expected_params: null pointer");
     BSC_REQUIRE(K >= 1 && D >= 1, "bsc_mog_expected_params: K=%d D=%d", K, D);
-    hipLaunchKernelGGL(mog_expected_params_kernel, dim3(1), dim3(1024), 0, ctx->stream, eta, (int)K,
-                       (int)D, Wmat, c);
+    hipLaunchKernelGGL(mog_expected_params_kernel, dim3(1), dim3(1024), 0, ctx->stream, eta,
+                       (const double*)nullptr, (int)K, (int)D, Wmat, c, (double*)nullptr);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_mog_expected_params_bound(bsc_ctx* ctx, const double* eta, const double* eta0, int32_t K, int32_t D,
+                                  float* Wmat, float* c, double* bound) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(eta && eta0 && Wmat && c && bound, "bsc_mog_expected_params_bound: null pointer");
+    BSC_REQUIRE(K >= 1 && D >= 1, "bsc_mog_expected_params_bound: K=%d D=%d", K, D);
+    if (K > 1024)
+        return bsc_fail(BSC_ERR_UNSUPPORTED, "bsc_mog_expected_params_bound: K=%d > 1024 components", K);
+    hipLaunchKernelGGL(mog_expected_params_kernel, dim3(1), dim3(1024), 0, ctx->stream, eta, eta0, (int)K,
+                       (int)D, Wmat, c, bound);
     BSC_LAUNCH_CHECK();
     return BSC_OK;
 }
@@ -395,7 +457,21 @@ int bsc_mog_natgrad(bsc_ctx* ctx, double* eta, const double* eta0, const double*
     BSC_REQUIRE(eta && eta0 && stats && K >= 1 && D >= 1, "bsc_mog_natgrad: bad arguments");
     const int64_t n = K + 4 * (int64_t)K * D;
     hipLaunchKernelGGL(mog_natgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       ctx->stream, eta, eta0, stats, (int)K, (int)D, scale, rho);
+                       ctx->stream, eta, eta0, stats, (int)K, (int)D, scale, rho, (const double*)nullptr,
+                       (const double*)nullptr, (double*)nullptr);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_mog_natgrad_elbo(bsc_ctx* ctx, double* eta, const double* eta0, const double* stats, int32_t K,
+                         int32_t D, double scale, double rho, const double* lse, const double* bound,
+                         double* elbo) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(eta && eta0 && stats && lse && bound && elbo && K >= 1 && D >= 1,
+                "bsc_mog_natgrad_elbo: bad arguments");
+    const int64_t n = K + 4 * (int64_t)K * D;
+    hipLaunchKernelGGL(mog_natgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, eta, eta0, stats, (int)K, (int)D, scale, rho, lse, bound, elbo);
     BSC_LAUNCH_CHECK();
     return BSC_OK;
 }

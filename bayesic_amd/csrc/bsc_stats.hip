@@ -174,9 +174,91 @@ __global__ __launch_bounds__(256) void dirichlet_expect_kernel(const float* __re
     }
 }
 
+// ---- ... and the factor's part of the evidence lower bound ----------------------------------------
+// bound = sum_r -KL(Dir(lam_r) || Dir(prior)) = sum_rc [(prior - lam_rc) E[log theta_rc] + lnGamma(lam_rc)]
+//         + sum_r [-lnGamma(sum_c lam_rc) + lnGamma(cols prior) - cols lnGamma(prior)]
+// (README.md:30-37; <eta0 - eta, E[T]> - A(eta0) + A(eta) with T = log theta, eta = lam - 1, the
+// decomposition of bayesic/distribution/base.py:47-69; oracle.svi.dirichlet_neg_kl).  psi and lnGamma of
+// an element share the shift to y >= 8 and log y, so the bound costs one more log and a short series
+// per element on top of the expectation.  Per-block float64 partials, added in block order.
+__global__ __launch_bounds__(1024) void row_sum_bound_kernel(const float* __restrict__ lam, int64_t cols,
+                                                             int64_t ld, double prior,
+                                                             double* __restrict__ row_psi,
+                                                             double* __restrict__ row_const) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = lam + (int64_t)blockIdx.x * ld;
+    double acc = 0.0;
+    for (int64_t c = tid; c < cols; c += 1024) acc += (double)row[c];
+    acc = wave_allsum_f64(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        row_psi[blockIdx.x] = digamma_f64_stats(t);
+        row_const[blockIdx.x] = -bsc_lgamma_f64(t) + bsc_lgamma_f64((double)cols * prior) -
+                                (double)cols * bsc_lgamma_f64(prior);
+    }
+}
+
+__global__ __launch_bounds__(256) void dirichlet_expect_bound_kernel(const float* __restrict__ lam,
+                                                                     int64_t rows, int64_t cols, int64_t ld,
+                                                                     double prior,
+                                                                     const double* __restrict__ row_psi,
+                                                                     float* __restrict__ out,
+                                                                     double* __restrict__ partial) {
+#pragma clang fp contract(off)
+    __shared__ double red[4];
+    const int64_t n = rows * cols;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / cols, c = i - r * cols;
+        const double x0 = (double)lam[r * ld + c];
+        double x = x0, P = 1.0, dP = 0.0;
+        while (x < 8.0) {
+            dP = dP * x + P;
+            P *= x;
+            x += 1.0;
+        }
+        const double inv = 1.0 / x, inv2 = inv * inv, logy = log(x);
+        const double psi_series = inv2 * (1.0 / 12.0 - inv2 * (1.0 / 120.0 - inv2 * (1.0 / 252.0 - inv2 *
+                                  (1.0 / 240.0 - inv2 * (5.0 / 660.0 - inv2 * (691.0 / 32760.0))))));
+        const double elog = logy - 0.5 * inv - psi_series - dP / P - row_psi[r];     // E[log theta_rc]
+        out[i] = (float)exp(elog);
+        const double lg_series = inv * (1.0 / 12.0 - inv2 * (1.0 / 360.0 - inv2 * (1.0 / 1260.0 - inv2 *
+                                 (1.0 / 1680.0 - inv2 * (1.0 / 1188.0 - inv2 * (691.0 / 360360.0))))));
+        const double lg = (x - 0.5) * logy - x + 0.91893853320467274178032973640562 + lg_series - log(P);
+        acc += (prior - x0) * elog + lg;
+    }
+    acc = wave_allsum_f64(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// out[0] = sum of a[0..n) then b[0..m), one wave, fixed order
+__global__ __launch_bounds__(64) void ordered_sum2_kernel(const double* __restrict__ a, int64_t n,
+                                                          const double* __restrict__ b, int64_t m,
+                                                          double scale, double* __restrict__ out) {
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 64) acc += a[i];
+    for (int64_t i = threadIdx.x; i < m; i += 64) acc += b[i];
+    acc = wave_allsum_f64(acc);
+    if (threadIdx.x == 0) out[0] = scale * acc;
+}
+
+// With `elbo`: elbo[0] = scale * (ll[0] + local_bound[0]) + global_bound[0] before the step (the bound at
+// the lambda the statistics were taken with).
 __global__ void natgrad_update_f32_kernel(float* __restrict__ eta, float eta0,
                                           const float* __restrict__ message, int64_t n,
-                                          float scale, float rho) {
+                                          float scale, float rho, const double* __restrict__ ll,
+                                          const double* __restrict__ local_bound,
+                                          const double* __restrict__ global_bound, double scale64,
+                                          double* __restrict__ elbo) {
+    if (elbo && blockIdx.x == 0 && threadIdx.x == 0)
+        elbo[0] = scale64 * (ll[0] + local_bound[0]) + global_bound[0];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         eta[i] = (1.0f - rho) * eta[i] + rho * (eta0 + scale * message[i]);
@@ -363,7 +445,48 @@ int bsc_natgrad_update_f32(bsc_ctx* ctx, float* eta, float eta0, const float* me
     int64_t blocks = (n + 255) / 256;
     if (blocks > 8 * (int64_t)ctx->cu_count) blocks = 8 * (int64_t)ctx->cu_count;
     hipLaunchKernelGGL(natgrad_update_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                       eta, eta0, message, n, scale, rho);
+                       eta, eta0, message, n, scale, rho, (const double*)nullptr, (const double*)nullptr,
+                       (const double*)nullptr, 0.0, (double*)nullptr);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_natgrad_update_f32_elbo(bsc_ctx* ctx, float* eta, float eta0, const float* message, int64_t n,
+                                float scale, float rho, const double* ll, const double* local_bound,
+                                const double* global_bound, double* elbo) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(eta && message && n > 0 && ll && local_bound && global_bound && elbo,
+                "bsc_natgrad_update_f32_elbo: bad arguments");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8 * (int64_t)ctx->cu_count) blocks = 8 * (int64_t)ctx->cu_count;
+    hipLaunchKernelGGL(natgrad_update_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       eta, eta0, message, n, scale, rho, ll, local_bound, global_bound, (double)scale, elbo);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_dirichlet_expectation_bound(bsc_ctx* ctx, const float* lam, int64_t rows, int64_t cols, int64_t ld,
+                                    double prior, float* out, double* bound) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(lam && out && bound && rows >= 1 && cols >= 1 && ld >= cols && rows <= 65535 * 32 && prior > 0.0,
+                "bsc_dirichlet_expectation_bound: bad arguments");
+    int64_t blocks = (rows * cols + 255) / 256;
+    if (blocks > 8 * (int64_t)ctx->cu_count) blocks = 8 * (int64_t)ctx->cu_count;
+    void* ws = nullptr;
+    int rc = bsc_workspace(ctx, (size_t)(2 * rows + blocks) * sizeof(double), &ws);
+    if (rc != BSC_OK) return rc;
+    ctx->slab_rows = 0;
+    double* row_psi = (double*)ws;
+    double* row_const = row_psi + rows;
+    double* partial = row_const + rows;
+    hipLaunchKernelGGL(row_sum_bound_kernel, dim3((unsigned)rows), dim3(1024), 0, ctx->stream, lam, cols, ld,
+                       prior, row_psi, row_const);
+    BSC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dirichlet_expect_bound_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, lam,
+                       rows, cols, ld, prior, (const double*)row_psi, out, partial);
+    BSC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ordered_sum2_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)partial, blocks,
+                       (const double*)row_const, rows, 1.0, bound);
     BSC_LAUNCH_CHECK();
     return BSC_OK;
 }

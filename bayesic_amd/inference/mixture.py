@@ -70,6 +70,10 @@ class DiagonalMixtureVMP(object):
         self.vmp.update("TM", rho)
         return rho
 
+    def close(self):
+        """Release the data's constant marks on the backend (and what the executor cached from them)."""
+        self.vmp.close()
+
     def eta_fused_layout(self):
         """Natural parameters in the layout of svi/mog.py and oracle.svi:
         [alpha - 1 | kappa m | kappa | 2a - 1 | 2b + kappa m^2]."""

@@ -544,10 +544,15 @@ class MeanFieldVMP(object):
                 node.bind(self.backend)
         self._data = {name: self.backend.from_host(value, *types[name])
                       for name, value in data.items() if name in types}
+        self._marked = []
         if hasattr(self.backend, "mark_constant"):
             # the data never changes between updates: element-wise values of data alone (x^2 in every
-            # message of a Gaussian model) are computed once by the device executor, not per message
-            self.backend.mark_constant(*self._data.values())
+            # message of a Gaussian model) are computed once by the device executor, not per message.
+            # The marks are THIS model's: close() (or the model's collection) takes them back, with every
+            # value the executor cached from them, so a backend shared by successive models neither keeps
+            # their data alive nor serves one model's cached values to the next.
+            self._marked = list(self._data.values())
+            self.backend.mark_constant(*self._marked)
         carried = {self._carrier(t) for n in self.nodes for t in n.statistics} - {None}
         missing = [n for n in types
                    if n not in self._data and n not in carried and n not in self._by_name]
@@ -616,10 +621,24 @@ class MeanFieldVMP(object):
                 raise TypeError("%s is not an input of the log-joint" % name)
             self._data[name] = self.backend.from_host(value, *self._types[name])
         if hasattr(self.backend, "mark_constant"):
-            self.backend.forget_constants()
-            self.backend.mark_constant(*self._data.values())
+            # only this model's marks: other models on the same backend keep theirs
+            self.backend.unmark_constant(*self._marked)
+            self._marked = list(self._data.values())
+            self.backend.mark_constant(*self._marked)
         if self._elbo_fns is not None:
             self._elbo_data = dict(self._data)
+
+    def close(self):
+        """Give the data's constant marks (and the values the executor cached from them) back."""
+        marked, self._marked = getattr(self, "_marked", []), []
+        if marked and hasattr(self.backend, "unmark_constant"):
+            self.backend.unmark_constant(*marked)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: the backend may already be gone
+            pass
 
     def elbo(self):
         """E_q[log p(data, latents)] + sum of the factors' entropies, up to whatever constants

@@ -162,18 +162,20 @@ class BLRReparamSVI:
         return code
 
     def _passes_per_update(self):
-        """Launches of the pass kernel per update, as bsc_blr_data_pass issues them: eight draws per
-        pass, or sixteen while more than eight are left (D = 256, BSC_BLR_WIDE not 0)."""
-        import os
+        """Launches of the pass kernel per update, as bsc_blr_data_pass issues them (asked of the library
+        once per batch pointer: eight draws per pass, or sixteen while more than eight are left at D = 256)."""
         if self.S <= 8:
             return 1
-        if self.D == 256 and os.environ.get("BSC_BLR_WIDE", "1") != "0":
-            n, left = 0, self.S
-            while left > 0:
-                left -= 16 if left > 8 else 8
-                n += 1
-            return n
-        return (self.S + 7) // 8
+        key = self._yarg if isinstance(self._yarg, int) else self._yarg.data_ptr()
+        if getattr(self, "_pass_count", (None, 0))[0] != key:
+            if hasattr(self.ctx, "lib"):
+                import ctypes
+                n = ctypes.c_int32(0)
+                self.ctx.call("bsc_blr_pass_count", self._yarg, self.D, self.S, ctypes.byref(n))
+                self._pass_count = (key, int(n.value))
+            else:                                   # a test double without the library: eight per pass
+                self._pass_count = (key, (self.S + 7) // 8)
+        return self._pass_count[1]
 
     # -- current views ---------------------------------------------------------
     @property

@@ -16,6 +16,17 @@ in compressed-sparse-column form and walks only the nonzeros (bsc_lda_sstats_csc
 The Dirichlet expectation and the natural-gradient step on lambda [K, V] are their
 own kernels.  Data-parallel over documents: one all-reduce of sstats (K*V float32,
 51.2 MB at K=128, V=100k) per update.
+
+``self.elbo`` (device, float64) holds, after every ``step()``, the mini-batch estimate of the evidence
+lower bound at the lambda the step started from (README.md:30-37, 69-79; oracle.svi.lda_elbo):
+
+    (docs_total / docs) * [sum_dv C log(phinorm) - sum_d KL(Dir(gamma_d) || Dir(alpha))]
+        - sum_k KL(Dir(lambda_k) || Dir(eta))
+
+The words' term is accumulated INSIDE the statistic kernel, where phinorm lives in registers
+(bsc_lda_sstats_bound); the topics' term comes out of the Dirichlet-expectation kernel of lambda
+(bsc_dirichlet_expectation_bound); the documents' term is constant (gamma is fixed) and taken once.
+Data-parallel: one more all-reduce of ONE float64 per update.  ``elbo=False`` skips all of it.
 """
 import torch
 
@@ -26,7 +37,8 @@ from .exchange import Exchange
 
 
 class LDAFixedGammaSVI:
-    def __init__(self, C, gamma, lam0, eta=0.01, docs_total=None, ctx=None, group=None, via=None):
+    def __init__(self, C, gamma, lam0, eta=0.01, docs_total=None, ctx=None, group=None, via=None,
+                 alpha=None, elbo=True):
         self.ctx = ctx or default_context()
         dev = self.ctx.device
         f32 = torch.float32
@@ -67,8 +79,21 @@ class LDAFixedGammaSVI:
         self.docs_total = float(docs_total) if docs_total is not None else self.batch_docs
         self.Th = torch.empty((self.docs, self.K), dtype=f32, device=dev)
         self.Bt = torch.empty((self.K, self.V), dtype=f32, device=dev)
-        self.ctx.call("bsc_dirichlet_expectation", gamma.contiguous(), self.docs, self.K, self.K,
-                      self.Th)                          # gamma is fixed: Th is computed once
+        self.alpha = float(alpha) if alpha is not None else 1.0 / self.K      # the documents' Dirichlet prior
+        self.with_elbo = bool(elbo)
+        f64 = torch.float64
+        # [words' term | documents' term]: the two per-rank sums one all-reduce carries
+        self._local = torch.zeros(2, dtype=f64, device=dev)
+        self._ll, self._theta_bound = self._local[:1], self._local[1:]
+        self._beta_bound = torch.zeros(1, dtype=f64, device=dev)
+        self.elbo = torch.zeros(1, dtype=f64, device=dev)
+        if self.with_elbo:      # gamma is fixed: Th and -sum_d KL(Dir(gamma_d) || Dir(alpha)) are computed once
+            self.ctx.call("bsc_dirichlet_expectation_bound", gamma.contiguous(), self.docs, self.K, self.K,
+                          self.alpha, self.Th, self._theta_bound)
+            self._theta_local = self._theta_bound.clone()
+        else:
+            self.ctx.call("bsc_dirichlet_expectation", gamma.contiguous(), self.docs, self.K, self.K,
+                          self.Th)
         if via is None:
             via = "kernel" if self.K in (32, 64, 96, 128) else "executor"
         if via not in ("kernel", "executor", "csc"):
@@ -81,23 +106,42 @@ class LDAFixedGammaSVI:
             self.expr = Bm * A.dot(Th.T, Cv / A.dot(Th, Bm))
             self.backend = DeviceBackend(self.ctx)
             self._sstats_fn = self.expr.compile(self.backend).device_fn
+            # the words' term as an expression of its own (a third product over C: this route is the
+            # general one, not the fast one); counts of zero contribute nothing whatever phinorm is
+            self._ll_fn = A.sum(Cv * A.log(A.dot(Th, Bm))).compile(self.backend).device_fn
         if self.C is not None and self.C.stride(1) != 1:
             self.C = self.C.contiguous()
         self.sstats = torch.zeros((self.K, self.V), dtype=f32, device=dev)
         self.t = 0
 
     def local_step(self):
-        """sstats = Bt * dot(Th.T, C / dot(Th, Bt)) for the current lambda."""
-        self.ctx.call("bsc_dirichlet_expectation", self.lam, self.K, self.V, self.V, self.Bt)
+        """sstats = Bt * dot(Th.T, C / dot(Th, Bt)) for the current lambda (and, with ``elbo``, the words'
+        and the topics' terms of the bound at it)."""
+        if not self.with_elbo:
+            self.ctx.call("bsc_dirichlet_expectation", self.lam, self.K, self.V, self.V, self.Bt)
+            if self.via == "csc":
+                colptr, rowidx, vals = self._csc
+                self.ctx.call("bsc_lda_sstats_csc", colptr, rowidx, vals, self.docs, self.V, self.K,
+                              self.Th, self.K, self.Bt, self.V, self.sstats, self.V)
+            elif self.via == "kernel":
+                self.ctx.call("bsc_lda_sstats", self.C, self.C.stride(0), self.docs, self.V, self.K,
+                              self.Th, self.K, self.Bt, self.V, self.sstats, self.V)
+            else:
+                self.sstats = self._sstats_fn(Th=self.Th, C=self.C, Bm=self.Bt)
+            return self.sstats
+        self.ctx.call("bsc_dirichlet_expectation_bound", self.lam, self.K, self.V, self.V, self.eta, self.Bt,
+                      self._beta_bound)
         if self.via == "csc":
             colptr, rowidx, vals = self._csc
-            self.ctx.call("bsc_lda_sstats_csc", colptr, rowidx, vals, self.docs, self.V, self.K,
-                          self.Th, self.K, self.Bt, self.V, self.sstats, self.V)
+            self.ctx.call("bsc_lda_sstats_csc_bound", colptr, rowidx, vals, self.docs, self.V, self.K,
+                          self.Th, self.K, self.Bt, self.V, self.sstats, self.V, self._ll)
         elif self.via == "kernel":
-            self.ctx.call("bsc_lda_sstats", self.C, self.C.stride(0), self.docs, self.V, self.K,
-                          self.Th, self.K, self.Bt, self.V, self.sstats, self.V)
+            self.ctx.call("bsc_lda_sstats_bound", self.C, self.C.stride(0), self.docs, self.V, self.K,
+                          self.Th, self.K, self.Bt, self.V, self.sstats, self.V, self._ll)
         else:
             self.sstats = self._sstats_fn(Th=self.Th, C=self.C, Bm=self.Bt)
+            ll = self.backend.materialize(self._ll_fn(Th=self.Th, C=self.C, Bm=self.Bt))
+            self._ll.copy_(self.backend._convert(ll.reshape(1), torch.float64))
         return self.sstats
 
     def step(self, rho=None):
@@ -106,5 +150,13 @@ class LDAFixedGammaSVI:
             rho = (self.t + 1.0) ** -0.7
         self.local_step()
         self.exchange.all_reduce(self.sstats)
-        self.ctx.call("bsc_natgrad_update_f32", self.lam, self.eta, self.sstats, self.lam.numel(),
-                      self.docs_total / self.batch_docs, float(rho))
+        if not self.with_elbo:
+            self.ctx.call("bsc_natgrad_update_f32", self.lam, self.eta, self.sstats, self.lam.numel(),
+                          self.docs_total / self.batch_docs, float(rho))
+            return
+        if self.world > 1 or self.exchange.rccl:
+            self._theta_bound.copy_(self._theta_local)      # (the all-reduce below sums in place)
+            self.exchange.all_reduce(self._local)
+        self.ctx.call("bsc_natgrad_update_f32_elbo", self.lam, self.eta, self.sstats, self.lam.numel(),
+                      self.docs_total / self.batch_docs, float(rho), self._ll, self._theta_bound,
+                      self._beta_bound, self.elbo)

@@ -88,6 +88,11 @@ class MoGNatGradSVI:
         self.buf = torch.zeros(self.K * (1 + 2 * self.D) + 1, dtype=f64, device=dev)
         self.stats = self.buf[:-1]
         self.lse = self.buf[-1:]
+        # the evidence lower bound at the parameters each step STARTS from (README.md:30-37, 69-79):
+        # scale * sum_n logsumexp_k + E_q[log p(theta)] - E_q[log q(theta)], formed on the device by the
+        # two parameter kernels that run anyway (oracle.svi.mog_elbo)
+        self._bound = torch.zeros(1, dtype=f64, device=dev)
+        self.elbo = torch.zeros(1, dtype=f64, device=dev)
         self.t = 0
         if via is None:
             via = "kernel" if (self.K <= 64 and self.D <= 16) else "executor"
@@ -115,8 +120,8 @@ class MoGNatGradSVI:
                 be.mark_constant(self.X)
 
     def expected_params(self):
-        self.ctx.call("bsc_mog_expected_params", self.eta, self.K, self.D, self.Wmat,
-                      self.c)
+        self.ctx.call("bsc_mog_expected_params_bound", self.eta, self.eta0, self.K, self.D, self.Wmat,
+                      self.c, self._bound)
 
     def local_step(self):
         if self.via == "kernel":
@@ -141,12 +146,13 @@ class MoGNatGradSVI:
             be.unmark_constant(R)       # before the buffer can be reused
 
     def step(self, rho=None):
-        """One SVI update; rho defaults to the Robbins-Monro schedule (t+1)^-0.6."""
+        """One SVI update; rho defaults to the Robbins-Monro schedule (t+1)^-0.6.  ``self.elbo`` (device,
+        float64) then holds the mini-batch estimate of the bound at the parameters the step started from."""
         self.t += 1
         if rho is None:
             rho = (self.t + 1.0) ** -0.6
         self.expected_params()
         self.local_step()
         self.exchange.all_reduce(self.buf)
-        self.ctx.call("bsc_mog_natgrad", self.eta, self.eta0, self.stats, self.K,
-                      self.D, self.n_total / self.batch_rows, float(rho))
+        self.ctx.call("bsc_mog_natgrad_elbo", self.eta, self.eta0, self.stats, self.K,
+                      self.D, self.n_total / self.batch_rows, float(rho), self.lse, self._bound, self.elbo)

@@ -1,6 +1,6 @@
 """ELBO-gradient updates/sec on a 1M-row mini-batch (BASELINE.json's metric), MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--config cfg2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling both|weak|strong] [--config cfg2]
 
 Default workload = BASELINE config 2 (the configuration the metric is quoted on): Bayesian
 linear regression, 1M x 256 float32 mini-batch, reparameterisation-trick ELBO, S = 8, Adam.
@@ -15,9 +15,22 @@ process never touches the GPU, starts N rank processes itself, relays rank 0's J
 exits non-zero if any rank failed.  torch.distributed (gloo) is only the host channel (unique
 id, barrier, max over ranks); the data path's one collective is bsc_allreduce_sum (RCCL/xGMI).
 
---scaling weak (default): every rank holds its own full-size mini-batch, `value` counts
-1M-row mini-batch equivalents per second over all ranks.  --scaling strong: ONE global
-mini-batch of the configured size is split into N row blocks.
+--scaling strong: ONE global mini-batch of the configured size (the metric's "1M-row mini-batch at
+1/2/4/8 GPUs") is split into N row blocks.  --scaling weak: every rank holds its own full-size
+mini-batch, `value` counts 1M-row mini-batch equivalents per second over all ranks.  Default
+(`both`): at N > 1 the line carries BOTH -- `value` / `scaling` = the metric's reading (strong) and
+`value_weak` beside it; at N = 1 the two coincide.
+
+What `value` is on config 2 (the metric's configuration): the update loop ROTATES over --batches
+(default 3) distinct mini-batches resident in HBM, a different one every step, as an SVI loop over
+fresh subsamples does (README.md:69-79) -- nothing of a step's 1.03 GB is left in the 256 MiB
+Infinity Cache for the next.  The same loop over ONE resident mini-batch (alternating sweeps, each
+pass starting in the rows the previous one left on-die) is timed beside it: `value_same_batch`,
+`roofline.same_batch`.
+
+The timed region is EXACTLY K steps between barrier + synchronize; it is repeated (same K) until
+--min-timed-s of it has been measured, `ms_per_step` / `value` are the MEDIAN block's and
+`timed_blocks` gives min / median / max.
 
 Prints ONE JSON line on rank 0.
 """
@@ -42,7 +55,13 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="both", choices=["both", "weak", "strong"])
+    ap.add_argument("--batches", type=int, default=3,
+                    help="cfg2: distinct resident mini-batches the update loop rotates over (1 = the same "
+                         "mini-batch every step)")
+    ap.add_argument("--min-timed-s", type=float, default=0.25,
+                    help="repeat the timed block of K steps until this much of it has been measured")
+    ap.add_argument("--max-blocks", type=int, default=100)
     ap.add_argument("--rows", type=int, default=None,
                     help="mini-batch rows (cfg4: documents): per GPU when weak, global when strong; "
                          "default = the BASELINE size of the config")
@@ -198,6 +217,18 @@ class Cfg2(Workload):
             y = X @ w_true + 0.5 * torch.randn(rows, generator=g, device=dev)
             self.host = None
         self.X, self.y, self.rows, self.D, self.S = X, y, rows, D, S
+        # further resident mini-batches of the same shape (drawn on the device: their values are
+        # not compared with anything); the loop visits batch t % n at step t
+        self.batches = [(X, y)]
+        for b in range(1, max(1, args.batches)):
+            gb = torch.Generator(device=dev).manual_seed(99_991 * b + 1234 + seed_off)
+            Xb = torch.randn((rows, D), generator=gb, device=dev, dtype=torch.float32)
+            wb = torch.from_numpy((np.random.RandomState(1).standard_normal(D) / 16.0).astype(np.float32)).to(dev)
+            yb = Xb @ wb + 0.5 * torch.randn(rows, generator=gb, device=dev)
+            self.batches.append((Xb, yb))
+        self.rotate = len(self.batches) > 1 and not args.reproducible
+        self._visit = 0
+        self._spin_visit = 0
         self.n_total = float(global_rows)       # the resident global batch is the data set
         self.model = BLRReparamSVI(X, y, n_total=self.n_total, n_samples=S, seed=1234, lr=1e-3, ctx=ctx,
                                    group=args.exchange_group, fused=not args.unfused, reproducible=args.reproducible,
@@ -208,18 +239,35 @@ class Cfg2(Workload):
                          % (rows, D, "per GPU" if args.scaling == "weak" else
                             "block of a global %d-row batch" % global_rows, S))
         self.config = {"rows_per_gpu": rows, "global_rows": global_rows, "dim": D, "mc_samples": S,
-                       "reproducible": bool(args.reproducible), "sweep": args.sweep}
+                       "reproducible": bool(args.reproducible), "sweep": args.sweep,
+                       "minibatches_resident": len(self.batches),
+                       "value_is": ("update loop rotating over %d distinct HBM-resident mini-batches, a different "
+                                    "one every step (no cross-update Infinity-Cache reuse)" % len(self.batches))
+                       if self.rotate else "update loop over ONE resident mini-batch (sweep = %s)" % args.sweep}
+
+    def set_mode(self, mode):
+        """'rotate' (a different resident mini-batch every step) or 'same' (batch 0 every step)."""
+        self.rotate = mode == "rotate" and len(self.batches) > 1 and not self.args.reproducible
+        if not self.rotate:
+            self.model.set_batch(*self.batches[0])
 
     def spin(self):
-        # the same launch the update loop makes, in the same sweep order (alternating directions
-        # over the resident batch unless --sweep stream)
+        # the same launch the update loop makes: streaming over the next batch of the rotation, or --
+        # one resident batch -- in the loop's sweep order (alternating directions unless --sweep stream)
         code = 0
-        if self.model.sweep == "alternate" and not self.model.reproducible:
+        X, y = self.batches[0]
+        if self.rotate:
+            self._spin_visit = (self._spin_visit + 1) % len(self.batches)
+            X, y = self.batches[self._spin_visit]
+        elif self.model.sweep == "alternate" and not self.model.reproducible:
             code = self._spin_sweep = 3 - getattr(self, "_spin_sweep", 2)
-        self.ctx.call("bsc_blr_data_pass_partial_sweep", self.X, self.X.stride(0), self.y, self.rows,
+        self.ctx.call("bsc_blr_data_pass_partial_sweep", X, X.stride(0), y, self.rows,
                       self.D, self.model.W, min(self.S, 8), code)
 
     def step(self):
+        if self.rotate:
+            self._visit = (self._visit + 1) % len(self.batches)
+            self.model.set_batch(*self.batches[self._visit])
         self.model.step()
 
     def result(self):
@@ -260,23 +308,27 @@ class Cfg2(Workload):
             return done, dt
 
         unit = "updates/s (%d-row mini-batch)" % Xh.shape[0]
-        all_cores = os.cpu_count() or 1
+        facts = lb.host_facts()
+        pools = [p.get("num_threads") for p in facts["blas"]] if isinstance(facts.get("blas"), list) else []
+        blas_threads = max([t for t in pools if t] or [1])
         n, dt = run(lb.blr_data_pass_lowered, budget_s)
-        out = {"value": n / dt, "unit": unit, "cores": all_cores, "kind": "port",
+        # cores = the threads this leg actually ran on: the BLAS pool (the GEMMs of the lowered tree); its
+        # element-wise nodes are single-threaded numpy.  The host's logical CPU count is in host.cpu_count.
+        out = {"value": n / dt, "unit": unit, "cores": blas_threads, "threads": blas_threads, "kind": "port",
                "sample": "%d full updates on the same %dx%d mini-batch in %.1f s: numpy float32 / BLAS "
                          "executing the lowered op tree of the pass (%s), float64 numpy finish; "
                          "numpy restatement, not Theano"
                          % (n, Xh.shape[0], D, dt, lb.blr_pass_functions()["lowered"]),
-               "host": lb.host_facts()}
+               "host": facts}
         with lb.threads(1):
             n, dt = run(lb.blr_data_pass_lowered, budget_s)
-        out["one_core"] = {"value": n / dt, "unit": unit, "cores": 1,
+        out["one_core"] = {"value": n / dt, "unit": unit, "cores": 1, "threads": 1,
                            "sample": "%d updates in %.1f s, BLAS threads = 1" % (n, dt)}
         try:
             from oracle import cbuild
             threads = int(cbuild.load().oracle_threads())
             n, dt = run(cbuild.blr_data_pass, budget_s)
-            out["c_port"] = {"value": n / dt, "unit": unit, "cores": threads,
+            out["c_port"] = {"value": n / dt, "unit": unit, "cores": threads, "threads": threads,
                              "sample": "%d updates in %.1f s: float64 C + OpenMP restatement of the pass "
                                        "(oracle/c), scalar inner loops" % (n, dt)}
         except Exception as e:   # no gcc and no prebuilt library on this host
@@ -338,7 +390,7 @@ class Cfg3(Workload):
         self.model.step()
 
     def result(self):
-        return {"final_bound_term": float(self.model.lse.item())}
+        return {"final_elbo": float(self.model.elbo.item()), "final_bound_term": float(self.model.lse.item())}
 
     def roofline(self, avg_s):
         return _mfma_roofline("mog_estep_kernel", 8.0 * self.K * self.D * self.rows,
@@ -487,7 +539,7 @@ class Cfg4(Workload):
         self.model.step()
 
     def result(self):
-        return {"lambda_sum": float(self.model.lam.sum().item())}
+        return {"final_elbo": float(self.model.elbo.item()), "lambda_sum": float(self.model.lam.sum().item())}
 
     def roofline(self, avg_s):
         return _mfma_roofline("lda_sstats_stream_kernel", 4.0 * self.docs * self.V * self.K,
@@ -586,68 +638,119 @@ def run_rank(args):
                              "%d rank(s)%s)" % (int(flag.item()), "; this rank: " + err if err else ""))
     elif world == 1 and args.rccl_world1:
         ctx.comm_init(ctx.comm_unique_id(), 0, 1)
-    wl = WORKLOADS[args.config](args, ctx, torch, rank, world)
-
     def barrier():
         if world > 1:
             dist.barrier()
 
-    # device spin-up (not steps: the model state is untouched)
-    spin_launches = int(args.spin_up_ms / wl.kernel_ms) if args.spin_up_ms > 0 else 0
-    for _ in range(spin_launches):
-        wl.spin()
-    for _ in range(args.warmup):
-        wl.step()
-    torch.cuda.synchronize()
-    timing = not args.no_kernel_timing
-    ctx.profile(max(1, args.time_every) if timing else 0)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    in_region = {s: ctx.profile_read(s) for s in (0, 1, 2)} if timing else {}
-    ctx.profile(0)
+    def reduce_max(values):
+        t = torch.tensor(list(values), dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t]
 
-    # dedicated burst AFTER the timed region: every launch of the dominant kernel timed on the
-    # launch stream, so roofline.avg_launch_us rests on >= 50 samples whatever --steps was
-    burst_ms, burst_n = 0.0, 0
-    if timing and args.burst > 0:
-        ctx.profile(1)
-        for _ in range(args.burst):
+    def measure(wl, spin_up=True, burst=True):
+        """Spin-up, W warm-up steps, then timed blocks of EXACTLY K steps each (barrier + synchronize on both
+        sides, max over ranks), repeated until --min-timed-s has been measured; then the dominant kernel's
+        burst.  Returns a dict."""
+        spin_launches = int(args.spin_up_ms / wl.kernel_ms) if (spin_up and args.spin_up_ms > 0) else 0
+        for _ in range(spin_launches):
             wl.spin()
-        burst_ms, burst_n = ctx.profile_read(0)
+        for _ in range(args.warmup):
+            wl.step()
+        torch.cuda.synchronize()
+        timing = not args.no_kernel_timing
+        ctx.profile(max(1, args.time_every) if timing else 0)
+        blocks, n_blocks = [], 1
+        while len(blocks) < n_blocks:
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                wl.step()
+            torch.cuda.synchronize()
+            barrier()
+            blocks.append(time.perf_counter() - t0)
+            if len(blocks) == 1:       # every rank derives the same count from the same (max-reduced) time
+                first = reduce_max(blocks)[0]
+                n_blocks = max(1, min(args.max_blocks, int(-(-args.min_timed_s // max(first, 1e-9)))))
+        in_region = {s: ctx.profile_read(s) for s in (0, 1, 2)} if timing else {}
         ctx.profile(0)
-    read_ceiling = ctx.read_probe(wl.X) if (rank == 0 and args.config == "cfg2") else None
+        # dedicated burst AFTER the timed region: every launch of the dominant kernel timed on the
+        # launch stream, so roofline.avg_launch_us rests on >= 50 samples whatever --steps was
+        burst_ms, burst_n = 0.0, 0
+        if timing and burst and args.burst > 0:
+            ctx.profile(1)
+            for _ in range(args.burst):
+                wl.spin()
+            burst_ms, burst_n = ctx.profile_read(0)
+            ctx.profile(0)
+        blocks = sorted(reduce_max(blocks))
+        median = blocks[len(blocks) // 2] if len(blocks) % 2 else 0.5 * (blocks[len(blocks) // 2 - 1] + blocks[len(blocks) // 2])
+        return {"blocks": blocks, "median_s": median, "in_region": in_region, "burst": (burst_ms, burst_n),
+                "spin_launches": spin_launches}
 
-    t = torch.tensor([elapsed], dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    extra = wl.result()
+    def block_stats(m):
+        k = args.steps
+        return {"n": len(m["blocks"]), "steps_per_block": k, "ms_per_step_min": m["blocks"][0] / k * 1e3,
+                "ms_per_step_median": m["median_s"] / k * 1e3, "ms_per_step_max": m["blocks"][-1] / k * 1e3,
+                "timed_s": sum(m["blocks"])}
+
+    import copy
+    if args.scaling == "both":
+        modes = ["strong", "weak"] if world > 1 else ["weak"]
+    else:
+        modes = [args.scaling]
+    runs = {}
+    wl = None
+    for mode in modes:
+        del wl
+        margs = copy.copy(args)
+        margs.scaling = mode
+        wl = WORKLOADS[args.config](margs, ctx, torch, rank, world)
+        m = measure(wl)
+        m["units_per_step"], m["describe"], m["config"] = wl.units_per_step, wl.describe, wl.config
+        if mode == modes[0]:
+            m["roofline_wl"] = wl
+            # config 2: the same loop over ONE resident mini-batch (alternating sweeps) beside the rotation
+            if args.config == "cfg2" and getattr(wl, "rotate", False):
+                wl.set_mode("same")
+                m["same"] = measure(wl, spin_up=False)
+                wl.set_mode("rotate")
+            m["read_ceiling"] = ctx.read_probe(wl.X) if (rank == 0 and args.config == "cfg2") else None
+            m["extra"] = wl.result()
+        runs[mode] = m
+    head = runs[modes[0]]
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = wl.units_per_step * args.steps / elapsed
+        k = args.steps
+        ms_per_step = head["median_s"] / k * 1e3
+        value = head["units_per_step"] * k / head["median_s"]
         roofline = None
+        burst_ms, burst_n = head["burst"]
+        rwl = head["roofline_wl"]
         if burst_n:
             avg_s = burst_ms / burst_n * 1e-3
-            roofline = wl.roofline(avg_s)
+            roofline = rwl.roofline(avg_s)
             roofline.update({"avg_launch_us": avg_s * 1e6, "launches": burst_n,
                              "timed": "burst of %d consecutive launches after the timed region, one "
                                       "hipEvent pair each on the launch stream" % burst_n})
-            ms0, n0 = in_region.get(0, (0.0, 0))
+            ms0, n0 = head["in_region"].get(0, (0.0, 0))
             if n0:
                 roofline["avg_launch_us_in_timed_region"] = ms0 / n0 * 1e3
                 roofline["launches_in_timed_region"] = n0
-            if read_ceiling:
-                roofline["read_ceiling_this_box"] = read_ceiling
-                roofline["frac_of_read_ceiling"] = roofline["achieved"] / read_ceiling
-        ms1, n1 = in_region.get(1, (0.0, 0))
-        ms2, n2 = in_region.get(2, (0.0, 0))
+            if head.get("read_ceiling"):
+                roofline["read_ceiling_this_box"] = head["read_ceiling"]
+                roofline["frac_of_read_ceiling"] = roofline["achieved"] / head["read_ceiling"]
+            if "same" in head and head["same"]["burst"][1]:
+                sb_ms, sb_n = head["same"]["burst"]
+                sb = rwl.roofline(sb_ms / sb_n * 1e-3)
+                roofline["passes"] = "each launch streams a mini-batch the previous launch did not touch"
+                roofline["same_batch"] = {"achieved": sb["achieved"], "frac": sb["frac"],
+                                          "avg_launch_us": sb_ms / sb_n * 1e3, "launches": sb_n,
+                                          "passes": "alternating sweeps over ONE resident mini-batch: each launch "
+                                                    "starts in the ~230 MB the previous one left in the Infinity Cache"}
+        ms1, n1 = head["in_region"].get(1, (0.0, 0))
+        ms2, n2 = head["in_region"].get(2, (0.0, 0))
         info = ctx.comm_info()
         out = {
             "metric": "ELBO-grad updates/sec (1M-row mini-batch)",
@@ -659,11 +762,12 @@ def run_rank(args):
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": modes[0],
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": dict({"workload": wl.describe, "parallelism": "dp%d" % world}, **wl.config),
+            "config": dict({"workload": head["describe"], "parallelism": "dp%d" % world}, **head["config"]),
+            "timed_blocks": block_stats(head),
             "roofline": roofline,
             "allreduce_us": (ms1 / n1 * 1e3) if n1 else None,
             "finish_us": (ms2 / n2 * 1e3) if n2 else None,
@@ -672,12 +776,25 @@ def run_rank(args):
             "exchange": ("rccl via bsc_allreduce_sum on the ctx stream" if ctx.has_comm else
                          exchange_note if exchange_note else
                          ("gloo (rehearsal: all ranks on one GPU)" if world > 1 else "none (one rank)")),
-            "spin_up_launches": spin_launches,
+            "spin_up_launches": head["spin_launches"],
         }
-        out.update(extra)
+        if "same" in head:
+            same = head["same"]
+            out["value_same_batch"] = head["units_per_step"] * k / same["median_s"]
+            out["ms_per_step_same_batch"] = same["median_s"] / k * 1e3
+            out["timed_blocks_same_batch"] = block_stats(same)
+        if len(modes) > 1:
+            weak = runs["weak"]
+            out["value_weak"] = weak["units_per_step"] * k / weak["median_s"]
+            out["ms_per_step_weak"] = weak["median_s"] / k * 1e3
+            out["timed_blocks_weak"] = block_stats(weak)
+            out["config_weak"] = dict({"workload": weak["describe"]}, **weak["config"])
+            out["scaling_note"] = ("value = ONE global mini-batch of the configured size split over the ranks "
+                                   "(the metric's reading); value_weak = one full-size mini-batch PER rank")
+        out.update(head["extra"])
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = wl.cpu_baseline(args.cpu_budget_s)
+                out["cpu_baseline"] = rwl.cpu_baseline(args.cpu_budget_s)
             except Exception as e:
                 out["cpu_baseline"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
         else:

@@ -224,6 +224,11 @@ int bsc_blr_data_pass_partial_sweep(bsc_ctx* ctx, const float* X, int64_t ldx, c
                                     int64_t B, int32_t D, const float* W, int32_t S,
                                     int32_t sweep);
 
+/* How many launches of the pass kernel bsc_blr_data_pass[_sweep] makes for S draws (eight per pass, or
+ * sixteen while more than eight are left at D = 256): what a caller that alternates sweep directions
+ * per update needs to know, answered by the library that decides it. */
+int bsc_blr_pass_count(bsc_ctx* ctx, const float* y, int32_t D, int32_t S, int32_t* count);
+
 /* Monte-Carlo ELBO and pathwise gradient from the (all-reduced) pass outputs.
  * batch_rows = global mini-batch rows, scale = N_total / batch_rows.
  * Writes elbo[1], grad[2D+2] (float64). */
@@ -314,6 +319,34 @@ int bsc_lda_sstats_csc(bsc_ctx* ctx, const int64_t* colptr, const int32_t* rowid
                        int64_t docs, int64_t V, int32_t K, const float* Th, int64_t ldth,
                        const float* Bt, int64_t ldb, float* sstats, int64_t ldo);
 
+/* The evidence lower bound of the same model (ABSENT in the reference; README.md:30-37, mini-batch
+ * form README.md:69-79; Hoffman, Blei, Bach 2010 eq. 7 with the per-word assignments at their
+ * optimum; oracle.svi.lda_elbo):
+ *   ELBO = scale * [ sum_dv C_dv log(phinorm_dv) - sum_d KL(Dir(gamma_d) || Dir(alpha)) ]
+ *          - sum_k KL(Dir(lambda_k) || Dir(eta)),          phinorm = Th Bt.
+ * bsc_lda_sstats_bound / bsc_lda_sstats_csc_bound are the statistic kernels above that ALSO return
+ * ll[0] = sum_dv C_dv log(phinorm_dv) (float64, device): phinorm exists only in their registers, so
+ * the sum is taken there -- a v_log_f32 and an fma per element, float32 per-wave partials, added in
+ * float64 in a fixed order; no extra pass over C.
+ * bsc_dirichlet_expectation_bound is bsc_dirichlet_expectation that also returns
+ * bound[0] = sum_r -KL(Dir(lam_r) || Dir(prior)) (symmetric scalar prior; float64, fixed order), from
+ * the digamma values it computes anyway plus one lnGamma per element (both factors' terms: rows =
+ * topics for lambda, rows = documents for gamma).
+ * bsc_natgrad_update_f32_elbo is bsc_natgrad_update_f32 that first writes
+ * elbo[0] = scale * (ll[0] + local_bound[0]) + global_bound[0]: the bound at the lambda the step
+ * starts from (ll and local_bound all-reduced when data-parallel). */
+int bsc_lda_sstats_bound(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int64_t V, int32_t K,
+                         const float* Th, int64_t ldth, const float* Bt, int64_t ldb, float* sstats,
+                         int64_t ldo, double* ll);
+int bsc_lda_sstats_csc_bound(bsc_ctx* ctx, const int64_t* colptr, const int32_t* rowidx, const float* vals,
+                             int64_t docs, int64_t V, int32_t K, const float* Th, int64_t ldth,
+                             const float* Bt, int64_t ldb, float* sstats, int64_t ldo, double* ll);
+int bsc_dirichlet_expectation_bound(bsc_ctx* ctx, const float* lam, int64_t rows, int64_t cols, int64_t ld,
+                                    double prior, float* out, double* bound);
+int bsc_natgrad_update_f32_elbo(bsc_ctx* ctx, float* eta, float eta0, const float* message, int64_t n,
+                                float scale, float rho, const double* ll, const double* local_bound,
+                                const double* global_bound, double* elbo);
+
 /* ---- summed sufficient statistics of iid draws ---------------------------
  * ExpFamIndependentObservations.sufficient_statistics,
  * bayesic/distribution/base.py:328-332; Normal t(x)=(x,x^2),
@@ -358,6 +391,24 @@ int bsc_mog_expected_params(bsc_ctx* ctx, const double* eta, int32_t K, int32_t 
                             float* c);
 int bsc_mog_natgrad(bsc_ctx* ctx, double* eta, const double* eta0, const double* stats, int32_t K,
                     int32_t D, double scale, double rho);
+
+/* The evidence lower bound of the mixture (ABSENT in the reference; README.md:30-37 "maximise a
+ * lower bound on the model evidence", mini-batch form README.md:69-79; every factor decomposed as
+ * bayesic/distribution/base.py:47-69).  With the assignments marginalised by summation
+ * (README.md:43,72) the bound at q(theta) = eta is
+ *     ELBO = scale * sum_n logsumexp_k(logit_nk) + bound,
+ *     bound = E_q[log p(pi,mu,tau)] - E_q[log q(pi,mu,tau)] = sum_factors <eta0-eta, E_q[T]> - A(eta0) + A(eta)
+ * (oracle.svi.mog_elbo / mog_global_bound).  bsc_mog_expected_params_bound is
+ * bsc_mog_expected_params that also writes `bound` (one float64, device) from the same digamma / log
+ * values; bsc_mog_natgrad_elbo is bsc_mog_natgrad that first writes
+ * elbo[0] = scale * lse[0] + bound[0] (lse: what bsc_mog_estep returned for THIS eta, all-reduced
+ * when data-parallel) -- the bound at the parameters the step starts from.  No extra launch, no
+ * extra pass.  K <= 1024. */
+int bsc_mog_expected_params_bound(bsc_ctx* ctx, const double* eta, const double* eta0, int32_t K, int32_t D,
+                                  float* Wmat, float* c, double* bound);
+int bsc_mog_natgrad_elbo(bsc_ctx* ctx, double* eta, const double* eta0, const double* stats, int32_t K,
+                         int32_t D, double scale, double rho, const double* lse, const double* bound,
+                         double* elbo);
 
 /* ---- black-box VI, score-function gradient with control variate ------------
  * (ABSENT in reference; README.md:52 -> ref [3]; config 5: hierarchical logistic

@@ -292,9 +292,10 @@ def mog_unpack(eta, K, D):
     return alpha, m, kappa, a, b
 
 
-def mog_expected_params(eta, K, D):
+def mog_expected_params(eta, K, D, dtype=np.float32):
     """Coefficients of the per-row logits: logit_nk = c_k + sum_d (A_kd x_nd^2 + B_kd x_nd).
-    Returns float32 Wmat [K, 2D] = [B | A] (x features first, then x^2) and c [K]."""
+    Returns float32 Wmat [K, 2D] = [B | A] (x features first, then x^2) and c [K] -- rounded to
+    ``dtype`` (float32: what the device streams)."""
     from scipy.special import digamma
     alpha, m, kappa, a, b = mog_unpack(eta, K, D)
     T = a / b                                            # E[tau]
@@ -302,7 +303,7 @@ def mog_expected_params(eta, K, D):
     c = elog_pi + (0.5 * (digamma(a) - np.log(b)) - 0.5 * LOG_2PI
                    - 0.5 * T * m * m - 0.5 / kappa).sum(axis=1)
     Wmat = np.concatenate([T * m, -0.5 * T], axis=1)
-    return Wmat.astype(np.float32), c.astype(np.float32)
+    return Wmat.astype(dtype), c.astype(dtype)
 
 
 def mog_local_step(X, Wmat, c, chunk=65536):
@@ -478,3 +479,96 @@ def lda_svi_step(lam, gamma, C, eta, docs_total, rho):
     ss = lda_sstats(C, Th, Bt)
     new = (1.0 - rho) * np.asarray(lam, np.float64) + rho * (eta + docs_total / C.shape[0] * ss)
     return new, ss
+
+
+# --------------------------------------------------------------------------
+# The evidence lower bound of configs 3 and 4 (README.md:30-37: "maximise a lower bound on
+# the model evidence"; README.md:69-79: the mini-batch estimate of it; decomposition of every
+# factor per bayesic/distribution/base.py:47-69 -- log p = <T, eta> - A(eta) + base).
+#
+# For a conjugate factor with prior natural parameters eta0 and variational eta (same family,
+# same statistics T, the base measure cancels):
+#
+#     E_q[log p(theta)] - E_q[log q(theta)] = <eta0 - eta, E_q[T]> - A(eta0) + A(eta) = -KL(q || p)
+#
+# and for a finite discrete local latent held at its optimum (marginalised by summation,
+# README.md:43,72) the local part is  sum_n logsumexp_k E_q[log p(x_n, z_n = k | theta)].
+# --------------------------------------------------------------------------
+
+def dirichlet_log_normalizer(alpha):
+    """A = sum lnGamma(alpha_k) - lnGamma(sum alpha) along the last axis (statistics log theta_k,
+    natural parameters alpha_k - 1)."""
+    from scipy.special import gammaln
+    a = np.asarray(alpha, np.float64)
+    return gammaln(a).sum(axis=-1) - gammaln(a.sum(axis=-1))
+
+
+def dirichlet_neg_kl(alpha, alpha0):
+    """-KL(Dir(alpha) || Dir(alpha0)) per leading index; alpha0 broadcasts."""
+    from scipy.special import digamma
+    a = np.asarray(alpha, np.float64)
+    a0 = np.broadcast_to(np.asarray(alpha0, np.float64), a.shape)
+    elog = digamma(a) - digamma(a.sum(axis=-1, keepdims=True))
+    return ((a0 - a) * elog).sum(axis=-1) - dirichlet_log_normalizer(a0) + dirichlet_log_normalizer(a)
+
+
+def normal_gamma_log_normalizer(kappa, a, b):
+    """A(eta) of NormalGamma(mu, tau | m, kappa, a, b) w.r.t. the statistics
+    T = (tau mu, -tau mu^2 / 2, log(tau) / 2, -tau / 2) whose natural parameters are
+    (kappa m, kappa, 2a - 1, 2b + kappa m^2) -- the layout of ``normal_gamma_to_natural``:
+    A = lnGamma(a) - a log b - log(kappa) / 2 + log(2 pi) / 2."""
+    from scipy.special import gammaln
+    return gammaln(a) - a * np.log(b) - 0.5 * np.log(kappa) + 0.5 * LOG_2PI
+
+
+def normal_gamma_expected_statistics(m, kappa, a, b):
+    """E[T] for the statistics above: (m a/b, -(1/kappa + m^2 a/b)/2, (psi(a) - log b)/2, -a/(2b))."""
+    from scipy.special import digamma
+    T = a / b
+    return T * m, -0.5 * (1.0 / kappa + m * m * T), 0.5 * (digamma(a) - np.log(b)), -0.5 * T
+
+
+def mog_global_bound(eta, eta0, K, D):
+    """E_q[log p(pi, mu, tau)] - E_q[log q(pi, mu, tau)] of config 3's global factors (a Dirichlet and
+    K*D Normal-Gammas), natural parameters in the flat layout above."""
+    eta, eta0 = np.asarray(eta, np.float64), np.asarray(eta0, np.float64)
+    alpha, m, kappa, a, b = mog_unpack(eta, K, D)
+    alpha0, _, kappa0, a0, b0 = mog_unpack(eta0, K, D)
+    total = float(dirichlet_neg_kl(alpha, alpha0))
+    ET = normal_gamma_expected_statistics(m, kappa, a, b)
+    KD = K * D
+    for j in range(4):
+        e = eta[K + j * KD: K + (j + 1) * KD].reshape(K, D)
+        e0 = eta0[K + j * KD: K + (j + 1) * KD].reshape(K, D)
+        total += float(((e0 - e) * ET[j]).sum())
+    total += float((normal_gamma_log_normalizer(kappa, a, b) - normal_gamma_log_normalizer(kappa0, a0, b0)).sum())
+    return total
+
+
+def mog_elbo(eta, eta0, lse_total, scale, K, D):
+    """Mini-batch estimate of config 3's bound at q(theta) = eta with q(z) at its optimum:
+    scale * sum_n logsumexp_k(logit_nk) + mog_global_bound.  ``lse_total`` is what
+    ``mog_local_step`` returns for the same eta."""
+    return scale * float(lse_total) + mog_global_bound(eta, eta0, K, D)
+
+
+def lda_local_bound(C, Th, Bt):
+    """sum_dv C_dv log(phinorm_dv), phinorm = Th Bt: the words' part of the bound with the
+    per-word topic assignments at their optimum phi_dvk ~ Th_dk Bt_kv (Hoffman, Blei, Bach 2010,
+    eq. 7 with the phi terms collapsed).  float32 operands, float64 arithmetic."""
+    C64, Th64, Bt64 = (np.asarray(v, np.float32).astype(np.float64) for v in (C, Th, Bt))
+    phinorm = Th64 @ Bt64
+    nz = C64 != 0
+    return float((C64[nz] * np.log(phinorm[nz])).sum())
+
+
+def lda_elbo(lam, gamma, C, eta, alpha, docs_total):
+    """Config 4's bound for one mini-batch of documents with fixed gamma:
+    (docs_total / docs) * [ sum_dv C log phinorm - sum_d KL(Dir(gamma_d) || Dir(alpha)) ]
+      - sum_k KL(Dir(lambda_k) || Dir(eta))."""
+    Th = dirichlet_expectation(gamma).astype(np.float32)
+    Bt = dirichlet_expectation(lam).astype(np.float32)
+    docs, K = np.shape(gamma)
+    scale = docs_total / docs
+    local = lda_local_bound(C, Th, Bt) + float(dirichlet_neg_kl(gamma, alpha).sum())
+    return scale * local + float(dirichlet_neg_kl(lam, eta).sum())

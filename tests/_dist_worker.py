@@ -105,6 +105,14 @@ class OracleContext:
         Wmat.copy_(torch.from_numpy(w))
         c.copy_(torch.from_numpy(cc))
 
+    def bsc_mog_expected_params_bound(self, eta, eta0, K, D, Wmat, c, bound):
+        self.bsc_mog_expected_params(eta, K, D, Wmat, c)
+        bound[0] = svi.mog_global_bound(eta.numpy(), eta0.numpy(), K, D)
+
+    def bsc_mog_natgrad_elbo(self, eta, eta0, stats, K, D, scale, rho, lse, bound, elbo):
+        elbo[0] = scale * float(lse[0]) + float(bound[0])
+        self.bsc_mog_natgrad(eta, eta0, stats, K, D, scale, rho)
+
     def bsc_mog_estep(self, X, ldx, N, D, K, Wmat, c, stats, lse):
         s, l = svi.mog_local_step(X.numpy(), Wmat.numpy(), c.numpy())
         stats.copy_(torch.from_numpy(s.ravel()))
@@ -156,6 +164,18 @@ class OracleContext:
 
     def bsc_lda_sstats(self, C, ldc, docs, V, K, Th, ldth, Bt, ldb, out, ldo):
         out.copy_(torch.from_numpy(svi.lda_sstats(C.numpy(), Th.numpy(), Bt.numpy()).astype(np.float32)))
+
+    def bsc_dirichlet_expectation_bound(self, lam, rows, cols, ld, prior, out, bound):
+        self.bsc_dirichlet_expectation(lam, rows, cols, ld, out)
+        bound[0] = float(svi.dirichlet_neg_kl(lam.numpy(), prior).sum())
+
+    def bsc_lda_sstats_bound(self, C, ldc, docs, V, K, Th, ldth, Bt, ldb, out, ldo, ll):
+        self.bsc_lda_sstats(C, ldc, docs, V, K, Th, ldth, Bt, ldb, out, ldo)
+        ll[0] = svi.lda_local_bound(C.numpy(), Th.numpy(), Bt.numpy())
+
+    def bsc_natgrad_update_f32_elbo(self, eta, eta0, message, n, scale, rho, ll, local_bound, global_bound, elbo):
+        elbo[0] = scale * (float(ll[0]) + float(local_bound[0])) + float(global_bound[0])
+        self.bsc_natgrad_update_f32(eta, eta0, message, n, scale, rho)
 
     def bsc_natgrad_update_f32(self, eta, eta0, message, n, scale, rho):
         new = (1.0 - rho) * eta.numpy().astype(np.float64) + \
@@ -230,7 +250,7 @@ def main():
         lda.step()
     np.savez(out_path % rank, lam=lam, lam_rep=lam_rep, elbo=model.elbo.numpy(), eta=mog.eta.numpy(),
              lse=mog.lse.numpy(), bbvi_lam=bb.lam.numpy(), bbvi_elbo=bb.elbo.numpy(),
-             lda_lam=lda.lam.numpy())
+             lda_lam=lda.lam.numpy(), mog_elbo=mog.elbo.numpy(), lda_elbo=lda.elbo.numpy())
     dist.barrier()
     dist.destroy_process_group()
 

@@ -78,28 +78,22 @@ def test_lowered_tree_baseline_equals_the_oracle_pass():
     assert lb.host_facts()["cpu_count"] == os.cpu_count()
 
 
-def test_sweep_bookkeeping_of_the_config2_driver(monkeypatch):
-    """BLRReparamSVI alternates the sweep order per PASS: the number of passes per update follows
-    bsc_blr_data_pass (eight draws per pass; sixteen while more than eight are left at D = 256), and
-    a freshly swapped-in batch is streamed once.  Host logic only -- no device."""
+def test_sweep_bookkeeping_of_the_config2_driver():
+    """BLRReparamSVI alternates the sweep order per PASS; a freshly swapped-in batch is streamed once.
+    Host logic only -- no device.  (The number of passes per update is the library's answer,
+    bsc_blr_pass_count: tests/test_blr_gpu.py::test_pass_count_is_the_librarys_answer.)"""
     from types import SimpleNamespace
     from bayesic_amd.svi.blr import BLRReparamSVI, SWEEP_STREAM, SWEEP_FORWARD_KEEP, SWEEP_BACKWARD_KEEP
 
     def fake(S, D=256, sweep="alternate", reproducible=False):
+        passes = 1 if S <= 8 else 2
         return SimpleNamespace(S=S, D=D, sweep=sweep, reproducible=reproducible, _fresh_batch=False,
-                               _sweep_next=SWEEP_FORWARD_KEEP,
-                               _passes_per_update=lambda: BLRReparamSVI._passes_per_update(me[0]))
+                               _sweep_next=SWEEP_FORWARD_KEEP, _passes_per_update=lambda: passes)
 
     me = [None]
-    monkeypatch.delenv("BSC_BLR_WIDE", raising=False)
-    for S, D, want in [(1, 256, 1), (8, 256, 1), (9, 256, 1), (16, 256, 1), (17, 256, 2), (24, 256, 2),
-                       (25, 256, 2), (33, 256, 3), (64, 256, 4), (20, 128, 3), (64, 64, 8)]:
-        me[0] = fake(S, D)
-        assert BLRReparamSVI._passes_per_update(me[0]) == want, (S, D)
-    monkeypatch.setenv("BSC_BLR_WIDE", "0")
-    me[0] = fake(64)
-    assert BLRReparamSVI._passes_per_update(me[0]) == 8
-    monkeypatch.delenv("BSC_BLR_WIDE")
+    # without the library (a test double as context) the driver assumes eight draws per pass
+    plain = SimpleNamespace(S=20, D=128, _yarg=0, ctx=SimpleNamespace())
+    assert BLRReparamSVI._passes_per_update(plain) == 3
     # one pass per update: forward, backward, forward, ...
     me[0] = fake(8)
     assert [BLRReparamSVI._take_sweep(me[0]) for _ in range(4)] == [1, 2, 1, 2]

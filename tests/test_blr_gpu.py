@@ -512,3 +512,47 @@ def test_sixteen_draws_per_pass_equals_eight_per_pass(monkeypatch):
         np.testing.assert_allclose(Qa, Qb, rtol=1e-5)
         np.testing.assert_allclose(Qa, Qr, rtol=2e-5)
         np.testing.assert_allclose(Ga, Gb, rtol=1e-4, atol=2e-4 * np.abs(Gr).max())
+
+
+def test_pass_count_is_the_librarys_answer(ctx, monkeypatch):
+    """bsc_blr_pass_count: launches of the pass kernel per update as bsc_blr_data_pass issues them -- eight draws
+    per pass; sixteen while more than eight are left at D = 256 (BSC_BLR_WIDE=0: always eight).  The driver asks
+    the library instead of re-deriving the rule from the environment."""
+    import ctypes
+    from bayesic_amd.device import Context
+    from bayesic_amd.svi.blr import BLRReparamSVI
+    y = ctx.zeros(64)
+
+    def count(c, D, S):
+        n = ctypes.c_int32(-1)
+        c.call("bsc_blr_pass_count", y, D, S, ctypes.byref(n))
+        return n.value
+
+    for S, D, want in [(1, 256, 1), (8, 256, 1), (9, 256, 1), (16, 256, 1), (17, 256, 2), (24, 256, 2),
+                       (25, 256, 2), (33, 256, 3), (64, 256, 4), (20, 128, 3), (64, 64, 8)]:
+        assert count(ctx, D, S) == want, (S, D)
+    monkeypatch.setenv("BSC_BLR_WIDE", "0")
+    narrow = Context(0)
+    assert count(narrow, 256, 64) == 8
+    monkeypatch.delenv("BSC_BLR_WIDE")
+    X = ctx.zeros((64, 256))
+    model = BLRReparamSVI(X, y, n_samples=24, ctx=ctx)
+    assert model._passes_per_update() == 2
+    # a context that reads BSC_BLR_WIDE=0 and a driver that runs later agree, whatever the environment says by then
+    model = BLRReparamSVI(X, y, n_samples=64, ctx=narrow)
+    assert model._passes_per_update() == 8
+
+
+def test_profiling_only_builds_need_an_explicit_second_switch(monkeypatch):
+    """BSC_BLR_MX=4 / BSC_GEMM_DBG / BSC_BBVI_DBG select kernels with parts deleted (wrong results, for timing):
+    a context refuses them unless BSC_PROFILING_BUILDS=1 is set as well."""
+    from bayesic_amd._ffi import BayesicHipError
+    from bayesic_amd.device import Context
+    for name, value in (("BSC_BLR_MX", "4"), ("BSC_GEMM_DBG", "1"), ("BSC_BBVI_DBG", "3")):
+        monkeypatch.setenv(name, value)
+        with pytest.raises(BayesicHipError, match="WRONG results"):
+            Context(0)
+        monkeypatch.setenv("BSC_PROFILING_BUILDS", "1")
+        Context(0).close()
+        monkeypatch.delenv("BSC_PROFILING_BUILDS")
+        monkeypatch.delenv(name)

@@ -47,9 +47,13 @@ def test_two_gloo_ranks_equal_single_process(tmp_path):
     eta0 = svi.mog_prior_eta(3, 4)
     eta = svi.mog_init_eta(Xm[:300], 3, 4, seed=2)
     for t in range(1, 4):
+        before = eta
         eta, _, lse = svi.mog_svi_step(eta, eta0, Xm, 12000, (t + 1.0) ** -0.6, 3, 4)
     np.testing.assert_allclose(r0["eta"], eta, rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(r0["lse"][0], lse, rtol=1e-10)
+    # the bound at the parameters the last step started from: local part all-reduced, global part replicated
+    np.testing.assert_allclose(r0["mog_elbo"][0], svi.mog_elbo(before, eta0, lse, 10.0, 3, 4), rtol=1e-10)
+    np.testing.assert_array_equal(r0["mog_elbo"], r1["mog_elbo"])
     # config 5: the S log-likelihoods are the only exchanged object
     np.testing.assert_array_equal(r0["bbvi_lam"], r1["bbvi_lam"])
     X5, y5, g5, _, _ = svi.make_cfg5(600, 8, 5)
@@ -66,5 +70,9 @@ def test_two_gloo_ranks_equal_single_process(tmp_path):
     gamma4 = rs.gamma(100.0, 0.01, (90, 32)).astype(np.float32)
     lam4 = rs.gamma(100.0, 0.01, (32, 40)).astype(np.float32).astype(np.float64)
     for t in range(1, 3):
+        before4 = lam4.astype(np.float32)
         lam4, _ = svi.lda_svi_step(lam4.astype(np.float32), gamma4, C4, 0.01, 900, (t + 1.0) ** -0.7)
     np.testing.assert_allclose(r0["lda_lam"], lam4, rtol=2e-6)
+    # the words' and the documents' terms are per-rank sums (one all-reduce of two float64), the topics' term is replicated
+    np.testing.assert_allclose(r0["lda_elbo"][0], svi.lda_elbo(before4, gamma4, C4, 0.01, 1.0 / 32, 900.0), rtol=1e-6)
+    np.testing.assert_array_equal(r0["lda_elbo"], r1["lda_elbo"])

@@ -892,6 +892,31 @@ def test_derived_diagonal_mixture_equals_the_config3_svi_step():
     npt.assert_allclose(model.eta_fused_layout(), host.eta_fused_layout(), rtol=1e-9)
 
 
+def test_oracle_mog_elbo_equals_the_derived_engines_bound():
+    """oracle.svi.mog_elbo (config 3's bound with q(z) collapsed to its optimum, what the fused path
+    reports) against MeanFieldVMP.elbo() of the same model written as a symbolic log-joint, right after
+    the local update: equal to 1e-9 once the constants the symbolic log-joint drops are added back
+    (the -1/2 log 2 pi of every datum and column, and the priors' log-normalisers)."""
+    from bayesic_amd.inference.mixture import DiagonalMixtureVMP
+    from oracle import svi
+    n, d, k = 800, 3, 4
+    X = svi.make_cfg3(n, d, k)[0].astype(np.float64)
+    eta0 = svi.mog_prior_eta(k, d)
+    eta = svi.mog_init_eta(X[:300], k, d, seed=2)
+    for rho in (1.0, 0.6):
+        alpha, m, kappa, a, b = svi.mog_unpack(eta, k, d)
+        model = DiagonalMixtureVMP(X, k, n_total=float(n), init=(alpha, m, kappa, a, b), backend=B64,
+                                   dtype="float64", resident=False, resident_globals=False)
+        model.vmp.update("Z", 1.0)
+        Wmat, c = svi.mog_expected_params(eta, k, d, dtype=np.float64)
+        _, lse = svi.mog_local_step(X, Wmat, c)
+        alpha0, _, kappa0, a0, b0 = svi.mog_unpack(eta0, k, d)
+        dropped = -0.5 * n * d * svi.LOG_2PI - float(svi.dirichlet_log_normalizer(alpha0)) \
+            - float(svi.normal_gamma_log_normalizer(kappa0, a0, b0).sum())
+        npt.assert_allclose(svi.mog_elbo(eta, eta0, lse, 1.0, k, d), model.vmp.elbo() + dropped, rtol=1e-9)
+        eta = svi.natgrad_update(eta, eta0, svi.mog_message(svi.mog_local_step(X, Wmat, c)[0], k, d), 1.0, rho)
+
+
 def test_derived_mixture_with_resident_global_factors():
     """resident_globals=True: the Dirichlet and NormalGamma factors keep their natural parameters and
     expectations on the backend (digamma, log, reciprocals as element-wise backend ops), so an update
@@ -976,3 +1001,52 @@ def test_softmax_inside_the_logits_product_is_the_same_update(ctx):
     npt.assert_allclose(rf, rp, rtol=1e-3, atol=1e-5)
     npt.assert_allclose(fused.z.entropy(), plain.z.entropy(), rtol=1e-4)
     npt.assert_allclose(fused.vmp.elbo(), plain.vmp.elbo(), rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_successive_models_on_one_backend_do_not_share_cached_constants(ctx):
+    """the executor caches values of marked constants (X * X, the wide operand
+    [X | X^2 | 1], R^T [X | X^2 | 1]) keyed by ADDRESS.  A second same-shaped model built on the same backend
+    after the first was dropped used to receive the first model's block from the allocator -- and its cached
+    values.  The marks now hold the tensors (an address in use cannot be handed out again) and a model takes
+    its marks back when it is closed or collected.  Both orders: first model dropped, and both alive."""
+    import gc
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from bayesic_amd.inference.mixture import DiagonalMixtureVMP
+    from oracle import svi
+    be = DeviceBackend(ctx)
+    n, d, k = 20_000, 16, 8
+
+    def build(seed):
+        rs = np.random.RandomState(seed)
+        centres = rs.standard_normal((k, d)) * 4.0
+        X = (centres[rs.randint(k, size=n)] + rs.standard_normal((n, d))).astype(np.float32)
+        eta = svi.mog_init_eta(X[:500], k, d, seed=2)
+        alpha, m, kappa, a, b = svi.mog_unpack(eta, k, d)
+        return X, eta, DiagonalMixtureVMP(X, k, n_total=float(n), init=(alpha, m, kappa, a, b), backend=be)
+
+    def check(model, X, eta):
+        eta0 = svi.mog_prior_eta(k, d)
+        for t in range(1, 3):
+            rho = (t + 1.0) ** -0.6
+            model.step(rho)
+            eta, _, _ = svi.mog_svi_step(eta, eta0, X, float(n), rho, k, d)
+        got = model.eta_fused_layout()
+        scale = np.maximum(np.abs(eta), 1.0)
+        assert (np.abs(got - eta) <= 1e-3 * scale).all(), np.abs((got - eta) / scale).max()
+
+    X1, eta1, first = build(11)
+    check(first, X1, eta1)
+    cached = len(be._const_cache)
+    assert cached > 0
+    del first
+    gc.collect()
+    assert len(be._const_cache) == 0 and not be._const          # the dropped model took its marks and their values
+    X2, eta2, second = build(12)                                 # (same shapes: the allocator reuses the blocks)
+    check(second, X2, eta2)
+    X3, eta3, third = build(13)                                  # two live models on one backend
+    check(third, X3, eta3)
+    second.close()
+    assert be._const                                             # the third model's marks survive the second's close
+    third.close()
+    assert not be._const and not be._const_cache

@@ -212,3 +212,115 @@ def test_fused_lda_statistics_persistent_kernel_rounds_and_split_blocks(ctx, doc
     ctx.call("bsc_lda_sstats", C, ldc, docs, V, K, Th, ldth, Bt, ldb, out2, ldo)
     ctx.sync()
     npt.assert_array_equal(outs[0][:, :V], out2.cpu().numpy()[:, :V])      # run-to-run identical
+
+
+# ---- the evidence lower bound of config 4 (oracle.svi.lda_elbo) ---------------------------------
+
+def test_dirichlet_bound_matches_oracle(ctx):
+    """bsc_dirichlet_expectation_bound: the same expectations plus sum_r -KL(Dir(lam_r) || Dir(prior))."""
+    rs = np.random.RandomState(0)
+    for rows, cols, prior in [(1, 1, 0.5), (7, 33, 0.01), (128, 5000, 0.01), (300, 16, 1.0 / 16), (2, 3, 1.0)]:
+        lam = rs.gamma(1.0, 2.0, (rows, cols)).astype(np.float32) + 1e-3
+        d = ctx.to_device(lam)
+        out = ctx.zeros((rows, cols))
+        bound = ctx.zeros(1, torch.float64)
+        ctx.call("bsc_dirichlet_expectation_bound", d, rows, cols, cols, prior, out, bound)
+        ctx.sync()
+        npt.assert_allclose(out.cpu().numpy(), svi.dirichlet_expectation(lam), rtol=2e-6, atol=1e-37)
+        want = float(svi.dirichlet_neg_kl(lam, prior).sum())
+        npt.assert_allclose(bound.item(), want, rtol=1e-11, atol=1e-9)
+        again = ctx.zeros(1, torch.float64)
+        ctx.call("bsc_dirichlet_expectation_bound", d, rows, cols, cols, prior, out, again)
+        ctx.sync()
+        assert again.item() == bound.item()                                   # fixed order
+    # KL(p || p) = 0
+    flat = ctx.to_device(np.full((5, 40), 0.3, np.float32))
+    ctx.call("bsc_dirichlet_expectation_bound", flat, 5, 40, 40, float(np.float32(0.3)), ctx.zeros((5, 40)), bound)
+    ctx.sync()
+    assert abs(bound.item()) < 1e-9
+
+
+@pytest.mark.parametrize("docs,V,K", [(32, 128, 128), (1, 1, 32), (45, 130, 64), (700, 1000, 96), (5000, 3000, 128),
+                                      (700, 67840, 128), (4100, 1028, 64), (33, 132, 32), (0, 77, 128)])
+def test_words_term_of_the_bound_inside_the_statistic_kernels(ctx, docs, V, K):
+    """bsc_lda_sstats_bound / bsc_lda_sstats_csc_bound: sum_dv C log(phinorm) taken where phinorm lives, on every
+    kernel variant (persistent LDS-DMA kernel, one block per workgroup, K = 96, sparse), and the statistic
+    itself bit-identical to the entry point without the bound."""
+    import os
+    import scipy.sparse as sparse
+    from bayesic_amd.device import Context
+    os.environ["BSC_LDA_STREAM"] = "0"
+    try:
+        plain = Context(0)
+    finally:
+        del os.environ["BSC_LDA_STREAM"]
+    rs = np.random.RandomState(docs + V + K)
+    C = rs.poisson(0.3, (docs, V)).astype(np.float32)
+    Th = (rs.rand(docs, K) + 0.05).astype(np.float32)
+    Bt = (rs.rand(K, V) + 0.05).astype(np.float32)
+    dC, dTh, dBt = ctx.to_device(C), ctx.to_device(Th), ctx.to_device(Bt)
+    want = svi.lda_local_bound(C, Th, Bt) if docs else 0.0
+    scale = float((C.astype(np.float64) * np.abs(np.log(Th.astype(np.float64) @ Bt.astype(np.float64)))).sum()) if docs else 1.0
+    for c in (ctx, plain):
+        ref = torch.full((K, V), float("nan"), dtype=torch.float32, device=ctx.device)
+        c.call("bsc_lda_sstats", dC, V, docs, V, K, dTh, K, dBt, V, ref, V)
+        out = torch.full((K, V), float("nan"), dtype=torch.float32, device=ctx.device)
+        ll = torch.full((1,), float("nan"), dtype=torch.float64, device=ctx.device)
+        c.call("bsc_lda_sstats_bound", dC, V, docs, V, K, dTh, K, dBt, V, out, V, ll)
+        c.sync()
+        npt.assert_array_equal(out.cpu().numpy(), ref.cpu().numpy())
+        # v_log_f32 is good to ~1 ulp of log2, float32 products and per-lane float32 partial sums
+        assert abs(ll.item() - want) <= 3e-6 * scale + 1e-9, (ll.item(), want)
+    if docs:
+        csc = sparse.csc_matrix(C)
+        colptr = torch.as_tensor(csc.indptr.astype(np.int64)).to(ctx.device)
+        rowidx = torch.as_tensor(csc.indices.astype(np.int32)).to(ctx.device)
+        vals = torch.as_tensor(csc.data.astype(np.float32)).to(ctx.device)
+        ref = torch.empty((K, V), dtype=torch.float32, device=ctx.device)
+        ctx.call("bsc_lda_sstats_csc", colptr, rowidx, vals, docs, V, K, dTh, K, dBt, V, ref, V)
+        out = torch.empty_like(ref)
+        ll = torch.full((1,), float("nan"), dtype=torch.float64, device=ctx.device)
+        ctx.call("bsc_lda_sstats_csc_bound", colptr, rowidx, vals, docs, V, K, dTh, K, dBt, V, out, V, ll)
+        ctx.sync()
+        npt.assert_array_equal(out.cpu().numpy(), ref.cpu().numpy())
+        assert abs(ll.item() - want) <= 3e-6 * scale + 1e-9, (ll.item(), want)
+
+
+@pytest.mark.parametrize("via", ["kernel", "executor", "csc"])
+def test_lda_elbo_tracks_the_oracle_and_rises_under_unit_steps(ctx, via):
+    import scipy.sparse as sparse
+    from bayesic_amd.svi.lda import LDAFixedGammaSVI
+    rs = np.random.RandomState(3)
+    docs, V, K = 300, 900, 64
+    C = rs.poisson(0.3, (docs, V)).astype(np.float32)
+    gamma = (rs.gamma(2.0, 1.0, (docs, K)) + 0.1).astype(np.float32)
+    lam = (rs.gamma(1.0, 1.0, (K, V)) + 0.05).astype(np.float32)
+    Carg = sparse.csr_matrix(C) if via == "csc" else C
+    model = LDAFixedGammaSVI(Carg, gamma, lam, eta=0.02, docs_total=10 * docs, ctx=ctx, alpha=0.3,
+                             via=None if via == "csc" else via)
+    assert model.via == via
+    for t in range(1, 4):
+        before = model.lam.cpu().numpy()
+        model.step()
+        ctx.sync()
+        want = svi.lda_elbo(before, gamma, C, 0.02, 0.3, 10.0 * docs)
+        npt.assert_allclose(model.elbo.item(), want, rtol=3e-6)
+    full = LDAFixedGammaSVI(Carg, gamma, lam, eta=0.02, docs_total=docs, ctx=ctx, alpha=0.3,
+                            via=None if via == "csc" else via)
+    bounds = []
+    for _ in range(6):
+        full.step(rho=1.0)
+        ctx.sync()
+        bounds.append(full.elbo.item())
+    bounds = np.array(bounds)
+    assert np.all(np.diff(bounds) >= -2e-6 * np.abs(bounds[:-1])), bounds
+    assert bounds[-1] > bounds[0]
+    # elbo=False: the same lambda without the bound's work
+    quiet = LDAFixedGammaSVI(Carg, gamma, lam, eta=0.02, docs_total=docs, ctx=ctx, alpha=0.3,
+                             via=None if via == "csc" else via, elbo=False)
+    loud = LDAFixedGammaSVI(Carg, gamma, lam, eta=0.02, docs_total=docs, ctx=ctx, alpha=0.3,
+                            via=None if via == "csc" else via)
+    quiet.step()
+    loud.step()
+    ctx.sync()
+    npt.assert_allclose(quiet.lam.cpu().numpy(), loud.lam.cpu().numpy(), rtol=1e-5)

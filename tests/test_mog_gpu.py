@@ -113,6 +113,63 @@ def test_svi_steps_track_the_oracle_and_recover_clusters(ctx):
     assert (dist.min(axis=0) < 0.5).sum() >= K - 2       # (local optima may merge a pair)
 
 
+def test_global_bound_kernel_matches_oracle(ctx):
+    """bsc_mog_expected_params_bound: E_q[log p(theta)] - E_q[log q(theta)] of the Dirichlet and the K*D
+    Normal-Gamma factors, and the same logit coefficients as bsc_mog_expected_params."""
+    from bayesic_amd._ffi import ptr
+    f64 = torch.float64
+    for K, D, seed in ((37, 9, 2), (64, 16, 3), (1, 1, 4), (200, 40, 5)):
+        rs = np.random.RandomState(seed)
+        X = rs.standard_normal((max(500, 2 * K), D)).astype(np.float32) * 2
+        eta0 = svi.mog_prior_eta(K, D, alpha0=0.7, m0=0.3, kappa0=0.05, a0=1.5, b0=0.8)
+        eta = svi.mog_init_eta(X, K, D, seed=3) + rs.uniform(0, 5, K + 4 * K * D) * \
+            np.concatenate([np.ones(K), np.zeros(K * D), np.ones(2 * K * D), np.zeros(K * D)])
+        etad, eta0d = ctx.to_device(eta, f64), ctx.to_device(eta0, f64)
+        Wmat, c, bound = ctx.zeros((K, 2 * D)), ctx.zeros(K), ctx.zeros(1, f64)
+        ctx.call("bsc_mog_expected_params_bound", ptr(etad), ptr(eta0d), K, D, ptr(Wmat), ptr(c), ptr(bound))
+        W2, c2 = ctx.zeros((K, 2 * D)), ctx.zeros(K)
+        ctx.call("bsc_mog_expected_params", ptr(etad), K, D, ptr(W2), ptr(c2))
+        ctx.sync()
+        npt.assert_array_equal(Wmat.cpu().numpy(), W2.cpu().numpy())
+        npt.assert_array_equal(c.cpu().numpy(), c2.cpu().numpy())
+        want = svi.mog_global_bound(eta, eta0, K, D)
+        npt.assert_allclose(bound.item(), want, rtol=1e-11, atol=1e-9)
+        # at the prior itself the bound vanishes (KL(p || p) = 0)
+        ctx.call("bsc_mog_expected_params_bound", ptr(eta0d), ptr(eta0d), K, D, ptr(Wmat), ptr(c), ptr(bound))
+        ctx.sync()
+        assert abs(bound.item()) <= 1e-9 * K * D
+
+
+@pytest.mark.parametrize("via", ["kernel", "executor"])
+def test_elbo_tracks_the_oracle_and_rises_under_unit_steps(ctx, via):
+    """model.elbo after step() = oracle.svi.mog_elbo at the parameters the step started from; with the full
+    data set and rho = 1 (coordinate ascent, README.md:36) it can only rise."""
+    from bayesic_amd.svi.mog import MoGNatGradSVI
+    K, D = 8, 16
+    X, _, _ = svi.make_cfg3(40000, D, K)
+    eta0 = svi.mog_prior_eta(K, D)
+    eta = svi.mog_init_eta(X[:4000], K, D, seed=1)
+    model = MoGNatGradSVI(X, K, eta0, eta, n_total=3 * len(X), ctx=ctx, via=via)
+    for t in range(1, 4):                       # damped mini-batch steps, scale = 3
+        Wmat, c = svi.mog_expected_params(eta, K, D)
+        _, lse = svi.mog_local_step(X, Wmat, c)
+        want = svi.mog_elbo(eta, eta0, lse, 3.0, K, D)
+        model.step()
+        eta, _, _ = svi.mog_svi_step(eta, eta0, X, 3 * len(X), (t + 1.0) ** -0.6, K, D)
+        ctx.sync()
+        npt.assert_allclose(model.elbo.item(), want, rtol=2e-6)
+        model.eta.copy_(torch.as_tensor(eta, dtype=torch.float64))
+    full = MoGNatGradSVI(X, K, eta0, svi.mog_init_eta(X[:4000], K, D, seed=1), n_total=len(X), ctx=ctx, via=via)
+    bounds = []
+    for _ in range(8):
+        full.step(rho=1.0)
+        ctx.sync()
+        bounds.append(full.elbo.item())
+    bounds = np.array(bounds)
+    assert np.all(np.diff(bounds) >= -1e-6 * np.abs(bounds[:-1])), bounds
+    assert bounds[-1] > bounds[0]
+
+
 def test_unsupported_sizes_fail_loudly(ctx):
     from bayesic_amd._ffi import BayesicHipError, ptr
     X, W, c = ctx.zeros((8, 17)), ctx.zeros((4, 34)), ctx.zeros(4)

@@ -141,3 +141,164 @@ def test_product_side_mog_helpers_match_the_oracle():
     eta = mog.init_eta(X, K, D, seed=1)
     for a, b in zip(mog.unpack(eta, K, D), svi.mog_unpack(eta, K, D)):
         np.testing.assert_allclose(a, b)
+
+
+# ---- the bound of configs 3 and 4 (oracle.svi.mog_elbo / lda_elbo) --------------------------------
+
+def test_dirichlet_neg_kl_against_quadrature():
+    # K = 2: a Dirichlet is a Beta; integrate q (log p - log q) with scipy's densities
+    from scipy.integrate import quad
+    for (a, b), (a0, b0) in (((2.5, 1.7), (1.0, 1.0)), ((0.8, 3.0), (0.5, 0.5)), ((40.0, 7.0), (2.0, 3.0))):
+        q, p = st.beta(a, b), st.beta(a0, b0)
+        want, _ = quad(lambda x: q.pdf(x) * (p.logpdf(x) - q.logpdf(x)), 0.0, 1.0, epsabs=1e-12, epsrel=1e-12,
+                       limit=400)
+        got = svi.dirichlet_neg_kl(np.array([a, b]), np.array([a0, b0]))
+        np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-9)
+    # the entropy term alone against scipy's closed form: -KL(q || uniform) = H[q] + log density of the uniform, ln Gamma(K)
+    alpha = np.array([0.7, 2.0, 3.5, 1.1])
+    np.testing.assert_allclose(svi.dirichlet_neg_kl(alpha, np.ones(4)),
+                               st.dirichlet(alpha).entropy() + math.lgamma(4.0), rtol=1e-12)
+
+
+def test_normal_gamma_bound_against_quadrature():
+    m, kappa, a, b = 0.7, 2.5, 3.0, 1.5
+    m0, kappa0, a0, b0 = -0.2, 0.4, 1.5, 0.8
+
+    def logpdf(mu, tau, m_, k_, a_, b_):     # scipy's densities: N(mu | m, 1/(kappa tau)) Gamma(tau | a, rate b)
+        return st.norm.logpdf(mu, m_, 1.0 / np.sqrt(k_ * tau)) + st.gamma.logpdf(tau, a_, scale=1.0 / b_)
+
+    # E_q over mu | tau by Gauss-Hermite (the integrand is quadratic in mu: exact), over u = log tau by the
+    # trapezoid rule on a smooth, doubly decaying integrand (spectrally convergent)
+    x, w = np.polynomial.hermite.hermgauss(40)
+    u = np.linspace(-40.0, 6.0, 20001)
+    tau = np.exp(u)[:, None]
+    mu = m + np.sqrt(2.0) * x[None, :] / np.sqrt(kappa * tau)
+    inner = ((logpdf(mu, tau, m0, kappa0, a0, b0) - logpdf(mu, tau, m, kappa, a, b)) * w[None, :]).sum(axis=1) / math.sqrt(math.pi)
+    dens = np.exp(st.gamma.logpdf(tau[:, 0], a, scale=1.0 / b) + u)          # q(tau) d tau = q(tau) tau du
+    want = float(((dens * inner)[1:] + (dens * inner)[:-1]).sum() * 0.5 * (u[1] - u[0]))
+    eta = svi.normal_gamma_to_natural(m, kappa, a, b)
+    eta0 = svi.normal_gamma_to_natural(m0, kappa0, a0, b0)
+    ET = svi.normal_gamma_expected_statistics(m, kappa, a, b)
+    got = sum((eta0[j] - eta[j]) * ET[j] for j in range(4)) \
+        + svi.normal_gamma_log_normalizer(kappa, a, b) - svi.normal_gamma_log_normalizer(kappa0, a0, b0)
+    np.testing.assert_allclose(got, want, rtol=1e-7)
+    # the expected statistics are the gradient of the log-normaliser (exponential family identity)
+    def A_of(e):
+        mm, kk, aa, bb = svi.normal_gamma_from_natural(e)
+        return svi.normal_gamma_log_normalizer(kk, aa, bb)
+    for j in range(4):
+        h = 1e-6 * max(1.0, abs(eta[j]))
+        ep, em = eta.copy(), eta.copy()
+        ep[j] += h
+        em[j] -= h
+        np.testing.assert_allclose((A_of(ep) - A_of(em)) / (2 * h), ET[j], rtol=1e-6)
+
+
+def _small_mixture(n=600, d=3, k=4, seed=0):
+    rs = np.random.RandomState(seed)
+    centres = rs.standard_normal((k, d)) * 3.0
+    X = (centres[rs.randint(k, size=n)] + rs.standard_normal((n, d))).astype(np.float32)
+    eta0 = svi.mog_prior_eta(k, d)
+    return X, eta0, svi.mog_init_eta(X, k, d, seed=1)
+
+
+def _mog_bound_at(eta, eta0, X, scale, K, D, dtype=np.float64):
+    Wmat, c = svi.mog_expected_params(eta, K, D, dtype=dtype)
+    _, lse = svi.mog_local_step(X, Wmat, c)
+    return svi.mog_elbo(eta, eta0, lse, scale, K, D)
+
+
+def test_mog_elbo_rises_under_full_batch_unit_steps():
+    # rho = 1 on the full data set is coordinate ascent (README.md:36): q(z) at its optimum, then both
+    # global factors at theirs -- the bound can only go up
+    K, D = 4, 3
+    X, eta0, eta = _small_mixture()
+    bounds = []
+    for _ in range(12):
+        bounds.append(_mog_bound_at(eta, eta0, X, 1.0, K, D))
+        eta, _, _ = svi.mog_svi_step(eta, eta0, X, float(len(X)), 1.0, K, D)
+    bounds = np.array(bounds)
+    assert np.all(np.diff(bounds) >= -1e-6 * np.abs(bounds[:-1])), bounds   # (float32 logit coefficients inside the step)
+    assert bounds[-1] > bounds[0] + 10.0
+
+
+def test_mog_elbo_gradient_is_fisher_times_natural_gradient():
+    # conjugate-exponential identity (Hoffman et al. ref [4], eq. 14): d L / d eta = A''(eta) (eta* - eta) with
+    # eta* = eta0 + scale * message at the optimal q(z); by the envelope theorem q(z) may follow eta
+    K, D = 3, 2
+    X, eta0, eta = _small_mixture(n=200, d=D, k=K, seed=3)
+    scale = 2.5
+    f = lambda e: _mog_bound_at(e, eta0, X, scale, K, D)
+
+    def A_total(e):
+        alpha, m, kappa, a, b = svi.mog_unpack(e, K, D)
+        return float(svi.dirichlet_log_normalizer(alpha) + svi.normal_gamma_log_normalizer(kappa, a, b).sum())
+
+    Wmat, c = svi.mog_expected_params(eta, K, D, dtype=np.float64)
+    stats, _ = svi.mog_local_step(X, Wmat, c)
+    direction = eta0 + scale * svi.mog_message(stats, K, D) - eta
+    n = eta.size
+    h = 1e-4
+    grad = np.zeros(n)
+    for i in range(n):
+        ep, em = eta.copy(), eta.copy()
+        ep[i] += h
+        em[i] -= h
+        grad[i] = (f(ep) - f(em)) / (2 * h)
+    # Fisher . direction by differencing the log-normaliser's gradient along the direction
+    def gradA(e):
+        g = np.zeros(n)
+        for i in range(n):
+            ep, em = e.copy(), e.copy()
+            ep[i] += h
+            em[i] -= h
+            g[i] = (A_total(ep) - A_total(em)) / (2 * h)
+        return g
+    t = 1e-4 * float(np.min(np.abs(eta) / np.maximum(np.abs(direction), 1e-300)))   # stay inside the domain
+    fisher_dir = (gradA(eta + t * direction) - gradA(eta - t * direction)) / (2 * t)
+    np.testing.assert_allclose(grad, fisher_dir, rtol=2e-4, atol=2e-4 * np.abs(fisher_dir).max())
+
+
+def _small_lda(docs=40, V=60, K=5, seed=0):
+    rs = np.random.RandomState(seed)
+    C = rs.poisson(0.4, size=(docs, V)).astype(np.float32)
+    gamma = rs.gamma(2.0, 1.0, size=(docs, K)).astype(np.float32) + 0.1
+    lam = rs.gamma(1.0, 1.0, size=(K, V)) + 0.05
+    return C, gamma, lam
+
+
+def test_lda_elbo_equals_the_bound_with_explicit_assignments():
+    # Hoffman, Blei, Bach (2010) eq. 7 written out with phi_dvk, against the collapsed form
+    from scipy.special import digamma, gammaln
+    C, gamma, lam = _small_lda()
+    eta, alpha, docs_total = 0.02, 0.3, 400.0
+    docs, K = gamma.shape
+    V = lam.shape[1]
+    Th = svi.dirichlet_expectation(gamma).astype(np.float32).astype(np.float64)
+    Bt = svi.dirichlet_expectation(lam).astype(np.float32).astype(np.float64)
+    elt, elb = np.log(Th), np.log(Bt)              # E[log theta], E[log beta] as the pass sees them
+    phi = Th[:, None, :] * Bt.T[None, :, :]        # [docs, V, K]
+    phi /= phi.sum(axis=2, keepdims=True)
+    C64 = C.astype(np.float64)
+    words = (C64[:, :, None] * phi * (elt[:, None, :] + elb.T[None, :, :] - np.log(phi))).sum()
+    g64, l64 = gamma.astype(np.float64), lam
+    elt_exact = digamma(g64) - digamma(g64.sum(1, keepdims=True))
+    elb_exact = digamma(l64) - digamma(l64.sum(1, keepdims=True))
+    theta = ((alpha - g64) * elt_exact).sum() + gammaln(g64).sum() - gammaln(g64.sum(1)).sum() \
+        + docs * (gammaln(K * alpha) - K * gammaln(alpha))
+    beta = ((eta - l64) * elb_exact).sum() + gammaln(l64).sum() - gammaln(l64.sum(1)).sum() \
+        + K * (gammaln(V * eta) - V * gammaln(eta))
+    want = docs_total / docs * (words + theta) + beta
+    np.testing.assert_allclose(svi.lda_elbo(lam, gamma, C, eta, alpha, docs_total), want, rtol=1e-12)
+
+
+def test_lda_elbo_rises_under_full_batch_unit_steps():
+    C, gamma, lam = _small_lda(docs=60, V=80, K=6, seed=2)
+    eta, alpha = 0.05, 0.2
+    bounds = []
+    for _ in range(10):
+        bounds.append(svi.lda_elbo(lam, gamma, C, eta, alpha, float(len(C))))
+        lam, _ = svi.lda_svi_step(lam, gamma, C, eta, float(len(C)), 1.0)
+    bounds = np.array(bounds)
+    assert np.all(np.diff(bounds) >= -1e-6 * np.abs(bounds[:-1])), bounds
+    assert bounds[-1] > bounds[0]

@@ -41,7 +41,7 @@ def main():
         for dbg, what in ((16, "no strip waits (reads race the DMAs)"), (1, "no X refill loads"), (2, "no epilogue"), (3, "no X loads, no epilogue"),
                           (11, "no X loads, epilogue, side loads"), (7, "MFMA + side loads only"),
                           (15, "MFMA only")):
-            variants["r2b dbg=%d %s" % (dbg, what)] = make_ctx({"BSC_BBVI_KERNEL": "1", "BSC_BBVI_DBG": str(dbg)})
+            variants["r2b dbg=%d %s" % (dbg, what)] = make_ctx({"BSC_BBVI_KERNEL": "1", "BSC_BBVI_DBG": str(dbg), "BSC_PROFILING_BUILDS": "1"})
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(0)
     N, D, G = 1_000_000, 256, 1000

@@ -75,6 +75,7 @@ def main():
         for alt, keep in [(0, 0), (1, -1), (20, 0), (21, -1), (211, 7), (40, 0), (41, 33)]:
             os.environ["BSC_BLR_KEEP"] = str(keep)
             os.environ["BSC_BLR_MX"] = str((alt % 100) // 10)
+            os.environ["BSC_PROFILING_BUILDS"] = "1"      # (BSC_BLR_MX=4 is a deletion build: wrong results, timing only)
             os.environ["BSC_BLR_ROT"] = str(alt // 100)
             os.environ["BSC_BLR_TILE_ROWS"] = "16"
             ctxs[(alt, keep)] = Context(0)
