@@ -53,12 +53,26 @@ struct LdaArgs {
 // of these kernels, so the sum is taken there -- one v_log_f32 and one fma per element next to the v_rcp_f32
 // of the ratio, per-lane float32 partials, one float per wave at the end, added in float64 in a fixed order
 // (lda_ll_reduce_kernel).  Padded documents / columns carry zero counts and contribute 0 * log2(1e-30) = -0.
-__global__ __launch_bounds__(64) void lda_ll_reduce_kernel(const float* __restrict__ slab, int64_t n, double mult,
-                                                           double* __restrict__ out) {
+__global__ __launch_bounds__(256) void lda_ll_reduce_kernel(const float* __restrict__ slab, int64_t n, double mult,
+                                                            double* __restrict__ out) {
+    // 256 lanes x 8 independent loads in flight (a single wave walking the slab paid one memory round trip
+    // per element: 12 us for 2 048 floats); lane partials in index order, lanes by the fixed butterfly, waves in order
+    __shared__ double red[4];
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 64) acc += (double)slab[i];
+    for (int64_t i0 = 0; i0 < n; i0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = i0 + u * 256 + threadIdx.x;
+            v[u] = i < n ? slab[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
     acc = wave_allsum_f64(acc);
-    if (threadIdx.x == 0) out[0] = mult * acc;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = mult * ((red[0] + red[1]) + (red[2] + red[3]));
 }
 
 // global -> registers for one step: Th tile [32][K] and C tile [32][128]
@@ -921,7 +935,7 @@ int lda_sstats_impl(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int
         }
         BSC_LAUNCH_CHECK();
         if (ll) {
-            hipLaunchKernelGGL(lda_ll_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, (const float*)g.ll_slab,
+            hipLaunchKernelGGL(lda_ll_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)g.ll_slab,
                                (int64_t)4 * g.n_wg, LN2, ll);
             BSC_LAUNCH_CHECK();
         }
@@ -981,7 +995,7 @@ int lda_sstats_impl(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int
         BSC_LAUNCH_CHECK();
     }
     if (ll) {
-        hipLaunchKernelGGL(lda_ll_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, (const float*)a.ll_slab,
+        hipLaunchKernelGGL(lda_ll_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)a.ll_slab,
                            (int64_t)ll_floats, LN2, ll);
         BSC_LAUNCH_CHECK();
     }
@@ -1078,7 +1092,7 @@ int lda_sstats_csc_impl(bsc_ctx* ctx, const int64_t* colptr, const int32_t* rowi
     BSC_LAUNCH_CHECK();
     if (ll) {
         // every lane of a 16-lane group added the group's term: 1/16 of the wave sums
-        hipLaunchKernelGGL(lda_ll_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, (const float*)a.ll_slab,
+        hipLaunchKernelGGL(lda_ll_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)a.ll_slab,
                            (int64_t)4 * grid.x, LN2 / 16.0, ll);
         BSC_LAUNCH_CHECK();
     }

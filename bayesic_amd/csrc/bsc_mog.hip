@@ -322,6 +322,33 @@ __device__ __forceinline__ double digamma_f64(double x) { return bsc_digamma_f64
 // Dirichlet  T = log pi_k,  A = sum lnGamma(alpha_k) - lnGamma(sum alpha);
 // NormalGamma T = (tau mu, -tau mu^2/2, log(tau)/2, -tau/2), A = lnGamma(a) - a log b - log(kappa)/2 + log(2 pi)/2.
 // Fixed-order sums: 16-lane butterfly per component, components in index order by one thread.
+// (psi(x), lnGamma(x)) of up to six arguments through ONE copy of the series' code: this kernel runs once per
+// update behind a 0.7 ms pass, its instructions are in no cache, and straight-line float64 log / lgamma code is
+// fetched at ~0.5 us per 64-byte line ("the finish kernel starts instruction-cache cold") -- with
+// every call inlined at its own site the bound cost 15 us of fetch for 1 us of arithmetic.
+struct PsiLg {
+    double psi, lg;
+};
+__device__ __forceinline__ PsiLg psi_lgamma_f64(double x) {
+#pragma clang fp contract(off)
+    double P = 1.0, dP = 0.0;
+    while (x < 8.0) {
+        dP = dP * x + P;
+        P *= x;
+        x += 1.0;
+    }
+    const double rden = 1.0 / (P * x);
+    const double inv = P * rden, inv2 = inv * inv, logy = log(x), logP = log(P);
+    const double ps = inv2 * (1.0 / 12.0 - inv2 * (1.0 / 120.0 - inv2 * (1.0 / 252.0 - inv2 *
+                      (1.0 / 240.0 - inv2 * (5.0 / 660.0 - inv2 * (691.0 / 32760.0))))));
+    const double ls = inv * (1.0 / 12.0 - inv2 * (1.0 / 360.0 - inv2 * (1.0 / 1260.0 - inv2 *
+                      (1.0 / 1680.0 - inv2 * (1.0 / 1188.0 - inv2 * (691.0 / 360360.0))))));
+    PsiLg r;
+    r.psi = logy - 0.5 * inv - ps - dP * x * rden;
+    r.lg = (x - 0.5) * logy - x + 0.91893853320467274178032973640562 + ls - logP;
+    return r;
+}
+
 __global__ __launch_bounds__(1024) void mog_expected_params_kernel(const double* __restrict__ eta,
                                                                    const double* __restrict__ eta0,
                                                                    int K, int D,
@@ -332,11 +359,12 @@ __global__ __launch_bounds__(1024) void mog_expected_params_kernel(const double*
     __shared__ double comp_bound[1024];
     const int dl = threadIdx.x & 15;
     const double LOG_2PI = 1.8378770664093454835606594728112;
+    const bool with_bound = eta0 != nullptr;
     if (threadIdx.x < 64) {   // one wave: the Dirichlet's total, fixed order
         double a = 0.0, a0 = 0.0;
         for (int j = threadIdx.x; j < K; j += 64) {
             a += eta[j] + 1.0;
-            if (eta0) a0 += eta0[j] + 1.0;
+            if (with_bound) a0 += eta0[j] + 1.0;
         }
         const double tot = wave_allsum_f64(a);
         const double tot0 = wave_allsum_f64(a0);
@@ -347,34 +375,67 @@ __global__ __launch_bounds__(1024) void mog_expected_params_kernel(const double*
     }
     __syncthreads();
     const int64_t KD = (int64_t)K * D;
+    double tail = 0.0;        // thread 0: lnGamma(sum alpha0) - lnGamma(sum alpha)
     // 16 lanes per component, 64 components per sweep (the trip count is uniform over a wave's
     // four 16-lane groups only up to the tail, so the shuffles below stay inside a group)
     for (int k0 = 0; k0 < K; k0 += 64) {
         const int k = k0 + (threadIdx.x >> 4);
         double c = 0.0, gb = 0.0;
-        if (k < K) {
-            for (int d = dl; d < D; d += 16) {
-                const int64_t i = (int64_t)k * D + d;
-                const double e1 = eta[K + i], e3 = eta[K + 2 * KD + i], e4 = eta[K + 3 * KD + i];
-                const double kappa = eta[K + KD + i];
-                const double m = e1 / kappa;
-                const double a = 0.5 * (e3 + 1.0);
-                const double b = 0.5 * (e4 - kappa * m * m);
-                const double T = a / b;
-                const double elog_tau = digamma_f64(a) - log(b);
+        for (int d0 = 0; d0 < D; d0 += 16) {              // (uniform trip count: the series' loop below is shared)
+            const int d = d0 + dl;
+            const bool cell = k < K && d < D;             // this lane has a (component, column) cell in this trip
+            const bool head = k < K && dl == 0 && d0 == 0;    // ... and the component's Dirichlet entry
+            const int64_t i = cell ? (int64_t)k * D + d : 0;
+            const double e1 = eta[K + i], kappa = eta[K + KD + i], e3 = eta[K + 2 * KD + i], e4 = eta[K + 3 * KD + i];
+            const double m = e1 / kappa, a = 0.5 * (e3 + 1.0), b = 0.5 * (e4 - kappa * m * m), T = a / b;
+            double p1 = e1, kappa0 = kappa, p3 = e3, p4 = e4;
+            if (with_bound) {
+                p1 = eta0[K + i];
+                kappa0 = eta0[K + KD + i];
+                p3 = eta0[K + 2 * KD + i];
+                p4 = eta0[K + 3 * KD + i];
+            }
+            const double m0 = p1 / kappa0, a0 = 0.5 * (p3 + 1.0), b0 = 0.5 * (p4 - kappa0 * m0 * m0);
+            const double al = head ? eta[k] + 1.0 : 1.0, al0 = (head && with_bound) ? eta0[k] + 1.0 : 1.0;
+            // six (psi, lnGamma) pairs and four logs through one copy of each routine
+            PsiLg r_a = {0.0, 0.0}, r_a0 = r_a, r_al = r_a, r_al0 = r_a, r_s = r_a, r_s0 = r_a;
+#pragma unroll 1
+            for (int q = 0; q < 6; ++q) {
+                const double x = q == 0 ? a : q == 1 ? a0 : q == 2 ? al : q == 3 ? al0 : q == 4 ? alpha_sum
+                                                                                          : (with_bound ? alpha0_sum : 1.0);
+                const PsiLg r = psi_lgamma_f64(x);
+                if (q == 0) r_a = r;
+                else if (q == 1) r_a0 = r;
+                else if (q == 2) r_al = r;
+                else if (q == 3) r_al0 = r;
+                else if (q == 4) r_s = r;
+                else r_s0 = r;
+            }
+            double log_b = 0.0, log_b0 = 0.0, log_k = 0.0, log_k0 = 0.0;
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                const double l = log(q == 0 ? b : q == 1 ? b0 : q == 2 ? kappa : kappa0);
+                if (q == 0) log_b = l;
+                else if (q == 1) log_b0 = l;
+                else if (q == 2) log_k = l;
+                else log_k0 = l;
+            }
+            const double elog_tau = r_a.psi - log_b;
+            if (cell) {
                 c += 0.5 * elog_tau - 0.5 * LOG_2PI - 0.5 * T * m * m - 0.5 / kappa;
                 Wmat[(int64_t)k * 2 * D + d] = (float)(T * m);
                 Wmat[(int64_t)k * 2 * D + D + d] = (float)(-0.5 * T);
-                if (eta0) {
-                    const double p1 = eta0[K + i], kappa0 = eta0[K + KD + i], p3 = eta0[K + 2 * KD + i],
-                                 p4 = eta0[K + 3 * KD + i];
-                    const double m0 = p1 / kappa0, a0 = 0.5 * (p3 + 1.0), b0 = 0.5 * (p4 - kappa0 * m0 * m0);
+                if (with_bound)
                     gb += (p1 - e1) * (T * m) + (kappa0 - kappa) * (-0.5 * (1.0 / kappa + m * m * T)) +
                           (p3 - e3) * (0.5 * elog_tau) + (p4 - e4) * (-0.5 * T) +
-                          (lgamma(a) - a * log(b) - 0.5 * log(kappa)) -
-                          (lgamma(a0) - a0 * log(b0) - 0.5 * log(kappa0));
-                }
+                          (r_a.lg - a * log_b - 0.5 * log_k) - (r_a0.lg - a0 * log_b0 - 0.5 * log_k0);
             }
+            if (head) {
+                const double elog_pi = r_al.psi - r_s.psi;
+                c += elog_pi;
+                if (with_bound) gb += (eta0[k] - eta[k]) * elog_pi + r_al.lg - r_al0.lg;
+            }
+            if (threadIdx.x == 0 && k0 == 0 && d0 == 0) tail = r_s0.lg - r_s.lg;
         }
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) {
@@ -382,18 +443,17 @@ __global__ __launch_bounds__(1024) void mog_expected_params_kernel(const double*
             gb += __shfl_xor(gb, off);
         }
         if (k < K && dl == 0) {
-            const double elog_pi = digamma_f64(eta[k] + 1.0) - digamma_f64(alpha_sum);
-            cvec[k] = (float)(c + elog_pi);
-            if (eta0)
-                comp_bound[k] = gb + (eta0[k] - eta[k]) * elog_pi + lgamma(eta[k] + 1.0) - lgamma(eta0[k] + 1.0);
+            cvec[k] = (float)c;
+            comp_bound[k] = gb;
         }
     }
-    if (eta0 && bound) {
+    if (with_bound && bound) {
         __syncthreads();
-        if (threadIdx.x == 0) {
-            double tot = lgamma(alpha0_sum) - lgamma(alpha_sum);
-            for (int k = 0; k < K; ++k) tot += comp_bound[k];
-            bound[0] = tot;
+        if (threadIdx.x < 64) {       // components in index order per lane, lanes by the fixed butterfly
+            double tot = 0.0;
+            for (int k = threadIdx.x; k < K; k += 64) tot += comp_bound[k];
+            tot = wave_allsum_f64(tot);
+            if (threadIdx.x == 0) bound[0] = tot + tail;
         }
     }
 }

@@ -189,7 +189,27 @@ __global__ __launch_bounds__(1024) void row_sum_bound_kernel(const float* __rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* row = lam + (int64_t)blockIdx.x * ld;
     double acc = 0.0;
-    for (int64_t c = tid; c < cols; c += 1024) acc += (double)row[c];
+    if ((ld & 3) == 0 && (((uintptr_t)lam) & 15) == 0) {       // (the loop of row_sum_kernel: same order, same sums)
+        const int64_t n4 = cols >> 2;
+        const float4* row4 = reinterpret_cast<const float4*>(row);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int64_t c = tid;
+        for (; c + 3 * 1024 < n4; c += 4 * 1024) {
+            const float4 v0 = row4[c], v1 = row4[c + 1024], v2 = row4[c + 2048], v3 = row4[c + 3072];
+            a0 += ((double)v0.x + (double)v0.y) + ((double)v0.z + (double)v0.w);
+            a1 += ((double)v1.x + (double)v1.y) + ((double)v1.z + (double)v1.w);
+            a2 += ((double)v2.x + (double)v2.y) + ((double)v2.z + (double)v2.w);
+            a3 += ((double)v3.x + (double)v3.y) + ((double)v3.z + (double)v3.w);
+        }
+        for (; c < n4; c += 1024) {
+            const float4 v0 = row4[c];
+            a0 += ((double)v0.x + (double)v0.y) + ((double)v0.z + (double)v0.w);
+        }
+        acc = (a0 + a1) + (a2 + a3);
+        for (int64_t t = 4 * n4 + tid; t < cols; t += 1024) acc += (double)row[t];
+    } else {
+        for (int64_t c = tid; c < cols; c += 1024) acc += (double)row[c];
+    }
     acc = wave_allsum_f64(acc);
     if (lane == 0) red[wave] = acc;
     __syncthreads();
@@ -197,11 +217,19 @@ __global__ __launch_bounds__(1024) void row_sum_bound_kernel(const float* __rest
         double t = 0.0;
         for (int k = 0; k < 16; ++k) t += red[k];
         row_psi[blockIdx.x] = digamma_f64_stats(t);
-        row_const[blockIdx.x] = -bsc_lgamma_f64(t) + bsc_lgamma_f64((double)cols * prior) -
-                                (double)cols * bsc_lgamma_f64(prior);
+        // -lnGamma(sum_c lam) + lnGamma(cols prior) - cols lnGamma(prior): one Stirling body for the three
+        double args[3] = {t, (double)cols * prior, prior}, lg[3];
+#pragma unroll 1
+        for (int q = 0; q < 3; ++q) lg[q] = bsc_lgamma_f64(args[q]);
+        row_const[blockIdx.x] = -lg[0] + lg[1] - (double)cols * lg[2];
     }
 }
 
+// One log more than the expectation alone: psi and lnGamma of an element share the shift to y >= 8,
+//   psi(x)     = log y - 1/(2y) - series_psi(1/y^2) - P'/P
+//   lnGamma(x) = (y - 1/2) log y - y + log(2 pi)/2 + series_lg(1/y) - log P,      P = prod_{i<n} (x + i),
+// the two quotients come from ONE division, and the log P of successive elements are taken together:
+// a running product, renormalised (one log) only when it nears the float64 range.
 __global__ __launch_bounds__(256) void dirichlet_expect_bound_kernel(const float* __restrict__ lam,
                                                                      int64_t rows, int64_t cols, int64_t ld,
                                                                      double prior,
@@ -212,7 +240,7 @@ __global__ __launch_bounds__(256) void dirichlet_expect_bound_kernel(const float
     __shared__ double red[4];
     const int64_t n = rows * cols;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    double acc = 0.0;
+    double acc = 0.0, prodP = 1.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int64_t r = i / cols, c = i - r * cols;
         const double x0 = (double)lam[r * ld + c];
@@ -222,31 +250,54 @@ __global__ __launch_bounds__(256) void dirichlet_expect_bound_kernel(const float
             P *= x;
             x += 1.0;
         }
-        const double inv = 1.0 / x, inv2 = inv * inv, logy = log(x);
+        const double rden = 1.0 / (P * x);
+        const double inv = P * rden, inv2 = inv * inv;           // 1 / y
+        const double logy = log(x);
         const double psi_series = inv2 * (1.0 / 12.0 - inv2 * (1.0 / 120.0 - inv2 * (1.0 / 252.0 - inv2 *
                                   (1.0 / 240.0 - inv2 * (5.0 / 660.0 - inv2 * (691.0 / 32760.0))))));
-        const double elog = logy - 0.5 * inv - psi_series - dP / P - row_psi[r];     // E[log theta_rc]
+        const double elog = logy - 0.5 * inv - psi_series - dP * x * rden - row_psi[r];     // E[log theta_rc]
         out[i] = (float)exp(elog);
         const double lg_series = inv * (1.0 / 12.0 - inv2 * (1.0 / 360.0 - inv2 * (1.0 / 1260.0 - inv2 *
                                  (1.0 / 1680.0 - inv2 * (1.0 / 1188.0 - inv2 * (691.0 / 360360.0))))));
-        const double lg = (x - 0.5) * logy - x + 0.91893853320467274178032973640562 + lg_series - log(P);
-        acc += (prior - x0) * elog + lg;
+        acc += (prior - x0) * elog + ((x - 0.5) * logy - x + 0.91893853320467274178032973640562 + lg_series);
+        prodP *= P;
+        if (__builtin_expect(prodP > 1.0e250 || prodP < 1.0e-250, 0)) {
+            acc -= log(prodP);
+            prodP = 1.0;
+        }
     }
+    acc -= log(prodP);
     acc = wave_allsum_f64(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// out[0] = sum of a[0..n) then b[0..m), one wave, fixed order
-__global__ __launch_bounds__(64) void ordered_sum2_kernel(const double* __restrict__ a, int64_t n,
-                                                          const double* __restrict__ b, int64_t m,
-                                                          double scale, double* __restrict__ out) {
+// out[0] = scale * (sum of a[0..n) and b[0..m)), fixed order: lane partials in index order (eight independent
+// loads in flight per lane), lanes by the fixed butterfly, waves in order
+__global__ __launch_bounds__(256) void ordered_sum2_kernel(const double* __restrict__ a, int64_t n,
+                                                           const double* __restrict__ b, int64_t m,
+                                                           double scale, double* __restrict__ out) {
+    __shared__ double red[4];
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 64) acc += a[i];
-    for (int64_t i = threadIdx.x; i < m; i += 64) acc += b[i];
+    for (int pass = 0; pass < 2; ++pass) {
+        const double* src = pass ? b : a;
+        const int64_t len = pass ? m : n;
+        for (int64_t i0 = 0; i0 < len; i0 += 256 * 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = i0 + u * 256 + threadIdx.x;
+                v[u] = i < len ? src[i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+    }
     acc = wave_allsum_f64(acc);
-    if (threadIdx.x == 0) out[0] = scale * acc;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = scale * ((red[0] + red[1]) + (red[2] + red[3]));
 }
 
 // With `elbo`: elbo[0] = scale * (ll[0] + local_bound[0]) + global_bound[0] before the step (the bound at
@@ -485,7 +536,7 @@ int bsc_dirichlet_expectation_bound(bsc_ctx* ctx, const float* lam, int64_t rows
     hipLaunchKernelGGL(dirichlet_expect_bound_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, lam,
                        rows, cols, ld, prior, (const double*)row_psi, out, partial);
     BSC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ordered_sum2_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)partial, blocks,
+    hipLaunchKernelGGL(ordered_sum2_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)partial, blocks,
                        (const double*)row_const, rows, 1.0, bound);
     BSC_LAUNCH_CHECK();
     return BSC_OK;

@@ -631,8 +631,14 @@ class MeanFieldVMP(object):
     def close(self):
         """Give the data's constant marks (and the values the executor cached from them) back."""
         marked, self._marked = getattr(self, "_marked", []), []
-        if marked and hasattr(self.backend, "unmark_constant"):
+        if not hasattr(self.backend, "unmark_constant"):
+            return
+        if marked:
             self.backend.unmark_constant(*marked)
+        for node in getattr(self, "nodes", []):        # a resident node's responsibilities are marked while they stand
+            cache = getattr(node, "_cache", None)
+            if node.resident and cache is not None and hasattr(cache[0], "data_ptr"):
+                self.backend.unmark_constant(cache[0])
 
     def __del__(self):
         try:

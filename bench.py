@@ -219,10 +219,17 @@ class Cfg2(Workload):
         self.X, self.y, self.rows, self.D, self.S = X, y, rows, D, S
         # further resident mini-batches of the same shape (drawn on the device: their values are
         # not compared with anything); the loop visits batch t % n at step t
+        # (one allocation, so that the read-ceiling probe can stream through all of them: nb x 1.03 GB
+        # against a 256 MiB Infinity Cache -- a ceiling for FRESH data, like the rotation itself)
+        nb = max(1, args.batches)
+        self.X_all = torch.empty((nb * rows, D), dtype=torch.float32, device=dev)
+        self.X_all[:rows].copy_(X)
+        X = self.X = self.X_all[:rows]
         self.batches = [(X, y)]
-        for b in range(1, max(1, args.batches)):
+        for b in range(1, nb):
             gb = torch.Generator(device=dev).manual_seed(99_991 * b + 1234 + seed_off)
-            Xb = torch.randn((rows, D), generator=gb, device=dev, dtype=torch.float32)
+            Xb = self.X_all[b * rows:(b + 1) * rows]
+            Xb.normal_(generator=gb)
             wb = torch.from_numpy((np.random.RandomState(1).standard_normal(D) / 16.0).astype(np.float32)).to(dev)
             yb = Xb @ wb + 0.5 * torch.randn(rows, generator=gb, device=dev)
             self.batches.append((Xb, yb))
@@ -716,7 +723,7 @@ def run_rank(args):
                 wl.set_mode("same")
                 m["same"] = measure(wl, spin_up=False)
                 wl.set_mode("rotate")
-            m["read_ceiling"] = ctx.read_probe(wl.X) if (rank == 0 and args.config == "cfg2") else None
+            m["read_ceiling"] = ctx.read_probe(getattr(wl, "X_all", wl.X)) if (rank == 0 and args.config == "cfg2") else None
             m["extra"] = wl.result()
         runs[mode] = m
     head = runs[modes[0]]

@@ -1041,7 +1041,7 @@ def test_successive_models_on_one_backend_do_not_share_cached_constants(ctx):
     assert cached > 0
     del first
     gc.collect()
-    assert len(be._const_cache) == 0 and not be._const          # the dropped model took its marks and their values
+    assert len(be._const_cache) == 0 and not be._const and not be._const_ptrs   # the dropped model took its marks and their values
     X2, eta2, second = build(12)                                 # (same shapes: the allocator reuses the blocks)
     check(second, X2, eta2)
     X3, eta3, third = build(13)                                  # two live models on one backend
@@ -1049,4 +1049,4 @@ def test_successive_models_on_one_backend_do_not_share_cached_constants(ctx):
     second.close()
     assert be._const                                             # the third model's marks survive the second's close
     third.close()
-    assert not be._const and not be._const_cache
+    assert not be._const and not be._const_cache and not be._const_ptrs
