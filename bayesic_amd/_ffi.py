@@ -68,6 +68,11 @@ SIGNATURES = {
                                      c_double, c_double, c_double, c_int64, c_double, c_double,
                                      c_double, c_double, c_uint64, c_uint32, c_void_p, c_int32,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bsc_blr_fused_update_general": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,
+                                             c_double, c_double, c_double, c_double, c_int64, c_double, c_double,
+                                             c_double, c_double, c_uint64, c_uint32, c_void_p, c_int32,
+                                             c_void_p, c_void_p, c_void_p, c_void_p]),
     "bsc_blr_noise": (c_int, [c_void_p, c_int32, c_int32, c_uint64, c_uint32, c_int32, c_void_p]),
     "bsc_blr_elbo_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_int32, c_int32, c_double, c_double, c_double,
@@ -88,8 +93,9 @@ SIGNATURES = {
     "bsc_mog_expected_params": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "bsc_mog_natgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,
                                 c_double]),
-    "bsc_mog_expected_params_bound": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
-                                              c_void_p]),
+    "bsc_mog_expected_params_bound": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p,
+                                              c_void_p, c_void_p]),
+    "bsc_mog_log_normalizer": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "bsc_mog_natgrad_elbo": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,
                                      c_double, c_void_p, c_void_p, c_void_p]),
     "bsc_bbvi_sample": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_uint64, c_uint32,

@@ -306,6 +306,15 @@ class DeviceBackend(Backend):
 
     # -- host <-> device ---------------------------------------------------------
     def from_host(self, array, dtype, ndim):
+        if isinstance(array, torch.Tensor) and array.is_cuda:
+            # already resident (a mini-batch the caller keeps in HBM): taken as it is, no copy
+            if array.dim() != ndim:
+                raise ValueError("input has ndim %d, expected %d" % (array.dim(), ndim))
+            want = {"float32": torch.float32, "float64": torch.float64}.get(str(np.dtype(dtype)))
+            if want is None or array.dtype != want:
+                raise TypeError("a device tensor passed as input must already have dtype %s (got %s)"
+                                % (dtype, array.dtype))
+            return array
         a = np.asarray(array)
         if a.ndim != ndim:
             raise ValueError("input has ndim %d, expected %d" % (a.ndim, ndim))

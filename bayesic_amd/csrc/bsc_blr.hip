@@ -962,9 +962,10 @@ struct FusedArgs {
     double* elbo;
     double* grad;
     int D, S;
-    double batch_rows, scale, alpha0, beta0;
+    // the log-joint per draw as a member of the family (bsc_blr_fused_update_general):
+    //   f(w, xi; Q) = c0 + c_xi xi + e^{-xi} (-s_q Q / 2 - k_w |w|^2 / 2 - beta)
+    double c0, c_xi, s_q, k_w, beta;
     double lr, beta1, beta2, adam_eps, corr1, corr2;
-    double log_prior_const;  // alpha0 * log(beta0) - lgamma(alpha0), computed on the host
     uint64_t seed;
     uint32_t next_step;
 };
@@ -1039,7 +1040,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
 #pragma unroll
             for (int k = 1; k < FUSED_WAVES; ++k) g += red[k][lane];
             if (live) {
-                const double dw = e_mxs * (a.scale * g - wv);
+                const double dw = e_mxs * (a.s_q * g - a.k_w * wv);
                 gm = dw;
                 gr = dw * ev;
             }
@@ -1050,7 +1051,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
                 if (d < D) {
                     const double g = a.stats[S + (int64_t)s * D + d];
                     const double wv = (double)a.W[(int64_t)s * D + d];
-                    const double dw = exp(-a.xi[s]) * (a.scale * g - wv);
+                    const double dw = exp(-a.xi[s]) * (a.s_q * g - a.k_w * wv);
                     gm += dw;
                     gr += dw * a.eps[(int64_t)s * (D + 1) + d];
                 }
@@ -1176,14 +1177,11 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
     if (tid < S) {
         const int s = tid;
         const double x = x_s, e = exp(-x);
-        const double dxi = -0.5 * (a.scale * a.batch_rows + (double)D) - a.alpha0 +
-                           e * (0.5 * a.scale * Qs[s] + 0.5 * wsq[s] + a.beta0);
-        const double loglik = a.scale * (-0.5 * a.batch_rows * (LOG_2PI + x) - 0.5 * e * Qs[s]);
-        const double logpw = -0.5 * (double)D * (LOG_2PI + x) - 0.5 * e * wsq[s];
-        const double logpxi = a.log_prior_const - a.alpha0 * x - a.beta0 * e;
+        const double inner = 0.5 * a.s_q * Qs[s] + 0.5 * a.k_w * wsq[s] + a.beta;
+        const double dxi = a.c_xi + e * inner;
         t_dxi[s] = dxi;
         t_dxe[s] = dxi * e_sD;
-        t_f[s] = loglik + logpw + logpxi;
+        t_f[s] = a.c0 + a.c_xi * x - e * inner;
     }
     __syncthreads();
     if (tid == 0) {
@@ -1473,33 +1471,30 @@ int bsc_blr_elbo_grad(bsc_ctx* ctx, const double* lam, const double* eps, const 
     return BSC_OK;
 }
 
-int bsc_blr_fused_update(bsc_ctx* ctx, const double* stats, const double* lam_in, double* lam_out,
-                         double* m1, double* m2, const double* eps, const float* W,
-                         const double* xi, int32_t D, int32_t S, double batch_rows, double scale,
-                         double alpha0, double beta0, int64_t t, double lr, double beta1,
-                         double beta2, double adam_eps, uint64_t seed, uint32_t next_step,
-                         double* eps_next, int32_t eps_next_ready, float* W_next, double* xi_next,
-                         double* elbo, double* grad) {
+namespace {
+int fused_update_impl(bsc_ctx* ctx, const char* who, const double* stats, const double* lam_in, double* lam_out,
+                      double* m1, double* m2, const double* eps, const float* W, const double* xi, int32_t D,
+                      int32_t S, double c0, double c_xi, double s_q, double k_w, double beta, int64_t t, double lr,
+                      double beta1, double beta2, double adam_eps, uint64_t seed, uint32_t next_step,
+                      double* eps_next, int32_t eps_next_ready, float* W_next, double* xi_next, double* elbo,
+                      double* grad) {
     BSC_CHECK_CTX(ctx);
-    BSC_REQUIRE(lam_in && lam_out && m1 && m2 && eps && W && xi && elbo && grad,
-                "bsc_blr_fused_update: null pointer");
-    BSC_REQUIRE(lam_in != lam_out, "bsc_blr_fused_update: lam_in and lam_out must differ");
-    BSC_REQUIRE(D > 0 && S >= 1 && S <= FIN_MAX_S, "bsc_blr_fused_update: D=%d S=%d (S<=%d)", D,
-                S, FIN_MAX_S);
-    BSC_REQUIRE(alpha0 > 0 && beta0 > 0 && t >= 1, "bsc_blr_fused_update: bad hyper-parameters");
+    BSC_REQUIRE(lam_in && lam_out && m1 && m2 && eps && W && xi && elbo && grad, "%s: null pointer", who);
+    BSC_REQUIRE(lam_in != lam_out, "%s: lam_in and lam_out must differ", who);
+    BSC_REQUIRE(D > 0 && S >= 1 && S <= FIN_MAX_S, "%s: D=%d S=%d (S<=%d)", who, D, S, FIN_MAX_S);
+    BSC_REQUIRE(t >= 1, "%s: the Adam step count starts at 1", who);
     BSC_REQUIRE((eps_next && W_next && xi_next) || (!eps_next && !W_next && !xi_next),
-                "bsc_blr_fused_update: next-draw buffers must be all set or all null");
+                "%s: next-draw buffers must be all set or all null", who);
     BSC_REQUIRE(!eps_next || (eps_next != eps && W_next != W && xi_next != xi),
-                "bsc_blr_fused_update: next-draw buffers must not alias the current draws");
+                "%s: next-draw buffers must not alias the current draws", who);
     FusedArgs a;
     a.stats = stats;
     a.slab = nullptr;
     a.n_slab = 0;
     if (!stats) {
         BSC_REQUIRE(ctx->slab_rows > 0 && ctx->workspace,
-                    "bsc_blr_fused_update: stats is null and no bsc_blr_data_pass_partial slab "
-                    "is pending");
-        BSC_REQUIRE(S <= SG && D <= GCOLS, "bsc_blr_fused_update: slab input needs S<=8, D<=256");
+                    "%s: stats is null and no bsc_blr_data_pass_partial slab is pending", who);
+        BSC_REQUIRE(S <= SG && D <= GCOLS, "%s: slab input needs S<=8, D<=256", who);
         a.slab = (const float*)ctx->workspace;
         a.n_slab = ctx->slab_rows;
     }
@@ -1509,11 +1504,10 @@ int bsc_blr_fused_update(bsc_ctx* ctx, const double* stats, const double* lam_in
     a.eps_next_ready = eps_next_ready != 0;
     a.elbo = elbo; a.grad = grad;
     a.D = D; a.S = S;
-    a.batch_rows = batch_rows; a.scale = scale; a.alpha0 = alpha0; a.beta0 = beta0;
+    a.c0 = c0; a.c_xi = c_xi; a.s_q = s_q; a.k_w = k_w; a.beta = beta;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.adam_eps = adam_eps;
     a.corr1 = 1.0 - pow(beta1, (double)t);
     a.corr2 = 1.0 - pow(beta2, (double)t);
-    a.log_prior_const = alpha0 * log(beta0) - lgamma(alpha0);
     a.seed = seed;
     a.next_step = next_step;
     {
@@ -1528,6 +1522,36 @@ int bsc_blr_fused_update(bsc_ctx* ctx, const double* stats, const double* lam_in
     }
     BSC_LAUNCH_CHECK();
     return BSC_OK;
+}
+}  // namespace
+
+int bsc_blr_fused_update(bsc_ctx* ctx, const double* stats, const double* lam_in, double* lam_out,
+                         double* m1, double* m2, const double* eps, const float* W,
+                         const double* xi, int32_t D, int32_t S, double batch_rows, double scale,
+                         double alpha0, double beta0, int64_t t, double lr, double beta1,
+                         double beta2, double adam_eps, uint64_t seed, uint32_t next_step,
+                         double* eps_next, int32_t eps_next_ready, float* W_next, double* xi_next,
+                         double* elbo, double* grad) {
+    BSC_REQUIRE(alpha0 > 0 && beta0 > 0, "bsc_blr_fused_update: bad hyper-parameters");
+    // config 2 (oracle.svi.blr_log_joint) as a member of the family:
+    //   scale [-B/2 (log 2 pi + xi) - e Q / 2] - D/2 (log 2 pi + xi) - e |w|^2 / 2 + alpha0 log beta0 - lnGamma(alpha0) - alpha0 xi - beta0 e
+    const double half = 0.5 * (scale * batch_rows + (double)D);
+    return fused_update_impl(ctx, "bsc_blr_fused_update", stats, lam_in, lam_out, m1, m2, eps, W, xi, D, S,
+                             -half * LOG_2PI + alpha0 * log(beta0) - lgamma(alpha0), -half - alpha0, scale, 1.0, beta0,
+                             t, lr, beta1, beta2, adam_eps, seed, next_step, eps_next, eps_next_ready, W_next,
+                             xi_next, elbo, grad);
+}
+
+int bsc_blr_fused_update_general(bsc_ctx* ctx, const double* stats, const double* lam_in, double* lam_out,
+                                 double* m1, double* m2, const double* eps, const float* W, const double* xi,
+                                 int32_t D, int32_t S, double c0, double c_xi, double s_q, double k_w, double beta,
+                                 int64_t t, double lr, double beta1, double beta2, double adam_eps, uint64_t seed,
+                                 uint32_t next_step, double* eps_next, int32_t eps_next_ready, float* W_next,
+                                 double* xi_next, double* elbo, double* grad) {
+    BSC_REQUIRE(s_q >= 0.0 && k_w >= 0.0, "bsc_blr_fused_update_general: s_q=%g k_w=%g must not be negative", s_q, k_w);
+    return fused_update_impl(ctx, "bsc_blr_fused_update_general", stats, lam_in, lam_out, m1, m2, eps, W, xi, D, S,
+                             c0, c_xi, s_q, k_w, beta, t, lr, beta1, beta2, adam_eps, seed, next_step, eps_next,
+                             eps_next_ready, W_next, xi_next, elbo, grad);
 }
 
 }  // extern "C"

@@ -349,38 +349,37 @@ __device__ __forceinline__ PsiLg psi_lgamma_f64(double x) {
     return r;
 }
 
+// `prior_A` = A(eta0), the prior's log-normaliser: a constant of the model, taken ONCE (this kernel with
+// eta = eta0 and `A_out`), not per update.  Per update a lane then evaluates (psi, lnGamma) twice -- its
+// cell's a, and alpha_k (the component's first lane) or sum alpha (every other lane; the first lane takes
+// psi(sum alpha) from its neighbour) -- and two logs.
 __global__ __launch_bounds__(1024) void mog_expected_params_kernel(const double* __restrict__ eta,
                                                                    const double* __restrict__ eta0,
+                                                                   const double* __restrict__ prior_A,
                                                                    int K, int D,
                                                                    float* __restrict__ Wmat,
                                                                    float* __restrict__ cvec,
-                                                                   double* __restrict__ bound) {
-    __shared__ double alpha_sum, alpha0_sum;
-    __shared__ double comp_bound[1024];
+                                                                   double* __restrict__ bound,
+                                                                   double* __restrict__ A_out) {
+    __shared__ double alpha_sum;
+    __shared__ double comp_bound[1024], comp_A[1024];
     const int dl = threadIdx.x & 15;
     const double LOG_2PI = 1.8378770664093454835606594728112;
     const bool with_bound = eta0 != nullptr;
     if (threadIdx.x < 64) {   // one wave: the Dirichlet's total, fixed order
-        double a = 0.0, a0 = 0.0;
-        for (int j = threadIdx.x; j < K; j += 64) {
-            a += eta[j] + 1.0;
-            if (with_bound) a0 += eta0[j] + 1.0;
-        }
+        double a = 0.0;
+        for (int j = threadIdx.x; j < K; j += 64) a += eta[j] + 1.0;
         const double tot = wave_allsum_f64(a);
-        const double tot0 = wave_allsum_f64(a0);
-        if (threadIdx.x == 0) {
-            alpha_sum = tot;
-            alpha0_sum = tot0;
-        }
+        if (threadIdx.x == 0) alpha_sum = tot;
     }
     __syncthreads();
     const int64_t KD = (int64_t)K * D;
-    double tail = 0.0;        // thread 0: lnGamma(sum alpha0) - lnGamma(sum alpha)
+    double lg_sum = 0.0;      // lnGamma(sum alpha), as seen by the second lane of every group
     // 16 lanes per component, 64 components per sweep (the trip count is uniform over a wave's
     // four 16-lane groups only up to the tail, so the shuffles below stay inside a group)
     for (int k0 = 0; k0 < K; k0 += 64) {
         const int k = k0 + (threadIdx.x >> 4);
-        double c = 0.0, gb = 0.0;
+        double c = 0.0, gb = 0.0, ga = 0.0;
         for (int d0 = 0; d0 < D; d0 += 16) {              // (uniform trip count: the series' loop below is shared)
             const int d = d0 + dl;
             const bool cell = k < K && d < D;             // this lane has a (component, column) cell in this trip
@@ -388,72 +387,72 @@ __global__ __launch_bounds__(1024) void mog_expected_params_kernel(const double*
             const int64_t i = cell ? (int64_t)k * D + d : 0;
             const double e1 = eta[K + i], kappa = eta[K + KD + i], e3 = eta[K + 2 * KD + i], e4 = eta[K + 3 * KD + i];
             const double m = e1 / kappa, a = 0.5 * (e3 + 1.0), b = 0.5 * (e4 - kappa * m * m), T = a / b;
-            double p1 = e1, kappa0 = kappa, p3 = e3, p4 = e4;
-            if (with_bound) {
-                p1 = eta0[K + i];
-                kappa0 = eta0[K + KD + i];
-                p3 = eta0[K + 2 * KD + i];
-                p4 = eta0[K + 3 * KD + i];
-            }
-            const double m0 = p1 / kappa0, a0 = 0.5 * (p3 + 1.0), b0 = 0.5 * (p4 - kappa0 * m0 * m0);
-            const double al = head ? eta[k] + 1.0 : 1.0, al0 = (head && with_bound) ? eta0[k] + 1.0 : 1.0;
-            // six (psi, lnGamma) pairs and four logs through one copy of each routine
-            PsiLg r_a = {0.0, 0.0}, r_a0 = r_a, r_al = r_a, r_al0 = r_a, r_s = r_a, r_s0 = r_a;
+            const double al = head ? eta[k] + 1.0 : alpha_sum;
+            PsiLg r_a = {0.0, 0.0}, r_al = r_a;
 #pragma unroll 1
-            for (int q = 0; q < 6; ++q) {
-                const double x = q == 0 ? a : q == 1 ? a0 : q == 2 ? al : q == 3 ? al0 : q == 4 ? alpha_sum
-                                                                                          : (with_bound ? alpha0_sum : 1.0);
-                const PsiLg r = psi_lgamma_f64(x);
+            for (int q = 0; q < 2; ++q) {
+                const PsiLg r = psi_lgamma_f64(q == 0 ? a : al);
                 if (q == 0) r_a = r;
-                else if (q == 1) r_a0 = r;
-                else if (q == 2) r_al = r;
-                else if (q == 3) r_al0 = r;
-                else if (q == 4) r_s = r;
-                else r_s0 = r;
+                else r_al = r;
             }
-            double log_b = 0.0, log_b0 = 0.0, log_k = 0.0, log_k0 = 0.0;
+            double log_b = 0.0, log_k = 0.0;
 #pragma unroll 1
-            for (int q = 0; q < 4; ++q) {
-                const double l = log(q == 0 ? b : q == 1 ? b0 : q == 2 ? kappa : kappa0);
+            for (int q = 0; q < 2; ++q) {
+                const double l = log(q == 0 ? b : kappa);
                 if (q == 0) log_b = l;
-                else if (q == 1) log_b0 = l;
-                else if (q == 2) log_k = l;
-                else log_k0 = l;
+                else log_k = l;
             }
+            // psi(sum alpha) for the group's first lane: from its neighbour (lane 1 of the 16-lane group)
+            const double psi_sum = __shfl(r_al.psi, (threadIdx.x & 63 & ~15) | 1);
+            if (dl == 1 && d0 == 0) lg_sum = r_al.lg;
             const double elog_tau = r_a.psi - log_b;
             if (cell) {
                 c += 0.5 * elog_tau - 0.5 * LOG_2PI - 0.5 * T * m * m - 0.5 / kappa;
                 Wmat[(int64_t)k * 2 * D + d] = (float)(T * m);
                 Wmat[(int64_t)k * 2 * D + D + d] = (float)(-0.5 * T);
-                if (with_bound)
+                ga += r_a.lg - a * log_b - 0.5 * log_k;
+                if (with_bound) {
+                    const double p1 = eta0[K + i], kappa0 = eta0[K + KD + i], p3 = eta0[K + 2 * KD + i],
+                                 p4 = eta0[K + 3 * KD + i];
                     gb += (p1 - e1) * (T * m) + (kappa0 - kappa) * (-0.5 * (1.0 / kappa + m * m * T)) +
-                          (p3 - e3) * (0.5 * elog_tau) + (p4 - e4) * (-0.5 * T) +
-                          (r_a.lg - a * log_b - 0.5 * log_k) - (r_a0.lg - a0 * log_b0 - 0.5 * log_k0);
+                          (p3 - e3) * (0.5 * elog_tau) + (p4 - e4) * (-0.5 * T);
+                }
             }
             if (head) {
-                const double elog_pi = r_al.psi - r_s.psi;
+                const double elog_pi = r_al.psi - psi_sum;
                 c += elog_pi;
-                if (with_bound) gb += (eta0[k] - eta[k]) * elog_pi + r_al.lg - r_al0.lg;
+                ga += r_al.lg;
+                if (with_bound) gb += (eta0[k] - eta[k]) * elog_pi;
             }
-            if (threadIdx.x == 0 && k0 == 0 && d0 == 0) tail = r_s0.lg - r_s.lg;
         }
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) {
             c += __shfl_xor(c, off);
             gb += __shfl_xor(gb, off);
+            ga += __shfl_xor(ga, off);
         }
         if (k < K && dl == 0) {
             cvec[k] = (float)c;
             comp_bound[k] = gb;
+            comp_A[k] = ga;
         }
     }
-    if (with_bound && bound) {
+    if (bound || A_out) {
         __syncthreads();
         if (threadIdx.x < 64) {       // components in index order per lane, lanes by the fixed butterfly
-            double tot = 0.0;
-            for (int k = threadIdx.x; k < K; k += 64) tot += comp_bound[k];
-            tot = wave_allsum_f64(tot);
-            if (threadIdx.x == 0) bound[0] = tot + tail;
+            double cross = 0.0, A = 0.0;
+            for (int k = threadIdx.x; k < K; k += 64) {
+                cross += comp_bound[k];
+                A += comp_A[k];
+            }
+            cross = wave_allsum_f64(cross);
+            A = wave_allsum_f64(A);
+            const double lgs = __shfl(lg_sum, 1);     // thread 1 holds lnGamma(sum alpha)
+            if (threadIdx.x == 0) {
+                A -= lgs;
+                if (A_out) A_out[0] = A;
+                if (bound) bound[0] = cross + A - (prior_A ? prior_A[0] : 0.0);
+            }
         }
     }
 }
@@ -493,20 +492,36 @@ int bsc_mog_expected_params(bsc_ctx* ctx, const double* eta, int32_t K, int32_t 
     BSC_REQUIRE(eta && Wmat && c, "bsc_mog_expected_params: null pointer");
     BSC_REQUIRE(K >= 1 && D >= 1, "bsc_mog_expected_params: K=%d D=%d", K, D);
     hipLaunchKernelGGL(mog_expected_params_kernel, dim3(1), dim3(1024), 0, ctx->stream, eta,
-                       (const double*)nullptr, (int)K, (int)D, Wmat, c, (double*)nullptr);
+                       (const double*)nullptr, (const double*)nullptr, (int)K, (int)D, Wmat, c, (double*)nullptr,
+                       (double*)nullptr);
     BSC_LAUNCH_CHECK();
     return BSC_OK;
 }
 
-int bsc_mog_expected_params_bound(bsc_ctx* ctx, const double* eta, const double* eta0, int32_t K, int32_t D,
-                                  float* Wmat, float* c, double* bound) {
+int bsc_mog_log_normalizer(bsc_ctx* ctx, const double* eta, int32_t K, int32_t D, double* A_out) {
     BSC_CHECK_CTX(ctx);
-    BSC_REQUIRE(eta && eta0 && Wmat && c && bound, "bsc_mog_expected_params_bound: null pointer");
+    BSC_REQUIRE(eta && A_out && K >= 1 && D >= 1, "bsc_mog_log_normalizer: bad arguments");
+    if (K > 1024) return bsc_fail(BSC_ERR_UNSUPPORTED, "bsc_mog_log_normalizer: K=%d > 1024 components", K);
+    void* ws = nullptr;      // the coefficients this launch also forms are not wanted: they go to the workspace
+    int rc = bsc_workspace(ctx, ((size_t)K * 2 * D + K) * sizeof(float), &ws);
+    if (rc != BSC_OK) return rc;
+    ctx->slab_rows = 0;
+    hipLaunchKernelGGL(mog_expected_params_kernel, dim3(1), dim3(1024), 0, ctx->stream, eta,
+                       (const double*)nullptr, (const double*)nullptr, (int)K, (int)D, (float*)ws,
+                       (float*)ws + (size_t)K * 2 * D, (double*)nullptr, A_out);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_mog_expected_params_bound(bsc_ctx* ctx, const double* eta, const double* eta0, const double* prior_A,
+                                  int32_t K, int32_t D, float* Wmat, float* c, double* bound) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(eta && eta0 && prior_A && Wmat && c && bound, "bsc_mog_expected_params_bound: null pointer");
     BSC_REQUIRE(K >= 1 && D >= 1, "bsc_mog_expected_params_bound: K=%d D=%d", K, D);
     if (K > 1024)
         return bsc_fail(BSC_ERR_UNSUPPORTED, "bsc_mog_expected_params_bound: K=%d > 1024 components", K);
-    hipLaunchKernelGGL(mog_expected_params_kernel, dim3(1), dim3(1024), 0, ctx->stream, eta, eta0, (int)K,
-                       (int)D, Wmat, c, bound);
+    hipLaunchKernelGGL(mog_expected_params_kernel, dim3(1), dim3(1024), 0, ctx->stream, eta, eta0, prior_A, (int)K,
+                       (int)D, Wmat, c, bound, (double*)nullptr);
     BSC_LAUNCH_CHECK();
     return BSC_OK;
 }

@@ -39,11 +39,24 @@ def depends_on(expr, variable):
 
 
 def _carried_axes(factor):
-    """Axes of a factor that are real; an Einsum whose out index occurs on none of
-    its factors has a BROADCAST axis there (bayesic/algebra.py:340-344)."""
+    """Axes of a factor that are real.  An Einsum whose out index occurs on none of its factors --
+    or only on broadcast axes of them -- has a BROADCAST axis there (bayesic/algebra.py:340-344); an
+    element-wise node (opaque to the einsum form: log, exp, pow, add) is broadcast along an axis
+    exactly when all its arguments are: ``log(dimshuffle(v, 0, 'x'))`` has one real axis, and a sum
+    over the other counts it extent-of-the-axis times once it is taken out of the ``add`` it was
+    broadcast in (the value semantics the reference inherits from Theano's broadcastable axes)."""
+    from ..algebra.expr import elemwise
     if isinstance(factor, Einsum):
-        return {n for _, indices in factor.factors_and_indices for kind, n in indices
-                if kind == "out"}
+        carried = set()
+        for inner, indices in factor.factors_and_indices:
+            real = _carried_axes(inner)
+            carried.update(n for axis, (kind, n) in enumerate(indices) if kind == "out" and axis in real)
+        return carried
+    if isinstance(factor, elemwise):
+        carried = set()
+        for parent in factor.parents:
+            carried |= _carried_axes(parent)
+        return carried
     return set(range(factor.ndim))
 
 
@@ -73,7 +86,11 @@ def expand_terms(expr):
                 extents = []
                 for lost in sorted(sum_indices - carried):
                     ax = list(indices).index(lost)
-                    donor = next(s for s in factor.terms() if ax in _carried_axes(s))
+                    donor = next((s for s in factor.terms() if ax in _carried_axes(s)), None)
+                    if donor is None:
+                        # broadcast in EVERY summand: the axis has extent 1 in this add (where it was
+                        # broadcast against something wider, that level has supplied the extent already)
+                        continue
                     extents.append((A.shape(donor, ax), ()))
                 out += expand_terms(A.einsum(replaced + extents, expr.ndim))
             return out

@@ -1,0 +1,275 @@
+"""Recognising, in a symbolic log-joint, the data-sized structure one of the fused kernels computes.
+
+The plugin surface of the path is the reference's: a model is written with Distribution nodes
+(bayesic/distribution/base.py:9-172) and ``bayesic.algebra`` expressions, and evaluated through
+``Expression.compile()`` (bayesic/algebra.py:42-58).  Evaluated literally, config 2's log-joint is two
+skinny products over X and a few dozen [S, N] element-wise launches (0.85 ms at 1M x 256); the same
+numbers come out of ONE pass over X (csrc/bsc_blr.hip) if one knows that the data enter only through
+
+    Q_s = sum_n (y_n - x_n . w_s)^2      (and  G_s = sum_n (y_n - x_n . w_s) x_n  for the gradient).
+
+``match`` (bayesic/algebra.py:1037-1063) is the tool the reference built for pulling the coefficient of a
+statistic out of a multilinear term; here the "statistics" are the three data-sized contractions a
+Gaussian-linear likelihood expands into,
+
+    sum_nd y_n X_nd W_sd,     sum_nde X_nd W_sd X_ne W_se,     sum_n y_n^2,
+
+and the coefficients c1, c2, c3 must stand in the ratio -2 : 1 : 1 for the three to be c2 * Q_s.  What is
+left of the log-joint is parameter-sized.  Whether THAT belongs to the family the fused finish kernel
+computes (``bsc_blr_fused_update_general``) is decided by fitting the family's five numbers at a few
+probe points and checking the fit at random others, in host float64 (``_param_backend``) -- identity
+testing by evaluation, which does not care in which of many equivalent ways the model was written
+(``exp(-xi)``, ``1 / exp(xi)``, ``pow(var, -1)`` ...).
+"""
+import numpy as np
+
+from .. import algebra as A
+from ..algebra.einsum_form import OUT, SUM, Einsum
+from ..algebra.expr import Expression, add, constant, elemwise, eye, shape, var
+from ._param_backend import ParameterBackend, ShapeOnly
+from .conjugacy import _carried_axes, expand_terms
+
+_PROBE = ParameterBackend()
+
+
+# ---- small tree utilities ------------------------------------------------------------------------
+
+def rewrite(expr, fn):
+    """Bottom-up reconstruction: ``fn(node_with_rewritten_parents)`` may return a replacement or None."""
+    expr = A.wrap_if_literal(expr)
+    if isinstance(expr, Einsum):
+        rebuilt = A.einsum([(rewrite(f, fn), idx) for f, idx in expr.factors_and_indices], expr.ndim)
+    elif isinstance(expr, add):
+        rebuilt = add(*[rewrite(p, fn) for p in expr.parents])
+    elif isinstance(expr, elemwise):
+        rebuilt = elemwise(expr.op, *[rewrite(p, fn) for p in expr.parents], name=expr.name)
+    elif isinstance(expr, shape):
+        rebuilt = shape(rewrite(expr.parents[0], fn), expr.axis)
+    elif isinstance(expr, eye):
+        rebuilt = eye(*[rewrite(p, fn) for p in expr.parents])
+    else:
+        rebuilt = expr
+    replaced = fn(rebuilt)
+    return rebuilt if replaced is None else replaced
+
+
+def static_extent(expr, axis, shapes):
+    """Extent of one axis from the shapes of the inputs alone (no evaluation); 1 for a broadcast axis."""
+    if isinstance(expr, var):
+        return int(shapes[expr.name][axis])
+    if isinstance(expr, constant):
+        return int(np.shape(expr.value)[axis])
+    if isinstance(expr, Einsum):
+        for factor, indices in expr.factors_and_indices:
+            real = _carried_axes(factor)
+            for ax, (kind, n) in enumerate(indices):
+                if kind == OUT and n == axis and ax in real:
+                    return static_extent(factor, ax, shapes)
+        return 1
+    if isinstance(expr, elemwise):
+        return max(static_extent(p, axis, shapes) for p in expr.parents)
+    if isinstance(expr, eye):
+        return int(round(float(_PROBE.evaluate(_without_shapes(expr.parents[0], shapes), {}))))
+    raise ValueError("cannot tell the extent of %r" % (expr,))
+
+
+def _without_shapes(expr, shapes):
+    """``shape(e, axis)`` nodes replaced by the number they stand for."""
+    return rewrite(expr, lambda node: constant(float(static_extent(node.parents[0], node.axis, shapes)))
+                   if isinstance(node, shape) else None)
+
+
+def _constant_value(expr):
+    """The value of an expression made of constants only (a broadcast literal such as the exponent of
+    ``x ** 2``), or None."""
+    if expr.input_types:
+        return None
+    try:
+        value = np.asarray(_PROBE.evaluate(expr, {}), np.float64)
+    except (ValueError, KeyError):
+        return None
+    return float(value.reshape(-1)[0]) if value.size and np.all(value == value.reshape(-1)[0]) else None
+
+
+def normalise(expr, shapes):
+    """Shapes resolved to numbers; ``pow(E, 2)`` written as the product ``E * E`` -- the front end keeps
+    ``pow`` opaque (bayesic/algebra.py:1435-1448), so the square of a mean would hide the contraction
+    inside it from the einsum form."""
+    def step(node):
+        if isinstance(node, shape):
+            return constant(float(static_extent(node.parents[0], node.axis, shapes)))
+        if isinstance(node, elemwise) and not isinstance(node, add) and node.op.scalar_op.name == "pow" \
+                and _constant_value(node.parents[1]) == 2.0:
+            return A.mul(node.parents[0], node.parents[0])
+        return None
+    return rewrite(expr, step)
+
+
+def _names(expr):
+    return set(expr.input_types)
+
+
+# ---- the Gaussian-linear data term -------------------------------------------------------------
+
+class GaussianLinear(object):
+    """What ``gaussian_linear`` found: the data enter the log-joint only as ``coefficient_s * Q_s``.
+
+    X, y, W      : names of the design matrix [N, D], the targets [N] and the latent weights [S, D]
+    coefficient  : expression [S] over the other latents (c2 above; for a Normal likelihood
+                   -scale / (2 variance_s))
+    rest         : the parameter-sized terms, a list of [S] expressions (shapes resolved)
+    surrogate    : rest + coefficient * Q with ``Q`` the input ``Q_NAME`` [S]: the whole log-joint per draw
+                   as a parameter-sized expression
+    family       : (c0, c_xi, s_q, k_w, beta, xi_name) when the surrogate is
+                   c0 + c_xi xi + e^{-xi} (-s_q Q / 2 - k_w |w|^2 / 2 - beta) for the one other latent xi
+                   [S, 1] -- what bsc_blr_fused_update_general computes --, else None
+    """
+    Q_NAME = "_gl_Q"
+
+    def __init__(self, X, y, W, coefficient, rest, family=None):
+        self.X, self.y, self.W = X, y, W
+        self.coefficient, self.rest, self.family = coefficient, rest, family
+        Q = var(self.Q_NAME, 1)
+        self.surrogate = add(*(list(rest) + [coefficient * Q])) if rest else coefficient * Q
+
+
+def _templates(X, y, W):
+    s, n, d, e = (OUT, 0), (SUM, 0), (SUM, 1), (SUM, 2)
+    out = []
+    for slot_nd in (1, 2):
+        Z = var("_gl_slot", slot_nd)
+        z = [s] if slot_nd == 1 else [s, n]
+        out.append((Z,
+                    Einsum([(y, [n]), (X, [n, d]), (W, [s, d]), (Z, z)], 1),
+                    Einsum([(X, [n, d]), (W, [s, d]), (X, [n, e]), (W, [s, e]), (Z, z)], 1),
+                    Einsum([(y, [n]), (y, [n]), (Z, z)], 1)))
+    return out
+
+
+def _coefficient(term, templates, which, forbidden):
+    """Coefficient [S] of data statistic ``which`` (0, 1, 2) in ``term``, or None."""
+    for Z, *stats in templates:
+        c = A.match(term, stats[which], Z)
+        if c is None or (_names(c) & forbidden):
+            continue
+        if Z.ndim == 2:
+            # the coefficient was broadcast along the rows (a variance written [S, 'x']): it must not
+            # vary along them; summing the extent-1 axis takes it back to [S]
+            c = A.wrap_if_literal(c)
+            if 1 in _carried_axes(Einsum._wrap_if_not_einsum(c)):
+                continue
+            c = A.sum(c, axis=1)
+        return c
+    return None
+
+
+def _evaluate(expr, latents, S, rng, extra=None):
+    inputs = {v.name: rng.standard_normal((S, n)) * 0.7 for v, n in latents}
+    if extra:
+        inputs.update(extra)
+    return np.asarray(_PROBE.evaluate(expr, inputs), np.float64), inputs
+
+
+def gaussian_linear(log_joint, latents, data_shapes, n_samples):
+    """``log_joint``: expression of ndim 1 (one value per draw); ``latents``: [(var [S, size], size)];
+    ``data_shapes``: {data input name: shape}.  Returns a ``GaussianLinear`` or None -- None means "not
+    this structure", never an error: the caller then evaluates the expression as written."""
+    latent_names = {v.name for v, _ in latents}
+    shapes = dict(data_shapes)
+    shapes.update({v.name: (n_samples, n) for v, n in latents})
+    try:
+        # (distributing over an add can introduce extents of its own -- shape nodes -- for summands that
+        # were broadcast inside it: resolved again afterwards)
+        terms = [_without_shapes(t, shapes) for t in expand_terms(normalise(log_joint, shapes))]
+    except (ValueError, KeyError, TypeError):
+        return None
+    data_names = set(data_shapes)
+    data_terms = [t for t in terms if _names(t) & data_names]
+    rest = [t for t in terms if not (_names(t) & data_names)]
+    if not data_terms or any(t.ndim != 1 for t in terms):
+        return None
+    types = log_joint.input_types
+    rng = np.random.RandomState(20240)
+    for Xn in sorted(n for n in data_names if types.get(n, (None, 0))[1] == 2):
+        for yn in sorted(n for n in data_names if types.get(n, (None, 0))[1] == 1
+                         and data_shapes[n][0] == data_shapes[Xn][0]):
+            for Wv, width in latents:
+                if width != data_shapes[Xn][1]:
+                    continue
+                X, y = var(Xn, 2, types[Xn][0]), var(yn, 1, types[yn][0])
+                templates = _templates(X, y, Wv)
+                forbidden = {Xn, yn, Wv.name}
+                found = [[], [], []]
+                for term in data_terms:
+                    for which in (1, 0, 2):                 # the quadratic form first: it contains the others' factors
+                        c = _coefficient(term, templates, which, forbidden)
+                        if c is not None:
+                            found[which].append(c)
+                            break
+                    else:
+                        break
+                else:
+                    if not all(found):
+                        continue
+                    c1, c2, c3 = (cs[0] if len(cs) == 1 else add(*cs) for cs in found)
+                    others = [(v, n) for v, n in latents if v.name != Wv.name]
+                    ok = True
+                    for _ in range(3):          # c1 = -2 c2 and c3 = c2 as functions of the other latents
+                        v2, inputs = _evaluate(c2, others, 3, rng)
+                        v1 = np.asarray(_PROBE.evaluate(c1, inputs), np.float64)
+                        v3 = np.asarray(_PROBE.evaluate(c3, inputs), np.float64)
+                        tol = 1e-12 * np.abs(v2).max()
+                        if not (np.all(np.abs(v1 + 2.0 * v2) <= tol) and np.all(np.abs(v3 - v2) <= tol)
+                                and np.all(v2 <= 0.0)):
+                            ok = False
+                    if not ok:
+                        continue
+                    plan = GaussianLinear(Xn, yn, Wv.name, c2, rest)
+                    plan.family = _fit_family(plan, Wv, width, others, rng)
+                    return plan
+    return None
+
+
+def _fit_family(plan, Wv, D, others, rng):
+    """The five numbers of  f = c0 + c_xi xi + e^{-xi} (-s_q Q / 2 - k_w |w|^2 / 2 - beta)  from probe
+    evaluations of the surrogate, verified at random points; None when the surrogate is not of that form."""
+    if len(others) != 1 or others[0][1] != 1:
+        return None
+    xi_v = others[0][0]
+
+    def f(w, xi, q):
+        w = np.atleast_2d(np.asarray(w, np.float64))
+        S = w.shape[0]
+        inputs = {Wv.name: w, xi_v.name: np.full((S, 1), 0.0) + np.reshape(xi, (-1, 1)),
+                  GaussianLinear.Q_NAME: np.zeros(S) + q}
+        return np.asarray(_PROBE.evaluate(plan.surrogate, inputs), np.float64).reshape(-1)
+
+    try:
+        zero = np.zeros((1, D))
+        t = 2.0
+        g0, g1, g2 = f(zero, [0.0], 0.0)[0], f(zero, [t], 0.0)[0], f(zero, [-t], 0.0)[0]
+        # g(xi) = c0 + c_xi xi - beta e^{-xi} at xi = 0, t, -t:
+        #   g1 + g2 - 2 g0 = -beta (e^{-t} + e^{t} - 2),   g1 - g2 = 2 c_xi t + beta (e^{t} - e^{-t})
+        beta = -((g1 + g2) - 2.0 * g0) / (np.exp(-t) + np.exp(t) - 2.0)
+        c_xi = ((g1 - g2) - beta * (np.exp(t) - np.exp(-t))) / (2.0 * t)
+        c0 = g0 + beta
+        s_q = -2.0 * (f(zero, [0.0], 1.0)[0] - g0)
+        unit = np.zeros((1, D))
+        unit[0, 0] = 1.0
+        k_w = -2.0 * (f(unit, [0.0], 0.0)[0] - g0)
+        if not (np.isfinite([c0, c_xi, s_q, k_w, beta]).all() and s_q > 0.0 and k_w >= 0.0):
+            return None
+        for _ in range(4):
+            S = 3
+            w = rng.standard_normal((S, D))
+            xi = rng.standard_normal(S) * 0.8
+            q = rng.uniform(0.5, 50.0, S)
+            e = np.exp(-xi)
+            want = c0 + c_xi * xi + e * (-0.5 * s_q * q - 0.5 * k_w * (w * w).sum(axis=1) - beta)
+            got = f(w, xi, q)
+            scale = np.abs(c0) + np.abs(c_xi * xi) + e * (0.5 * s_q * q + 0.5 * k_w * (w * w).sum(axis=1) + abs(beta))
+            if not np.all(np.abs(got - want) <= 1e-10 * scale):
+                return None
+    except (ValueError, KeyError, FloatingPointError):
+        return None
+    return (float(c0), float(c_xi), float(s_q), float(k_w), float(beta), xi_v.name)

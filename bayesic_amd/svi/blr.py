@@ -50,7 +50,11 @@ class BLRReparamSVI:
 
     def __init__(self, X, y, n_total=None, n_samples=8, seed=1234, lr=1e-2, alpha0=1.0,
                  beta0=1.0, ctx=None, group=None, lam0=None, fused=True, reproducible=False,
-                 sweep="alternate"):
+                 sweep="alternate", family=None):
+        """``family`` = (c0, c_xi, s_q, k_w, beta): the log-joint per draw as a member of
+        f(w, xi; Q) = c0 + c_xi xi + e^{-xi} (-s_q Q / 2 - k_w |w|^2 / 2 - beta) instead of the
+        Normal-InverseGamma model above (bsc_blr_fused_update_general) -- what ``inference.ReparamVI``
+        passes when it has recognised such a model in a symbolic log-joint."""
         self.ctx = ctx or default_context()
         dev = self.ctx.device
         self.X = X if isinstance(X, torch.Tensor) else self.ctx.to_device(X, torch.float32)
@@ -67,6 +71,9 @@ class BLRReparamSVI:
         self.seed = int(seed)
         self.lr = float(lr)
         self.alpha0, self.beta0 = float(alpha0), float(beta0)
+        self.family = None if family is None else tuple(float(v) for v in family)
+        if self.family is not None and len(self.family) != 5:
+            raise ValueError("family must be (c0, c_xi, s_q, k_w, beta)")
         self.group = group
         self.exchange = Exchange(self.ctx, group)   # RCCL behind the C ABI when ctx has a communicator
         self.world = self.exchange.world
@@ -252,13 +259,23 @@ class BLRReparamSVI:
         c, n = self.cur, 1 - self.cur
         t = self.t + 1                  # Adam step count; Philox step of the NEXT draw
         self._ensure_noise(t)
-        self.ctx.call("bsc_blr_fused_update", stats,
-                      self._lam[c], self._lam[n], self.m1, self.m2,
-                      self._eps[self.t % self._ring], self._W[c], self._xi[c], self.D, self.S,
-                      self.batch_rows, self.n_total / self.batch_rows, self.alpha0, self.beta0,
-                      t, self.lr, 0.9, 0.999, 1e-8, self.seed, t,
-                      self._eps[t % self._ring], 1, self._W[n], self._xi[n], self.elbo,
-                      self.grad)
+        if self.family is None:
+            self.ctx.call("bsc_blr_fused_update", stats,
+                          self._lam[c], self._lam[n], self.m1, self.m2,
+                          self._eps[self.t % self._ring], self._W[c], self._xi[c], self.D, self.S,
+                          self.batch_rows, self.n_total / self.batch_rows, self.alpha0, self.beta0,
+                          t, self.lr, 0.9, 0.999, 1e-8, self.seed, t,
+                          self._eps[t % self._ring], 1, self._W[n], self._xi[n], self.elbo,
+                          self.grad)
+        else:
+            c0, c_xi, s_q, k_w, beta = self.family
+            self.ctx.call("bsc_blr_fused_update_general", stats,
+                          self._lam[c], self._lam[n], self.m1, self.m2,
+                          self._eps[self.t % self._ring], self._W[c], self._xi[c], self.D, self.S,
+                          c0, c_xi, s_q, k_w, beta,
+                          t, self.lr, 0.9, 0.999, 1e-8, self.seed, t,
+                          self._eps[t % self._ring], 1, self._W[n], self._xi[n], self.elbo,
+                          self.grad)
         self.t = t
 
     def step(self):

@@ -93,6 +93,8 @@ class MoGNatGradSVI:
         # two parameter kernels that run anyway (oracle.svi.mog_elbo)
         self._bound = torch.zeros(1, dtype=f64, device=dev)
         self.elbo = torch.zeros(1, dtype=f64, device=dev)
+        self._prior_A = torch.zeros(1, dtype=f64, device=dev)      # A(eta0): a constant of the model, taken once
+        self.ctx.call("bsc_mog_log_normalizer", self.eta0, self.K, self.D, self._prior_A)
         self.t = 0
         if via is None:
             via = "kernel" if (self.K <= 64 and self.D <= 16) else "executor"
@@ -120,8 +122,8 @@ class MoGNatGradSVI:
                 be.mark_constant(self.X)
 
     def expected_params(self):
-        self.ctx.call("bsc_mog_expected_params_bound", self.eta, self.eta0, self.K, self.D, self.Wmat,
-                      self.c, self._bound)
+        self.ctx.call("bsc_mog_expected_params_bound", self.eta, self.eta0, self._prior_A, self.K, self.D,
+                      self.Wmat, self.c, self._bound)
 
     def local_step(self):
         if self.via == "kernel":

@@ -56,6 +56,11 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--scaling", default="both", choices=["both", "weak", "strong"])
+    ap.add_argument("--via", default="driver", choices=["driver", "plugin"],
+                    help="cfg2: driver = the hand-written host driver (svi/blr.py); plugin = the SAME model written "
+                         "with Normal / InverseGamma nodes and bayesic.algebra expressions (inference/models.py) "
+                         "and stepped by the general engine inference.ReparamVI, which has to recognise the data "
+                         "term itself (inference/recognise.py) to reach the fused kernels")
     ap.add_argument("--batches", type=int, default=3,
                     help="cfg2: distinct resident mini-batches the update loop rotates over (1 = the same "
                          "mini-batch every step)")
@@ -237,9 +242,24 @@ class Cfg2(Workload):
         self._visit = 0
         self._spin_visit = 0
         self.n_total = float(global_rows)       # the resident global batch is the data set
-        self.model = BLRReparamSVI(X, y, n_total=self.n_total, n_samples=S, seed=1234, lr=1e-3, ctx=ctx,
-                                   group=args.exchange_group, fused=not args.unfused, reproducible=args.reproducible,
-                                   sweep=args.sweep)
+        self.engine = None
+        if getattr(args, "via", "driver") == "plugin":
+            if world > 1 or args.unfused or args.reproducible:
+                raise SystemExit("bench.py: --via plugin is the single-GPU fused route")
+            from bayesic_amd.algebra.device_backend import DeviceBackend
+            from bayesic_amd.inference import ReparamVI
+            from bayesic_amd.inference.models import linear_regression_log_joint
+            lj, v = linear_regression_log_joint(self.n_total / rows, 1.0, 1.0)
+            lam0 = np.zeros(2 * (D + 1))
+            lam0[D + 1:] = np.log(0.1)              # the driver's starting point (oracle.svi.blr_init_lam)
+            self.engine = ReparamVI(lj, [(v["W"], D), (v["xi"], 1)], dict(X=X, y=y), n_samples=S, seed=1234,
+                                    lr=1e-3, backend=DeviceBackend(ctx), lam0=lam0, route="fused")
+            self.model = self.engine._fused         # (the harness reads W / sweep bookkeeping off the driver behind it)
+            self.model.sweep = args.sweep
+        else:
+            self.model = BLRReparamSVI(X, y, n_total=self.n_total, n_samples=S, seed=1234, lr=1e-3, ctx=ctx,
+                                       group=args.exchange_group, fused=not args.unfused,
+                                       reproducible=args.reproducible, sweep=args.sweep)
         self.units_per_step = global_rows / 1e6 if args.scaling == "strong" else world * rows / 1e6
         self.describe = ("cfg2: Bayesian linear regression (Normal-InverseGamma), %dx%d f32 mini-batch %s, "
                          "reparam-trick ELBO, S=%d, Adam"
@@ -247,6 +267,9 @@ class Cfg2(Workload):
                             "block of a global %d-row batch" % global_rows, S))
         self.config = {"rows_per_gpu": rows, "global_rows": global_rows, "dim": D, "mc_samples": S,
                        "reproducible": bool(args.reproducible), "sweep": args.sweep,
+                       "via": ("plugin surface: inference.ReparamVI over Normal / InverseGamma nodes + bayesic.algebra "
+                               "(route = %s)" % self.engine.route) if self.engine is not None else
+                              "hand-written host driver svi/blr.py",
                        "minibatches_resident": len(self.batches),
                        "value_is": ("update loop rotating over %d distinct HBM-resident mini-batches, a different "
                                     "one every step (no cross-update Infinity-Cache reuse)" % len(self.batches))
@@ -256,7 +279,13 @@ class Cfg2(Workload):
         """'rotate' (a different resident mini-batch every step) or 'same' (batch 0 every step)."""
         self.rotate = mode == "rotate" and len(self.batches) > 1 and not self.args.reproducible
         if not self.rotate:
-            self.model.set_batch(*self.batches[0])
+            self._set_batch(*self.batches[0])
+
+    def _set_batch(self, X, y):
+        if self.engine is not None:
+            self.engine.set_data(X=X, y=y)
+        else:
+            self.model.set_batch(X, y)
 
     def spin(self):
         # the same launch the update loop makes: streaming over the next batch of the rotation, or --
@@ -274,8 +303,8 @@ class Cfg2(Workload):
     def step(self):
         if self.rotate:
             self._visit = (self._visit + 1) % len(self.batches)
-            self.model.set_batch(*self.batches[self._visit])
-        self.model.step()
+            self._set_batch(*self.batches[self._visit])
+        (self.engine or self.model).step()
 
     def result(self):
         return {"final_elbo": float(self.model.elbo.item())}

@@ -256,6 +256,23 @@ int bsc_blr_fused_update(bsc_ctx* ctx, const double* stats, const double* lam_in
                          int32_t eps_next_ready, float* W_next, double* xi_next, double* elbo,
                          double* grad);
 
+/* The same fused finish for any log-joint per draw of the family
+ *     f(w, xi; Q) = c0 + c_xi xi + e^{-xi} (-s_q Q / 2 - k_w |w|^2 / 2 - beta),   Q = sum_n (y_n - x_n.w)^2,
+ *     d f / d w = e^{-xi} (s_q G - k_w w),   d f / d xi = c_xi + e^{-xi} (s_q Q / 2 + k_w |w|^2 / 2 + beta)
+ * -- a Gaussian-linear likelihood with log noise variance xi, a zero-mean Gaussian prior on w of precision
+ * k_w e^{-xi} and a log-variance prior linear in xi and e^{-xi} (an inverse-Gamma on the variance, a Gamma
+ * on the precision, flat).  bsc_blr_fused_update is the member c0 = -(scale B + D)/2 log 2 pi + alpha0 log
+ * beta0 - lnGamma(alpha0), c_xi = -(scale B + D)/2 - alpha0, s_q = scale, k_w = 1, beta = beta0.  This is what
+ * bayesic_amd.inference.ReparamVI launches when it recognises such a model written with Distribution nodes
+ * and bayesic.algebra expressions (bayesic/distribution/base.py:47-69 decomposition; coefficient extraction
+ * with match, bayesic/algebra.py:1037-1063). */
+int bsc_blr_fused_update_general(bsc_ctx* ctx, const double* stats, const double* lam_in, double* lam_out,
+                                 double* m1, double* m2, const double* eps, const float* W, const double* xi,
+                                 int32_t D, int32_t S, double c0, double c_xi, double s_q, double k_w, double beta,
+                                 int64_t t, double lr, double beta1, double beta2, double adam_eps, uint64_t seed,
+                                 uint32_t next_step, double* eps_next, int32_t eps_next_ready, float* W_next,
+                                 double* xi_next, double* elbo, double* grad);
+
 /* ---- parameter updates --------------------------------------------------- */
 
 /* Adam ascent on a flat float64 vector; t is the 1-based step count. */
@@ -398,14 +415,16 @@ int bsc_mog_natgrad(bsc_ctx* ctx, double* eta, const double* eta0, const double*
  * (README.md:43,72) the bound at q(theta) = eta is
  *     ELBO = scale * sum_n logsumexp_k(logit_nk) + bound,
  *     bound = E_q[log p(pi,mu,tau)] - E_q[log q(pi,mu,tau)] = sum_factors <eta0-eta, E_q[T]> - A(eta0) + A(eta)
- * (oracle.svi.mog_elbo / mog_global_bound).  bsc_mog_expected_params_bound is
- * bsc_mog_expected_params that also writes `bound` (one float64, device) from the same digamma / log
- * values; bsc_mog_natgrad_elbo is bsc_mog_natgrad that first writes
+ * (oracle.svi.mog_elbo / mog_global_bound).  bsc_mog_log_normalizer writes A(eta) (one float64, device):
+ * called once with the prior's eta0, it gives the constant `prior_A` of the model.
+ * bsc_mog_expected_params_bound is bsc_mog_expected_params that also writes `bound` (one float64,
+ * device) from the same digamma / log values; bsc_mog_natgrad_elbo is bsc_mog_natgrad that first writes
  * elbo[0] = scale * lse[0] + bound[0] (lse: what bsc_mog_estep returned for THIS eta, all-reduced
  * when data-parallel) -- the bound at the parameters the step starts from.  No extra launch, no
  * extra pass.  K <= 1024. */
-int bsc_mog_expected_params_bound(bsc_ctx* ctx, const double* eta, const double* eta0, int32_t K, int32_t D,
-                                  float* Wmat, float* c, double* bound);
+int bsc_mog_log_normalizer(bsc_ctx* ctx, const double* eta, int32_t K, int32_t D, double* A_out);
+int bsc_mog_expected_params_bound(bsc_ctx* ctx, const double* eta, const double* eta0, const double* prior_A,
+                                  int32_t K, int32_t D, float* Wmat, float* c, double* bound);
 int bsc_mog_natgrad_elbo(bsc_ctx* ctx, double* eta, const double* eta0, const double* stats, int32_t K,
                          int32_t D, double scale, double rho, const double* lse, const double* bound,
                          double* elbo);

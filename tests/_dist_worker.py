@@ -105,7 +105,11 @@ class OracleContext:
         Wmat.copy_(torch.from_numpy(w))
         c.copy_(torch.from_numpy(cc))
 
-    def bsc_mog_expected_params_bound(self, eta, eta0, K, D, Wmat, c, bound):
+    def bsc_mog_log_normalizer(self, eta, K, D, A_out):
+        alpha, m, kappa, a, b = svi.mog_unpack(eta.numpy(), K, D)
+        A_out[0] = float(svi.dirichlet_log_normalizer(alpha) + svi.normal_gamma_log_normalizer(kappa, a, b).sum())
+
+    def bsc_mog_expected_params_bound(self, eta, eta0, prior_A, K, D, Wmat, c, bound):
         self.bsc_mog_expected_params(eta, K, D, Wmat, c)
         bound[0] = svi.mog_global_bound(eta.numpy(), eta0.numpy(), K, D)
 

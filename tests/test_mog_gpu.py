@@ -125,17 +125,27 @@ def test_global_bound_kernel_matches_oracle(ctx):
         eta = svi.mog_init_eta(X, K, D, seed=3) + rs.uniform(0, 5, K + 4 * K * D) * \
             np.concatenate([np.ones(K), np.zeros(K * D), np.ones(2 * K * D), np.zeros(K * D)])
         etad, eta0d = ctx.to_device(eta, f64), ctx.to_device(eta0, f64)
-        Wmat, c, bound = ctx.zeros((K, 2 * D)), ctx.zeros(K), ctx.zeros(1, f64)
-        ctx.call("bsc_mog_expected_params_bound", ptr(etad), ptr(eta0d), K, D, ptr(Wmat), ptr(c), ptr(bound))
+        Wmat, c, bound, prior_A = ctx.zeros((K, 2 * D)), ctx.zeros(K), ctx.zeros(1, f64), ctx.zeros(1, f64)
+        ctx.call("bsc_mog_log_normalizer", ptr(eta0d), K, D, ptr(prior_A))
+        ctx.sync()
+        alpha0, _, kappa0, a0, b0 = svi.mog_unpack(eta0, K, D)
+        npt.assert_allclose(prior_A.item(), float(svi.dirichlet_log_normalizer(alpha0)
+                                                  + svi.normal_gamma_log_normalizer(kappa0, a0, b0).sum()), rtol=1e-12)
+        ctx.call("bsc_mog_expected_params_bound", ptr(etad), ptr(eta0d), ptr(prior_A), K, D, ptr(Wmat), ptr(c),
+                 ptr(bound))
         W2, c2 = ctx.zeros((K, 2 * D)), ctx.zeros(K)
         ctx.call("bsc_mog_expected_params", ptr(etad), K, D, ptr(W2), ptr(c2))
         ctx.sync()
         npt.assert_array_equal(Wmat.cpu().numpy(), W2.cpu().numpy())
         npt.assert_array_equal(c.cpu().numpy(), c2.cpu().numpy())
+        Wr, cr = svi.mog_expected_params(eta, K, D)
+        npt.assert_allclose(Wmat.cpu().numpy(), Wr, rtol=1e-6)
+        npt.assert_allclose(c.cpu().numpy(), cr, rtol=1e-6, atol=1e-6)
         want = svi.mog_global_bound(eta, eta0, K, D)
         npt.assert_allclose(bound.item(), want, rtol=1e-11, atol=1e-9)
         # at the prior itself the bound vanishes (KL(p || p) = 0)
-        ctx.call("bsc_mog_expected_params_bound", ptr(eta0d), ptr(eta0d), K, D, ptr(Wmat), ptr(c), ptr(bound))
+        ctx.call("bsc_mog_expected_params_bound", ptr(eta0d), ptr(eta0d), ptr(prior_A), K, D, ptr(Wmat), ptr(c),
+                 ptr(bound))
         ctx.sync()
         assert abs(bound.item()) <= 1e-9 * K * D
 

@@ -1,0 +1,106 @@
+"""inference/recognise.py on the CPU: which symbolic log-joints are read as "the data enter only through
+c_s * sum_n (y_n - x_n . w_s)^2" (match on the three contractions a Gaussian-linear likelihood expands into),
+and which of those have a parameter-sized part of the fused finish kernel's family.  Recognition never
+touches data values: the data are given by their shapes."""
+import math
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from bayesic_amd import algebra as A
+from bayesic_amd.inference import recognise as R
+from bayesic_amd.inference.models import linear_regression_log_joint
+
+N, D, S = 1000, 16, 8
+SHAPES = {"X": (N, D), "y": (N,)}
+
+
+def _want(scale, alpha0, beta0):
+    half = 0.5 * (scale * N + D)
+    return (-half * math.log(2 * math.pi) + alpha0 * math.log(beta0) - math.lgamma(alpha0), -half - alpha0, scale,
+            1.0, beta0)
+
+
+@pytest.mark.parametrize("scale,alpha0,beta0", [(1.0, 1.0, 1.0), (10.0, 2.5, 0.7), (37.5, 0.3, 4.0)])
+def test_config2_written_with_distribution_nodes_is_recognised(scale, alpha0, beta0):
+    lj, v = linear_regression_log_joint(scale, alpha0, beta0)
+    for latents in ([(v["W"], D), (v["xi"], 1)], [(v["xi"], 1), (v["W"], D)]):
+        plan = R.gaussian_linear(lj, latents, SHAPES, S)
+        assert plan is not None and (plan.X, plan.y, plan.W) == ("X", "y", "W")
+        assert plan.family is not None and plan.family[5] == "xi"
+        npt.assert_allclose(plan.family[:5], _want(scale, alpha0, beta0), rtol=1e-9)
+    # the surrogate is the oracle's log-joint as a function of (w, xi, Q)
+    from oracle import svi
+    rng = np.random.RandomState(0)
+    w, x, q = rng.standard_normal((3, D)), rng.standard_normal(3), rng.uniform(1, 9, 3)
+    got = R._PROBE.evaluate(plan.surrogate, {"W": w, "xi": x[:, None], R.GaussianLinear.Q_NAME: q})
+    npt.assert_allclose(got, svi.blr_log_joint(w, x, q, N, scale, alpha0, beta0), rtol=1e-12)
+
+
+def test_the_same_model_written_by_hand_in_residual_form():
+    X, y, W, xi = A.var("X", 2), A.var("y", 1), A.var("W", 2), A.var("xi", 2)
+    x = A.sum(xi, axis=1)
+    r = A.dimshuffle(y, "x", 0) - A.dot(W, X.T)
+    e = A.exp(-x)
+    lj = (A.sum(r * r, axis=1) * e * (-0.5) - x * (0.5 * N)) * 4.0 \
+        + A.sum(W * W, axis=1) * e * (-0.5 * 3.0) - x * (0.5 * D) - x * 2.0 - e * 0.25
+    plan = R.gaussian_linear(lj, [(W, D), (xi, 1)], SHAPES, S)
+    assert plan is not None and plan.family is not None
+    c0, c_xi, s_q, k_w, beta, _ = plan.family
+    npt.assert_allclose([c0, c_xi, s_q, k_w, beta], [0.0, -0.5 * (4.0 * N + D) - 2.0, 4.0, 3.0, 0.25], rtol=1e-9,
+                        atol=1e-9)
+
+
+def test_known_noise_variance_has_the_data_term_but_not_the_family():
+    X, y, W = A.var("X", 2), A.var("y", 1), A.var("W", 2)
+    r = A.dimshuffle(y, "x", 0) - A.dot(W, X.T)
+    lj = A.sum(r * r, axis=1) * (-0.5 / 0.25) + A.sum(W * W, axis=1) * (-0.5)
+    plan = R.gaussian_linear(lj, [(W, D)], SHAPES, S)
+    assert plan is not None and plan.family is None
+    npt.assert_allclose(R._PROBE.evaluate(plan.coefficient, {}), -2.0)
+
+
+def test_what_is_not_a_gaussian_linear_data_term_is_left_alone():
+    X, y, W, xi = A.var("X", 2), A.var("y", 1), A.var("W", 2), A.var("xi", 2)
+    logits = A.dot(W, X.T)
+    yb = A.dimshuffle(y, "x", 0)
+    # a Bernoulli-logit likelihood: the data enter through softplus(logits)
+    bern = A.sum(yb * logits - A.log(1.0 + A.exp(logits)), axis=1) + A.sum(W * W, axis=1) * (-0.5)
+    assert R.gaussian_linear(bern, [(W, D)], SHAPES, S) is None
+    # the cross term with the wrong weight: not a multiple of the squared residual
+    r2 = A.sum(yb * yb, axis=1) - A.sum(yb * logits, axis=1) * 1.5 + A.sum(logits * logits, axis=1)
+    assert R.gaussian_linear(r2 * (-0.5) + A.sum(W * W, axis=1) * (-0.5), [(W, D)], SHAPES, S) is None
+    # a noise variance per datum (a data-sized coefficient) is not the pass's statistic either
+    V = A.var("V", 2)          # [S, N] latent-by-datum variances
+    het = A.sum((yb - logits) * (yb - logits) * A.exp(-V), axis=1) * (-0.5) + A.sum(W * W, axis=1) * (-0.5)
+    assert R.gaussian_linear(het, [(W, D), (V, N)], SHAPES, S) is None
+    # a positive coefficient would be a log-joint that grows with the residual
+    grow = A.sum((yb - logits) * (yb - logits), axis=1) * 0.5
+    assert R.gaussian_linear(grow, [(W, D)], SHAPES, S) is None
+
+
+def test_broadcast_axes_of_opaque_nodes_are_counted_once_per_extent():
+    """log(v[:, 'x']) + M[S, N] summed over the rows counts the log N times -- the value semantics of a
+    broadcast axis -- also when the broadcast sits inside an element-wise node the einsum form cannot see
+    into (conjugacy.expand_terms / _carried_axes)."""
+    from bayesic_amd.inference.conjugacy import expand_terms
+    v, M = A.var("v", 1), A.var("M", 2)
+    expr = A.sum(A.log(A.dimshuffle(v, 0, "x")) + M, axis=1)
+    shapes = {"v": (3,), "M": (3, 5)}
+    terms = [R._without_shapes(t, shapes) for t in expand_terms(expr)]
+    vv, MM = np.array([1.5, 2.0, 0.3]), np.arange(15.0).reshape(3, 5)
+    total = sum(np.asarray(R._PROBE.evaluate(t, {"v": vv, "M": MM})) for t in terms)
+    npt.assert_allclose(total, 5 * np.log(vv) + MM.sum(axis=1), rtol=1e-14)
+
+
+def test_parameter_probe_refuses_data_sized_operands():
+    from bayesic_amd.inference._param_backend import MAX_ELEMENTS, ParameterBackend, ShapeOnly
+    P = ParameterBackend()
+    with pytest.raises(ValueError, match="data-sized"):
+        P.from_host(np.zeros(MAX_ELEMENTS + 1), "float64", 1)
+    with pytest.raises(ValueError, match="data input"):
+        P.mul(ShapeOnly((10, 3)), np.ones(3))
+    from bayesic_amd.algebra.backend import resolve_backend
+    import bayesic_amd.algebra.backend as B
+    assert not isinstance(B._default, ParameterBackend)
