@@ -87,6 +87,9 @@ SIGNATURES = {
     "bsc_softmax_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "bsc_gemm_softmax_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64,
                                       c_int64, c_int32, c_float, c_void_p, c_int64, c_void_p, c_void_p]),
+    "bsc_gemm_softmax_stats": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64,
+                                       c_int64, c_int32, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                       c_void_p]),
     "bsc_suffstats_normal": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "bsc_mog_estep": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p,
                               c_void_p, c_void_p, c_void_p]),

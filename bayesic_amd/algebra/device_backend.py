@@ -112,6 +112,104 @@ def _i64(values):
     return (ctypes.c_int64 * max(len(values), 1))(*values)
 
 
+class DeferredSoftmax(object):
+    """R = softmax_rows(alpha * X_wide . Y) that has NOT been written: the responsibilities of a resident
+    Categorical node right after its update (``evaluate_softmax_rows(..., defer=True)``).  What the node's
+    neighbours ask of them is, for an exponential-family mixture, always a contraction over the rows with
+    constituents of the SAME wide operand the logits came from -- ``dot(R.T, X)``, ``dot(R.T, X * X)``,
+    ``sum(R, 0)`` (bayesic/distribution/base.py:329-332: statistics of iid draws add up) -- i.e. column blocks
+    of R^T . X_wide, and that the device forms in the pass that forms the softmax (bsc_gemm_softmax_stats,
+    csrc/bsc_rowsoftmax.hip): the [rows, N] responsibilities never reach memory.  Anything else asked of the
+    object (an element-wise use, a product with other data) writes them after all -- ``realise()``, the
+    launch ``evaluate_softmax_rows`` would have made -- and carries on with the tensor."""
+
+    def __init__(self, backend, xcat, wkey, ycat, alpha, transposed=False, state=None, factor=1.0):
+        self.backend, self.xcat, self.wkey, self.ycat, self.alpha = backend, xcat, wkey, ycat, float(alpha)
+        self.transposed = transposed
+        self.factor = float(factor)          # a scalar the responsibilities have been multiplied by (N / B ...)
+        self._state = state if state is not None else {}      # shared between a view and its transpose
+        m, n = xcat.shape[0], ycat.shape[1]
+        self.shape = (n, m) if transposed else (m, n)
+        self.dtype = torch.float32
+
+    def dim(self):
+        return 2
+
+    @property
+    def ndim(self):
+        return 2
+
+    @property
+    def T(self):
+        return DeferredSoftmax(self.backend, self.xcat, self.wkey, self.ycat, self.alpha, not self.transposed,
+                               self._state, self.factor)
+
+    def scaled(self, c):
+        return DeferredSoftmax(self.backend, self.xcat, self.wkey, self.ycat, self.alpha, self.transposed,
+                               self._state, self.factor * float(c))
+
+    def statistics(self):
+        """(R^T . X_wide [N, kp] float32, sum_rows lse float64 [1]) -- one pass, computed once."""
+        if "stats" not in self._state:
+            ctx = self.backend.ctx
+            m, kp = self.xcat.shape
+            n = self.ycat.shape[1]
+            stats = ctx.empty((n, kp), torch.float32)
+            lse = ctx.empty((1,), torch.float64)
+            # a ones column that closes the wide operand (everything after it padding) goes out of the product:
+            # it becomes the kernel's bias row, and its statistic -- the column sums -- lands in its own column
+            ones = self.backend._wide.get(("ones", m))
+            k_feat, bias = kp, None
+            if ones is not None and ones[0] == self.wkey and ones[1] % 8 == 0 and 8 <= ones[1] <= 56 \
+                    and kp - ones[1] <= 8:
+                k_feat = ones[1]
+                bias = self.ycat[k_feat]
+                ctx.call("bsc_memset", stats, 0, stats.numel() * 4)        # (the padding columns are never written)
+            ctx.call("bsc_gemm_softmax_stats", _ffi.ptr(self.xcat), self.xcat.stride(0), m, k_feat,
+                     _ffi.ptr(self.ycat), self.ycat.stride(0), self.ycat.stride(1), n, self.alpha,
+                     None if bias is None else _ffi.ptr(bias), None, n, _ffi.ptr(stats), kp, _ffi.ptr(lse))
+            self._state["stats"] = (stats, lse)
+        return self._state["stats"]
+
+    def realise(self):
+        """(R [rows, N], lse [rows], cross [rows]) written after all (bsc_gemm_softmax_rows)."""
+        if "rows" not in self._state:
+            ctx = self.backend.ctx
+            m, kp = self.xcat.shape
+            n = self.ycat.shape[1]
+            R, lse, cross = ctx.empty((m, n), torch.float32), ctx.empty((m,), torch.float32), \
+                ctx.empty((m,), torch.float32)
+            ctx.call("bsc_gemm_softmax_rows", _ffi.ptr(self.xcat), self.xcat.stride(0), m, kp, _ffi.ptr(self.ycat),
+                     self.ycat.stride(0), self.ycat.stride(1), n, self.alpha, _ffi.ptr(R), n, _ffi.ptr(lse),
+                     _ffi.ptr(cross))
+            self._state["rows"] = (R, lse, cross)
+        return self._state["rows"]
+
+    def tensor(self):
+        R = self.realise()[0]
+        R = R.t() if self.transposed else R
+        return R if self.factor == 1.0 else self.backend._force(self.backend._combine("mul", [HostScalar(self.factor), R]))
+
+    def block(self, part):
+        """Column block of R^T . X_wide for the constituent ``part`` of the wide operand, or None."""
+        entry = self.backend._wide.get(part)
+        if entry is None or entry[0] != self.wkey or self.backend._const_cache.get(self.wkey) is not self.xcat:
+            return None
+        width = 1 if part[0] == "ones" else part[1]
+        block = self.statistics()[0][:, entry[1]:entry[1] + width]
+        if self.factor == 1.0:
+            return block
+        return self.backend._force(self.backend._combine("mul", [HostScalar(self.factor), block]))   # (parameter-sized)
+
+    def entropy_terms(self):
+        """(sum_rows lse, sum_rows sum_c r * logit) as host floats: the factor's entropy is their difference.
+        The second is <coefficients, statistics> -- logit = alpha * X_wide . Y is linear in the features."""
+        stats, lse = self.statistics()
+        self.backend.ctx.sync()
+        cross = self.alpha * float((stats.double().cpu().numpy() * self.ycat.double().cpu().numpy().T).sum())
+        return float(lse.item()), cross
+
+
 class DeviceBackend(Backend):
     name = "mi355x-hip"
 
@@ -536,6 +634,8 @@ class DeviceBackend(Backend):
     def _force(self, v):
         if isinstance(v, LazyGemm):
             return self._launch_gemm(v)
+        if isinstance(v, DeferredSoftmax):
+            return v.tensor()
         return self._launch(v) if isinstance(v, Lazy) else v
 
     def _launch_gemm(self, g):
@@ -733,6 +833,26 @@ class DeviceBackend(Backend):
         width = 1 if part[0] == "ones" else part[1]
         return prod[:, off:off + width]
 
+    def _deferred_statistics(self, x, y, x_dot, y_dot, x_batch, y_batch):
+        """dot(R^T-like, Y) with R deferred (never written) and Y a constituent of the wide operand R's logits
+        were formed from: a column block of the statistics the fused pass leaves -- or None."""
+        if x_batch or y_batch or len(x_dot) != 1 or len(y_dot) != 1:
+            return None
+        swap = not isinstance(x, DeferredSoftmax)
+        r, other, r_dot, o_dot = (y, x, y_dot[0], x_dot[0]) if swap else (x, y, x_dot[0], y_dot[0])
+        if isinstance(other, (DeferredSoftmax, Lazy, LazyGemm, HostScalar)) or other.dim() != 2:
+            return None
+        rows_axis = 1 if r.transposed else 0
+        if r_dot != rows_axis or other.dtype != torch.float32:
+            return None
+        free = 1 - o_dot
+        if other.stride(free) != 1 or not self._is_const(other):
+            return None
+        block = r.block((other.data_ptr(), other.shape[free], other.stride(o_dot)))
+        if block is None:
+            return None
+        return block.t() if swap else block          # [N, width], or [width, N] when R is the right operand
+
     def _fold_into_gemm(self, rest, host):
         """scale * dot ** power * E as ONE launch when the product has exactly one other operand,
         a float32 matrix of the result's shape (or broadcast along one of its axes); else None."""
@@ -782,7 +902,7 @@ class DeviceBackend(Backend):
 
     # -- hooks --------------------------------------------------------------------------
     def elemwise(self, op_name, *args):
-        args = list(args)
+        args = [a.tensor() if isinstance(a, DeferredSoftmax) else a for a in args]   # (an element-wise use writes them)
         if all(isinstance(a, HostScalar) for a in args):
             return HostScalar(self._host_elemwise(op_name, [a.value for a in args]))
         if op_name in ("add", "mul"):
@@ -794,9 +914,20 @@ class DeviceBackend(Backend):
         return self._unary(op_name, args[0])
 
     def mul(self, *factors):
-        return self._combine("mul", list(factors))
+        deferred = [f for f in factors if isinstance(f, DeferredSoftmax)]
+        if len(deferred) == 1 and all(isinstance(f, HostScalar) for f in factors if f is not deferred[0]):
+            # a scalar multiple of responsibilities that were not written is still not written
+            return deferred[0].scaled(math.prod(float(f.value) for f in factors if f is not deferred[0]))
+        return self._combine("mul", [f.tensor() if isinstance(f, DeferredSoftmax) else f for f in factors])
 
     def sum(self, x, axes):
+        if isinstance(x, DeferredSoftmax):
+            # column sums of responsibilities that were never written: the ones column of R^T . X_wide
+            rows_axis = 1 if x.transposed else 0
+            col = x.block(("ones", x.xcat.shape[0])) if [a % 2 for a in axes] == [rows_axis] else None
+            if col is not None:
+                return col.reshape(x.ycat.shape[1])
+            x = x.tensor()
         if isinstance(x, LazyGemm):
             x = self._force(x)
         if isinstance(x, HostScalar):
@@ -840,6 +971,12 @@ class DeviceBackend(Backend):
         return y
 
     def dimshuffle(self, x, axes):
+        if isinstance(x, DeferredSoftmax):
+            if tuple(axes) == (1, 0):
+                return x.T
+            if tuple(axes) == (0, 1):
+                return x
+            x = x.tensor()
         if isinstance(x, LazyGemm):
             x = self._force(x)
         if isinstance(x, HostScalar):
@@ -854,13 +991,18 @@ class DeviceBackend(Backend):
         x = self._force(x)
         return torch.diagonal(x, 0, axis1, axis2)     # view; the diagonal axis goes last
 
-    def evaluate_softmax_rows(self, expr, inputs, bindings=None, scale=1.0):
+    def evaluate_softmax_rows(self, expr, inputs, bindings=None, scale=1.0, defer=False):
         """softmax over the last axis of ``scale`` times the value of ``expr`` (a resident Categorical node's update).
         Returns (R, lse, cross, logits): when the value is a tall-skinny product nothing else reads --
         the logits of a mixture, after _concat_products one product [X | X^2 | 1] . coefficients --
         ONE launch (bsc_gemm_softmax_rows) produces R, lse and cross = sum_c R * logits, and
         ``logits`` is None: they never reach memory.  Otherwise the logits are evaluated as usual and
-        returned with their softmax (cross is then None)."""
+        returned with their softmax (cross is then None).
+
+        ``defer=True``: in that one-product case with the left operand a cached wide operand, NOTHING is launched:
+        R comes back as a ``DeferredSoftmax`` (lse and cross None) whose statistics against constituents of the
+        wide operand are formed, when first asked for, in the pass that takes the softmax -- the responsibilities
+        are not written at all unless something else wants them."""
         self._plan, self._cursor = self._plan_for(expr), 0
         logits = None
         try:
@@ -871,6 +1013,13 @@ class DeviceBackend(Backend):
                 if g.power == 1 and g.E is None and xb == 1 and sxk == 1 and k % 8 == 0 \
                         and k <= 64 and n <= 64 and n % 4 == 0 and sxm % 4 == 0 and x.data_ptr() % 16 == 0 \
                         and g.dtype == torch.float32 and len(g.shape) == 2:
+                    wkey = next((key for key, t in self._const_cache.items() if t is x and key[0] == "kcat"), None) \
+                        if defer else None
+                    if wkey is not None and syn == 1 and syk == n:
+                        # (the stacked coefficients live in a plan buffer the next evaluation rewrites: kept apart)
+                        ycat = self.ctx.empty((k, n), torch.float32)
+                        self._map_into(ycat, [k, n], [(y, [syk, syn])])
+                        return DeferredSoftmax(self, x, wkey, ycat, float(g.scale) * float(scale)), None, None, None
                     R = self.ctx.empty((m, n), torch.float32)
                     lse = self.ctx.empty((m,), torch.float32)
                     cross = self.ctx.empty((m,), torch.float32)
@@ -1027,6 +1176,15 @@ class DeviceBackend(Backend):
         return out.permute(1, 0, 2) if swap else out
 
     def tensordot(self, x, y, x_dot, y_dot, x_batch, y_batch):
+        if isinstance(x, DeferredSoftmax) or isinstance(y, DeferredSoftmax):
+            # (the partner may be a deferred element-wise value of constants -- X * X --, whose forced value is
+            # the cached constituent of the wide operand)
+            x = x if isinstance(x, DeferredSoftmax) else self._force(x)
+            y = y if isinstance(y, DeferredSoftmax) else self._force(y)
+            out = self._deferred_statistics(x, y, x_dot, y_dot, x_batch, y_batch)
+            if out is not None:
+                return out
+            x, y = self._force(x), self._force(y)
         free_x = x.dim() - len(x_dot) - len(x_batch)
         free_y = y.dim() - len(y_dot) - len(y_batch)
         if self.fuse:

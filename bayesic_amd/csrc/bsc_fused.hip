@@ -145,6 +145,29 @@ __global__ __launch_bounds__(256) void map_strided_kernel(MapArgs a) {
     }
 }
 
+// Parameter-sized strided maps (a [64, 16] coefficient block transposed into a stacked operand, a column of a
+// statistics matrix): rank <= 2, float32, at most 2^20 elements.  Behind a data-sized pass these run with cold
+// instruction caches, and the generic kernel above -- six 64-bit divisions per element, operand loops over
+// MAXIN x MAXR -- is several KB of code: 28 us per launch for 1 024 elements (profiles/r03_derived_mog_*).  Here
+// the index arithmetic is one 32-bit division and the operand loop has its real trip count.
+template <int NIN>
+__global__ __launch_bounds__(256) void map_small_f32_kernel(MapArgs a) {
+    const unsigned n = (unsigned)a.n_out;
+    const unsigned n1 = a.keep.rank == 2 ? (unsigned)a.keep.shape[1] : 1u;
+    const int s_out0 = (int)a.out_strides[0], s_out1 = a.keep.rank == 2 ? (int)a.out_strides[1] : 0;
+    for (unsigned flat = blockIdx.x * 256u + threadIdx.x; flat < n; flat += gridDim.x * 256u) {
+        const unsigned i = a.keep.rank == 2 ? flat / n1 : flat, j = a.keep.rank == 2 ? flat - i * n1 : 0u;
+        float v = a.combine == BSC_OP_MUL ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            const int off = (int)i * (int)a.keep_strides[k][0] + (int)j * (int)a.keep_strides[k][1];
+            const float x = apply_unary<float, false>(a.pre_op[k], static_cast<const float*>(a.in[k])[off], a.pre_arg[k]);
+            v = a.combine == BSC_OP_MUL ? v * x : v + x;
+        }
+        static_cast<float*>(a.out)[(int)i * s_out0 + (int)j * s_out1] = finish_value<float, false>(a, v);
+    }
+}
+
 // every operand dense in the output's order (or one broadcast value): 16 B per lane,
 // U float4 per operand in flight
 // (period_mask: operand k is a row vector of `period4` float4 repeated down the rows -- a bias
@@ -675,6 +698,31 @@ void sort_axes(AxisGroup& g, int n_rows, int key) {
 
 extern "C" {
 
+}  // extern "C"
+
+namespace {
+// every offset of the small map fits 32 bits, and pow (if any) is one of the cheap cases
+bool small_ok(const MapArgs& m, int rank, int n_in) {
+    auto span = [&](const int64_t* strides) {
+        int64_t lo = 0, hi = 0;
+        for (int a = 0; a < rank; ++a) {
+            const int64_t e = (m.keep.shape[a] - 1) * strides[a];
+            if (e < 0) lo += e; else hi += e;
+        }
+        return lo > -(int64_t(1) << 30) && hi < (int64_t(1) << 30);
+    };
+    auto pow_ok = [](int op, double arg) {
+        return op != BSC_OP_POW || arg == -1.0 || arg == 2.0 || arg == 0.5 || arg == 1.0;
+    };
+    if (!span(m.out_strides) || !pow_ok(m.post_op, m.post_arg)) return false;
+    for (int k = 0; k < n_in; ++k)
+        if (!span(m.keep_strides[k]) || !pow_ok(m.pre_op[k], m.pre_arg[k])) return false;
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
 int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
                    const int64_t* host_keep_shape, int rank_red, const int64_t* host_red_shape,
                    int n_in, const void* const* host_in, const int64_t* host_in_keep_strides,
@@ -846,6 +894,14 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
             else
                 hipLaunchKernelGGL(map_dense_f32_kernel<2>, dim3((unsigned)blocks), dim3(256), 0,
                                    ctx->stream, m, n4, scalar_mask);
+        } else if (!special && dtype == BSC_F32 && keep.rank <= 2 && n_out <= (1 << 20) && n_in <= 4 && small_ok(m, keep.rank, n_in)) {
+            const unsigned blocks = (unsigned)((n_out + 255) / 256);
+            switch (n_in) {
+                case 1: hipLaunchKernelGGL(map_small_f32_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, m); break;
+                case 2: hipLaunchKernelGGL(map_small_f32_kernel<2>, dim3(blocks), dim3(256), 0, ctx->stream, m); break;
+                case 3: hipLaunchKernelGGL(map_small_f32_kernel<3>, dim3(blocks), dim3(256), 0, ctx->stream, m); break;
+                default: hipLaunchKernelGGL(map_small_f32_kernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, m); break;
+            }
         } else {
             int64_t blocks = (n_out + 255) / 256;
             const int64_t cap = (int64_t)ctx->cu_count * 8;

@@ -346,6 +346,9 @@ class CategoricalNode(LatentNode):
             # H = sum_n (lse_n - sum_k r_nk eta_nk): no log of a responsibility that underflowed
             b = self._backend
             r = self.expectations_backend()[0]
+            if hasattr(r, "entropy_terms"):        # responsibilities that were never written: from their statistics
+                lse_total, cross_total = r.entropy_terms()
+                return lse_total - cross_total
             if self.eta[0] is None:
                 return float(np.prod(self._shape[:-1]) * math.log(self._shape[-1]))
             lse = self._cache[1]
@@ -507,6 +510,8 @@ class MeanFieldVMP(object):
         from ..algebra.backend import resolve_backend
         self.backend = resolve_backend(backend)
         self.fuse_softmax = True    # (False: a resident Categorical node's logits are always materialised)
+        # the responsibilities of a resident Categorical node are not written when only their statistics are wanted
+        self.defer_responsibilities = True
         self._log_joint = list(log_joint) if isinstance(log_joint, (list, tuple)) else [log_joint]
         self._elbo_fns = None
         self.nodes = list(nodes)
@@ -683,7 +688,11 @@ class MeanFieldVMP(object):
             c, _, bound = self._messages[name][0]
             inputs = dict(self._data)
             inputs.update(self._expectation_inputs(node))
-            r, lse, cross, logits = self.backend.evaluate_softmax_rows(c, inputs, bound, scale=message_scale)
+            # (defer: when every neighbour asks only for statistics of the responsibilities against the features
+            # the logits were formed from, the device takes them in the softmax's own pass and the [rows, K]
+            # responsibilities are never written -- device_backend.DeferredSoftmax)
+            r, lse, cross, logits = self.backend.evaluate_softmax_rows(c, inputs, bound, scale=message_scale,
+                                                                       **({"defer": True} if self.defer_responsibilities else {}))
             if logits is None:
                 node.set_softmax(r, lse, cross)
             else:

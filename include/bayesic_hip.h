@@ -316,6 +316,21 @@ int bsc_gemm_softmax_rows(bsc_ctx* ctx, const float* A, int64_t lda, int64_t row
                           const float* B, int64_t ldbk, int64_t ldbn, int32_t N, float alpha, float* R,
                           int64_t ldr, float* lse, float* cross);
 
+/* ... and the statistics every neighbour of that latent asks for, in the same pass:
+ *   stats[c, f] = sum_r R[r, c] A[r, f]          (float32 [N, K], rows ldst apart),   lse_sum[0] = sum_r lse[r]
+ * -- R^T . A with A = [T_1(x) | T_2(x) | .. | 1] the feature matrix the logits were formed from: the
+ * responsibility-weighted sufficient statistics of a mixture with exponential-family components (statistics
+ * of iid draws add up, bayesic/distribution/base.py:329-332; marginalisation by summation README.md:43,72) and,
+ * through the ones column, the responsibilities' column sums.  The tile's responsibilities go from the softmax
+ * registers through wave-private LDS into the backward MFMAs; R (may be NULL) is written only when something
+ * else reads it.  csrc/bsc_mog.hip's E-step for any feature matrix of up to 64 columns; float64 fixed-order
+ * finish.  `bias` (may be NULL; N values ldbn apart): L = alpha * (A . B + bias) -- the feature matrix's ones
+ * column taken out of the product; its statistic, the column sums sum_r R[r, c], is then written to
+ * stats[c, K] (ldst >= K + 1, K <= 56).  Same limits as bsc_gemm_softmax_rows otherwise. */
+int bsc_gemm_softmax_stats(bsc_ctx* ctx, const float* A, int64_t lda, int64_t rows, int32_t K,
+                           const float* B, int64_t ldbk, int64_t ldbn, int32_t N, float alpha, const float* bias,
+                           float* R, int64_t ldr, float* stats, int64_t ldst, double* lse_sum);
+
 /* Fixed-gamma local step of the LDA-style Dirichlet-Multinomial model (BASELINE
  * config 4): sstats[k,v] = Bt[k,v] * sum_d Th[d,k] C[d,v] / (sum_k' Th[d,k'] Bt[k',v]),
  * the algebra expression Bt * dot(Th.T, C / dot(Th, Bt)) (lowered by
