@@ -44,7 +44,7 @@ from ..device import Context, default_context
 from .backend import Backend
 
 _OPS = {"add": 0, "mul": 1, "log": 2, "exp": 3, "pow": 4, "abs_": 5, "copy": 6, "gammaln": 7,
-        "digamma": 8}
+        "digamma": 8, "scale": 9}
 _DT = {torch.float32: 0, torch.float64: 1}
 _MAX_RANK = 6
 
@@ -105,6 +105,22 @@ class LazyGemm(object):
 
     def dim(self):
         return len(self.shape)
+
+
+class LazyLda(LazyGemm):
+    """``dot(Th.T, C / dot(Th, Bt))`` not launched yet: the inner product with its division folded in
+    (``inner``, a LazyGemm with power -1 and E = C) under an outer product with the SAME Th.  If the consumer is
+    ``Bt * (.)`` with the same Bt -- the fixed-gamma statistic of an LDA-style Dirichlet-Multinomial model,
+    ``Bt * dot(Th.T, C / dot(Th, Bt))`` (cfg 4) -- the whole expression is ONE pass over the
+    count matrix (bsc_lda_sstats, csrc/bsc_lda.hip: neither docs x V intermediate exists); anything else forces
+    the two products as before."""
+
+    __slots__ = ("inner", "outer_x", "outer_axes", "C", "Th", "Bt")
+
+    def __init__(self, inner, outer_x, outer_axes, C, Th, Bt, shape):
+        LazyGemm.__init__(self, None, shape, torch.float32)
+        self.inner, self.outer_x, self.outer_axes = inner, outer_x, outer_axes
+        self.C, self.Th, self.Bt = C, Th, Bt
 
 
 def _i64(values):
@@ -639,6 +655,10 @@ class DeviceBackend(Backend):
         return self._launch(v) if isinstance(v, Lazy) else v
 
     def _launch_gemm(self, g):
+        if isinstance(g, LazyLda):          # not consumed by Bt * (.): the two products after all
+            q = self._launch_gemm(g.inner)
+            x_dot, y_dot = g.outer_axes
+            return self._force(self.tensordot(g.outer_x, q, x_dot, y_dot, [], []))
         xb, m, n, k, x, sxb, sxm, sxk, y, syb, syk, syn = g.gemm
         out = self._empty(g.shape, g.dtype)
         if g.power == 1 and g.E is None and g.scale == 1.0:
@@ -658,6 +678,8 @@ class DeviceBackend(Backend):
         return out
 
     def _unary(self, op_name, x, arg=0.0):
+        if isinstance(x, LazyLda):
+            x = self._force(x)
         if isinstance(x, LazyGemm):
             if self.fuse and op_name == "pow" and float(arg) in (1.0, -1.0) and x.E is None and \
                     x.power == 1 and x.scale == 1.0:
@@ -677,6 +699,12 @@ class DeviceBackend(Backend):
         rest = [a for a in args if not isinstance(a, HostScalar)]
         if not rest:
             return HostScalar(self._host_elemwise(op_name, host))
+        ldas = [a for a in rest if isinstance(a, LazyLda)]
+        if ldas:
+            out = self._lda_statistic(rest, host) if (mul and len(ldas) == 1) else None
+            if out is not None:
+                return out
+            rest = [self._force(a) if isinstance(a, LazyLda) else a for a in rest]
         gemms = [a for a in rest if isinstance(a, LazyGemm)]
         if gemms:
             fused = self._fold_into_gemm(rest, host) if (mul and self.fuse and len(gemms) == 1) else None
@@ -704,6 +732,12 @@ class DeviceBackend(Backend):
                     else:
                         coef = coef + a.shift
                     terms += a.terms
+                    continue
+                if not mul and single and a.post is None and a.shift == 0.0 and a.terms[0][1] is None \
+                        and a.dtype == torch.float32:
+                    # c * t as an addend: the coefficient rides on the operand (BSC_OP_SCALE), so that
+                    # (1 - rho) eta + rho m -- every damped update -- is one launch instead of three
+                    terms.append((a.terms[0][0], "scale", float(a.scale)))
                     continue
                 a = self._force(a)
             terms.append((a, None, 0.0))
@@ -852,6 +886,41 @@ class DeviceBackend(Backend):
         if block is None:
             return None
         return block.t() if swap else block          # [N, width], or [width, N] when R is the right operand
+
+    def _lda_pattern(self, x, y, x_dot, y_dot):
+        """x = Th^T (a view), y = C / dot(Th, Bt) still deferred: a LazyLda, or None."""
+        if not (isinstance(x, torch.Tensor) and x.dim() == 2 and x.dtype == torch.float32 and y.scale == 1.0
+                and y.dtype == torch.float32 and len(y.shape) == 2 and list(y_dot) == [0] and len(x_dot) == 1):
+            return None
+        xb, docs, V, K, Th, sxb, ldth, sxk, Bt, syb, ldb, syn = y.gemm
+        C = y.E
+        kx = 1 - x_dot[0]                           # x's free axis: the topics
+        if xb != 1 or sxk != 1 or syn != 1 or K not in (32, 64, 96, 128) or x.shape[kx] != K \
+                or x.shape[x_dot[0]] != docs or x.data_ptr() != Th.data_ptr() or x.stride(kx) != 1 \
+                or x.stride(x_dot[0]) != ldth or not isinstance(C, torch.Tensor) or tuple(C.shape) != (docs, V) \
+                or C.stride(1) != 1 or ldth < K or ldb < V or C.stride(0) < V:
+            return None
+        out = LazyLda(y, x, (list(x_dot), list(y_dot)), C, (Th, ldth), (Bt, ldb), (K, V) if kx == 0 else (V, K))
+        return out if kx == 0 else None
+
+    def _lda_statistic(self, rest, host):
+        """Bt * LazyLda with the LazyLda's own Bt: bsc_lda_sstats (one pass over C), else None."""
+        g = next(a for a in rest if isinstance(a, LazyLda))
+        others = [a for a in rest if a is not g]
+        (Bt, ldb), (Th, ldth) = g.Bt, g.Th
+        K, V = g.shape
+        if len(others) != 1 or not isinstance(others[0], torch.Tensor):
+            return None
+        E = others[0]
+        if E.dtype != torch.float32 or tuple(E.shape) != (K, V) or E.data_ptr() != Bt.data_ptr() or \
+                E.stride(1) != 1 or E.stride(0) != ldb:
+            return None
+        docs = g.C.shape[0]
+        out = self._empty((K, V), torch.float32)
+        self.ctx.call("bsc_lda_sstats", _ffi.ptr(g.C), g.C.stride(0), docs, V, K, _ffi.ptr(Th), ldth, _ffi.ptr(Bt),
+                      ldb, _ffi.ptr(out), V)
+        scale = math.prod(host) if host else 1.0
+        return out if scale == 1.0 else self._combine("mul", [HostScalar(scale), out])
 
     def _fold_into_gemm(self, rest, host):
         """scale * dot ** power * E as ONE launch when the product has exactly one other operand,
@@ -1007,7 +1076,7 @@ class DeviceBackend(Backend):
         logits = None
         try:
             root = Backend.evaluate(self, expr, inputs, bindings)
-            g = root if isinstance(root, LazyGemm) else None
+            g = root if (isinstance(root, LazyGemm) and not isinstance(root, LazyLda)) else None
             if g is not None and self._keep is None:
                 xb, m, n, k, x, sxb, sxm, sxk, y, syb, syk, syn = g.gemm
                 if g.power == 1 and g.E is None and xb == 1 and sxk == 1 and k % 8 == 0 \
@@ -1176,6 +1245,11 @@ class DeviceBackend(Backend):
         return out.permute(1, 0, 2) if swap else out
 
     def tensordot(self, x, y, x_dot, y_dot, x_batch, y_batch):
+        if self.fuse and isinstance(y, LazyGemm) and not isinstance(y, LazyLda) and y.power == -1 and y.E is not None \
+                and not x_batch and not y_batch and self._plan is not None:
+            lda = self._lda_pattern(x, y, x_dot, y_dot)
+            if lda is not None:
+                return lda
         if isinstance(x, DeferredSoftmax) or isinstance(y, DeferredSoftmax):
             # (the partner may be a deferred element-wise value of constants -- X * X --, whose forced value is
             # the cached constituent of the wide operand)

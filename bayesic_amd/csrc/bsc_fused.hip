@@ -94,6 +94,7 @@ __device__ __forceinline__ T apply_unary(int op, T x, double arg) {
         case BSC_OP_LOG: return log(x);
         case BSC_OP_EXP: return exp(x);
         case BSC_OP_ABS: return fabs(x);
+        case BSC_OP_SCALE: return x * (T)arg;
         case BSC_OP_POW:
             if (arg == -1.0) return (T)1 / x;
             if (arg == 2.0) return x * x;
@@ -738,7 +739,7 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
     BSC_REQUIRE(n_in >= 1 && n_in <= MAXIN && host_in && host_pre_op && host_pre_arg && out,
                 "bsc_map_reduce: bad operands");
     auto unary_ok = [](int op) {
-        return op == BSC_OP_COPY || op == BSC_OP_LOG || op == BSC_OP_EXP || op == BSC_OP_ABS ||
+        return op == BSC_OP_COPY || op == BSC_OP_SCALE || op == BSC_OP_LOG || op == BSC_OP_EXP || op == BSC_OP_ABS ||
                op == BSC_OP_POW || op == BSC_OP_LGAMMA || op == BSC_OP_DIGAMMA;
     };
     BSC_REQUIRE(unary_ok(post_op), "bsc_map_reduce: post op %d is not unary", post_op);

@@ -410,7 +410,7 @@ __global__ __launch_bounds__(1024) void mog_expected_params_kernel(const double*
                 c += 0.5 * elog_tau - 0.5 * LOG_2PI - 0.5 * T * m * m - 0.5 / kappa;
                 Wmat[(int64_t)k * 2 * D + d] = (float)(T * m);
                 Wmat[(int64_t)k * 2 * D + D + d] = (float)(-0.5 * T);
-                ga += r_a.lg - a * log_b - 0.5 * log_k;
+                ga += r_a.lg - a * log_b - 0.5 * log_k + 0.5 * LOG_2PI;
                 if (with_bound) {
                     const double p1 = eta0[K + i], kappa0 = eta0[K + KD + i], p3 = eta0[K + 2 * KD + i],
                                  p4 = eta0[K + 3 * KD + i];

@@ -18,6 +18,16 @@ everything parameter-sized (S x P numbers) is host float64.
 Noise is Philox4x32-10 keyed (parameter block, sample, stream 2, step) -- the keying of
 bsc_bbvi_sample -- so with the same seed this engine and the fused config-5 kernel see the
 same draws (tests/test_inference.py cross-checks them).
+
+**The fused route** (``route="auto"``, the default).  ``recognise.logistic_hierarchy`` evaluates the
+log-joint on a seven-row instance in host float64 and asks whether it IS
+scale * sum_n [y_n l_ns - softplus(l_ns)] + the hierarchical Gaussian / Gamma prior of config 5 for some
+(scale, a0, b0), the group of a row given by a one-hot matrix ``Gm`` (``dot(Gm, B.T)`` is how the plugin
+surface writes a gathered intercept).  If so -- and ``Gm`` really is one-hot, which is checked on the
+device -- the update is svi/bbvi.py's: bsc_logreg_bbvi_loglik (ONE pass over X on fp32 MFMA) and
+bsc_bbvi_update (f, control variate, gradient, Adam, next draws), state on the device, ``step()``
+asynchronous, ``elbo`` / ``grad`` / ``f`` / ``lam`` read back on access; same draws, so the same update as
+the general route up to float32 evaluation order.  ``route="general"`` never takes it, ``"fused"`` insists.
 """
 import math
 
@@ -35,7 +45,7 @@ class ScoreFunctionVI(object):
     """
 
     def __init__(self, log_joint, latents, data, n_samples, seed=0, lr=1e-2, backend=None,
-                 lam0=None, graph=False):
+                 lam0=None, graph=False, route="auto"):
         from ..algebra.backend import resolve_backend
         from ..algebra.device_backend import DeviceBackend
         self.backend = resolve_backend(backend)
@@ -50,13 +60,14 @@ class ScoreFunctionVI(object):
                 raise ValueError("latent %s must be [samples, size] (ndim 2)" % v.name)
         self.P = sum(n for _, n in self.latents)
         self.S, self.seed, self.lr = int(n_samples), int(seed), float(lr)
-        self.lam = np.zeros(2 * self.P)
+        self._fused = None
+        self._lam = np.zeros(2 * self.P)
         if lam0 is None:
-            self.lam[self.P:] = math.log(0.05)
+            self._lam[self.P:] = math.log(0.05)
         else:
-            self.lam[:] = np.asarray(lam0, np.float64)
-        self.m1, self.m2 = np.zeros_like(self.lam), np.zeros_like(self.lam)
-        self.t = 0
+            self._lam[:] = np.asarray(lam0, np.float64)
+        self.m1, self.m2 = np.zeros_like(self._lam), np.zeros_like(self._lam)
+        self._t = 0
         # graph=True: the evaluation's launches are recorded once as a hipGraph and replayed
         # (DeviceBackend.compile(graph=True)); the latent draws then live in fixed device buffers
         self._graph = bool(graph)
@@ -71,7 +82,102 @@ class ScoreFunctionVI(object):
         self._types = types
         import torch
         self._eps_dev = torch.zeros((self.S, self.P), dtype=torch.float64, device=self.backend.ctx.device)
-        self.elbo, self.grad, self.f = None, None, None
+        self._elbo, self._grad, self._fv = None, None, None
+        if route not in ("auto", "general", "fused"):
+            raise ValueError("route must be 'auto', 'general' or 'fused'")
+        self.route, self.plan = "general", None
+        if route != "general":
+            why = self._try_fused_route(log_joint)
+            if why is not None and route == "fused":
+                raise ValueError("route='fused': %s" % why)
+
+    # -- the fused route (module docstring) -------------------------------------------------------
+    def _try_fused_route(self, log_joint):
+        import torch
+        from . import recognise
+        shapes = {n: tuple(int(k) for k in v.shape) for n, v in self._data.items()}
+        plan = recognise.logistic_hierarchy(log_joint, self.latents, shapes, self.S)
+        if plan is None:
+            return "the log-joint is not config 5's hierarchical logistic regression in any parameterisation"
+        self.plan = plan
+        X, y, Gm = self._data[plan.X], self._data[plan.y], self._data[plan.onehot]
+        if not all(isinstance(t, torch.Tensor) and t.dtype == torch.float32 for t in (X, y, Gm)):
+            return "the fused pass streams float32 data"
+        N, D = X.shape
+        G = Gm.shape[1]
+        if D > 256 or D % 4 or self.S > 128 or X.stride(1) != 1:
+            return "outside the fused pass's envelope (D <= 256 and a multiple of 4, S <= 128, row-major X)"
+        # the group matrix must be one-hot: every entry 0 or 1 (sum of squares = sum) and one per row (sum = N,
+        # every row sum 1) -- reductions through the executor; the index vector is the matrix times 0 .. G - 1
+        b = self.backend
+        from .. import algebra as A
+        Gv = A.var("Gm", 2)
+        ramp = b.from_host(np.arange(G, dtype=np.float32), "float32", 1)
+        # (no negative entry: sum |x| = sum x; rows sum to one: sum_n r_n = sum_n r_n^2 = N; then sum x^2 = N iff one-hot)
+        checks = [A.sum(Gv), A.sum(Gv * Gv), A.sum(A.sum(Gv, axis=1) * A.sum(Gv, axis=1)), A.sum(A.abs_(Gv))]
+        total, squares, row_squares, absolute = (float(np.asarray(b.to_host(e.compile(b).device_fn(Gm=Gm))))
+                                                 for e in checks)
+        if not (total == float(N) and squares == float(N) and row_squares == float(N) and absolute == float(N)):
+            return "the group matrix %s is not one-hot" % plan.onehot
+        g = b.materialize(A.dot(Gv, A.var("ramp", 1)).compile(b).device_fn(Gm=Gm, ramp=ramp))
+        g = g.round().to(torch.int32)                     # (dtype conversion: plumbing)
+        order = [v.name for v, _ in self.latents]
+        if order != [plan.W, plan.B, plan.zeta]:
+            return "latents must be listed as (weights, group intercepts, log precision) for the fused layout"
+        from ..svi.bbvi import LogRegBBVI
+        self._fused = LogRegBBVI(X, y, g, G, n_total=plan.scale * N, n_samples=self.S, seed=self.seed, lr=self.lr,
+                                 a0=plan.a0, b0=plan.b0, ctx=b.ctx, lam0=self._lam)
+        self.route = "fused: bsc_logreg_bbvi_loglik + bsc_bbvi_update"
+        return None
+
+    @property
+    def lam(self):
+        return self._fused.lam.cpu().numpy() if self._fused is not None else self._lam
+
+    @lam.setter
+    def lam(self, value):
+        if self._fused is not None:
+            raise AttributeError("on the fused route the variational parameters live on the device; build the "
+                                 "engine with lam0=")
+        self._lam = value
+
+    @property
+    def t(self):
+        return self._fused.t if self._fused is not None else self._t
+
+    @t.setter
+    def t(self, value):
+        self._t = value
+
+    @property
+    def elbo(self):
+        if self._fused is not None:
+            return float(self._fused.elbo.item()) + self.plan.offset if self._fused.t else None
+        return self._elbo
+
+    @elbo.setter
+    def elbo(self, value):
+        self._elbo = value
+
+    @property
+    def grad(self):
+        if self._fused is not None:
+            return self._fused.grad.cpu().numpy() if self._fused.t else None
+        return self._grad
+
+    @grad.setter
+    def grad(self, value):
+        self._grad = value
+
+    @property
+    def f(self):
+        if self._fused is not None:
+            return self._fused.f.cpu().numpy() + self.plan.offset if self._fused.t else None
+        return self._fv
+
+    @f.setter
+    def f(self, value):
+        self._fv = value
 
     def set_data(self, **arrays):
         """Replace data inputs (the next mini-batch; write the data term times N / B)."""
@@ -79,6 +185,9 @@ class ScoreFunctionVI(object):
             if name not in self._types or name in {v.name for v, _ in self.latents}:
                 raise TypeError("%s is not a data input of the log-joint" % name)
             self._data[name] = self.backend.from_host(value, *self._types[name])
+        if self._fused is not None:
+            raise NotImplementedError("set_data on the fused route: build a new engine for another mini-batch "
+                                      "(the one-hot group matrix is converted to an index vector at construction)")
 
     def draw(self, step):
         """eps [S, P] for Philox step `step` (device draw, downloaded: parameter-sized)."""
@@ -124,6 +233,9 @@ class ScoreFunctionVI(object):
         return f.mean(), grad, f
 
     def step(self):
+        if self._fused is not None:
+            self._fused.step()          # asynchronous: one pass over X + the fused update, on the context's stream
+            return None
         self.t += 1
         self.elbo, self.grad, self.f = self.estimate(self.t - 1)
         b1, b2, eps = 0.9, 0.999, 1e-8

@@ -273,3 +273,169 @@ def _fit_family(plan, Wv, D, others, rng):
     except (ValueError, KeyError, FloatingPointError):
         return None
     return (float(c0), float(c_xi), float(s_q), float(k_w), float(beta), xi_v.name)
+
+
+# ---- the diagonal Gaussian mixture (config 3) ---------------------------------------------------
+
+def _mog_message_fused(R, X, K, D):
+    """The natural-parameter increment svi/mog.py's kernels apply, from responsibilities: fused layout
+    [sum r (K) | R^T X (K D) | sum r (K D) | sum r (K D) | R^T X^2 (K D)]."""
+    Rk = R.sum(axis=0)
+    Rkd = np.repeat(Rk[:, None], D, axis=1)
+    return np.concatenate([Rk, (R.T @ X).ravel(), Rkd.ravel(), Rkd.ravel(), (R.T @ (X * X)).ravel()])
+
+
+def diagonal_mixture(log_joint, Z, pi, ng_vars, X_name, K, D, scale, dtype="float64"):
+    """Is the mean-field update DERIVED from ``log_joint`` (conjugacy.conjugate_coefficients: every message a
+    coefficient ``match`` pulled out of a term) the update csrc/bsc_mog.hip computes -- a Categorical local
+    latent ``Z`` [N, K] whose logits are E[log pi_k] + sum_d (E[tau mu] x - E[tau] x^2 / 2 + E[log tau] / 2 -
+    E[tau mu^2] / 2), a Dirichlet ``pi`` and Normal-Gamma factors (``ng_vars`` = the four statistic variables)
+    receiving [sum r | R^T X | R^T X^2] times ``scale`` on top of their priors?  Decided by running the derived
+    update rules on a six-row instance in host float64 and comparing with that closed form at random
+    parameters: identity testing by evaluation.  Returns the prior's natural parameters in the fused layout
+    [alpha0 - 1 | kappa0 m0 | kappa0 | 2 a0 - 1 | 2 b0 + kappa0 m0^2], or None."""
+    from scipy.special import digamma
+    from .vmp import CategoricalNode, DirichletNode, MeanFieldVMP, NormalGammaNode
+    rng = np.random.RandomState(77)
+    n = 6
+    eta0 = None
+    try:
+        for trial in range(2):
+            X = rng.standard_normal((n, D)) * 1.3
+            alpha = rng.uniform(0.5, 4.0, K)
+            m, kappa = rng.standard_normal((K, D)), rng.uniform(0.5, 3.0, (K, D))
+            a, b = rng.uniform(1.0, 4.0, (K, D)), rng.uniform(0.5, 3.0, (K, D))
+            R = rng.dirichlet(np.ones(K), n)
+            z = CategoricalNode(Z, log_prob=np.log(R))
+            vmp = MeanFieldVMP(log_joint, [z, DirichletNode(pi, alpha=alpha),
+                                           NormalGammaNode(*ng_vars, m=m, kappa=kappa, a=a, b=b)],
+                               {X_name: X}, backend=_PROBE)
+            # messages of the global factors, in the fused layout (NormalGammaNode keeps
+            # (kappa m, -kappa / 2, a - 1/2, -b - kappa m^2 / 2): the fused layout is (e1, -2 e2, 2 e3, -2 e4))
+            (m_pi,) = vmp.message(pi.name)
+            g = [np.broadcast_to(np.asarray(v, np.float64), (K, D)) for v in vmp.message(ng_vars[0].name)]
+            got = np.concatenate([np.broadcast_to(m_pi, (K,)), g[0].ravel(), (-2.0 * g[1]).ravel(),
+                                  (2.0 * g[2]).ravel(), (-2.0 * g[3]).ravel()])
+            prior = got - scale * _mog_message_fused(R, X, K, D)
+            if eta0 is None:
+                eta0 = prior
+            elif not np.allclose(prior, eta0, rtol=1e-9, atol=1e-9):
+                return None                 # not "prior + scale * statistics" with a fixed prior
+            # the local latent's logits (up to a constant per row, which the softmax does not see)
+            (logits,) = vmp.message(Z.name)
+            T = a / b
+            want = scale * ((digamma(alpha) - digamma(alpha.sum()))[None, :]
+                            + X @ (T * m).T - 0.5 * (X * X) @ T.T
+                            + (0.5 * (digamma(a) - np.log(b)) - 0.5 * (1.0 / kappa + m * m * T)).sum(axis=1)[None, :])
+            d1 = logits - logits[:, :1]
+            d2 = want - want[:, :1]
+            if not np.allclose(d1, d2, rtol=1e-9, atol=1e-9 * np.abs(d2).max()):
+                return None
+    except Exception:       # not conjugate, other node types, shapes that do not fit ...: not this model
+        return None
+    kappa0 = eta0[K + K * D:K + 2 * K * D]
+    if not (np.all(kappa0 > 0.0) and np.all(eta0[:K] > -1.0)):
+        return None
+    return eta0
+
+
+# ---- hierarchical logistic regression (config 5) ----------------------------------------------------
+
+class LogisticHierarchy(object):
+    """What ``logistic_hierarchy`` found: log p(data, z_s) = scale * sum_n [y_n l_ns - softplus(l_ns)] +
+    log N(w_s | 0, I) + sum_g log N(b_sg | 0, e^{-zeta_s}) + log Gamma(e^{zeta_s} | a0, b0) + zeta_s + offset,
+    l_ns = x_n . w_s + b_{s, g_n} -- the model csrc/bsc_bbvi.hip's kernels compute, the group of row n given
+    by a one-hot matrix in the symbolic form (``dot(Gm, B.T)``) and by an index vector on the device."""
+
+    def __init__(self, X, y, onehot, W, B, zeta, scale, a0, b0, offset):
+        self.X, self.y, self.onehot, self.W, self.B, self.zeta = X, y, onehot, W, B, zeta
+        self.scale, self.a0, self.b0, self.offset = scale, a0, b0, offset
+
+
+def logistic_hierarchy(log_joint, latents, data_shapes, n_samples):
+    """Identity testing by evaluation on a seven-row instance (host float64): the log-joint must be the closed
+    form above for SOME (scale, a0, b0, offset), whatever way it was written.  Returns a ``LogisticHierarchy``
+    or None."""
+    import math
+    types = log_joint.input_types
+    if len(latents) != 3:
+        return None
+    # explicit extents (a log-normaliser times the number of rows) keep the REAL data's value; the sums over the
+    # rows are then taken over the instance's rows
+    shapes = dict(data_shapes)
+    shapes.update({v.name: (n_samples, size) for v, size in latents})
+    try:
+        log_joint = _without_shapes(log_joint, shapes)
+    except (ValueError, KeyError):
+        return None
+    two_d = [n for n in data_shapes if types.get(n, (None, 0))[1] == 2]
+    one_d = [n for n in data_shapes if types.get(n, (None, 0))[1] == 1]
+    rng = np.random.RandomState(31)
+    n = 7
+    for Xn in two_d:
+        for Gn in two_d:
+            if Gn == Xn or data_shapes[Gn][0] != data_shapes[Xn][0]:
+                continue
+            D, G = data_shapes[Xn][1], data_shapes[Gn][1]
+            by_size = {}
+            for v, size in latents:
+                by_size.setdefault(size, []).append(v)
+            if D == G or D == 1 or G == 1 or sorted(by_size) != sorted({D, G, 1}) \
+                    or any(len(vs) != 1 for vs in by_size.values()):
+                continue
+            Wv, Bv, Zv = by_size[D][0], by_size[G][0], by_size[1][0]
+            for yn in one_d:
+                if data_shapes[yn][0] != data_shapes[Xn][0]:
+                    continue
+                try:
+                    def draw_data():
+                        g = rng.randint(G, size=n)
+                        return rng.standard_normal((n, D)), (rng.uniform(size=n) < 0.5).astype(np.float64), g
+
+                    def F(data, w, b, zeta):
+                        X, y, g = data
+                        return np.asarray(_PROBE.evaluate(log_joint, {
+                            Xn: X, yn: y, Gn: np.eye(G)[g], Wv.name: w, Bv.name: b, Zv.name: zeta[:, None]}),
+                            np.float64).reshape(-1)
+
+                    def ell(data, w, b):
+                        X, y, g = data
+                        L = X @ w.T + b[:, g].T
+                        return (y[:, None] * L - np.logaddexp(0.0, L)).sum(axis=0)
+
+                    S = 3
+                    # the shapes of the REAL data enter the expression only through resolved extents: none here
+                    # (sums over rows are sums over the instance's rows), so the instance stands for any size
+                    d1, d2 = draw_data(), draw_data()
+                    w, b, zeta = rng.standard_normal((S, D)) * 0.5, rng.standard_normal((S, G)) * 0.5, rng.standard_normal(S) * 0.5
+                    de = ell(d1, w, b) - ell(d2, w, b)
+                    scale_s = (F(d1, w, b, zeta) - F(d2, w, b, zeta)) / de
+                    scale = float(scale_s[0])
+                    if not (np.isfinite(scale) and scale > 0 and np.allclose(scale_s, scale, rtol=1e-9)):
+                        continue
+                    zero_w, zero_b = np.zeros((1, D)), np.zeros((1, G))
+                    r = lambda zt: (F(d1, zero_w, zero_b, np.array([zt])) - scale * ell(d1, zero_w, zero_b))[0]
+                    t = 1.0
+                    r0, r1, r2 = r(0.0), r(t), r(-t)
+                    # r(zeta) = c + (a0 + G / 2) zeta - b0 e^{zeta}
+                    b0 = -((r1 + r2) - 2.0 * r0) / (math.exp(t) + math.exp(-t) - 2.0)
+                    slope = ((r1 - r2) + b0 * (math.exp(t) - math.exp(-t))) / (2.0 * t)
+                    a0 = slope - 0.5 * G
+                    c = r0 + b0
+                    if not (a0 > 0 and b0 > 0 and np.isfinite(c)):
+                        continue
+                    const = -0.5 * (D + G) * math.log(2 * math.pi) + a0 * math.log(b0) - math.lgamma(a0)
+                    ok = True
+                    for _ in range(3):
+                        w, b, zeta = rng.standard_normal((S, D)), rng.standard_normal((S, G)), rng.standard_normal(S) * 0.7
+                        d = draw_data()
+                        want = scale * ell(d, w, b) - 0.5 * (w * w).sum(1) + 0.5 * G * zeta \
+                            - 0.5 * np.exp(zeta) * (b * b).sum(1) + a0 * zeta - b0 * np.exp(zeta) + c
+                        got = F(d, w, b, zeta)
+                        ok = ok and np.allclose(got, want, rtol=1e-9, atol=1e-9 * np.abs(want).max())
+                    if ok:
+                        return LogisticHierarchy(Xn, yn, Gn, Wv.name, Bv.name, Zv.name, scale, float(a0), float(b0),
+                                                 float(c - const))
+                except Exception:
+                    continue
+    return None

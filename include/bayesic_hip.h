@@ -495,7 +495,9 @@ typedef enum bsc_op {
     BSC_OP_ABS = 5,
     BSC_OP_COPY = 6, /* materialise a strided view */
     BSC_OP_LGAMMA = 7,  /* log Gamma(x): unary, bsc_map_reduce only (log-normalisers of the */
-    BSC_OP_DIGAMMA = 8  /* Gamma / Dirichlet / Wishart nodes and their expectations)        */
+    BSC_OP_DIGAMMA = 8, /* Gamma / Dirichlet / Wishart nodes and their expectations)        */
+    BSC_OP_SCALE = 9    /* x * arg: unary, bsc_map_reduce only -- a per-operand coefficient, so that
+                         * (1 - rho) eta + rho m (the damped natural-gradient step, README.md:75-77) is one launch */
 } bsc_op;
 
 /* out[i] = op(in_0[i], ..., in_{n-1}[i]) over the index space `shape`;
@@ -521,7 +523,7 @@ int bsc_sum(bsc_ctx* ctx, int dtype, int rank_keep, const int64_t* host_keep_sha
  * 1284-1309, 1435-1448), which the reference leaves to Theano's graph optimiser.
  *   v(keep, red) = post( scale * COMBINE_i pre_i( in_i[keep, red] ) + shift )
  *   out[keep]    = sum over red of v(keep, red)     (rank_red == 0: out[keep] = v(keep))
- * combine is BSC_OP_ADD or BSC_OP_MUL; pre_op[i] and post_op are BSC_OP_COPY, LOG,
+ * combine is BSC_OP_ADD or BSC_OP_MUL; pre_op[i] and post_op are BSC_OP_COPY, SCALE, LOG,
  * EXP, ABS, LGAMMA, DIGAMMA or POW (x ** arg, arg taken from pre_arg[i] / post_arg).  in_keep_strides
  * is [n_in][rank_keep], in_red_strides [n_in][rank_red] (0 broadcasts); sums
  * accumulate in float64 in a fixed order. */

@@ -197,7 +197,7 @@ def test_elementwise_trees_fuse_and_match_numpy(dev):
         ((X + Y) * Z, (X_ + Y_) * Z_, 2),
         (exp(X).T * Y.T, np.exp(X_).T * Y_.T, 1),
         (X + Y + Z + 1, X_ + Y_ + Z_ + 1, 1),
-        (X - 2 * Y, X_ - 2 * Y_, 2),
+        (X - 2 * Y, X_ - 2 * Y_, 1),            # the coefficient rides on the operand (BSC_OP_SCALE)
     ]
     for expr, want, launches in cases:
         f = expr.compile(dev)

@@ -868,7 +868,7 @@ def _cfg3_derived_and_oracle(backend, dtype, n, d, k, steps, resident=True, resi
     alpha, m, kappa, a, b = svi.mog_unpack(eta, k, d)
     model = DiagonalMixtureVMP(X if dtype == "float32" else X.astype(np.float64), k, n_total=10.0 * n,
                                init=(alpha, m, kappa, a, b), backend=backend, dtype=dtype, resident=resident,
-                               resident_globals=resident_globals)
+                               resident_globals=resident_globals, route="derived")
     for t in range(1, steps + 1):
         rho = (t + 1.0) ** -0.6
         model.step(rho)
@@ -978,8 +978,9 @@ def test_softmax_inside_the_logits_product_is_the_same_update(ctx):
     models = []
     for fuse in (True, False):
         model = DiagonalMixtureVMP(X, k, n_total=float(n), init=(alpha, m, kappa, a, b),
-                                   backend=DeviceBackend(ctx), dtype="float32")
+                                   backend=DeviceBackend(ctx), dtype="float32", route="derived")
         model.vmp.fuse_softmax = fuse
+        model.vmp.defer_responsibilities = False      # this test is about WRITING the responsibilities in one pass
         calls = []
         real = ctx.call
 
@@ -1027,7 +1028,8 @@ def test_successive_models_on_one_backend_do_not_share_cached_constants(ctx):
         X = (centres[rs.randint(k, size=n)] + rs.standard_normal((n, d))).astype(np.float32)
         eta = svi.mog_init_eta(X[:500], k, d, seed=2)
         alpha, m, kappa, a, b = svi.mog_unpack(eta, k, d)
-        return X, eta, DiagonalMixtureVMP(X, k, n_total=float(n), init=(alpha, m, kappa, a, b), backend=be)
+        return X, eta, DiagonalMixtureVMP(X, k, n_total=float(n), init=(alpha, m, kappa, a, b), backend=be,
+                                          route="derived")
 
     def check(model, X, eta):
         eta0 = svi.mog_prior_eta(k, d)

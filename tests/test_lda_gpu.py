@@ -73,7 +73,9 @@ def test_fused_lda_statistics_match_oracle_and_executor(ctx, docs, V, K):
     npt.assert_allclose(got, want, rtol=3e-5, atol=1e-6)
     if docs:
         Thv, Cv, Bm = A.var("Th", 2), A.var("C", 2), A.var("Bm", 2)
-        f = (Bm * A.dot(Thv.T, Cv / A.dot(Thv, Bm))).compile(DeviceBackend(ctx)).device_fn
+        # (fuse=False: the expression as two products and element-wise launches -- with fusion on, the executor
+        # recognises it and calls the very kernel under test: test_lda_expression_through_compile_is_one_pass)
+        f = (Bm * A.dot(Thv.T, Cv / A.dot(Thv, Bm))).compile(DeviceBackend(ctx, fuse=False)).device_fn
         ex = f(Th=dTh, C=dC, Bm=dBt)
         ctx.sync()
         npt.assert_allclose(got, ex.cpu().numpy(), rtol=3e-5, atol=1e-6)
@@ -324,3 +326,54 @@ def test_lda_elbo_tracks_the_oracle_and_rises_under_unit_steps(ctx, via):
     loud.step()
     ctx.sync()
     npt.assert_allclose(quiet.lam.cpu().numpy(), loud.lam.cpu().numpy(), rtol=1e-5)
+
+
+def test_lda_expression_through_compile_is_one_pass(ctx):
+    """``Bt * dot(Th.T, C / dot(Th, Bt))`` written on the plugin surface and evaluated through
+    ``compile()`` reaches bsc_lda_sstats -- ONE pass over the counts, bit-identical to calling the entry point --
+    while expressions that only look like it take the general route and still get the right numbers."""
+    from bayesic_amd import algebra as A
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    rs = np.random.RandomState(11)
+    docs, V, K = 700, 1000, 64
+    C = rs.poisson(0.3, (docs, V)).astype(np.float32)
+    Th = (rs.rand(docs, K) + 0.05).astype(np.float32)
+    Bt = (rs.rand(K, V) + 0.05).astype(np.float32)
+    Bt2 = (rs.rand(K, V) + 0.05).astype(np.float32)
+    dC, dTh, dBt, dBt2 = (ctx.to_device(v) for v in (C, Th, Bt, Bt2))
+    Thv, Cv, Bm, Bo = A.var("Th", 2), A.var("C", 2), A.var("Bm", 2), A.var("Bo", 2)
+    be = DeviceBackend(ctx)
+    calls = []
+    real_call = ctx.call
+    ctx.call = lambda name, *a: (calls.append(name), real_call(name, *a))[1]
+    try:
+        got = (Bm * A.dot(Thv.T, Cv / A.dot(Thv, Bm))).compile(be).device_fn(Th=dTh, C=dC, Bm=dBt)
+        ctx.sync()
+        assert calls == ["bsc_lda_sstats"], calls
+        direct = torch.empty((K, V), dtype=torch.float32, device=ctx.device)
+        real_call("bsc_lda_sstats", dC, V, docs, V, K, dTh, K, dBt, V, direct, V)
+        ctx.sync()
+        npt.assert_array_equal(got.cpu().numpy(), direct.cpu().numpy())
+        # a scalar factor rides along
+        calls.clear()
+        scaled = (2.5 * (Bm * A.dot(Thv.T, Cv / A.dot(Thv, Bm)))).compile(be).device_fn(Th=dTh, C=dC, Bm=dBt)
+        ctx.sync()
+        assert calls.count("bsc_lda_sstats") == 1 and "bsc_gemm_epilogue" not in calls
+        npt.assert_allclose(scaled.cpu().numpy(), 2.5 * direct.cpu().numpy(), rtol=1e-6)
+        # another matrix outside than inside: not the statistic -- two products, right numbers
+        calls.clear()
+        other = (Bo * A.dot(Thv.T, Cv / A.dot(Thv, Bm))).compile(be).device_fn(Th=dTh, C=dC, Bm=dBt, Bo=dBt2)
+        ctx.sync()
+        assert "bsc_lda_sstats" not in calls
+        want = Bt2.astype(np.float64) * (Th.astype(np.float64).T @ (C / (Th.astype(np.float64) @ Bt.astype(np.float64))))
+        npt.assert_allclose(other.cpu().numpy(), want, rtol=3e-5, atol=1e-6)
+        # K outside the kernel's topic counts: general route
+        calls.clear()
+        K2 = 40
+        Th2, Bt3 = ctx.to_device(Th[:, :K2].copy()), ctx.to_device(Bt[:K2].copy())
+        gen = (Bm * A.dot(Thv.T, Cv / A.dot(Thv, Bm))).compile(be).device_fn(Th=Th2, C=dC, Bm=Bt3)
+        ctx.sync()
+        assert "bsc_lda_sstats" not in calls
+        npt.assert_allclose(gen.cpu().numpy(), svi.lda_sstats(C, Th[:, :K2], Bt[:K2]), rtol=3e-5, atol=1e-6)
+    finally:
+        ctx.call = real_call

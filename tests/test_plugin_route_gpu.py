@@ -131,3 +131,127 @@ def test_plugin_route_runs_at_the_fused_drivers_speed(ctx):
     print("plugin route %.1f us per update, hand-written driver %.1f us" % (t_eng * 1e6, t_ref * 1e6))
     assert t_eng <= 1.3 * t_ref, (t_eng, t_ref)
     assert t_eng <= 0.23e-3
+
+
+# ---- config 3: the symbolic mixture model reaches csrc/bsc_mog.hip -------------------------------------
+
+def test_symbolic_mixture_is_recognised_and_equals_the_oracle(ctx):
+    """inference/mixture.py's model is a symbolic log-joint; route='auto' checks that the update rules match
+    derived from it are the fused kernels' (recognise.diagonal_mixture) and runs those: equal to
+    oracle.svi.mog_svi_step, bound included, with the prior read off the derived messages."""
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from bayesic_amd.inference.mixture import DiagonalMixtureVMP
+    n, d, k = 50_000, 16, 64
+    X, _, _ = svi.make_cfg3(n, d, k)
+    prior = dict(alpha0=1.5, m0=0.1, kappa0=0.05, a0=2.0, b0=0.7)
+    eta0 = svi.mog_prior_eta(k, d, **prior)
+    eta = svi.mog_init_eta(X[:500], k, d, seed=2)
+    alpha, m, kappa, a, b = svi.mog_unpack(eta, k, d)
+    model = DiagonalMixtureVMP(X, k, n_total=10.0 * n, init=(alpha, m, kappa, a, b), backend=DeviceBackend(ctx), **prior)
+    assert model.route.startswith("fused"), model.route
+    derived = DiagonalMixtureVMP(X, k, n_total=10.0 * n, init=(alpha, m, kappa, a, b), backend=DeviceBackend(ctx),
+                                 route="derived", **prior)
+    for t in range(1, 4):
+        rho = (t + 1.0) ** -0.6
+        Wmat, c = svi.mog_expected_params(eta, k, d)
+        _, lse = svi.mog_local_step(X, Wmat, c)
+        want_elbo = svi.mog_elbo(eta, eta0, lse, 10.0, k, d)
+        model.step(rho)
+        derived.step(rho)
+        eta, _, _ = svi.mog_svi_step(eta, eta0, X, 10.0 * n, rho, k, d)
+        npt.assert_allclose(model.elbo(), want_elbo, rtol=2e-6)
+        got = model.eta_fused_layout()
+        scale = np.maximum(np.abs(eta), 1.0)
+        assert (np.abs(got - eta) <= 1e-3 * scale).all(), np.abs((got - eta) / scale).max()   # (K = 64 overlapping components: float32 responsibilities feed back)
+    # the node objects catch up on request: the derived engine's bound at the same state
+    model.sync_nodes()
+    derived.vmp.update("Z", 1.0, message_scale=1.0 / derived.scale)      # (sync_nodes leaves q(z) at its optimum for the new factors)
+    derived_bound = derived.vmp.elbo()
+    npt.assert_allclose(model.vmp.elbo(), derived_bound, rtol=1e-4)
+    with pytest.raises(ValueError, match="MI355X backend"):
+        from oracle.einsum_eval import NumpyBackend
+        ones = np.ones((4, d))
+        DiagonalMixtureVMP(X[:200].astype(np.float64), 4, init=(np.ones(4), 0.0 * ones, ones, ones, ones),
+                           backend=NumpyBackend(np.float64), dtype="float64", resident=False, route="fused")
+
+
+# ---- config 5: the score-function engine reaches csrc/bsc_bbvi.hip ---------------------------------------
+
+def _config5_expression(D, G, scale, a0, b0):
+    import math
+    from bayesic_amd import algebra as A
+    Xv, yv, Gm = A.var("X", 2), A.var("y", 1), A.var("Gm", 2)
+    W, Bg, Z = A.var("W", 2), A.var("Bg", 2), A.var("Z", 2)          # [S, D], [S, G], [S, 1]
+    L = A.dot(Xv, W.T) + A.dot(Gm, Bg.T)                              # logits [N, S]; the group of a row by a one-hot matrix
+    loglik = A.sum(A.dimshuffle(yv, 0, "x") * L - A.log(1 + A.exp(L)), axis=0)
+    zeta = A.sum(Z, axis=1)
+    lp_w = A.sum(-0.5 * (W * W), axis=1) - 0.5 * D * math.log(2 * math.pi)
+    lp_b = (-0.5 * G * math.log(2 * math.pi)) + (0.5 * G) * zeta - 0.5 * (A.exp(zeta) * A.sum(Bg * Bg, axis=1))
+    lp_z = (a0 * math.log(b0) - math.lgamma(a0)) + a0 * zeta - b0 * A.exp(zeta)
+    return scale * loglik + lp_w + lp_b + lp_z, [(W, D), (Bg, G), (Z, 1)]
+
+
+def test_config5_on_the_plugin_surface_equals_the_oracle_step(ctx):
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from bayesic_amd.inference import ScoreFunctionVI
+    N, D, G, S = 6000, 16, 7, 64
+    X, y, g, _, _ = svi.make_cfg5(N, D, G)
+    n_total, lr, seed = 10.0 * N, 0.05, 5
+    lj, latents = _config5_expression(D, G, n_total / N, 1.0, 1.0)
+    data = {"X": X, "y": y, "Gm": np.eye(G, dtype=np.float32)[g]}
+    eng = ScoreFunctionVI(lj, latents, data, n_samples=S, seed=seed, lr=lr, backend=DeviceBackend(ctx))
+    assert eng.route.startswith("fused"), eng.route
+    assert (eng.plan.scale, eng.plan.a0, eng.plan.b0) == pytest.approx((n_total / N, 1.0, 1.0), rel=1e-9)
+    general = ScoreFunctionVI(lj, latents, data, n_samples=S, seed=seed, lr=lr, backend=DeviceBackend(ctx),
+                              route="general")
+    P = D + G + 1
+    lam = svi.bbvi_init_lam(P)
+    m1, m2 = np.zeros_like(lam), np.zeros_like(lam)
+    for t in (1, 2, 3):
+        assert eng.step() is None
+        general.step()
+        lam, m1, m2, elbo, grad, ell = svi.bbvi_step(lam, m1, m2, t, X, y, g, D, G, S, seed, n_total, lr)
+        npt.assert_allclose(eng.elbo, elbo, rtol=2e-6)
+        gd = eng.grad
+        assert np.abs(gd - grad).max() <= 2e-4 * np.abs(grad).max()
+        npt.assert_allclose(eng.lam, lam, atol=2e-4)
+        # the same draws on both routes: the general route's update is the same up to float32 evaluation
+        npt.assert_allclose(general.elbo, eng.elbo, rtol=2e-5)
+    # a group matrix that is not one-hot is not given an index vector
+    bad = dict(data, Gm=data["Gm"] * 0.5)
+    assert ScoreFunctionVI(lj, latents, bad, n_samples=S, backend=DeviceBackend(ctx)).route == "general"
+    with pytest.raises(ValueError, match="one-hot"):
+        ScoreFunctionVI(lj, latents, bad, n_samples=S, backend=DeviceBackend(ctx), route="fused")
+
+
+def test_config5_plugin_route_runs_at_the_fused_drivers_speed(ctx):
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from bayesic_amd.inference import ScoreFunctionVI
+    from bayesic_amd.svi.bbvi import LogRegBBVI
+    N, D, G, S = 1_000_000, 256, 1000, 64
+    gen = torch.Generator(device=ctx.device).manual_seed(0)
+    X = torch.randn((N, D), generator=gen, device=ctx.device)
+    y = (torch.rand(N, generator=gen, device=ctx.device) < 0.4).float()
+    g = torch.randint(0, G, (N,), generator=gen, device=ctx.device, dtype=torch.int32)
+    Gm = torch.zeros((N, G), device=ctx.device)
+    Gm[torch.arange(N, device=ctx.device), g.long()] = 1.0
+    lj, latents = _config5_expression(D, G, 1.0, 1.0, 1.0)
+    eng = ScoreFunctionVI(lj, latents, {"X": X, "y": y, "Gm": Gm}, n_samples=S, seed=1, lr=1e-3, backend=DeviceBackend(ctx))
+    assert eng.route.startswith("fused"), eng.route
+    del Gm
+    ref = LogRegBBVI(X, y, g, G, n_samples=S, seed=1, lr=1e-3, ctx=ctx)
+
+    def per_step(model, steps=150):
+        for _ in range(250):
+            model.step()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model.step()
+        ctx.sync()
+        return (time.perf_counter() - t0) / steps
+
+    t_ref = min(per_step(ref) for _ in range(2))
+    t_eng = min(per_step(eng) for _ in range(2))
+    print("config 5: plugin route %.1f us per update, hand-written driver %.1f us" % (t_eng * 1e6, t_ref * 1e6))
+    assert t_eng <= 1.3 * t_ref, (t_eng, t_ref)

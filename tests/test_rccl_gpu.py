@@ -111,9 +111,16 @@ def test_bench_bare_two_ranks_rehearsal():
     """`python bench.py --gpus 2` from a bare shell: the parent spawns the ranks itself."""
     out = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--rows", "40000", "--no-cpu-baseline",
                   "--spin-up-ms", "5", "--burst", "8"], {"BSC_BENCH_REHEARSAL": "1"})
-    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["scaling"] == "weak"
-    assert out["config"]["rows_per_gpu"] == 40000 and out["value"] > 0
+    # default --scaling both: value = ONE global mini-batch of the configured size split over the ranks (the metric's
+    # reading), value_weak = a full-size mini-batch per rank, both from the one invocation
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["scaling"] == "strong"
+    assert out["config"]["rows_per_gpu"] == 20000 and out["config"]["global_rows"] == 40000 and out["value"] > 0
+    assert out["value_weak"] > 0 and out["config_weak"]["rows_per_gpu"] == 40000
+    assert out["timed_blocks"]["n"] >= 1 and out["timed_blocks_weak"]["steps_per_block"] == 6
     assert out["exchange"].startswith("gloo")
+    weak = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--rows", "40000", "--scaling", "weak",
+                   "--no-cpu-baseline", "--spin-up-ms", "5", "--burst", "8"], {"BSC_BENCH_REHEARSAL": "1"})
+    assert weak["scaling"] == "weak" and weak["config"]["rows_per_gpu"] == 40000 and "value_weak" not in weak
     strong = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--rows", "40000", "--scaling",
                      "strong", "--no-cpu-baseline", "--spin-up-ms", "5", "--burst", "8"],
                     {"BSC_BENCH_REHEARSAL": "1"})

@@ -104,3 +104,67 @@ def test_parameter_probe_refuses_data_sized_operands():
     from bayesic_amd.algebra.backend import resolve_backend
     import bayesic_amd.algebra.backend as B
     assert not isinstance(B._default, ParameterBackend)
+
+
+# ---- recognise.diagonal_mixture: config 3's update rules, read off the DERIVED messages -----------------
+
+def _mixture_vars():
+    v = lambda name, nd: A.var(name, nd, "float64")
+    return v("X", 2), v("Z", 2), v("pi", 1), (v("TM", 2), v("TM2", 2), v("LT", 2), v("T", 2))
+
+
+def test_the_symbolic_mixture_is_recognised_with_its_prior():
+    from bayesic_amd.inference.mixture import diagonal_mixture_log_joint
+    from oracle import svi
+    K, D, scale = 5, 3, 10.0
+    X, Z, pi, ng = _mixture_vars()
+    prior = (1.5, 0.2, 0.05, 2.0, 0.7)                    # alpha0, m0, kappa0, a0, b0
+    lj = diagonal_mixture_log_joint(X, Z, pi, *ng, scale, *prior)
+    eta0 = R.diagonal_mixture(lj, Z, pi, ng, "X", K, D, scale)
+    npt.assert_allclose(eta0, svi.mog_prior_eta(K, D, *prior), rtol=1e-10, atol=1e-12)
+    # the data terms written with another scale than the engine is told: not the fused update
+    assert R.diagonal_mixture(lj, Z, pi, ng, "X", K, D, 3.0) is None
+
+
+def test_other_mixtures_are_not_mistaken_for_it():
+    from bayesic_amd.inference.mixture import diagonal_mixture_log_joint
+    K, D, scale = 4, 3, 2.0
+    X, Z, pi, ng = _mixture_vars()
+    TM, TM2, LT, T = ng
+    row = lambda v: A.dimshuffle(v, "x", 0)
+    base = diagonal_mixture_log_joint(X, Z, pi, *ng, scale, 1.0, 0.0, 0.01, 1.0, 1.0)
+    # an extra data-dependent term in the assignments' logits (a per-row offset by component: a different model)
+    odd = base + A.sum(Z * A.dot(X * X * X, TM.T)) * 0.01
+    assert R.diagonal_mixture(odd, Z, pi, ng, "X", K, D, scale) is None
+    # the second moments entering with the wrong weight
+    lik = A.sum(Z * A.dot(X, TM.T)) + A.sum(Z * A.dot(X * X, T.T)) * (-0.25) \
+        + A.sum(Z * row(A.sum(LT, axis=1))) * 0.5 + A.sum(Z * row(A.sum(TM2, axis=1))) * (-0.5)
+    wrong = (lik + A.sum(Z * row(A.log(pi)))) * scale + A.sum(A.log(pi)) * 0.5 + A.sum(LT) * 0.5 + A.sum(T) * (-1.0) \
+        + A.sum(TM2) * (-0.005)
+    assert R.diagonal_mixture(wrong, Z, pi, ng, "X", K, D, scale) is None
+
+
+# ---- recognise.logistic_hierarchy: config 5 in any parameterisation ---------------------------------------
+
+def test_hierarchical_logistic_regression_is_recognised_with_its_hyperparameters():
+    N5, D5, G5, S5 = 3000, 8, 5, 16
+    scale, a0, b0 = 10.0, 1.5, 0.7
+    Xv, yv, Gm = A.var("X", 2), A.var("y", 1), A.var("Gm", 2)
+    W, Bg, Z = A.var("W", 2), A.var("Bg", 2), A.var("Z", 2)
+    L = A.dot(Xv, W.T) + A.dot(Gm, Bg.T)
+    loglik = A.sum(A.dimshuffle(yv, 0, "x") * L - A.log(1 + A.exp(L)), axis=0)
+    zeta = A.sum(Z, axis=1)
+    tau = A.exp(zeta)
+    shapes = {"X": (N5, D5), "y": (N5,), "Gm": (N5, G5)}
+    latents = [(W, D5), (Bg, G5), (Z, 1)]
+    prior = A.sum(W * W, axis=1) * (-0.5) + zeta * (0.5 * G5) - 0.5 * (tau * A.sum(Bg * Bg, axis=1)) + a0 * zeta - b0 * tau
+    plan = R.logistic_hierarchy(scale * loglik + prior, latents, shapes, S5)            # constants dropped
+    assert plan is not None and (plan.X, plan.y, plan.onehot, plan.W, plan.B, plan.zeta) == ("X", "y", "Gm", "W", "Bg", "Z")
+    npt.assert_allclose([plan.scale, plan.a0, plan.b0], [scale, a0, b0], rtol=1e-9)
+    want_offset = 0.5 * (D5 + G5) * math.log(2 * math.pi) - (a0 * math.log(b0) - math.lgamma(a0))
+    npt.assert_allclose(plan.offset, want_offset, rtol=1e-9)
+    # a probit-like link, or a group-level variance that does not scale the intercepts: other models
+    other = A.sum(A.dimshuffle(yv, 0, "x") * L - A.log(1 + A.exp(L * 2.0)), axis=0) * scale + prior
+    assert R.logistic_hierarchy(other, latents, shapes, S5) is None
+    flat = scale * loglik + A.sum(W * W, axis=1) * (-0.5) + A.sum(Bg * Bg, axis=1) * (-0.5) + a0 * zeta - b0 * tau
+    assert R.logistic_hierarchy(flat, latents, shapes, S5) is None

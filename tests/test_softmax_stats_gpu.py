@@ -105,7 +105,8 @@ def test_derived_mixture_does_not_write_its_responsibilities(ctx):
     alpha, m, kappa, a, b = svi.mog_unpack(eta, k, d)
     models = []
     for defer in (True, False):
-        model = DiagonalMixtureVMP(X, k, n_total=10.0 * n, init=(alpha, m, kappa, a, b), backend=DeviceBackend(ctx))
+        model = DiagonalMixtureVMP(X, k, n_total=10.0 * n, init=(alpha, m, kappa, a, b), backend=DeviceBackend(ctx),
+                                   route="derived")
         model.vmp.defer_responsibilities = defer
         models.append(model)
     calls = []

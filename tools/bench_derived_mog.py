@@ -34,8 +34,13 @@ def main():
     alpha, m, kappa, a, b = mog_mod.unpack(eta, K, D)
     fused = mog_mod.MoGNatGradSVI(ctx.to_device(X), K, eta0, eta, n_total=float(n), ctx=ctx)
     derived = DiagonalMixtureVMP(X, K, n_total=float(n), init=(alpha, m, kappa, a, b), backend=DeviceBackend(ctx),
-                                 resident_globals="--host-globals" not in sys.argv)
-    for name, step in (("fused (svi/mog.py)", fused.step), ("derived (inference/mixture.py)", derived.step)):
+                                 resident_globals="--host-globals" not in sys.argv, route="derived")
+    # the same symbolic model with route="auto": the derived update rules are recognised as the fused kernels' own
+    auto = DiagonalMixtureVMP(X, K, n_total=float(n), init=(alpha, m, kappa, a, b), backend=DeviceBackend(ctx))
+    print("route of the symbolic model: %s" % auto.route, flush=True)
+    for name, step in (("hand-written driver (svi/mog.py)", fused.step),
+                       ("symbolic model, route=auto", auto.step),
+                       ("symbolic model, route=derived", derived.step)):
         for _ in range(3):
             step()
         ctx.sync()
@@ -58,9 +63,12 @@ def main():
             st = torch.cuda.memory_stats()
             print("    torch allocator: %d device mallocs, %d frees, %.1f GB reserved"
                   % (st["num_device_alloc"], st["num_device_free"], st["reserved_bytes.all.current"] / 1e9))
-    got, want = derived.eta_fused_layout(), fused.eta.cpu().numpy()
+    want = fused.eta.cpu().numpy()
     scale = np.maximum(np.abs(want), 1.0)
-    print("max relative difference of the natural parameters after 13 updates: %.2e" % np.abs((got - want) / scale).max())
+    for name, model in (("derived", derived), ("auto", auto)):
+        got = model.eta_fused_layout()
+        print("max relative difference of the natural parameters after 13 updates (%s vs hand-written): %.2e"
+              % (name, np.abs((got - want) / scale).max()))
 
 
 if __name__ == "__main__":

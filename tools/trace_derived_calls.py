@@ -25,7 +25,7 @@ def main():
     X = rs.standard_normal((n, D)).astype(np.float32) * 3
     eta = mog_mod.init_eta(X[:2000], K, D, seed=2)
     alpha, m, kappa, a, b = mog_mod.unpack(eta, K, D)
-    derived = DiagonalMixtureVMP(X, K, n_total=float(n), init=(alpha, m, kappa, a, b), backend=DeviceBackend(ctx))
+    derived = DiagonalMixtureVMP(X, K, n_total=float(n), init=(alpha, m, kappa, a, b), backend=DeviceBackend(ctx), route="derived")
     for _ in range(2):
         derived.step()
     ctx.sync()
