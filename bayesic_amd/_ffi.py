@@ -134,8 +134,6 @@ SIGNATURES = {
     "bsc_hbm_read_probe": (c_int, [c_void_p, c_void_p, c_size_t, c_int, POINTER(c_double)]),
     "bsc_host_alloc": (c_int, [c_size_t, POINTER(c_void_p)]),
     "bsc_host_free": (c_int, [c_void_p]),
-    "bsc_host_register": (c_int, [c_void_p, c_size_t]),
-    "bsc_host_unregister": (c_int, [c_void_p]),
     "bsc_loader_create": (c_int, [c_void_p, c_int64, c_int32, c_int32, POINTER(c_void_p)]),
     "bsc_loader_destroy": (c_int, [c_void_p]),
     "bsc_loader_submit": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64]),

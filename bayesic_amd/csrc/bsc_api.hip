@@ -99,6 +99,7 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
     if (const char* e = getenv("BSC_BBVI_KERNEL")) ctx->bbvi_kernel = atoi(e);
     if (const char* e = getenv("BSC_BBVI_DBG")) ctx->bbvi_dbg = atoi(e);
     if (const char* e = getenv("BSC_CSC_FAST")) ctx->csc_fast = atoi(e) != 0;
+    if (const char* e = getenv("BSC_MOG_NT")) ctx->mog_nt = atoi(e) != 0;
     if (const char* e = getenv("BSC_WO_WG_PER_CU")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 8) ctx->wo_wg_per_cu = v;

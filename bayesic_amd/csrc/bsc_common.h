@@ -35,6 +35,7 @@ struct bsc_ctx {
     int bbvi_kernel = 1;         // bsc_logreg_bbvi_loglik: 1 = draws in LDS, X by LDS-DMA strips (S <= 64; S <= 128 X through VGPRs), 2 = X through VGPRs, 0 = first-generation LDS-staged tiles (S == 64)
     int bbvi_dbg = 0;            // BSC_BBVI_DBG: profiling-only deletion builds of the xreg kernel (wrong results)
     int csc_fast = 1;            // bsc_lda_sstats_csc: buffer-descriptor gathers (BSC_CSC_FAST=0 turns them off)
+    int mog_nt = 0;              // bsc_mog_estep: 1 = non-temporal loads of X (BSC_MOG_NT).  Default 0: both half-waves read the same rows and the L2 keeps a row for the second one -- 1.01 x the algorithmic bytes instead of 1.19 x, same time (profiles/r03_pmc_kernels.txt)
     int wo_wg_per_cu = 2;        // bsc_weighted_outer: resident workgroups per CU the grid is sized for
     int fused_waves_per_cu = 16; // bsc_map_reduce: reduce splits target this many waves per CU
     int blr_pk = 1;              // MFMA pass: backward rank-1 updates as packed FMAs (BSC_BLR_PK=0: scalar; +0.4 % in-process A/B, same bits)

@@ -7,9 +7,11 @@
 // Slot life cycle:  submit (H2D queued on the copy stream, ordered after the
 // kernels that last read the slot)  ->  acquire (compute stream waits for the
 // copy)  ->  release (marks the point on the compute stream after which the slot
-// may be overwritten).  Host buffers should be page-locked (bsc_host_register or
-// pinned allocation): a pageable source makes the runtime stage the copy through
-// its own bounce buffer at a fraction of the PCIe rate.
+// may be overwritten).  The device only ever reads host memory that the HIP runtime allocated page-locked
+// (bsc_host_alloc; torch pin_memory tensors) -- never pages that malloc owns: a pageable source is copied by the
+// host into the slot's page-locked bounce buffer inside submit.  (Round 2 registered numpy heap arrays in place
+// and let the runtime lock pageable sources on the fly; a later, unrelated blocking H2D then faulted on a heap
+// address.  Both ways of showing malloc's pages to the device are gone: DESIGN.md section 10.)
 #include "bsc_common.h"
 
 #include <cstring>
@@ -60,19 +62,11 @@ int bsc_host_alloc(size_t bytes, void** out) {
 }
 
 int bsc_host_free(void* host_ptr) {
-    if (host_ptr) BSC_HIP(hipHostFree(host_ptr));
-    return BSC_OK;
-}
-
-int bsc_host_register(void* host_ptr, size_t bytes) {
-    BSC_REQUIRE(host_ptr != nullptr && bytes > 0, "bsc_host_register: bad arguments");
-    BSC_HIP(hipHostRegister(host_ptr, bytes, hipHostRegisterDefault));
-    return BSC_OK;
-}
-
-int bsc_host_unregister(void* host_ptr) {
-    BSC_REQUIRE(host_ptr != nullptr, "bsc_host_unregister: null pointer");
-    BSC_HIP(hipHostUnregister(host_ptr));
+    if (!host_ptr) return BSC_OK;
+    // a copy out of this block may still be queued on some loader's copy stream: nothing may read it after
+    // this call returns, so the device is drained first (by construction, not by the caller's discipline)
+    BSC_HIP(hipDeviceSynchronize());
+    BSC_HIP(hipHostFree(host_ptr));
     return BSC_OK;
 }
 

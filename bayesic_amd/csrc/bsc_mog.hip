@@ -66,7 +66,11 @@ struct XRow {
 };
 
 // lane l loads row (row0 + (l&31)): 16 floats; rows past the end and columns >= D read 0
-template <bool FULL>   // FULL: D == 16, no column masking
+// NT: non-temporal loads (the default: X is read once).  Both half-waves load the SAME 32 rows -- the lower half
+// contracts x, the upper x^2 -- and with the non-temporal policy the L2 does not keep a line for the second
+// requester: FETCH_SIZE reads 1.19 x the algorithmic bytes (profiles/pmc_traffic.json), 1.0 x with NT off
+// (BSC_MOG_NT=0, profiles/r03_pmc_mog_nt.txt); the kernel is MFMA-bound either way (HBM time 80 of 710 us).
+template <bool FULL, bool NT = true>   // FULL: D == 16, no column masking
 __device__ __forceinline__ void load_rows(XRow& t, const float* __restrict__ X, int64_t ldx,
                                           int64_t row0, int64_t N, int D, int lane) {
     const int64_t rem = N - row0;
@@ -78,7 +82,7 @@ __device__ __forceinline__ void load_rows(XRow& t, const float* __restrict__ X, 
     const int off = (lane & 31) * (int)(ldx * 4);
 #pragma unroll
     for (int c4 = 0; c4 < MD / 4; ++c4) {
-        auto v = __builtin_amdgcn_raw_buffer_load_b128(xs, off + 16 * c4, 0, 2);  // nt: read once
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(xs, off + 16 * c4, 0, NT ? 2 : 0);  // nt: read once
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float f = __uint_as_float(v[j]);
@@ -94,7 +98,7 @@ __device__ __forceinline__ void load_rows(XRow& t, const float* __restrict__ X, 
 // v_exp_f32 (and a one-hot row stays exactly one-hot); the 1/sum of a row is folded into
 // the backward B operand when the row is staged (x/sum and x^2/sum, 32 multiplies per tile)
 // rather than into its 64 responsibilities; row buffers alternate instead of being copied.
-template <bool FULL>
+template <bool FULL, bool NT>
 __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
     const float* __restrict__ X, int64_t ldx, int64_t N, int D, const float* __restrict__ Wmat,
     const float* __restrict__ cvec, int K, float* __restrict__ slab, int n_iter) {
@@ -146,9 +150,9 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
     const int64_t stride = (int64_t)gridDim.x * MOG_WAVES;
     int64_t tile = (int64_t)blockIdx.x * MOG_WAVES + wave;
     XRow xa, xb;
-    load_rows<FULL>(xa, X, ldx, tile * MT, N, D, lane);
+    load_rows<FULL, NT>(xa, X, ldx, tile * MT, N, D, lane);
     auto one_tile = [&](const XRow& cur, XRow& nxt) {
-        load_rows<FULL>(nxt, X, ldx, (tile + stride) * MT, N, D, lane);   // unconditional prefetch
+        load_rows<FULL, NT>(nxt, X, ldx, (tile + stride) * MT, N, D, lane);   // unconditional prefetch
         const int64_t row0 = tile * MT;
         // forward: logits[comp][row] -- lane (row = l31, half) gets comps 32cb + drow(q, lane);
         // the C operand of the first k-step carries the bias
@@ -577,11 +581,14 @@ int bsc_mog_estep(bsc_ctx* ctx, const float* X, int64_t ldx, int64_t N, int32_t 
     ctx->slab_rows = 0;
     {
         bsc_prof_scope prof(ctx);
-        if (D == MD)
-            hipLaunchKernelGGL(mog_estep_kernel<true>, dim3(n_blocks), dim3(MOG_BLOCK), 0, ctx->stream, X,
+        if (D == MD && ctx->mog_nt)
+            hipLaunchKernelGGL((mog_estep_kernel<true, true>), dim3(n_blocks), dim3(MOG_BLOCK), 0, ctx->stream, X,
+                               ldx, N, (int)D, Wmat, c, (int)K, (float*)ws, n_iter);
+        else if (D == MD)
+            hipLaunchKernelGGL((mog_estep_kernel<true, false>), dim3(n_blocks), dim3(MOG_BLOCK), 0, ctx->stream, X,
                                ldx, N, (int)D, Wmat, c, (int)K, (float*)ws, n_iter);
         else
-            hipLaunchKernelGGL(mog_estep_kernel<false>, dim3(n_blocks), dim3(MOG_BLOCK), 0, ctx->stream, X,
+            hipLaunchKernelGGL((mog_estep_kernel<false, true>), dim3(n_blocks), dim3(MOG_BLOCK), 0, ctx->stream, X,
                                ldx, N, (int)D, Wmat, c, (int)K, (float*)ws, n_iter);
     }
     BSC_LAUNCH_CHECK();

@@ -13,14 +13,14 @@ kernels only ever see device-resident batches, so the hot path is unchanged.
         model.step()
         loader.release()                            # slot reusable once step t has run
 
-Host arrays should be page-locked: ``loader.pinned_empty(shape)`` gives a numpy array in
+Host arrays should be page-locked by the runtime: ``loader.pinned_empty(shape)`` gives a numpy array in
 hipHostMalloc memory (bsc_host_alloc; valid until ``close()``), torch tensors made with
-``pin_memory=True`` work too, and ``loader.pin(array)`` registers an existing numpy array in place
-(bsc_host_register; unregistered at ``close()`` -- keep the array alive until then).  A page-locked
-batch must stay valid and unchanged until ``n_slots`` further submits have returned (the loader
-keeps a reference that long).  A pageable source is copied by the host, inside ``submit``, into a
-page-locked bounce buffer of the slot -- a fraction of the PCIe rate, but the device never reads
-memory the runtime would have to lock on the fly, and the source is free when submit returns.
+``pin_memory=True`` work too.  A page-locked batch must stay valid and unchanged until ``n_slots``
+further submits have returned (the loader keeps a reference that long).  Anything else -- an ordinary
+numpy array -- is copied by the host, inside ``submit``, into a page-locked bounce buffer of the slot:
+a fraction of the PCIe rate, but the device never reads a page that malloc owns, and the source is free
+when submit returns.  (There is no ``pin(array)`` any more: registering heap memory in place is how a
+heap address became the address of a GPU fault in round 2 -- DESIGN.md section 10.)
 """
 import ctypes
 
@@ -51,7 +51,6 @@ class MiniBatchLoader(object):
                                              ctypes.byref(h)), "bsc_loader_create")
         self.handle = h
         self._in_flight = []       # host arrays whose copies may still be running
-        self._pinned = []
         self._host_allocs = []     # hipHostMalloc blocks handed out by pinned_empty
 
     @staticmethod
@@ -70,13 +69,6 @@ class MiniBatchLoader(object):
         self._host_allocs.append(p)
         buf = (ctypes.c_char * max(nbytes, 1)).from_address(p.value)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
-
-    def pin(self, array):
-        """Page-lock a numpy array in place for full-rate asynchronous copies."""
-        _ffi.check(self.ctx.lib.bsc_host_register(array.ctypes.data, array.nbytes),
-                   "bsc_host_register")
-        self._pinned.append(array)
-        return array
 
     def submit(self, X, y):
         ok, ldx = self._strides_ok(X, y)
@@ -104,11 +96,8 @@ class MiniBatchLoader(object):
 
     def close(self):
         if self.handle:
-            self.ctx.lib.bsc_loader_destroy(self.handle)
+            self.ctx.lib.bsc_loader_destroy(self.handle)      # drains the copy stream and the context's stream
             self.handle = None
-            for a in self._pinned:
-                self.ctx.lib.bsc_host_unregister(a.ctypes.data)
-            self._pinned = []
             self._in_flight = []
             for p in self._host_allocs:
                 self.ctx.lib.bsc_host_free(p)

@@ -622,6 +622,31 @@ def pmc_traffic(kernel, at_counted_size):
         return None
 
 
+def agree_on_exchange(dist, torch, rank, init, drop, fallback):
+    """Every rank tries ``init()`` (bsc_comm_init_rank through svi.exchange.init_comm); the ranks then agree over
+    the HOST channel whether ALL of them succeeded.  If any failed, every rank drops what it built (``drop()``) and
+    all of them build the fallback group together (``fallback()``: a torch.distributed RCCL process group -- same
+    library, same xGMI links, two stream hops more).  A communicator that came up on some ranks only would hang the
+    first collective; a rank that raised alone would leave the others waiting in it.  Returns (group or None, note
+    or None).  Collective: all ranks must call it.  (tests/test_bench_fallback_cpu.py drives it under gloo.)"""
+    err = None
+    try:
+        init()
+    except Exception as e:      # noqa: BLE001 -- reported, not swallowed
+        err = "%s: %s" % (type(e).__name__, e)
+        sys.stderr.write("bench.py rank %d: bsc_comm_init_rank failed (%s)\n" % (rank, err))
+    flag = torch.tensor([0 if err is None else 1], dtype=torch.int32)
+    dist.all_reduce(flag)                                   # host tensor over the gloo channel
+    failed = int(flag.item())
+    if failed == 0:
+        return None, None
+    drop()
+    group = fallback()
+    note = ("torch.distributed RCCL process group (fallback: bsc_comm_init_rank failed on %d rank(s)%s)"
+            % (failed, "; this rank: " + err if err else ""))
+    return group, note
+
+
 def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -658,20 +683,10 @@ def run_rank(args):
         # that fail on ANY rank (it has only ever run at world size 1: gpurun boxes have one GPU), all
         # ranks agree over the host channel to exchange through torch.distributed's own RCCL process
         # group instead -- same library, same xGMI links, two stream hops more -- and the line says so.
-        err = None
-        try:
-            init_comm(ctx)
-        except Exception as e:      # noqa: BLE001 -- reported, not swallowed
-            err = "%s: %s" % (type(e).__name__, e)
-            sys.stderr.write("bench.py rank %d: bsc_comm_init_rank failed (%s)\n" % (rank, err))
-        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32)
-        dist.all_reduce(flag)                                   # gloo, host tensor
-        if int(flag.item()) > 0:
-            if ctx.has_comm:
-                ctx.comm_destroy()
-            args.exchange_group = dist.new_group(backend="nccl")
-            exchange_note = ("torch.distributed RCCL process group (fallback: bsc_comm_init_rank failed on "
-                             "%d rank(s)%s)" % (int(flag.item()), "; this rank: " + err if err else ""))
+        args.exchange_group, exchange_note = agree_on_exchange(
+            dist, torch, rank, init=lambda: init_comm(ctx),
+            drop=lambda: ctx.comm_destroy() if ctx.has_comm else None,
+            fallback=lambda: dist.new_group(backend="nccl"))
     elif world == 1 and args.rccl_world1:
         ctx.comm_init(ctx.comm_unique_id(), 0, 1)
     def barrier():

@@ -135,20 +135,20 @@ int bsc_hbm_read_probe(bsc_ctx* ctx, const void* buf, size_t bytes, int reps, do
  * read the slot), acquire makes the context's stream wait for the oldest submitted
  * batch and returns its device pointers, release marks the point on the context's
  * stream after which the slot may be overwritten.  At most n_slots batches may be
- * between submit and release.  Host buffers should be page-locked: allocated with
- * bsc_host_alloc (hipHostMalloc), or registered in place with bsc_host_register (and
- * unregistered before their memory goes back to malloc).  A PAGEABLE source is copied by
- * the host, inside submit, into a page-locked bounce buffer of the slot -- the device never
- * reads memory the runtime would have to lock on the fly -- at a fraction of the PCIe rate;
- * it is free again when submit returns.  HOST BUFFER LIFETIME of a page-locked source: it
+ * between submit and release.  Host buffers should be page-locked BY THE RUNTIME: allocated
+ * with bsc_host_alloc (hipHostMalloc; torch pin_memory tensors qualify).  Memory that malloc
+ * owns is never shown to the device -- there is no register-in-place entry point (round 2 had
+ * one; a heap page it had registered, or the runtime had locked on the fly, was the address of a
+ * later GPU memory fault: DESIGN.md section 10): a PAGEABLE source is copied by
+ * the host, inside submit, into a page-locked bounce buffer of the slot, at a fraction of the
+ * PCIe rate; it is free again when submit returns.  bsc_host_free drains the device before it
+ * frees.  HOST BUFFER LIFETIME of a page-locked source: it
  * must stay valid and unchanged until submission k + n_slots has returned (submit
  * host-synchronises on the copy that last targeted the slot it is about to reuse), or
  * until bsc_loader_destroy.  Not thread-safe. */
 typedef struct bsc_loader bsc_loader;
 int bsc_host_alloc(size_t bytes, void** out);      /* hipHostMalloc: page-locked memory to stream from */
 int bsc_host_free(void* host_ptr);
-int bsc_host_register(void* host_ptr, size_t bytes);
-int bsc_host_unregister(void* host_ptr);
 int bsc_loader_create(bsc_ctx* ctx, int64_t max_rows, int32_t D, int32_t n_slots, bsc_loader** out);
 int bsc_loader_destroy(bsc_loader* loader);
 int bsc_loader_submit(bsc_loader* loader, const float* host_X, int64_t ldx, const float* host_y,

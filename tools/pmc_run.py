@@ -2,7 +2,7 @@
 passes (tools/pmc_collect.sh).  Inputs are random device tensors (counters do not depend on the
 values); the call is the same C-ABI entry point bench.py / the drivers use.
 
-    python3 tools/pmc_run.py cfg2|cfg3|cfg4|cfg5|rowsoftmax|wouter|gram|skinny|lda1|lda1e|lda2|sq4096nt|sq4096tn [reps]
+    python3 tools/pmc_run.py cfg2|cfg2rot|cfg3|cfg4|cfg4b|cfg5|rowsoftmax|softstats|wouter|gram|skinny|lda1|lda1e|lda2|sq4096nt|sq4096tn [reps]
 """
 import os
 import sys
@@ -18,6 +18,9 @@ from bayesic_amd.device import Context
 def main():
     which = sys.argv[1]
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+    if which == "cfg3l2":             # config 3's E-step with X through the default cache policy (BSC_MOG_NT=0)
+        os.environ["BSC_MOG_NT"] = "0"
+        which = "cfg3"
     ctx = Context(0)
     dev = ctx.device
     g = torch.Generator(device=dev).manual_seed(0)
@@ -39,6 +42,27 @@ def main():
         y = torch.randn(N, generator=g, device=dev)
         W = torch.randn((S, D), generator=g, device=dev) / 16
         fn = lambda: ctx.call("bsc_blr_data_pass_partial", X, D, y, N, D, W, S)
+    elif which == "cfg2rot":
+        # as bench.py's default loop issues it since round 3: a DIFFERENT resident mini-batch every launch, streamed
+        N, D, S, nb = 1_000_000, 256, 8, 3
+        Xs = [torch.randn((N, D), generator=g, device=dev) for _ in range(nb)]
+        y = torch.randn(N, generator=g, device=dev)
+        W = torch.randn((S, D), generator=g, device=dev) / 16
+        turn = [0]
+
+        def fn():
+            turn[0] += 1
+            ctx.call("bsc_blr_data_pass_partial_sweep", Xs[turn[0] % nb], D, y, N, D, W, S, 0)
+    elif which == "softstats":
+        # the derived mixture's WHOLE local step since round 3: softmax of [X | X^2] . coefficients + bias and the
+        # statistics R^T [X | X^2 | 1] in one pass, responsibilities not written (10M rows of a 40-column wide operand)
+        N, K, C = 10_000_000, 32, 64
+        A = torch.randn((N, 40), generator=g, device=dev)
+        A[:, 32] = 1.0
+        B = torch.randn((40, C), generator=g, device=dev) * 0.3
+        stats = torch.empty((C, 40), device=dev)
+        lse = torch.empty(1, dtype=torch.float64, device=dev)
+        fn = lambda: ctx.call("bsc_gemm_softmax_stats", A, 40, N, K, B, C, 1, C, 1.0, B[32], None, C, stats, 40, lse)
     elif which == "rowsoftmax":
         # the derived mixture's local step: softmax_rows([X | X^2 | 1 | 0..] . coefficients), 10M x 40 -> 64
         N, K, C = 10_000_000, 40, 64
@@ -79,6 +103,15 @@ def main():
         Bt = torch.rand((K, V), generator=g, device=dev) + 0.5
         out = torch.empty((K, V), device=dev)
         fn = lambda: ctx.call("bsc_lda_sstats", C, V, docs, V, K, Th, K, Bt, V, out, V)
+    elif which == "cfg4b":
+        # ... with the words' term of the bound accumulated in the same pass (what the driver issues since round 3)
+        docs, V, K = 6250, 100_000, 128
+        C = torch.poisson(torch.full((docs, V), 0.05, device=dev), generator=g)
+        Th = torch.rand((docs, K), generator=g, device=dev) + 0.5
+        Bt = torch.rand((K, V), generator=g, device=dev) + 0.5
+        out = torch.empty((K, V), device=dev)
+        ll = torch.empty(1, dtype=torch.float64, device=dev)
+        fn = lambda: ctx.call("bsc_lda_sstats_bound", C, V, docs, V, K, Th, K, Bt, V, out, V, ll)
     elif which == "gram":
         N, D = 1_000_000, 256
         X = torch.randn((N, D), generator=g, device=dev)
