@@ -27,7 +27,15 @@ log-variance prior linear in xi and e^{-xi}), the whole update is the two launch
 pass over X (csrc/bsc_blr.hip) and the fused finish (ELBO, pathwise gradient, Adam, next draw).  Config 2
 written with ``Normal`` / ``InverseGamma`` nodes is such a model: 0.17 ms per update instead of 0.85.
 ``route="auto"`` (default) takes the fused route when the model qualifies, ``"general"`` never does,
-``"fused"`` insists (ValueError otherwise).  On the fused route the state (lam, Adam moments) lives on the
+``"fused"`` insists (ValueError otherwise).
+
+**The pass route.**  When the data term is recognised but the parameter-sized remainder is NOT of that family
+(a known noise variance, another prior, more latents), the step still needs the data only through
+Q_s = sum_n (y_n - x_n . w_s)^2 and G_s = sum_n (y_n - x_n . w_s) x_n: ONE ``bsc_blr_data_pass_sweep`` gives
+both, and the remainder -- the recogniser's *surrogate* ``rest + coefficient * Q`` with Q an input -- is
+parameter-sized work for the executor and autodiff (d surrogate / d Q is the coefficient, so
+d log p / d w = d surrogate / d w - 2 (d surrogate / d Q) G).  Two skinny products over X and a dozen [S, N]
+element-wise launches become one pass; the estimator and its noise are the general route's.  On the fused route the state (lam, Adam moments) lives on the
 device, ``step()`` is asynchronous and returns None, ``elbo`` / ``grad`` / ``lam`` read back on access, and
 the draws are ``bsc_blr_noise``'s (Philox streams 0 and 1, as ``oracle.svi.blr_sample``) -- with the
 same seed the update equals ``oracle.svi.blr_step``.
@@ -92,6 +100,7 @@ class ReparamVI(object):
         self._graph = bool(graph) and hasattr(self.backend, "graph_call")
         self._z_dev = None
         self._elbo, self._grad = None, None
+        self._pass_plan = None
         if route not in ("auto", "general", "fused"):
             raise ValueError("route must be 'auto', 'general' or 'fused'")
         self.route = "general"
@@ -115,9 +124,6 @@ class ReparamVI(object):
         if plan is None:
             return "the data do not enter the log-joint as coefficient_s * sum_n (y_n - x_n . w_s)^2"
         self.plan = plan
-        if plan.family is None:
-            return ("Gaussian-linear data term recognised, but the parameter-sized part is not of the family "
-                    "c0 + c_xi xi + e^{-xi} (-s_q Q / 2 - k_w |w|^2 / 2 - beta) with one scalar latent xi")
         import torch
         X, y = self._data[plan.X], self._data[plan.y]
         D = int(X.shape[1])
@@ -125,6 +131,16 @@ class ReparamVI(object):
             return "the fused pass streams float32 data"
         if D > 256 or self.S > 64 or X.stride(1) != 1:
             return "outside the fused pass's envelope (D <= 256, S <= 64, row-major X)"
+        if plan.family is None:
+            # the pass route: data term by the fused pass, the rest by the executor (module docstring)
+            self._pass_plan = plan
+            self._pass_Q = torch.zeros(self.S, dtype=torch.float64, device=X.device)
+            self._pass_G = torch.zeros((self.S, D), dtype=torch.float64, device=X.device)
+            self.backend.ctx.reserve((4 * self.backend.ctx.info()["cu_count"] + 8) * (8 * 256 + 8) * 4 * 2)
+            self.route = "pass: bsc_blr_data_pass_sweep + executor on the parameter-sized surrogate"
+            return ("Gaussian-linear data term recognised (one pass over X per step), but the parameter-sized part "
+                    "is not of the family c0 + c_xi xi + e^{-xi} (-s_q Q / 2 - k_w |w|^2 / 2 - beta) with one "
+                    "scalar latent xi")
         from ..svi.blr import BLRReparamSVI
         c0, c_xi, s_q, k_w, beta, xi_name = plan.family
         self._order = [v.name for v, _ in self.latents]          # [W, xi] or [xi, W]
@@ -243,8 +259,39 @@ class ReparamVI(object):
                             for r, (_, n) in zip(res[1:], self.latents)], axis=1)
         return f, g
 
+    def _log_joint_and_gradient_pass(self, z):
+        """The same with the data term through ONE fused pass (module docstring, "the pass route")."""
+        import torch
+        plan, b = self._pass_plan, self.backend
+        inputs, offset, W_dev = {}, 0, None
+        for v, n in self.latents:
+            block = np.ascontiguousarray(z[:, offset:offset + n], dtype=np.float32)
+            inputs[v.name] = b.from_host(block, "float32", 2)
+            if v.name == plan.W:
+                W_dev = inputs[v.name]
+            offset += n
+        X, y = self._data[plan.X], self._data[plan.y]
+        b.ctx.call("bsc_blr_data_pass_sweep", X, X.stride(0), y, X.shape[0], X.shape[1], W_dev, self.S,
+                   self._pass_Q, self._pass_G, 0)
+        inputs[plan.Q_NAME] = b._convert(self._pass_Q, torch.float32)
+        names = [v.name for v, _ in self.latents]
+        out, grads = value_and_grad(b, plan.surrogate, inputs, names + [plan.Q_NAME])
+        f = np.asarray(b.to_host(out), np.float64).reshape(self.S)
+        coefficient = np.asarray(b.to_host(grads[plan.Q_NAME]), np.float64).reshape(self.S)
+        G = self._pass_G.cpu().numpy()
+        blocks = []
+        for v, n in self.latents:
+            gv = grads.get(v.name)           # (a latent the parameter-sized part does not mention: no prior on it)
+            gv = np.zeros((self.S, n)) if gv is None else np.asarray(b.to_host(gv), np.float64).reshape(self.S, n)
+            if v.name == plan.W:
+                gv = gv - 2.0 * coefficient[:, None] * G          # d Q_s / d w_s = -2 G_s
+            blocks.append(gv)
+        return f, np.concatenate(blocks, axis=1)
+
     def log_joint_and_gradient(self, z):
         """(log p(data, z_s) [S], d log p / d z [S, P]) through the executor."""
+        if self._pass_plan is not None:
+            return self._log_joint_and_gradient_pass(z)
         if self._graph:
             return self._log_joint_and_gradient_graph(z)
         inputs = dict(self._data)

@@ -83,8 +83,10 @@ def test_reparam_engine_with_its_walk_recorded_as_a_graph(sctx):
     X, y, W = A.var("X", 2), A.var("y", 1), A.var("W", 2)
     r = A.dimshuffle(y, "x", 0) - A.dot(W, X.T)
     lj = A.sum(r * r, axis=1) * (-0.5 / 0.25) + A.sum(W * W, axis=1) * (-0.5)
+    # (route="general": this test is about the executor's walk recorded as a graph; the default route would
+    # recognise the Gaussian-linear data term and run it as one fused pass -- tests/test_plugin_route_gpu.py)
     engines = [ReparamVI(lj, [(W, D)], dict(X=Xs, y=ys), n_samples=S, seed=5, backend=DeviceBackend(sctx),
-                         lr=0.02, graph=graph) for graph in (False, True)]
+                         lr=0.02, graph=graph, route="general") for graph in (False, True)]
     for step in range(12):
         a, b = engines[0].step(), engines[1].step()
         assert a == b, (step, a, b)

@@ -26,9 +26,10 @@ def main():
     r = A.dimshuffle(y, "x", 0) - A.dot(W, X.T)
     lj = A.sum(r * r, axis=1) * (-0.5 / s2) + A.sum(W * W, axis=1) * (-0.5)
     ctx.set_stream(torch.cuda.Stream(ctx.device))          # a stream of its own: what a graph capture needs
-    data = dict(X=Xd.cpu().numpy(), y=yd.cpu().numpy())
-    for graph in (False, True):
-        eng = ReparamVI(lj, [(W, D)], data, n_samples=S, seed=1, backend=DeviceBackend(ctx), lr=1e-3, graph=graph)
+    data = dict(X=Xd, y=yd)
+    for graph, route in ((False, "general"), (True, "general"), (False, "auto")):
+        eng = ReparamVI(lj, [(W, D)], data, n_samples=S, seed=1, backend=DeviceBackend(ctx), lr=1e-3, graph=graph,
+                        route=route)
         for _ in range(5):
             eng.step()
         ctx.sync()
@@ -38,9 +39,9 @@ def main():
             eng.step()
         ctx.sync()
         dt = (time.perf_counter() - t0) / steps
-        print("general reparameterisation engine%s, %dx%d, S=%d: %.2f ms per update (%.1f updates/s), elbo %.6e; "
+        print("reparameterisation engine, route = %s%s, %dx%d, S=%d: %.2f ms per update (%.1f updates/s), elbo %.6e; "
               "the fused config-2 kernels: 0.17 ms"
-              % (" (walk recorded as a hipGraph)" if graph else "", N, D, S, dt * 1e3, 1.0 / dt, eng.elbo))
+              % (eng.route, " (walk recorded as a hipGraph)" if graph else "", N, D, S, dt * 1e3, 1.0 / dt, eng.elbo))
 
 
 if __name__ == "__main__":
