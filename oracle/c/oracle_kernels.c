@@ -177,6 +177,36 @@ void oracle_lda_sstats(const float* C, long ldc, long docs, long V, int K, const
     }
 }
 
+/* The words' term of config 4's evidence lower bound (README.md:30-37; Hoffman, Blei, Bach 2010 eq. 7 with the
+ * per-word assignments at their optimum): sum_dv C[d,v] log(sum_k Th[d,k] Bt[k,v]) -- oracle.svi.lda_local_bound
+ * restated.  Threads own document blocks; their partials are added in thread order. */
+double oracle_lda_local_bound(const float* C, long ldc, long docs, long V, int K, const float* Th,
+                              const float* Bt) {
+    const int nt = omp_get_max_threads();
+    double* part = (double*)calloc((size_t)nt, sizeof(double));
+#pragma omp parallel num_threads(nt)
+    {
+        long lo, hi;
+        row_block(docs, omp_get_thread_num(), nt, &lo, &hi);
+        double acc = 0.0;
+        for (long d = lo; d < hi; ++d) {
+            const float* th = Th + d * K;
+            for (long v = 0; v < V; ++v) {
+                const double cnt = (double)C[d * ldc + v];
+                if (cnt == 0.0) continue;
+                double p = 0.0;
+                for (int k = 0; k < K; ++k) p += (double)th[k] * (double)Bt[(long)k * V + v];
+                acc += cnt * log(p);
+            }
+        }
+        part[omp_get_thread_num()] = acc;
+    }
+    double total = 0.0;
+    for (int t = 0; t < nt; ++t) total += part[t];
+    free(part);
+    return total;
+}
+
 /* Full-covariance mixture statistic (t(x) = (x, x x^T), core.py:41-44, summed over rows):
  *   out[k,d,e] = sum_n R[n,k] X[n,d] Y[n,e].  Threads own row blocks; partials in thread order. */
 void oracle_weighted_outer(const float* R, const float* X, const float* Y, long N, int K, int D,

@@ -35,6 +35,8 @@ def load():
         lib.oracle_logreg_loglik.argtypes = [vp, c_long, vp, vp, c_long, c_int, c_int, vp, vp, c_int, vp]
         lib.oracle_mog_estep.argtypes = [vp, c_long, c_long, c_int, c_int, vp, vp, vp, vp]
         lib.oracle_lda_sstats.argtypes = [vp, c_long, c_long, c_long, c_int, vp, vp, vp]
+        lib.oracle_lda_local_bound.argtypes = [vp, c_long, c_long, c_long, c_int, vp, vp]
+        lib.oracle_lda_local_bound.restype = ctypes.c_double
         lib.oracle_weighted_outer.argtypes = [vp, vp, vp, c_long, c_int, c_int, c_int, vp]
         lib.oracle_weighted_outer.restype = None
         lib.oracle_threads.restype = c_int
@@ -85,6 +87,13 @@ def lda_sstats(C, Th, Bt):
     out = np.zeros((K, V))
     load().oracle_lda_sstats(_p(C), C.shape[1], C.shape[0], V, K, _p(Th), _p(Bt), _p(out))
     return out
+
+
+def lda_local_bound(C, Th, Bt):
+    import numpy as np
+    C, Th, Bt = (np.ascontiguousarray(a, np.float32) for a in (C, Th, Bt))
+    K, V = Bt.shape
+    return float(load().oracle_lda_local_bound(_p(C), C.shape[1], C.shape[0], V, K, _p(Th), _p(Bt)))
 
 
 def weighted_outer(R, X, Y):

@@ -47,6 +47,8 @@ def test_c_oracle_matches_numpy_oracle():
     Bt = rs.uniform(0.1, 1.0, (32, 40)).astype(np.float32)
     npt.assert_allclose(cbuild.lda_sstats(C, Th, Bt), svi.lda_sstats(C, Th, Bt), rtol=1e-12)
 
+    npt.assert_allclose(cbuild.lda_local_bound(C, Th, Bt), svi.lda_local_bound(C, Th, Bt), rtol=1e-12)
+
     Rr = rs.dirichlet(np.ones(6), 777).astype(np.float32)
     Yy = rs.standard_normal((777, 5)).astype(np.float32)
     npt.assert_allclose(cbuild.weighted_outer(Rr, X[:, :7], Yy),
@@ -171,3 +173,60 @@ def test_weighted_second_moment_full_size_against_c_oracle(ctx):
     # |sum| is bounded by sum_n r |x_d||x_e|; the diagonal entries are sums of positive terms
     bound = cbuild.weighted_outer(Rh, np.abs(Xh), np.abs(Xh))
     assert (np.abs(out.cpu().numpy() - want) <= 2e-5 * bound).all()
+
+
+@needs_gcc
+@pytest.mark.gpu
+def test_cfg3_full_size_elbo_against_c_oracle(ctx):
+    """10M x 16, K = 64: model.elbo of the fused driver = oracle.svi.mog_elbo with the local term from the C oracle's
+    pass over the very same data (the numpy oracle takes minutes at this size)."""
+    import torch
+    from bayesic_amd.svi.mog import MoGNatGradSVI
+    from oracle import cbuild
+    N, D, K = 10_000_000, 16, 64
+    X, _, _ = svi.make_cfg3(N, D, K)
+    eta0 = svi.mog_prior_eta(K, D)
+    eta = svi.mog_init_eta(X[:4000], K, D, seed=1)
+    model = MoGNatGradSVI(X, K, eta0, eta, n_total=4.0 * N, ctx=ctx)
+    for t in range(1, 3):
+        Wmat, c = svi.mog_expected_params(eta, K, D)
+        stats, lse = cbuild.mog_estep(X, Wmat, c)
+        want = svi.mog_elbo(eta, eta0, lse, 4.0, K, D)
+        rho = (t + 1.0) ** -0.6
+        model.step(rho)
+        ctx.sync()
+        npt.assert_allclose(model.elbo.item(), want, rtol=2e-6)
+        eta = svi.natgrad_update(eta, eta0, svi.mog_message(stats, K, D), 4.0, rho)
+        model.eta.copy_(torch.as_tensor(eta, dtype=torch.float64))
+
+
+@needs_gcc
+@pytest.mark.gpu
+def test_cfg4_full_size_elbo_against_c_oracle(ctx):
+    """6250 x 100 000 counts, K = 128 (one GPU's shard of config 4): the words' term taken inside the statistic kernel
+    (dense persistent kernel and sparse kernel) against the C oracle; the topics' and documents' terms against the
+    float64 numpy oracle (parameter-sized); model.elbo of the driver against their combination."""
+    import scipy.sparse as sp
+    import torch
+    from bayesic_amd.svi.lda import LDAFixedGammaSVI
+    from oracle import cbuild
+    docs, V, K = 6250, 100_000, 128
+    g = torch.Generator(device=ctx.device).manual_seed(24)
+    C = torch.poisson(torch.full((docs, V), 0.05, device=ctx.device), generator=g)
+    gamma = torch.rand((docs, K), generator=g, device=ctx.device) + 0.5
+    lam = torch.rand((K, V), generator=g, device=ctx.device) + 0.5
+    eta_prior, alpha, docs_total = 0.01, 1.0 / K, 50_000.0
+    Ch, gh, lh = C.cpu().numpy(), gamma.cpu().numpy(), lam.cpu().numpy()
+    Th = svi.dirichlet_expectation(gh).astype(np.float32)
+    Bt = svi.dirichlet_expectation(lh).astype(np.float32)
+    words = cbuild.lda_local_bound(Ch, Th, Bt)
+    want = docs_total / docs * (words + float(svi.dirichlet_neg_kl(gh, alpha).sum())) \
+        + float(svi.dirichlet_neg_kl(lh, eta_prior).sum())
+    for counts in (C, sp.csr_matrix(Ch)):
+        model = LDAFixedGammaSVI(counts, gamma, lam, eta=eta_prior, docs_total=docs_total, ctx=ctx, alpha=alpha)
+        model.step()
+        ctx.sync()
+        # (the device forms Th, Bt in float32 from float64 digammas exactly as the oracle does; the words' term sums
+        # 31 M float32 products)
+        npt.assert_allclose(model._ll.item(), words, rtol=3e-6)
+        npt.assert_allclose(model.elbo.item(), want, rtol=3e-6)
