@@ -29,6 +29,7 @@ SIGNATURES = {
     "bsc_capture_end": (c_int, [c_void_p, POINTER(c_void_p)]),
     "bsc_graph_launch": (c_int, [c_void_p, c_void_p]),
     "bsc_graph_destroy": (c_int, [c_void_p]),
+    "bsc_ctx_set_mfma_split": (c_int, [c_void_p, c_int]),
     "bsc_ctx_profile": (c_int, [c_void_p, c_int]),
     "bsc_ctx_profile_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
     "bsc_ctx_profile_read_slot": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int64)]),

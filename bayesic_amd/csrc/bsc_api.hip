@@ -98,8 +98,10 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
     if (const char* e = getenv("BSC_BBVI_WAVES")) ctx->bbvi_waves = atoi(e) == 8 ? 8 : 4;
     if (const char* e = getenv("BSC_BBVI_KERNEL")) ctx->bbvi_kernel = atoi(e);
     if (const char* e = getenv("BSC_BBVI_DBG")) ctx->bbvi_dbg = atoi(e);
+    if (const char* e = getenv("BSC_LDA_DBG")) ctx->lda_dbg = atoi(e);
     if (const char* e = getenv("BSC_CSC_FAST")) ctx->csc_fast = atoi(e) != 0;
     if (const char* e = getenv("BSC_MOG_NT")) ctx->mog_nt = atoi(e) != 0;
+    if (const char* e = getenv("BSC_MFMA_SPLIT")) { const int v = atoi(e); ctx->mfma_split = v == 2 || v == 3 ? v : 0; }
     if (const char* e = getenv("BSC_WO_WG_PER_CU")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 8) ctx->wo_wg_per_cu = v;
@@ -107,19 +109,19 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
     // BSC_BLR_MX=4, BSC_GEMM_DBG and BSC_BBVI_DBG select profiling-only builds whose RESULTS ARE WRONG
     // (deletion builds: a kernel without its stores, a pass that re-reads one window ...).  They exist
     // for tools/ab_*.py; a process gets them only by also saying BSC_PROFILING_BUILDS=1, and then loudly.
-    if (ctx->blr_mx == 4 || ctx->gemm_dbg != 0 || ctx->bbvi_dbg != 0) {
+    if (ctx->blr_mx == 4 || ctx->gemm_dbg != 0 || ctx->bbvi_dbg != 0 || ctx->lda_dbg != 0) {
         const char* allow = getenv("BSC_PROFILING_BUILDS");
         if (!allow || atoi(allow) != 1) {
-            const int mx = ctx->blr_mx, gd = ctx->gemm_dbg, bd = ctx->bbvi_dbg;
+            const int mx = ctx->blr_mx, gd = ctx->gemm_dbg, bd = ctx->bbvi_dbg, ld = ctx->lda_dbg;
             delete ctx;
             return bsc_fail(BSC_ERR_INVALID,
-                            "bsc_ctx_create: BSC_BLR_MX=%d / BSC_GEMM_DBG=%d / BSC_BBVI_DBG=%d select profiling-only "
-                            "kernels that compute WRONG results; set BSC_PROFILING_BUILDS=1 as well if that is "
-                            "what you want", mx, gd, bd);
+                            "bsc_ctx_create: BSC_BLR_MX=%d / BSC_GEMM_DBG=%d / BSC_BBVI_DBG=%d / BSC_LDA_DBG=%d select "
+                            "profiling-only kernels that compute WRONG results; set BSC_PROFILING_BUILDS=1 as well if "
+                            "that is what you want", mx, gd, bd, ld);
         }
         fprintf(stderr, "libbayesic_hip: WARNING -- profiling-only kernels selected (BSC_BLR_MX=%d BSC_GEMM_DBG=%d "
-                        "BSC_BBVI_DBG=%d): results of this context are WRONG by construction\n",
-                ctx->blr_mx, ctx->gemm_dbg, ctx->bbvi_dbg);
+                        "BSC_BBVI_DBG=%d BSC_LDA_DBG=%d): results of this context are WRONG by construction\n",
+                ctx->blr_mx, ctx->gemm_dbg, ctx->bbvi_dbg, ctx->lda_dbg);
     }
     *out = ctx;
     return BSC_OK;
@@ -150,6 +152,13 @@ int bsc_ctx_reserve(bsc_ctx* ctx, size_t bytes) {
     BSC_CHECK_CTX(ctx);
     void* p;
     return bsc_workspace(ctx, bytes, &p);
+}
+
+int bsc_ctx_set_mfma_split(bsc_ctx* ctx, int terms) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(terms == 0 || terms == 2 || terms == 3, "bsc_ctx_set_mfma_split: terms=%d (0, 2 or 3)", terms);
+    ctx->mfma_split = terms;
+    return BSC_OK;
 }
 
 int bsc_ctx_profile(bsc_ctx* ctx, int enable) {

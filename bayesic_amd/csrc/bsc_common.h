@@ -33,8 +33,10 @@ struct bsc_ctx {
     int fused_nt_store = 1;           // dense map: non-temporal stores of the result
     int bbvi_waves = 4;          // bsc_logreg_bbvi_loglik: waves per workgroup (4: one wave per 16 samples, 8: per (16 samples, 16 rows))
     int bbvi_kernel = 1;         // bsc_logreg_bbvi_loglik: 1 = draws in LDS, X by LDS-DMA strips (S <= 64; S <= 128 X through VGPRs), 2 = X through VGPRs, 0 = first-generation LDS-staged tiles (S == 64)
+    int lda_dbg = 0;             // BSC_LDA_DBG: profiling-only deletion builds of the split-operand LDA kernel (1: no DMAs after the first two steps; 2: no arithmetic) -- wrong results
     int bbvi_dbg = 0;            // BSC_BBVI_DBG: profiling-only deletion builds of the xreg kernel (wrong results)
     int csc_fast = 1;            // bsc_lda_sstats_csc: buffer-descriptor gathers (BSC_CSC_FAST=0 turns them off)
+    int mfma_split = 0;          // 0: f32 MFMA (exact f32 products; the default and the dtype of every reported line); 2 / 3: f32 operands as sums of two / three bf16 terms on the bf16 MFMA, 3 / 6 products (csrc/bsc_bf16split.h; BSC_MFMA_SPLIT, bsc_set_mfma_split) where a kernel offers it
     int mog_nt = 0;              // bsc_mog_estep: 1 = non-temporal loads of X (BSC_MOG_NT).  Default 0: both half-waves read the same rows and the L2 keeps a row for the second one -- 1.01 x the algorithmic bytes instead of 1.19 x, same time (profiles/r03_pmc_kernels.txt)
     int wo_wg_per_cu = 2;        // bsc_weighted_outer: resident workgroups per CU the grid is sized for
     int fused_waves_per_cu = 16; // bsc_map_reduce: reduce splits target this many waves per CU

@@ -23,6 +23,7 @@
 // those rows, so R feeds phase 2 straight from registers.
 #include "bsc_common.h"
 #include "bsc_stream.h"
+#include "bsc_bf16split.h"
 
 namespace {
 
@@ -702,6 +703,429 @@ __global__ __launch_bounds__(64) void lda_stream_fixup_kernel(LdaStreamArgs g) {
         if (col + q < g.V) g.out[k * g.ldo + col + q] = v[q] * g.Bt[k * g.ldb + col + q];
 }
 
+// ---- K = 128 on the operand-split bf16 route (ctx->mfma_split = 2 or 3; csrc/bsc_bf16split.h) ----
+//
+// The schedule, the C tile, the slab and the fix-up of lda_sstats_stream_kernel; both contractions on
+// v_mfma_f32_32x32x16_bf16 with Th and Bt written as sums of SPLIT bf16 terms by two parameter-sized
+// kernels in front (lda_split_th_kernel: [term][document][128]; lda_split_bt_kernel: transposed,
+// [term][word][128], so that a lane's eight contraction values are one 16-byte load) and the ratio split
+// in registers, where it is born:
+//   phase 1  P = Th Bt       A = a 16-byte row read of the Th image (lane = document), B = the Bt terms
+//                            held in registers for the whole column block (32 SPLIT VGPRs);
+//   ratio    as before, then registers 8 s .. 8 s + 7 converted pairwise are the B fragment of document
+//            k-step s of phase 2 -- in the permuted document order of a result tile;
+//   phase 2  S[32 kb ..] += Th^T R:  A = ds_read_b64_tr_b16 of THE SAME Th image (lane = topic) following
+//            that document order: no second, transposed copy of Th anywhere.
+// Per 32-document step and wave 16 SPLIT (SPLIT + 1) / 2 ... = 48 (SPLIT 2) or 96 (SPLIT 3) MFMAs of 32 cycles against
+// 128 of 64 cycles on the f32 route.
+struct LdaBxArgs {
+    LdaStreamArgs s;
+    const unsigned short* ThS;   // [SPLIT][docs_pad][128] bf16
+    const unsigned short* BtS;   // [SPLIT][V_pad][128] bf16, V_pad = 128 n column blocks
+    unsigned th_term_bytes;      // docs_pad * 256
+    int64_t bt_term_elems;       // V_pad * 128
+    int dbg;                     // profiling only (ctx->lda_dbg)
+};
+typedef stream_args_cptr<LdaBxArgs> lda_bx_cptr;
+
+__device__ __forceinline__ void lda_wait_lgkm16(int n) {
+    switch (n) {
+        case 9: __builtin_amdgcn_s_waitcnt(0xC97F); break;
+        case 10: __builtin_amdgcn_s_waitcnt(0xCA7F); break;
+        case 11: __builtin_amdgcn_s_waitcnt(0xCB7F); break;
+        case 12: __builtin_amdgcn_s_waitcnt(0xCC7F); break;
+        case 13: __builtin_amdgcn_s_waitcnt(0xCD7F); break;
+        case 14: __builtin_amdgcn_s_waitcnt(0xCE7F); break;
+        case 15: __builtin_amdgcn_s_waitcnt(0xCF7F); break;
+        default: lda_wait_lgkm(n); break;
+    }
+}
+
+// LDS: two Th images (from the L2: one step ahead is enough) and a ring of NC count tiles (from HBM: NC - 1 steps
+// ahead -- with one step ahead the kernel took the SUM of its DMA-only and arithmetic-only times, 0.83 ms of
+// 0.41 + 0.56 at config 4's size, tools/bench_lda_split.py under BSC_LDA_DBG).  SPLIT 2: 2 x 16 + 3 x 16 KiB = 80 KiB,
+// two workgroups per CU; SPLIT 3: 2 x 24 + 4 x 16 = 112 KiB, one.
+template <int SPLIT>
+struct LdaBxGeo {
+    static constexpr int THB = SPLIT * 8192, NC = SPLIT == 2 ? 3 : 4, CB0 = 2 * THB, LDS_BYTES = CB0 + NC * 16384;
+    static constexpr int PERIOD = NC == 3 ? 6 : 4;      // lcm(2, NC): the main loop's unroll
+};
+
+template <int SPLIT, bool BOUND>
+__device__ __forceinline__ void lda_sstats_bx_body(const LdaBxArgs& a, char* lds) {
+    constexpr int K = 128, THB = LdaBxGeo<SPLIT>::THB, NC = LdaBxGeo<SPLIT>::NC, CB0 = LdaBxGeo<SPLIT>::CB0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31, g16 = lane >> 4;
+    int w = blockIdx.x;
+    int n_units, tail_u0, tail_cnt;
+    {
+        const lda_bx_cptr gc = stream_cold_args<LdaBxArgs>();
+        if ((gc->s.n_wg & 7) == 0) w = (w & 7) * (gc->s.n_wg >> 3) + (w >> 3);
+        tail_u0 = stream_first_unit(&gc->s, w);
+        tail_cnt = stream_first_unit(&gc->s, w + 1) - tail_u0;
+        n_units = gc->s.rounds * gc->s.n_kt + tail_cnt;
+    }
+    if (n_units == 0) {
+        if (BOUND && lane == 0) a.s.ll_slab[blockIdx.x * 4 + wave] = 0.f;
+        return;
+    }
+    float ll = 0.f;
+    const int64_t step_c = 32 * a.s.ldc;
+    const int last_kt = a.s.n_kt - 1, d_tail = a.s.d_tail;
+    const int dbg = a.dbg;
+
+    // ---- issuing side: the wave's share of a step is 2 SPLIT 1-KiB pieces of the Th image and four of the C tile.  Piece
+    // (term c, rows 4 i ..) has its chunks permuted by ((row & 3) << 2) | (i & 3) on the global side; wave w takes the
+    // pieces with i % 4 == w (i = w, w + 4 of every term), so ONE lane offset serves them all and the rest is a scalar
+    // offset.  The same for the C tile: rows 2 (4 w + jj) + lane / 32.
+    StreamCursor it, ic;          // next step whose Th image / C tile is to be requested
+    it.begin(&stream_cold_args<LdaBxArgs>()->s, w, tail_u0, tail_cnt);
+    ic.begin(&stream_cold_args<LdaBxArgs>()->s, w, tail_u0, tail_cnt);
+    int issued_t = 0, issued_c = 0;
+    const unsigned vth = (unsigned)((lane >> 4) * 256 + 16 * ((lane & 15) ^ ((((lane >> 4) & 3) << 2) | wave)));
+    unsigned vc;
+    const unsigned short* th_ptr = stream_cold_args<LdaBxArgs>()->ThS + (int64_t)it.kt * (32 * 128);
+    const float* c_ptr;
+    auto c_tile = [&]() __attribute__((always_inline)) {
+        const lda_bx_cptr gc = stream_cold_args<LdaBxArgs>();
+        const int64_t v_base = (int64_t)ic.t * VT, v_left = gc->s.V - v_base;
+        const int ldc = (int)gc->s.ldc;
+        const int row = 8 * wave + (lane >> 5), col = 4 * (lane & 31);
+        vc = col < v_left ? (unsigned)(row * ldc + col) * 4u : LS_OUTSIDE;
+        c_ptr = gc->s.C + (int64_t)ic.kt * 32 * gc->s.ldc + v_base;
+    };
+    auto issue_th = [&](int buf) __attribute__((always_inline)) {
+        const auto rth = __builtin_amdgcn_make_buffer_rsrc((void*)stream_uniform_ptr((const float*)th_ptr), 0, LS_OUTSIDE, 0x00020000);
+        char* const dth = lds + buf * THB + wave * 1024;
+        const unsigned term_bytes = stream_cold_args<LdaBxArgs>()->th_term_bytes;
+        if (__builtin_expect(!((dbg & 1) && issued_t >= 2), 1)) {
+#pragma unroll
+            for (int c = 0; c < SPLIT; ++c)
+#pragma unroll
+                for (int half = 0; half < 2; ++half)      // rows 4 (w + 4 half) .. of term c (documents past the end: zero rows of ThS)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rth, (bsc_lds_ptr)(dth + c * 8192 + half * 4096), 16, vth,
+                                                             c * term_bytes + (4 * wave + 16 * half) * 256, 0, 0);
+        }
+        ++issued_t;
+        th_ptr += 32 * 128;
+        if (__builtin_expect(it.step(), 0) && issued_t < n_units) {
+            ++it.round;
+            it.segment(&stream_cold_args<LdaBxArgs>()->s, w, tail_u0);
+            th_ptr = stream_cold_args<LdaBxArgs>()->ThS + (int64_t)it.kt * (32 * 128);
+        }
+    };
+    auto issue_c = [&](int buf) __attribute__((always_inline)) {
+        const auto rc = __builtin_amdgcn_make_buffer_rsrc((void*)stream_uniform_ptr(c_ptr), 0, LS_OUTSIDE, 0x00020000);
+        char* const dst = lds + CB0 + buf * 16384 + wave * 4096;
+        const int row_bytes = 8 * (int)stream_cold_args<LdaBxArgs>()->s.ldc;       // two rows of C
+        if (__builtin_expect((dbg & 1) && issued_c >= NC, 0)) {
+        } else if (__builtin_expect(ic.kt != last_kt || d_tail == DT, 1)) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (bsc_lds_ptr)(dst + jj * 1024), 16, vc, jj * row_bytes, 0, 2);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const bool in = 2 * (4 * wave + jj) + (lane >> 5) < d_tail;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (bsc_lds_ptr)(dst + jj * 1024), 16, in ? vc : LS_OUTSIDE, jj * row_bytes, 0, 2);
+            }
+        }
+        ++issued_c;
+        c_ptr += step_c;
+        if (__builtin_expect(ic.step(), 0) && issued_c < n_units) {
+            ++ic.round;
+            ic.segment(&stream_cold_args<LdaBxArgs>()->s, w, tail_u0);
+            c_tile();
+        }
+    };
+
+    // ---- fragment addresses in Th image 0 / C tile 0 (buffer, term and k-step as immediates)
+    const unsigned lb = (unsigned)(uintptr_t)(bsc_lds_ptr)lds;
+    unsigned p1[8], p2[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) p1[ks] = lb + bsc_img256_off(j, 2 * ks + h);            // document j, topics 16 ks + 8 h ..
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)           // topics 32 kb + (lane & 31), documents 8 e + 4 h .. + 3 (+ 16 s: + 4096)
+            p2[2 * kb + e] = lb + bsc_img256_tr_addr(lane, 8 * e + 4 * (g16 >> 1), 32 * kb + 16 * (g16 & 1));
+    const unsigned pc = lb + CB0 + (unsigned)(4 * h * 512 + (32 * wave + j) * 4);
+
+    bsc_u32x4 bt[8][SPLIT];       // Bt[16 ks + 8 h ..][v], term c
+    bsc_f32x16 S[4];
+    bsc_f32x16 P;
+    unsigned ring[3][SPLIT][4];
+    bsc_u32x4 xf[2][SPLIT];
+
+    StreamCursor cc;
+    cc.begin(&stream_cold_args<LdaBxArgs>()->s, w, tail_u0, tail_cnt);
+    bool tile_start = true, whole = false, v_ok = false;
+    unsigned v_lane = 0;
+
+    auto step_body = [&](auto tb_c, auto cb_c, int u) __attribute__((always_inline)) {
+        constexpr int TB = decltype(tb_c)::value, CB = decltype(cb_c)::value;
+        constexpr int OFF = TB * THB, OFF_C = CB * 16384;
+        if (__builtin_expect(tile_start, 0)) {
+            tile_start = false;
+            const lda_bx_cptr gc = stream_cold_args<LdaBxArgs>();
+            const int64_t v = (int64_t)cc.t * VT + 32 * wave + j;
+            v_ok = v < gc->s.V;
+            v_lane = (unsigned)(v_ok ? v : gc->s.V - 1) * 4u;
+            whole = cc.kt == 0 && cc.left == gc->s.n_kt;
+            // (v < V_pad: zero columns past V.  Loads the compiler does not see: it would otherwise make every
+            // step wait for its vmcnt -- i.e. for the NEXT steps' DMAs -- before the first use of bt)
+            const unsigned off = (unsigned)v * 256u + 16u * (unsigned)h;
+            const unsigned short* base = gc->BtS;
+            const int64_t term = gc->bt_term_elems;
+#pragma unroll
+            for (int c = 0; c < SPLIT; ++c) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(bt[ks][c]) : "v"(off), "s"(base), "n"(32 * ks) : "memory");
+                base += term;
+            }
+            __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));      // (also the DMAs in flight: once per block)
+#pragma unroll
+            for (int c = 0; c < SPLIT; ++c)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(bt[ks][c]));
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[kb][r] = 0.f;
+        }
+        // LDS reads in issue order: G0 G1 | the sixteen counts (8 x ds_read2st64_b32: rows i, i + 1 of result registers
+        // 4 q + i) | G2 .. G7 | T0 .. T7, where G ks = the SPLIT row reads of phase-1 k-step ks and T (4 ds + kb) = the
+        // 2 SPLIT transposed reads of document k-step ds, topic block kb; each group is requested two groups before it is
+        // used, into a ring of three register sets.  The ratio and its split (131 vector instructions a step -- with the
+        // MFMAs of the wave's own phases around them they cost it nothing; in a block of their own they cost 500 cycles of
+        // 3 500): registers 0..7 between the phases, 8..15 behind the MFMAs of phase 2's first four groups.
+        constexpr int NG = 16;                       // G0..G7, T0..T7
+        auto group_size = [](int gi) { return gi < 8 ? SPLIT : 2 * SPLIT; };
+        float cv[16];
+        auto issue_group = [&](int gi) __attribute__((always_inline)) {
+            unsigned (&dst)[SPLIT][4] = ring[gi % 3];
+            if (gi < 8) {
+#pragma unroll
+                for (int c = 0; c < SPLIT; ++c) {
+                    bsc_u32x4 v4;
+                    BSC_LDS_B128(v4, p1[gi], OFF + c * 8192);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dst[c][e] = v4[e];
+                }
+            } else {
+                const int ds = (gi - 8) >> 2, kb = (gi - 8) & 3;
+#pragma unroll
+                for (int c = 0; c < SPLIT; ++c)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        bsc_u32x2 v2;
+                        BSC_LDS_TR_B64(v2, p2[2 * kb + e], OFF + c * 8192 + ds * 4096);
+                        dst[c][2 * e] = v2[0];
+                        dst[c][2 * e + 1] = v2[1];
+                    }
+            }
+        };
+        auto ratio = [&](int q) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float cnt = cv[4 * q + i];
+                // (padded documents / columns carry zero counts and P = 0: the clamp keeps 0 * rcp(0) from becoming NaN)
+                const int pi = __float_as_int(P[4 * q + i]), lo = __float_as_int(1.0e-30f);
+                const float pcl = __int_as_float(pi > lo ? pi : lo);
+                if constexpr (BOUND) ll = __builtin_fmaf(cnt, __builtin_amdgcn_logf(pcl), ll);
+                P[4 * q + i] = cnt * __builtin_amdgcn_rcpf(pcl);
+            }
+        };
+        auto split_pairs = [&](int ds, int t0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = t0; t < t0 + 2; ++t) {
+                unsigned pk[SPLIT];
+                bsc_split_pk<SPLIT>(P[8 * ds + 2 * t], P[8 * ds + 2 * t + 1], pk);
+#pragma unroll
+                for (int c = 0; c < SPLIT; ++c) xf[ds][c][t] = pk[c];
+            }
+        };
+        const bsc_f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (__builtin_expect(!(dbg & 2), 1)) {
+            issue_group(0);
+            issue_group(1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    bsc_f32x2 v2;
+                    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v2) : "v"(pc),
+                                 "n"(64 * CB + 2 * (i + 8 * q)), "n"(64 * CB + 2 * (i + 8 * q) + 2) : "memory");
+                    cv[4 * q + i] = v2[0];
+                    cv[4 * q + i + 1] = v2[1];
+                }
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                // group gi has landed; group gi + 1 (and, for gi = 0, the counts) may be in flight
+                lda_wait_lgkm16((gi + 1 < NG ? group_size(gi + 1) : 0) + (gi == 0 ? 8 : 0));
+                __builtin_amdgcn_sched_barrier(0);
+                if (gi + 2 < NG) issue_group(gi + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned (&f)[SPLIT][4] = ring[gi % 3];
+                bsc_u32x4 fa[SPLIT];
+#pragma unroll
+                for (int c = 0; c < SPLIT; ++c) fa[c] = bsc_u32x4{f[c][0], f[c][1], f[c][2], f[c][3]};
+                if (gi < 8) {
+                    P = bsc_mfma_split<SPLIT>(fa, bt[gi], gi == 0 ? zero16 : P);
+                    if (gi == 7) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        ratio(0);
+                        ratio(1);
+                        split_pairs(0, 0);
+                        split_pairs(0, 2);
+                    }
+                } else {
+                    const int ds = (gi - 8) >> 2, kb = (gi - 8) & 3;
+                    S[kb] = bsc_mfma_split<SPLIT>(fa, xf[ds], S[kb]);
+                    if (ds == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (kb == 0) ratio(2);
+                        else if (kb == 1) ratio(3);
+                        else split_pairs(1, 2 * (kb - 2));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (__builtin_expect(cc.step(), 0)) {
+            // ---- this run's share of the block is complete: register r of S[kb] is topic 32 kb + (r & 3) + 8 (r >> 2) + 4 h
+            const lda_bx_cptr gc = stream_cold_args<LdaBxArgs>();
+            if (whole) {
+                // sstats = Bt * S: a scalar row base and one lane offset per matrix (v_lane + 4 h rows), 16 factors in flight
+                const int64_t ldb = gc->s.ldb, ldo = gc->s.ldo;
+                const unsigned off_b = v_lane + (unsigned)(4 * h) * (unsigned)ldb * 4u;
+                const unsigned off_o = v_lane + (unsigned)(4 * h) * (unsigned)ldo * 4u;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    float fac[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float* base = gc->s.Bt + (int64_t)(32 * kb + (r & 3) + 8 * (r >> 2)) * ldb;
+                        asm volatile("global_load_dword %0, %1, %2" : "=v"(fac[r]) : "v"(off_b), "s"(base) : "memory");
+                    }
+                    __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+                    if (v_ok) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            asm volatile("" : "+v"(fac[r]));
+                            float* base = gc->s.out + (int64_t)(32 * kb + (r & 3) + 8 * (r >> 2)) * ldo;
+                            const float val = S[kb][r] * fac[r];
+                            asm volatile("global_store_dword %0, %1, %2" : : "v"(off_o), "v"(val), "s"(base) : "memory");
+                        }
+                    }
+                }
+            } else {
+                float* slot = gc->s.slab + ((int64_t)2 * w + (cc.round > gc->s.rounds ? 1 : 0)) * (K * VT) + 32 * wave + j;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) slot[(32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h) * VT] = S[kb][r];
+            }
+            ++cc.round;
+            cc.segment(&gc->s, w, tail_u0);
+            tile_start = true;
+        }
+        if (u + 1 < n_units) {
+            // step u + 1 needs its Th image (requested one step ago, FOLLOWED by the count tile of step u + NC - 1) and
+            // its count tile (requested before that): everything but that last request has to have landed
+            if (u - 1 + NC < n_units) __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(4));
+            else __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (u + 2 < n_units) issue_th(TB);
+            if (u + NC < n_units) issue_c(CB);
+        }
+    };
+
+    c_tile();
+    issue_th(0);
+    issue_c(0);
+    if (n_units > 1) issue_th(1);
+#pragma unroll
+    for (int b = 1; b < NC; ++b)
+        if (b < n_units) issue_c(b);
+    __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int u = 0; u < n_units; u += LdaBxGeo<SPLIT>::PERIOD) {
+        step_body(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, u);
+        if (u + 1 < n_units) step_body(std::integral_constant<int, 1>{}, std::integral_constant<int, 1 % NC>{}, u + 1);
+        if (u + 2 < n_units) step_body(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 % NC>{}, u + 2);
+        if (u + 3 < n_units) step_body(std::integral_constant<int, 1>{}, std::integral_constant<int, 3 % NC>{}, u + 3);
+        if constexpr (LdaBxGeo<SPLIT>::PERIOD == 6) {
+            if (u + 4 < n_units) step_body(std::integral_constant<int, 0>{}, std::integral_constant<int, 4 % NC>{}, u + 4);
+            if (u + 5 < n_units) step_body(std::integral_constant<int, 1>{}, std::integral_constant<int, 5 % NC>{}, u + 5);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+    if constexpr (BOUND) {
+        const float t = wave_allsum(ll);
+        if (lane == 0) stream_cold_args<LdaBxArgs>()->s.ll_slab[blockIdx.x * 4 + wave] = t;
+    }
+}
+
+#define LDA_BX_KERNEL(NAME, SPLIT_, BOUND_, OCC_)                                               \
+    __global__ __launch_bounds__(LDA_BLOCK, OCC_) void NAME(LdaBxArgs a) {                      \
+        __shared__ __attribute__((aligned(1024))) char lds[LdaBxGeo<SPLIT_>::LDS_BYTES];        \
+        lda_sstats_bx_body<SPLIT_, BOUND_>(a, lds);                                             \
+    }
+LDA_BX_KERNEL(lda_sstats_bx2_kernel, 2, false, 2)
+LDA_BX_KERNEL(lda_sstats_bx2_bound_kernel, 2, true, 2)
+LDA_BX_KERNEL(lda_sstats_bx3_kernel, 3, false, 1)
+LDA_BX_KERNEL(lda_sstats_bx3_bound_kernel, 3, true, 1)
+#undef LDA_BX_KERNEL
+
+// Th [docs][128] f32 -> SPLIT bf16 terms [term][docs_pad][128]; rows past `docs` are zeros.  One thread per pair.
+template <int SPLIT>
+__global__ __launch_bounds__(256) void lda_split_th_kernel(const float* __restrict__ Th, int64_t ldth, int64_t docs,
+                                                           int64_t docs_pad, unsigned* __restrict__ ThS) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // pair index: row i / 64, topics 2 (i % 64) ..
+    if (i >= docs_pad * 64) return;
+    const int64_t d = i >> 6;
+    const int k = 2 * (int)(i & 63);
+    float2 v = make_float2(0.f, 0.f);
+    if (d < docs) v = *reinterpret_cast<const float2*>(Th + d * ldth + k);
+    unsigned pk[SPLIT];
+    bsc_split_pk<SPLIT>(v.x, v.y, pk);
+#pragma unroll
+    for (int c = 0; c < SPLIT; ++c) ThS[c * docs_pad * 64 + i] = pk[c];
+}
+
+// Bt [128][V] f32 -> SPLIT bf16 terms, transposed: [term][V_pad][128]; words past V are zeros.  A workgroup
+// takes 64 words: the [128][64] tile through LDS, then 16 bytes (eight topics of one word) per store.
+template <int SPLIT>
+__global__ __launch_bounds__(256) void lda_split_bt_kernel(const float* __restrict__ Bt, int64_t ldb, int64_t V,
+                                                           int64_t V_pad, bsc_u32x4* __restrict__ BtS) {
+    __shared__ float tile[128][65];
+    const int tid = threadIdx.x;
+    const int64_t v0 = (int64_t)blockIdx.x * 64;
+    for (int e = tid; e < 128 * 64; e += 256) {
+        const int k = e >> 6, v = e & 63;
+        tile[k][v] = v0 + v < V ? Bt[k * ldb + v0 + v] : 0.f;
+    }
+    __syncthreads();
+    const int v = tid & 63;
+    for (int ch = tid >> 6; ch < 16; ch += 4) {          // topics 8 ch .. 8 ch + 7 of word v0 + v
+        bsc_u32x4 o[SPLIT];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            unsigned pk[SPLIT];
+            bsc_split_pk<SPLIT>(tile[8 * ch + 2 * t][v], tile[8 * ch + 2 * t + 1][v], pk);
+#pragma unroll
+            for (int c = 0; c < SPLIT; ++c) o[c][t] = pk[c];
+        }
+#pragma unroll
+        for (int c = 0; c < SPLIT; ++c) BtS[(c * V_pad + v0 + v) * 16 + ch] = o[c];
+    }
+}
+
 // ---- sparse counts (compressed sparse COLUMN): one pass over the nonzeros ----------
 //
 // Real bag-of-words data is ~1 % dense; the dense kernel above spends its MFMAs on
@@ -912,15 +1336,45 @@ int lda_sstats_impl(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int
         g.ldc = ldc; g.ldth = ldth; g.ldb = ldb; g.ldo = ldo; g.docs = docs; g.V = V; g.K = K;
         const int n_kt = (int)((docs + DT - 1) / DT);
         g.d_tail = (int)(docs - (int64_t)(n_kt - 1) * DT);
-        stream_plan(g, n_vt, n_kt, 2 * (int64_t)ctx->cu_count);
+        const int split = K == 128 && ldth % 2 == 0 && (K * ldo + V) * 4 < ((int64_t)1 << 32) ? ctx->mfma_split : 0;     // operand-split bf16 route (K = 128)
+        // (three terms: one workgroup per CU -- 288 registers per lane and 80 KiB of LDS)
+        stream_plan(g, n_vt, n_kt, (split == 3 ? 1 : 2) * (int64_t)ctx->cu_count);
         void* ws = nullptr;
         const size_t slab_floats = (size_t)2 * g.n_wg * K * VT;
-        int rc = bsc_workspace(ctx, (slab_floats + (size_t)4 * g.n_wg) * sizeof(float), &ws);
+        const int64_t docs_pad = (int64_t)n_kt * DT, V_pad = n_vt * VT;
+        const size_t th_bytes = (size_t)split * docs_pad * 256, bt_bytes = (size_t)split * V_pad * 256;
+        int rc = bsc_workspace(ctx, (slab_floats + (size_t)4 * g.n_wg) * sizeof(float) + th_bytes + bt_bytes, &ws);
         if (rc != BSC_OK) return rc;
         ctx->slab_rows = 0;
         g.slab = (float*)ws;
         g.ll_slab = ll ? (float*)ws + slab_floats : nullptr;
-        {
+        if (split) {
+            LdaBxArgs x{};
+            x.s = g;
+            char* const terms = (char*)((float*)ws + slab_floats + (size_t)4 * g.n_wg);
+            x.ThS = (const unsigned short*)terms;
+            x.BtS = (const unsigned short*)(terms + th_bytes);
+            x.th_term_bytes = (unsigned)(docs_pad * 256);
+            x.bt_term_elems = V_pad * 128;
+            x.dbg = ctx->lda_dbg;
+            const dim3 grid((unsigned)g.n_wg), block(LDA_BLOCK);
+            const unsigned th_blocks = (unsigned)((docs_pad * 64 + 255) / 256), bt_blocks = (unsigned)(V_pad / 64);
+            if (split == 2) {
+                hipLaunchKernelGGL(lda_split_th_kernel<2>, dim3(th_blocks), block, 0, ctx->stream, Th, ldth, docs, docs_pad, (unsigned*)terms);
+                hipLaunchKernelGGL(lda_split_bt_kernel<2>, dim3(bt_blocks), block, 0, ctx->stream, Bt, ldb, V, V_pad, (bsc_u32x4*)(terms + th_bytes));
+            } else {
+                hipLaunchKernelGGL(lda_split_th_kernel<3>, dim3(th_blocks), block, 0, ctx->stream, Th, ldth, docs, docs_pad, (unsigned*)terms);
+                hipLaunchKernelGGL(lda_split_bt_kernel<3>, dim3(bt_blocks), block, 0, ctx->stream, Bt, ldb, V, V_pad, (bsc_u32x4*)(terms + th_bytes));
+            }
+            BSC_LAUNCH_CHECK();
+            {
+                bsc_prof_scope prof(ctx);
+                if (split == 2 && ll) hipLaunchKernelGGL(lda_sstats_bx2_bound_kernel, grid, block, 0, ctx->stream, x);
+                else if (split == 2) hipLaunchKernelGGL(lda_sstats_bx2_kernel, grid, block, 0, ctx->stream, x);
+                else if (ll) hipLaunchKernelGGL(lda_sstats_bx3_bound_kernel, grid, block, 0, ctx->stream, x);
+                else hipLaunchKernelGGL(lda_sstats_bx3_kernel, grid, block, 0, ctx->stream, x);
+            }
+        } else {
             bsc_prof_scope prof(ctx);
             const dim3 grid((unsigned)g.n_wg), block(LDA_BLOCK);
             if (ll) {

@@ -47,6 +47,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:36
 F32_MFMA_PEAK_TF = 157.3  # fp32-input MFMA = fp32 vector peak, same guide :41-42
+BF16_MFMA_PEAK_TF = 2500.0   # dense bf16 MFMA, same guide :43 (the operand-split route, --mfma-split)
 
 
 def parse_args(argv=None):
@@ -75,6 +76,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0,
                     help="CPU seconds per leg of the cpu_baseline (there are up to three legs)")
+    ap.add_argument("--mfma-split", type=int, default=0, choices=[0, 2, 3],
+                    help="MFMA-bound contractions on the bf16 MFMA with every f32 operand a sum of 2 / 3 bf16 terms "
+                         "(3 / 6 products; bsc_ctx_set_mfma_split).  0 = f32 MFMA, the default and the dtype of the "
+                         "reported figures; honoured by cfg4")
     ap.add_argument("--unfused", action="store_true",
                     help="cfg2, N=1 through the multi-GPU code path (float64 statistics between the "
                          "pass and the finish, no collective): what the N>1 step costs besides RCCL")
@@ -372,12 +377,20 @@ class Cfg2(Workload):
         return out
 
 
-def _mfma_roofline(kernel, flops, algo_bytes, avg_s, traffic):
+def _mfma_roofline(kernel, flops, algo_bytes, avg_s, traffic, split=0):
     achieved = flops / avg_s / 1e12
-    return {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": F32_MFMA_PEAK_TF,
-            "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TF, "traffic": traffic,
-            "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": algo_bytes,
-            "hbm_frac": algo_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "launches_per_step": 1}
+    out = {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": F32_MFMA_PEAK_TF,
+           "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TF, "traffic": traffic,
+           "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": algo_bytes,
+           "hbm_frac": algo_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "launches_per_step": 1}
+    if split:
+        # every f32 product is 3 (two terms) or 6 (three terms) bf16 products: the flops the matrix pipe executes
+        # are priced against the dense bf16 peak; `f32_equivalent_tflops` is the algorithmic rate
+        products = 3 if split == 2 else 6
+        out.update({"achieved": products * achieved, "peak": BF16_MFMA_PEAK_TF,
+                    "frac": products * achieved / BF16_MFMA_PEAK_TF, "f32_equivalent_tflops": achieved,
+                    "bf16_products_per_f32_product": products})
+    return out
 
 
 class Cfg3(Workload):
@@ -559,6 +572,7 @@ class Cfg4(Workload):
         gamma = torch.rand((docs, K), generator=g, device=dev) + 0.5
         lam = torch.rand((K, V), generator=gp, device=dev) + 0.5      # replicated: same on every rank
         self.docs, self.V, self.K = docs, V, K
+        self.mfma_split = args.mfma_split
         self.model = LDAFixedGammaSVI(C, gamma, lam, docs_total=float(global_docs), ctx=ctx,
                                       group=args.exchange_group)
         self.units_per_step = 1.0 if args.scaling == "strong" else float(world)
@@ -578,9 +592,10 @@ class Cfg4(Workload):
         return {"final_elbo": float(self.model.elbo.item()), "lambda_sum": float(self.model.lam.sum().item())}
 
     def roofline(self, avg_s):
-        return _mfma_roofline("lda_sstats_stream_kernel", 4.0 * self.docs * self.V * self.K,
-                              4.0 * self.docs * self.V, avg_s,
-                              pmc_traffic("lda_sstats_stream_kernel", self.docs == 6250))
+        split = self.mfma_split
+        kernel = "lda_sstats_bx%d_bound_kernel" % split if split else "lda_sstats_stream_kernel"
+        return _mfma_roofline(kernel, 4.0 * self.docs * self.V * self.K, 4.0 * self.docs * self.V, avg_s,
+                              pmc_traffic(kernel, self.docs == 6250), split=split)
 
     def cpu_baseline(self, budget_s):
         from oracle import cbuild
@@ -676,6 +691,8 @@ def run_rank(args):
     from bayesic_amd.svi.exchange import init_comm
 
     ctx = Context(local_rank)
+    if args.mfma_split:
+        ctx.call("bsc_ctx_set_mfma_split", args.mfma_split)
     args.exchange_group = None
     exchange_note = None
     if world > 1 and not rehearsal:
@@ -815,7 +832,9 @@ def run_rank(args):
             "higher_is_better": True,
             "scaling": modes[0],
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if not args.mfma_split else
+                     "f32 operands as sums of %d bf16 terms, %d bf16 products per product, f32 accumulation "
+                     "(--mfma-split; NOT the headline dtype)" % (args.mfma_split, 3 if args.mfma_split == 2 else 6),
             "data": "synthetic",
             "config": dict({"workload": head["describe"], "parallelism": "dp%d" % world}, **head["config"]),
             "timed_blocks": block_stats(head),

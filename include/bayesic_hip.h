@@ -80,6 +80,16 @@ int bsc_h2d(bsc_ctx* ctx, void* dst, const void* host_src, size_t bytes);
 int bsc_d2h(bsc_ctx* ctx, void* host_dst, const void* src, size_t bytes); /* syncs */
 int bsc_memset(bsc_ctx* ctx, void* dst, int value, size_t bytes);
 
+/* Arithmetic of the MFMA-bound contractions.  terms = 0 (default; the dtype of every reported figure): f32
+ * operands on the f32 MFMA, products and sums exactly those of an fmaf chain.  terms = 2 or 3: every f32
+ * operand is written as a sum of that many bf16 terms (round to nearest, repeatedly) and the product is
+ * taken on the bf16 MFMA -- 16 x the f32 rate per instruction -- from the 3 resp. 6 leading cross products,
+ * accumulated in f32: relative error per product <= ~2^-17 resp. ~2^-23 (the f32 class).  Honoured by the
+ * entries that say so (bsc_lda_sstats* at K = 128); every other entry computes as with 0.  Environment:
+ * BSC_MFMA_SPLIT at bsc_ctx_create.  Replaces nothing in the reference (bayesic/algebra.py:1347-1383
+ * contracts in the dtype of its operands); SURVEY.md 8(d) config 4 leaves the operand-split variant open. */
+int bsc_ctx_set_mfma_split(bsc_ctx* ctx, int terms);
+
 /* Per-kernel timing of the dominant kernel of each entry point, with hipEvents
  * recorded on the ctx stream immediately around that one launch.  enable = 0: off
  * (default); enable = n >= 1: time every n-th such launch (an event pair costs a

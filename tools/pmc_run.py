@@ -2,7 +2,7 @@
 passes (tools/pmc_collect.sh).  Inputs are random device tensors (counters do not depend on the
 values); the call is the same C-ABI entry point bench.py / the drivers use.
 
-    python3 tools/pmc_run.py cfg2|cfg2rot|cfg3|cfg4|cfg4b|cfg5|rowsoftmax|softstats|wouter|gram|skinny|lda1|lda1e|lda2|sq4096nt|sq4096tn [reps]
+    python3 tools/pmc_run.py cfg2|cfg2rot|cfg3|cfg4|cfg4b|cfg4x2|cfg4x3|cfg5|rowsoftmax|softstats|wouter|gram|skinny|lda1|lda1e|lda2|sq4096nt|sq4096tn [reps]
 """
 import os
 import sys
@@ -111,6 +111,16 @@ def main():
         Bt = torch.rand((K, V), generator=g, device=dev) + 0.5
         out = torch.empty((K, V), device=dev)
         ll = torch.empty(1, dtype=torch.float64, device=dev)
+        fn = lambda: ctx.call("bsc_lda_sstats_bound", C, V, docs, V, K, Th, K, Bt, V, out, V, ll)
+    elif which in ("cfg4x2", "cfg4x3"):
+        # ... on the operand-split bf16 route (bsc_ctx_set_mfma_split 2 / 3)
+        docs, V, K = 6250, 100_000, 128
+        C = torch.poisson(torch.full((docs, V), 0.05, device=dev), generator=g)
+        Th = torch.rand((docs, K), generator=g, device=dev) + 0.5
+        Bt = torch.rand((K, V), generator=g, device=dev) + 0.5
+        out = torch.empty((K, V), device=dev)
+        ll = torch.empty(1, dtype=torch.float64, device=dev)
+        ctx.call("bsc_ctx_set_mfma_split", int(which[-1]))
         fn = lambda: ctx.call("bsc_lda_sstats_bound", C, V, docs, V, K, Th, K, Bt, V, out, V, ll)
     elif which == "gram":
         N, D = 1_000_000, 256
