@@ -17,6 +17,7 @@
 // k-step s of lane group k reads column 16(s/4) + 4k + (s%4): one ds_read_b128
 // feeds four MFMAs.  LDS row stride 264 floats makes those reads conflict-free.
 #include "bsc_common.h"
+#include "bsc_bf16split.h"
 
 namespace {
 
@@ -711,6 +712,240 @@ __global__ __launch_bounds__(64 * XW, 2) void logreg_loglik_dma_kernel(
 #undef BSC_LDS_B128
 }
 
+template <bool FULL>
+__global__ __launch_bounds__(64 * XW, 2) void logreg_loglik_dma_bx_kernel(
+    const float* __restrict__ X, int64_t ldx, const float* __restrict__ y,
+    const int* __restrict__ g, int64_t N, int D, const float* __restrict__ Wz,
+    const float* __restrict__ Bz, int n_groups, int S, double* __restrict__ slab, int n_iter) {
+    constexpr int NSB = 4, WREG = 1, NL = NSB - WREG, DBG = 0, SPLIT = 2;
+    // the draws as two bf16 terms, in B-operand order: [sb - WREG][k-step jj][term][lane] -> the eight columns
+    // 32 jj + 4 kq .. + 3 and 32 jj + 16 + 4 kq .. + 3 of sample NSB i16 + sb (the A operand takes the same eight from
+    // strips 2 jj and 2 jj + 1)
+    __shared__ __attribute__((aligned(16))) bsc_u32x4 wl[NL * 8 * SPLIT * 64];
+    __shared__ __attribute__((aligned(16))) char dma[XW * DMA_WAVE_BYTES];
+    __shared__ double red[XW][16 * NSB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+
+    auto draw_terms = [&](int sample, int jj, int q4, bsc_u32x4 (&t)[SPLIT]) {
+        f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+        const int c0 = 32 * jj + 4 * q4, c1 = c0 + 16;
+        if (sample < S && c0 < D) w0 = *reinterpret_cast<const f32x4*>(Wz + (int64_t)sample * D + c0);
+        if (sample < S && c1 < D) w1 = *reinterpret_cast<const f32x4*>(Wz + (int64_t)sample * D + c1);
+        unsigned pk[4][SPLIT];
+        bsc_split_pk<SPLIT>(w0[0], w0[1], pk[0]);
+        bsc_split_pk<SPLIT>(w0[2], w0[3], pk[1]);
+        bsc_split_pk<SPLIT>(w1[0], w1[1], pk[2]);
+        bsc_split_pk<SPLIT>(w1[2], w1[3], pk[3]);
+#pragma unroll
+        for (int c = 0; c < SPLIT; ++c) t[c] = bsc_u32x4{pk[0][c], pk[1][c], pk[2][c], pk[3][c]};
+    };
+    for (int idx = tid; idx < NL * 8 * 64; idx += 64 * XW) {
+        const int ln = idx & 63, jj = (idx >> 6) & 7, sb = (idx >> 9) + WREG;
+        bsc_u32x4 t[SPLIT];
+        draw_terms(NSB * (ln & 15) + sb, jj, ln >> 4, t);
+#pragma unroll
+        for (int c = 0; c < SPLIT; ++c) wl[(((sb - WREG) * 8 + jj) * SPLIT + c) * 64 + ln] = t[c];
+    }
+    bsc_u32x4 wreg[8][SPLIT];      // draws of sample NSB i16 + 0
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) draw_terms(NSB * i16, jj, kq, wreg[jj]);
+    __syncthreads();
+
+    const int64_t n_waves = (int64_t)gridDim.x * XW;
+    int64_t tile = (int64_t)blockIdx.x * XW + wave;
+    const int x_voff = i16 * (int)(ldx * 4) + 16 * kq;
+    char* const my = dma + wave * DMA_WAVE_BYTES;                       // this wave's DMA region
+    const unsigned my_addr = (unsigned)(uintptr_t)(lds_ptr)my;
+    constexpr int BZ_OFF = XR * 1024, Y_OFF = BZ_OFF + 4096, G_OFF = Y_OFF + 512;
+
+    // ---- the DMAs (every one counts in vmcnt, in this order) ----
+    auto x_dma = [&](decltype(x_tile_rsrc(X, ldx, D, N, 0)) rs, int j) {            // strip j -> slot j % XR
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(my + (j % XR) * 1024), 16, x_voff, 64 * j, 0, 2);
+    };
+    auto row_dma = [&](const void* base, int64_t row0, int lds_off) {              // lane l <- 4 bytes of row0 + l
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(row_vec_rsrc(base, N, row0), (lds_ptr)(my + lds_off), 4, 4 * lane, 0, 0, 0);
+    };
+    const auto bz_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Bz, 0, (unsigned)n_groups * (unsigned)S * 4u,
+                                                           0x00020000);
+    const int row_b = S * 4, soff = 4 * NSB * i16;
+    auto bz_dma = [&](const f32x4 ids) {    // ids (as int bits) of rows 4 kq .. +3 -> intercepts [r][lane][NSB]
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(bz_rsrc, (lds_ptr)(my + BZ_OFF + r * 1024), 16,
+                                                     __float_as_int(ids[r]) * row_b + soff, 0, 0, 0);
+    };
+    // ---- reads of DMA'd bytes: inline asm (see the header), valid after lds_ready() ----
+    const unsigned addr_lane = my_addr + 16u * lane;     // lane l's 16 bytes of a 1-KiB block
+    const unsigned addr_kq = my_addr + 16u * kq;         // the 4 rows 4 kq .. 4 kq + 3 of a row vector
+#define BSC_LDS_B128(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+    auto a_read = [&](int j) {
+        f32x4 f;
+        BSC_LDS_B128(f, addr_lane, (j % XR) * 1024);
+        return f;
+    };
+
+    // ---- prologue: strips 0 .. XR-1, y, ids and intercepts of the first tile, ids of the second ----
+    {
+        const auto rs = x_tile_rsrc(X, ldx, D, N, tile * XT);
+#pragma unroll
+        for (int j = 0; j < XR; ++j) x_dma(rs, j);
+    }
+    row_dma(y, tile * XT, Y_OFF);
+    row_dma(g, tile * XT, G_OFF);
+    row_dma(g, (tile + n_waves) * XT, G_OFF + 256);
+    __builtin_amdgcn_s_waitcnt(vmcnt_only(0));
+    asm volatile("" ::: "memory");
+    {
+        f32x4 ids;
+        BSC_LDS_B128(ids, addr_kq, G_OFF);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+        bz_dma(ids);
+    }
+    __builtin_amdgcn_s_waitcnt(vmcnt_only(0));
+    asm volatile("" ::: "memory");
+    f32x4 an = a_read(0), an2 = a_read(1);      // the A operand of the next k-step, read one step ahead
+
+    double acc_ll[NSB];
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) acc_ll[sb] = 0.0;
+
+    // LDS -> registers for the tile of parity `par`: its intercepts q[r] (lane l's 16 bytes = samples
+    // NSB i16 .., the first NSB count), its y, and the ids of the tile after it.  Valid after the
+    // next lgkmcnt(0).
+    f32x4 q[4], yv_n, ids_n;
+    auto side_read = [&](int par) {
+        BSC_LDS_B128(q[0], addr_lane, BZ_OFF);
+        BSC_LDS_B128(q[1], addr_lane, BZ_OFF + 1024);
+        BSC_LDS_B128(q[2], addr_lane, BZ_OFF + 2048);
+        BSC_LDS_B128(q[3], addr_lane, BZ_OFF + 3072);
+        if (par) {
+            BSC_LDS_B128(yv_n, addr_kq, Y_OFF + 256);
+            BSC_LDS_B128(ids_n, addr_kq, G_OFF);
+        } else {
+            BSC_LDS_B128(yv_n, addr_kq, Y_OFF);
+            BSC_LDS_B128(ids_n, addr_kq, G_OFF + 256);
+        }
+    };
+    side_read(0);
+
+    // `par` = parity of the tile within this wave's sequence (y and ids are double-buffered)
+    auto one_tile = [&](int par) {
+        const int64_t row0 = tile * XT;
+        const auto rs_cur = x_tile_rsrc(X, ldx, D, N, row0);
+        const auto rs_next = x_tile_rsrc(X, ldx, D, N, (tile + n_waves) * XT);
+        // this tile's intercepts (C input) and y and the next tile's ids were requested from LDS
+        // before the previous tile's epilogue (side_read): back long ago, the wait is for the compiler
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[NSB];
+        const f32x4 yv = yv_n, ids_next = ids_n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) acc[sb][r] = q[r][sb];
+        }
+        // side DMAs of the tiles ahead, FIRST (DMA_SIDE = 6 of them): older than this tile's strips,
+        // so the last strip wait of this tile also covers them
+        if (!(DBG & 8)) {
+            row_dma(y, (tile + n_waves) * XT, Y_OFF + (par ^ 1) * 256);
+            row_dma(g, (tile + 2 * n_waves) * XT, G_OFF + par * 256);
+            bz_dma(ids_next);
+        }
+        int wo = lane;          // opaque once per tile: keeps the static B-operand reads inside the loop
+        asm volatile("" : "+v"(wo));
+        const bsc_u32x4* wp = wl + wo;
+        bsc_u32x4 bn[NL][SPLIT];
+#pragma unroll
+        for (int sb = 0; sb < NL; ++sb)
+#pragma unroll
+            for (int c = 0; c < SPLIT; ++c) bn[sb][c] = wp[((sb * 8) * SPLIT + c) * 64];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            // `an`, `an2` (strips 2 jj, 2 jj + 1) were read a k-step ago, like this step's B operands: the wait finds them
+            // done -- placed BEFORE the next step's reads are issued (see logreg_loglik_dma_kernel)
+            if (jj > 0) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bsc_u32x4 b[NSB][SPLIT];
+#pragma unroll
+            for (int c = 0; c < SPLIT; ++c) b[0][c] = wreg[jj][c];
+#pragma unroll
+            for (int sb = 0; sb < NL; ++sb)
+#pragma unroll
+                for (int c = 0; c < SPLIT; ++c) b[sb + WREG][c] = bn[sb][c];
+            if (jj + 1 < 8) {
+#pragma unroll
+                for (int sb = 0; sb < NL; ++sb)
+#pragma unroll
+                    for (int c = 0; c < SPLIT; ++c) bn[sb][c] = wp[((sb * 8 + jj + 1) * SPLIT + c) * 64];
+            }
+            f32x4 a0 = an, a1 = an2;
+            if (!FULL && 32 * jj + 4 * kq >= D) a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!FULL && 32 * jj + 16 + 4 * kq >= D) a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            // DMA_WAIT: strips 2 jj + 2, 2 jj + 3 (of the next tile for jj = 7) must have landed.  LDS-DMA completes in
+            // issue order: a strip issued in the previous tile (2 jj + 3 < XR) is followed by the rest of that batch,
+            // this tile's side DMAs and this tile's 2 jj strips = XR - 4 + DMA_SIDE; one issued in this tile by XR - 4.
+            if (2 * jj + 3 < XR) __builtin_amdgcn_s_waitcnt(vmcnt_only(XR - 4 + DMA_SIDE));
+            else __builtin_amdgcn_s_waitcnt(vmcnt_only(XR - 4));
+            asm volatile("" ::: "memory");
+            an = a_read((2 * jj + 2) % 16);
+            an2 = a_read((2 * jj + 3) % 16);
+            __builtin_amdgcn_sched_barrier(0);
+            // the A operand: eight f32 of the row as two bf16 terms
+            bsc_u32x4 ah, am;
+            {
+                unsigned pk[4][SPLIT];
+                bsc_split_pk<SPLIT>(a0[0], a0[1], pk[0]);
+                bsc_split_pk<SPLIT>(a0[2], a0[3], pk[1]);
+                bsc_split_pk<SPLIT>(a1[0], a1[1], pk[2]);
+                bsc_split_pk<SPLIT>(a1[2], a1[3], pk[3]);
+                ah = bsc_u32x4{pk[0][0], pk[1][0], pk[2][0], pk[3][0]};
+                am = bsc_u32x4{pk[0][1], pk[1][1], pk[2][1], pk[3][1]};
+            }
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) {
+                acc[sb] = bsc_mfma16_bf16(ah, b[sb][1], acc[sb]);
+                acc[sb] = bsc_mfma16_bf16(am, b[sb][0], acc[sb]);
+                acc[sb] = bsc_mfma16_bf16(ah, b[sb][0], acc[sb]);
+            }
+            // slots (2 jj) % XR, (2 jj + 1) % XR are free (their strips are in a0, a1): strips 2 jj + XR, 2 jj + 1 + XR
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int j = 2 * jj + e;
+                if (j + XR < 16) x_dma(rs_cur, j + XR);
+                else x_dma(rs_next, j + XR - 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the next tile's side data: its DMAs were this tile's first, and the last strip wait
+        // (vmcnt <= XR - 2) has covered them; the epilogue below covers the LDS latency
+        if (!(DBG & 8)) side_read(par ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (DBG & 2) {
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) acc_ll[sb] += (double)(acc[sb][0] + acc[sb][1] + acc[sb][2] + acc[sb][3]);
+        } else {
+            loglik_epilogue<NSB>(acc, yv, row0 + XT <= N, row0, N, kq, acc_ll);
+        }
+        tile += n_waves;
+    };
+    for (int it = 0; it < n_iter; it += 2) {   // n_iter is even (host)
+        if (tile * XT >= N) break;             // (wave-uniform) nothing left for this wave
+        one_tile(0);
+        if (tile * XT >= N) break;
+        one_tile(1);
+    }
+    // no LDS-DMA of this wave may still be in flight when the workgroup's LDS is released
+    __builtin_amdgcn_s_waitcnt(vmcnt_only(0));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    loglik_finish<NSB>(acc_ll, red, wave, lane, tid, S, slab);
+#undef BSC_LDS_B128
+}
+
 // ell[s] = sum over the block partials, float64, fixed order.  One wave per sample (a single
 // 1024-thread workgroup walking all 64 columns took 10 us, mostly latency: a third of what the
 // whole parameter side of an update costs).
@@ -1137,6 +1372,11 @@ int bsc_logreg_bbvi_loglik(bsc_ctx* ctx, const float* X, int64_t ldx, const floa
                 case 16: hipLaunchKernelGGL((logreg_loglik_dma_kernel<true, 4, 16>), BSC_LL_ARGS); break;
                 default: hipLaunchKernelGGL((logreg_loglik_dma_kernel<true, 4>), BSC_LL_ARGS); break;
             }
+        } else if (dma_ok && ctx->mfma_split == 2) {
+            // the contraction on the bf16 MFMA, X and the draws as two bf16 terms (bsc_ctx_set_mfma_split; three
+            // terms of the draws do not fit the LDS next to the rings: that setting takes the f32 route here)
+            if (D == LD) hipLaunchKernelGGL((logreg_loglik_dma_bx_kernel<true>), BSC_LL_ARGS);
+            else hipLaunchKernelGGL((logreg_loglik_dma_bx_kernel<false>), BSC_LL_ARGS);
         } else if (dma_ok) {
             if (D == LD) hipLaunchKernelGGL((logreg_loglik_dma_kernel<true, 4>), BSC_LL_ARGS);
             else hipLaunchKernelGGL((logreg_loglik_dma_kernel<false, 4>), BSC_LL_ARGS);

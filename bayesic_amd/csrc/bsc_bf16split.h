@@ -51,6 +51,14 @@ __device__ __forceinline__ bsc_f32x16 bsc_mfma_bf16(bsc_u32x4 a, bsc_u32x4 b, bs
                                                    c, 0, 0, 0);
 }
 
+// 16x16x32: lane l = (r = l & 15, g = l >> 4) holds A[row r][k = 8 g + j], B[k = 8 g + j][col r]; result register i of
+// lane l is row 4 g + i, column r (the layout of v_mfma_f32_16x16x4_f32).
+typedef float bsc_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bsc_f32x4 bsc_mfma16_bf16(bsc_u32x4 a, bsc_u32x4 b, bsc_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bsc_bf16x8, a), __builtin_bit_cast(bsc_bf16x8, b),
+                                                   c, 0, 0, 0);
+}
+
 // The products of a SPLIT-term A with a SPLIT-term B, smallest terms first.
 template <int SPLIT>
 __device__ __forceinline__ bsc_f32x16 bsc_mfma_split(const bsc_u32x4 (&a)[SPLIT], const bsc_u32x4 (&b)[SPLIT],

@@ -23,6 +23,7 @@
 //   r is transposed through wave-private LDS ([row][comp], 16-byte writes)
 //   backward D[comp][feat] = A(r: lane = comp, k = row of the pair) * B(features from LDS)
 #include "bsc_common.h"
+#include "bsc_bf16split.h"
 
 namespace {
 
@@ -256,6 +257,265 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
         }
     }
     const float l = wave_allsum(lse_acc);   // one row per lane of the lower half
+    if (lane == 0) ep[MK * (1 + MF)] = l;
+    __syncthreads();
+    float* out = slab + (int64_t)blockIdx.x * MOG_SLAB;
+    for (int i = tid; i < MOG_SLAB; i += MOG_BLOCK) {
+        float v = lds[i];
+#pragma unroll
+        for (int k = 1; k < MOG_WAVES; ++k) v += lds[k * MOG_SLAB + i];
+        out[i] = v;
+    }
+}
+
+// ---- the same pass on the operand-split bf16 route (ctx->mfma_split != 0; csrc/bsc_bf16split.h) ----
+//
+// Forward on v_mfma_f32_32x32x16_bf16 with THREE bf16 terms per operand (6 products) whatever the context asks for:
+// a logit is c - tau (x - mu)^2 / 2 written out in x and x^2, a small difference of terms hundreds of times its
+// size, and two terms (2^-17 of each TERM) would leave the responsibilities with 1e-3 of error.  Backward with two
+// terms (3 products): sums of products of one sign class, r in (0, 1].  36 MFMAs of 32 cycles a tile against 64 of 64.
+//   * a lane loads HALF a row (x[8 h ..], 32 bytes): element j of its k-step-0 fragment is x[8 h + j], of k-step 1
+//     x[8 h + j]^2 -- the B operand (k = feature, n = row) with no data movement, no row read twice;
+//   * the result has the row on the lane and the components in registers, as before: the softmax is unchanged;
+//   * the backward sums over rows, i.e. over the LANE index of both its operands: e (unnormalised) and the
+//     features / sum go to wave-private LDS as bf16 terms, [row][32 components or features] with 64-byte rows, and
+//     come back transposed by ds_read_b64_tr_b16 (cdna_hip_programming.md "An accumulator tile as the next MFMA's
+//     operand").  8-byte chunk c of row r sits at chunk c ^ sw(r): sw = (r >> 1) & 7 for the e images (written 8
+//     bytes a lane: two lanes a bank, the floor), 2 ((r >> 1) & 3) for the feature image (written 16 bytes a lane);
+//     a transposed read's 32-lane half covers four whole rows = every bank once.
+constexpr int BX_E_IMG = 2048;                       // [32 rows][32 comps] bf16
+constexpr int BX_WAVE_LDS = (2 * 2 + 2) * BX_E_IMG;  // e: [cb][term]; features: [term]
+
+template <bool FULL>
+__global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_bx_kernel(
+    const float* __restrict__ X, int64_t ldx, int64_t N, int D, const float* __restrict__ Wmat,
+    const float* __restrict__ cvec, int K, float* __restrict__ slab, int n_iter) {
+    constexpr int LDS_BYTES = MOG_WAVES * BX_WAVE_LDS > MOG_WAVES * MOG_SLAB * 4 ? MOG_WAVES * BX_WAVE_LDS
+                                                                                  : MOG_WAVES * MOG_SLAB * 4;
+    __shared__ __attribute__((aligned(16))) char lds_raw[LDS_BYTES];
+    float* const lds = reinterpret_cast<float*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    char* const img = lds_raw + wave * BX_WAVE_LDS;
+    const unsigned img_addr = (unsigned)(uintptr_t)(bsc_lds_ptr)img;
+
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    // A operand of the forward product, three terms: W[comp = 32 cb + l31][k-step 0: x columns 8 half + j; 1: x^2 columns]
+    bsc_u32x4 wf[2][2][3];
+    f32x16 bias_q[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int comp = 32 * cb + drow(q, lane);
+            bias_q[cb][q] = comp < K ? cvec[comp] * LOG2E : -1.0e30f;
+        }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int comp = 32 * cb + l31;
+            float w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = 8 * half + j;
+                w[j] = (comp < K && d < D) ? Wmat[(int64_t)comp * 2 * D + (ks ? D + d : d)] * LOG2E : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                unsigned pk[3];
+                bsc_split_pk<3>(w[2 * t], w[2 * t + 1], pk);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) wf[cb][ks][c][t] = pk[c];
+            }
+        }
+
+    f32x16 S[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) S[cb][q] = 0.f;
+    f32x16 rsum[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rsum[cb][q] = 0.f;
+    float lse_acc = 0.f;
+
+    // where this lane writes its e registers 4 g .. 4 g + 3 (components 8 g + 4 half ..) and its features, and the
+    // transposed-read addresses: lane 4 q + p of a 16-lane group points at row r0 + q, 8-byte chunk c of the row
+    const int sw_e = (l31 >> 1) & 7, sw_g = 2 * ((l31 >> 1) & 3);
+    unsigned we[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) we[g] = img_addr + (unsigned)(l31 * 64 + 8 * ((2 * g + half) ^ sw_e));
+    const unsigned wg0 = img_addr + 4 * BX_E_IMG + (unsigned)(l31 * 64 + 8 * ((2 * half) ^ sw_g));          // x: chunks 2 h, 2 h + 1
+    const unsigned wg1 = img_addr + 4 * BX_E_IMG + (unsigned)(l31 * 64 + 8 * ((4 + 2 * half) ^ sw_g));      // x^2
+    const int gg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    // rows 8 (gg >> 1) + 4 e + tq (+ 16 s), chunk 4 (gg & 1) + tp
+    unsigned re[2], rg[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int row = 8 * (gg >> 1) + 4 * e + tq, ch = 4 * (gg & 1) + tp;
+        re[e] = img_addr + (unsigned)(row * 64 + 8 * (ch ^ ((row >> 1) & 7)));
+        rg[e] = img_addr + 4 * BX_E_IMG + (unsigned)(row * 64 + 8 * (ch ^ (2 * ((row >> 1) & 3))));
+    }
+
+    struct HalfRow { float x[8]; };
+    auto load_half = [&](HalfRow& t, int64_t row0) __attribute__((always_inline)) {
+        const int64_t rem = N - row0;
+        uint64_t bytes = 0;
+        if (rem > 0) bytes = ((uint64_t)(rem - 1) * (uint64_t)ldx + (uint64_t)D) * 4u;
+        const unsigned rec = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes;
+        const int64_t safe0 = rem > 0 ? row0 : 0;
+        auto xs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + safe0 * ldx), 0, rec, 0x00020000);
+        const int off = l31 * (int)(ldx * 4) + 32 * half;
+#pragma unroll
+        for (int c4 = 0; c4 < 2; ++c4) {
+            auto v = __builtin_amdgcn_raw_buffer_load_b128(xs, off + 16 * c4, 0, 2);        // nt: every byte is read once
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float f = __uint_as_float(v[j]);
+                if (!FULL && 8 * half + 4 * c4 + j >= D) f = 0.f;
+                t.x[4 * c4 + j] = f;
+            }
+        }
+    };
+
+    const int64_t stride = (int64_t)gridDim.x * MOG_WAVES;
+    int64_t tile = (int64_t)blockIdx.x * MOG_WAVES + wave;
+    HalfRow xa, xb;
+    load_half(xa, tile * MT);
+    auto one_tile = [&](const HalfRow& cur, HalfRow& nxt) __attribute__((always_inline)) {
+        load_half(nxt, (tile + stride) * MT);
+        const int64_t row0 = tile * MT;
+        // ---- forward: B = [x | x^2] of the row in three terms
+        float x2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x2[j] = cur.x[j] * cur.x[j];
+        bsc_u32x4 fb[2][3];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            unsigned pk[3];
+            bsc_split_pk<3>(cur.x[2 * t], cur.x[2 * t + 1], pk);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) fb[0][c][t] = pk[c];
+            bsc_split_pk<3>(x2[2 * t], x2[2 * t + 1], pk);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) fb[1][c][t] = pk[c];
+        }
+        f32x16 logit[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            logit[cb] = bsc_mfma_split<3>(wf[cb][0], fb[0], bias_q[cb]);
+            logit[cb] = bsc_mfma_split<3>(wf[cb][1], fb[1], logit[cb]);
+        }
+        // ---- softmax over the row's 64 components: 32 in this lane, 32 in lane ^ 32
+        const bool valid = row0 + l31 < N;
+        float m = -3.0e38f;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) m = __builtin_fmaxf(__builtin_fmaxf(logit[cb][q], logit[cb][q + 1]), m);
+        m = swap32_max(m);
+        float ssum = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                logit[cb][q] = __builtin_amdgcn_exp2f(logit[cb][q] - m);
+                ssum += logit[cb][q];
+            }
+        ssum = swap32_sum(ssum);
+        const float inv = valid ? 1.0f / ssum : 0.f;
+        if (valid && half == 0) lse_acc += LN2 * (m + __builtin_amdgcn_logf(ssum));
+        // ---- e (two terms) and the features / sum (two terms) to LDS
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) rsum[cb][q] = __builtin_fmaf(logit[cb][q], inv, rsum[cb][q]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned p0[2], p1[2];
+                bsc_split_pk<2>(logit[cb][4 * g], logit[cb][4 * g + 1], p0);
+                bsc_split_pk<2>(logit[cb][4 * g + 2], logit[cb][4 * g + 3], p1);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(we[g]), "v"(bsc_u32x2{p0[c], p1[c]}),
+                                 "n"((2 * cb + c) * BX_E_IMG) : "memory");
+            }
+        }
+        {
+            bsc_u32x4 gx[2], gx2[2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                unsigned pk[2];
+                bsc_split_pk<2>(cur.x[2 * t] * inv, cur.x[2 * t + 1] * inv, pk);
+                gx[0][t] = pk[0]; gx[1][t] = pk[1];
+                bsc_split_pk<2>(x2[2 * t] * inv, x2[2 * t + 1] * inv, pk);
+                gx2[0][t] = pk[0]; gx2[1][t] = pk[1];
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(wg0), "v"(gx[c]), "n"(c * BX_E_IMG) : "memory");
+                asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(wg1), "v"(gx2[c]), "n"(c * BX_E_IMG) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wave_lds_sync();
+        // ---- backward: S[comp][feat] += sum over rows e[row][comp] (f[row][feat] / sum[row]), 16 rows a k-step
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bsc_u32x2 g0[2], g1[2], e0[2][2], e1[2][2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                BSC_LDS_TR_B64(g0[c], rg[0], s * 1024 + c * BX_E_IMG);
+                BSC_LDS_TR_B64(g1[c], rg[1], s * 1024 + c * BX_E_IMG);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    BSC_LDS_TR_B64(e0[cb][c], re[0], s * 1024 + (2 * cb + c) * BX_E_IMG);
+                    BSC_LDS_TR_B64(e1[cb][c], re[1], s * 1024 + (2 * cb + c) * BX_E_IMG);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(g0[0]), "+v"(g0[1]), "+v"(g1[0]), "+v"(g1[1]), "+v"(e0[0][0]), "+v"(e0[0][1]), "+v"(e0[1][0]),
+                           "+v"(e0[1][1]), "+v"(e1[0][0]), "+v"(e1[0][1]), "+v"(e1[1][0]), "+v"(e1[1][1]));
+            bsc_u32x4 gb[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) gb[c] = bsc_u32x4{g0[c][0], g0[c][1], g1[c][0], g1[c][1]};
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                bsc_u32x4 ea[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) ea[c] = bsc_u32x4{e0[cb][c][0], e0[cb][c][1], e1[cb][c][0], e1[cb][c][1]};
+                S[cb] = bsc_mfma_split<2>(ea, gb, S[cb]);
+            }
+        }
+        wave_lds_sync();   // the next tile overwrites the images
+        tile += stride;
+    };
+    for (int it = 0; it < n_iter; it += 2) {   // n_iter is even (host): the row buffers alternate
+        one_tile(xa, xb);
+        one_tile(xb, xa);
+    }
+
+    // block reduction: per wave [comp][R | S] + L, then fixed-order sum over waves (as mog_estep_kernel)
+    __syncthreads();
+    float* ep = lds + wave * MOG_SLAB;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int comp = 32 * cb + drow(q, lane);
+            ep[comp * (1 + MF) + 1 + l31] = S[cb][q];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float r = half32_allsum(rsum[cb][q]);
+            if (l31 == 0) ep[(32 * cb + drow(q, lane)) * (1 + MF)] = r;
+        }
+    }
+    const float l = wave_allsum(lse_acc);
     if (lane == 0) ep[MK * (1 + MF)] = l;
     __syncthreads();
     float* out = slab + (int64_t)blockIdx.x * MOG_SLAB;
@@ -581,7 +841,13 @@ int bsc_mog_estep(bsc_ctx* ctx, const float* X, int64_t ldx, int64_t N, int32_t 
     ctx->slab_rows = 0;
     {
         bsc_prof_scope prof(ctx);
-        if (D == MD && ctx->mog_nt)
+        if (ctx->mfma_split) {
+            // bf16 MFMA: forward on three terms, backward on two (whichever of 2 / 3 the context asks for)
+            if (D == MD) hipLaunchKernelGGL((mog_estep_bx_kernel<true>), dim3(n_blocks), dim3(MOG_BLOCK), 0, ctx->stream, X,
+                                            ldx, N, (int)D, Wmat, c, (int)K, (float*)ws, n_iter);
+            else hipLaunchKernelGGL((mog_estep_bx_kernel<false>), dim3(n_blocks), dim3(MOG_BLOCK), 0, ctx->stream, X,
+                                    ldx, N, (int)D, Wmat, c, (int)K, (float*)ws, n_iter);
+        } else if (D == MD && ctx->mog_nt)
             hipLaunchKernelGGL((mog_estep_kernel<true, true>), dim3(n_blocks), dim3(MOG_BLOCK), 0, ctx->stream, X,
                                ldx, N, (int)D, Wmat, c, (int)K, (float*)ws, n_iter);
         else if (D == MD)

@@ -28,10 +28,12 @@ KERNELS = {
     "cfg2rot": ("blr_pass_mfma_kernel", "bsc_blr.hip", 4.0 * 1_000_000 * 256 + 4.0 * 1_000_000),
     "cfg3": ("mog_estep_kernel", "bsc_mog.hip", 4.0 * 10_000_000 * 16),
     "cfg3l2": ("mog_estep_kernel", "bsc_mog.hip", 4.0 * 10_000_000 * 16),
+    "cfg3x": ("mog_estep_bx_kernel", "bsc_mog.hip", 4.0 * 10_000_000 * 16),
     "softstats": ("gemm_softmax_stats_kernel", "bsc_rowsoftmax.hip", 4.0 * 10_000_000 * 32),
     "cfg4b": ("lda_sstats_stream_bound_kernel", "bsc_lda.hip", 4.0 * 6250 * 100_000),
     "cfg4x2": ("lda_sstats_bx2_bound_kernel", "bsc_lda.hip", 4.0 * 6250 * 100_000),
     "cfg4x3": ("lda_sstats_bx3_bound_kernel", "bsc_lda.hip", 4.0 * 6250 * 100_000),
+    "cfg5x2": ("logreg_loglik_dma_bx_kernel", "bsc_bbvi.hip", 4.0 * 1_000_000 * 256 + 8.0 * 1_000_000),
     "rowsoftmax": ("gemm_softmax_rows_kernel", "bsc_rowsoftmax.hip", 4.0 * 10_000_000 * (40 + 64 + 2)),
     "cfg4": ("lda_sstats_stream_kernel", "bsc_lda.hip", 4.0 * 6250 * 100_000),
     "cfg5": ("logreg_loglik_dma_kernel", "bsc_bbvi.hip", 4.0 * 1_000_000 * 256 + 8.0 * 1_000_000),

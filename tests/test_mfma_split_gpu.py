@@ -73,3 +73,139 @@ def test_split_is_off_by_default_and_rejects_other_term_counts(ctx):
     with pytest.raises(BayesicHipError):
         ctx.call("bsc_ctx_set_mfma_split", 1)
     ctx.call("bsc_ctx_set_mfma_split", 0)
+
+
+def _loglik(ctx, X, y, g, Wz, Bz):
+    D, G, S = X.shape[1], Bz.shape[0], Wz.shape[0]
+    Xd, yd = ctx.to_device(X), ctx.to_device(y)
+    gd = torch.as_tensor(g, dtype=torch.int32).to(ctx.device)
+    ell = ctx.zeros(S, torch.float64)
+    ctx.call("bsc_logreg_bbvi_loglik", Xd, D, yd, gd, X.shape[0], D, G, ctx.to_device(Wz), ctx.to_device(Bz), S, ell)
+    ctx.sync()
+    return ell.cpu().numpy()
+
+
+@pytest.mark.parametrize("N,D,G,S", [(32, 256, 7, 64), (1003, 256, 1000, 64), (5, 256, 3, 64), (4099, 64, 11, 64),
+                                     (20000, 252, 100, 64), (3000, 256, 9, 48), (70001, 256, 33, 64)])
+def test_logreg_loglik_on_split_operands(ctx, split_ctx, N, D, G, S):
+    """Config 5's data-sized contraction with X and the draws as two bf16 terms: tests/test_bbvi_gpu.py's comparison
+    and tolerance."""
+    import math
+    rs = np.random.RandomState(N + D + G)
+    X = rs.standard_normal((N, D)).astype(np.float32)
+    g = rs.randint(G, size=N).astype(np.int32)
+    y = (rs.uniform(size=N) < 0.4).astype(np.float32)
+    Wz = (rs.standard_normal((S, D)) / math.sqrt(D)).astype(np.float32)
+    Bz = rs.standard_normal((G, S)).astype(np.float32)
+    f32 = _loglik(ctx, X, y, g, Wz, Bz)
+    split_ctx(2)
+    ell = _loglik(ctx, X, y, g, Wz, Bz)
+    want = svi.logreg_loglik(X, y, g, Wz, Bz)
+    L = np.abs(X.astype(np.float64) @ Wz.astype(np.float64).T + Bz.astype(np.float64)[g])
+    bound = (L + 1.0).sum(axis=0)
+    assert (np.abs(ell - want) <= 2e-5 * bound + 1e-9).all(), np.abs((ell - want) / bound).max()
+    assert not np.array_equal(ell, f32)
+    npt.assert_array_equal(ell, _loglik(ctx, X, y, g, Wz, Bz))        # run-to-run identical
+    split_ctx(3)                                                       # three terms: not offered here -> the f32 route
+    npt.assert_array_equal(_loglik(ctx, X, y, g, Wz, Bz), f32)
+
+
+def test_logreg_loglik_split_operand_layout_with_exact_integers(ctx, split_ctx):
+    """tests/test_bbvi_gpu.py's layout test on the split route: integers are exact in one bf16 term, so any mix-up of
+    k order, sample or row mapping changes which rows count."""
+    N, D, G = 96, 256, 4
+    X = np.zeros((N, D), np.float32)
+    X[np.arange(N), (np.arange(N) * 7) % D] = 1.0
+    Wz = np.zeros((64, D), np.float32)
+    for s in range(64):
+        Wz[s, (s * 5) % D] = 40.0
+    Bz = np.full((G, 64), -20.0, np.float32)
+    g = (np.arange(N) % G).astype(np.int32)
+    y = (np.arange(N) % 3 == 0).astype(np.float32)
+    split_ctx(2)
+    ell = _loglik(ctx, X, y, g, Wz, Bz)
+    want = svi.logreg_loglik(X, y, g, Wz, Bz)
+    npt.assert_allclose(ell, want, rtol=1e-6, atol=1e-6)
+
+
+def _estep(ctx, X, Wmat, c):
+    K, twoD = Wmat.shape
+    D = twoD // 2
+    Xd = ctx.to_device(X) if X.shape[0] else ctx.zeros((1, D))
+    Wd, cd = ctx.to_device(Wmat), ctx.to_device(c)
+    stats, lse = ctx.zeros((K, 1 + 2 * D), torch.float64), ctx.zeros(1, torch.float64)
+    ctx.call("bsc_mog_estep", Xd, D, X.shape[0], D, K, Wd, cd, stats, lse)
+    ctx.sync()
+    return stats.cpu().numpy(), lse.item()
+
+
+@pytest.mark.parametrize("terms", [2, 3])
+@pytest.mark.parametrize("N,D,K", [(32, 16, 64), (1003, 16, 64), (7, 16, 64), (5000, 16, 33), (4097, 5, 64),
+                                   (333, 1, 2), (20000, 12, 40), (300000, 16, 64)])
+def test_mog_estep_on_split_operands(ctx, split_ctx, terms, N, D, K):
+    """Config 3's pass with the forward on three bf16 terms and the backward on two: tests/test_mog_gpu.py's
+    comparison and tolerances."""
+    rs = np.random.RandomState(N + D + K)
+    centres = rs.standard_normal((K, D)) * 3
+    X = (centres[rs.randint(K, size=N)] + rs.standard_normal((N, D))).astype(np.float32)
+    T = rs.uniform(0.5, 2.0, (K, D))
+    Wmat = np.concatenate([T * centres, -0.5 * T], axis=1).astype(np.float32)
+    c = (rs.standard_normal(K) - 0.5 * (T * centres ** 2).sum(1)).astype(np.float32)
+    f32_stats, _ = _estep(ctx, X, Wmat, c)
+    split_ctx(terms)
+    stats, lse = _estep(ctx, X, Wmat, c)
+    want, lse_ref = svi.mog_local_step(X, Wmat, c)
+    X64 = X.astype(np.float64)
+    scale = np.concatenate([[max(N, 1)], np.abs(X64).sum(0) + 1e-9, (X64 ** 2).sum(0) + 1e-9])
+    assert (np.abs(stats - want) <= 2e-5 * scale[None, :] + 1e-9).all(), \
+        np.abs((stats - want) / scale[None, :]).max()
+    npt.assert_allclose(stats[:, 0].sum(), N, rtol=1e-6, atol=1e-6)
+    npt.assert_allclose(lse, lse_ref, rtol=2e-6, atol=1e-4)
+    assert not np.array_equal(stats, f32_stats)
+    again, lse2 = _estep(ctx, X, Wmat, c)
+    npt.assert_array_equal(stats, again)
+    assert lse == lse2
+
+
+def test_mog_estep_split_operand_layout_with_separated_integer_data(ctx, split_ctx):
+    """tests/test_mog_gpu.py's layout test: one-hot responsibilities, integer data.  Counts and first moments are exact
+    (every operand fits its terms); squares of up to 18 bits do not fit two terms: 2^-17 of each."""
+    K, D, N = 64, 16, 64 * 40
+    k = np.arange(K)
+    centres = np.zeros((K, D))
+    centres[k, k % D] = 100.0 * (1 + k // D)
+    labels = np.arange(N) % K
+    offs = (np.arange(N)[:, None] * 7 + np.arange(D)[None, :] * 3) % 5 - 2
+    X = (centres[labels] + offs).astype(np.float32)
+    T = np.ones((K, D))
+    Wmat = np.concatenate([T * centres, -0.5 * T], axis=1).astype(np.float32)
+    c = (-0.5 * (centres ** 2).sum(1)).astype(np.float32)
+    split_ctx(2)
+    stats, _ = _estep(ctx, X, Wmat, c)
+    want = np.zeros((K, 1 + 2 * D))
+    for n in range(N):
+        want[labels[n], 0] += 1
+        want[labels[n], 1:1 + D] += X[n]
+        want[labels[n], 1 + D:] += X[n].astype(np.float64) ** 2
+    npt.assert_array_equal(stats[:, :1 + D], want[:, :1 + D])
+    npt.assert_allclose(stats[:, 1 + D:], want[:, 1 + D:], rtol=1e-5)
+
+
+def test_mog_driver_on_split_operands_tracks_the_oracle(ctx, split_ctx):
+    from bayesic_amd.svi.mog import MoGNatGradSVI
+    K, D = 8, 16
+    X, _, _ = svi.make_cfg3(40000, D, K)
+    eta0 = svi.mog_prior_eta(K, D)
+    eta = svi.mog_init_eta(X[:4000], K, D, seed=1)
+    split_ctx(2)
+    model = MoGNatGradSVI(X, K, eta0, eta, n_total=3 * len(X), ctx=ctx)
+    for t in range(1, 4):
+        Wmat, c = svi.mog_expected_params(eta, K, D)
+        _, lse = svi.mog_local_step(X, Wmat, c)
+        want = svi.mog_elbo(eta, eta0, lse, 3.0, K, D)
+        model.step()
+        eta, _, _ = svi.mog_svi_step(eta, eta0, X, 3 * len(X), (t + 1.0) ** -0.6, K, D)
+        ctx.sync()
+        npt.assert_allclose(model.elbo.item(), want, rtol=2e-6)
+        npt.assert_allclose(model.eta.cpu().numpy(), eta, rtol=2e-4, atol=1e-6)
+        model.eta.copy_(torch.as_tensor(eta, dtype=torch.float64))

@@ -2,7 +2,7 @@
 passes (tools/pmc_collect.sh).  Inputs are random device tensors (counters do not depend on the
 values); the call is the same C-ABI entry point bench.py / the drivers use.
 
-    python3 tools/pmc_run.py cfg2|cfg2rot|cfg3|cfg4|cfg4b|cfg4x2|cfg4x3|cfg5|rowsoftmax|softstats|wouter|gram|skinny|lda1|lda1e|lda2|sq4096nt|sq4096tn [reps]
+    python3 tools/pmc_run.py cfg2|cfg2rot|cfg3|cfg3x|cfg4|cfg4b|cfg4x2|cfg4x3|cfg5|cfg5x2|rowsoftmax|softstats|wouter|gram|skinny|lda1|lda1e|lda2|sq4096nt|sq4096tn [reps]
 """
 import os
 import sys
@@ -81,6 +81,17 @@ def main():
         stats = torch.zeros(K * (1 + 2 * D), dtype=torch.float64, device=dev)
         lse = torch.zeros(1, dtype=torch.float64, device=dev)
         fn = lambda: ctx.call("bsc_mog_estep", X, D, N, D, K, Wm, c, stats, lse)
+    elif which == "cfg3x":
+        # config 3's pass on the bf16 MFMA (forward on three terms, backward on two)
+        N, D, K = 10_000_000, 16, 64
+        X = torch.randn((N, D), generator=g, device=dev) * 3
+        Wm = torch.randn((K, 2 * D), generator=g, device=dev) * 0.1
+        Wm[:, D:] = -0.5
+        c = torch.zeros(K, device=dev)
+        stats = torch.zeros(K * (1 + 2 * D), dtype=torch.float64, device=dev)
+        lse = torch.zeros(1, dtype=torch.float64, device=dev)
+        ctx.call("bsc_ctx_set_mfma_split", 2)
+        fn = lambda: ctx.call("bsc_mog_estep", X, D, N, D, K, Wm, c, stats, lse)
     elif which == "wouter":
         N, D, K = 10_000_000, 16, 64
         X = torch.randn((N, D), generator=g, device=dev) * 3
@@ -122,6 +133,18 @@ def main():
         ll = torch.empty(1, dtype=torch.float64, device=dev)
         ctx.call("bsc_ctx_set_mfma_split", int(which[-1]))
         fn = lambda: ctx.call("bsc_lda_sstats_bound", C, V, docs, V, K, Th, K, Bt, V, out, V, ll)
+    elif which == "cfg5x2":
+        # config 5's pass with X and the draws as two bf16 terms
+        import math
+        N, D, G, S = 1_000_000, 256, 1000, 64
+        X = torch.randn((N, D), generator=g, device=dev)
+        y = (torch.rand(N, generator=g, device=dev) < 0.4).float()
+        ids = torch.randint(G, (N,), generator=g, device=dev, dtype=torch.int32)
+        Wz = torch.randn((S, D), generator=g, device=dev) / math.sqrt(D)
+        Bz = torch.randn((G, S), generator=g, device=dev)
+        ell = torch.empty(S, dtype=torch.float64, device=dev)
+        ctx.call("bsc_ctx_set_mfma_split", 2)
+        fn = lambda: ctx.call("bsc_logreg_bbvi_loglik", X, D, y, ids, N, D, G, Wz, Bz, S, ell)
     elif which == "gram":
         N, D = 1_000_000, 256
         X = torch.randn((N, D), generator=g, device=dev)
