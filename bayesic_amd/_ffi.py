@@ -158,6 +158,8 @@ SIGNATURES = {
     "bsc_eye": (c_int, [c_void_p, c_int, c_void_p, c_int64]),
     "bsc_logdet_spd": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                c_int64, c_void_p]),
+    "bsc_inverse_spd": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                c_int64, c_void_p, c_void_p]),
 }
 
 COMM_ID_BYTES = 128   # BSC_COMM_ID_BYTES

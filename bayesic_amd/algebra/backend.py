@@ -63,6 +63,11 @@ class Backend(object):
         """log det over the trailing two axes (bayesic/distribution/core.py:50)."""
         raise NotImplementedError
 
+    def inverse_spd(self, x):
+        """Inverse of symmetric positive-definite matrices over the trailing two axes: a resident
+        multivariate-normal / Wishart factor's natural parameters -> expectations (inference/vmp.py)."""
+        raise NotImplementedError
+
     def softmax_rows(self, x):
         """(softmax over the LAST axis, log-sum-exp over the last axis): the expectation of a
         Categorical node whose natural parameters live on the backend (inference/vmp.py)."""

@@ -1153,6 +1153,19 @@ class DeviceBackend(Backend):
                       xb.stride(1), xb.stride(2), _ffi.ptr(out))
         return out
 
+    def inverse_spd(self, x):
+        x = self._force(x)
+        n = x.shape[-1]
+        if x.dim() < 2 or x.shape[-2] != n:
+            raise ValueError("inverse_spd needs square matrices")
+        xb = x.reshape([-1, n, n]) if x.dim() != 3 else x     # view when possible
+        if not (x.dim() == 3 or xb.data_ptr() == x.data_ptr()):
+            xb = self._contiguous(x).reshape([-1, n, n])
+        out = self._empty(list(x.shape), x.dtype)
+        self.ctx.call("bsc_inverse_spd", _DT[x.dtype], xb.shape[0], n, _ffi.ptr(xb), xb.stride(0), xb.stride(1),
+                      xb.stride(2), _ffi.ptr(out), None)
+        return out
+
     @staticmethod
     def _merge(t, axes):
         """(extent, stride) of the axes `axes` of t collapsed into one, or None when

@@ -169,6 +169,65 @@ __global__ __launch_bounds__(1024) void logdet_spd_kernel(const T* __restrict__ 
     (void)red;
 }
 
+// Inverse (and log-determinant) of symmetric positive definite matrices, one workgroup each, float64 inside:
+// Cholesky A = L L^T in `work`, then L^-1 by forward substitution (column j of the inverse by thread j),
+// then A^-1 = L^-T L^-1.  Parameter-sized: what a resident multivariate-normal or Wishart factor needs to turn
+// its natural parameters (precision, V^-1) into expectations without leaving the device (inference/vmp.py).
+template <typename T>
+__global__ __launch_bounds__(1024) void inverse_spd_kernel(const T* __restrict__ A, int64_t n, int64_t s_b, int64_t s_r,
+                                                           int64_t s_c, double* __restrict__ work, T* __restrict__ out,
+                                                           T* __restrict__ logdet) {
+    __shared__ double pivot;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int64_t b = blockIdx.x;
+    double* L = work + b * 2 * n * n;
+    double* Li = L + n * n;
+    const T* src = A + b * s_b;
+    for (int64_t i = tid; i < n * n; i += nt) {
+        const int64_t r = i / n, c = i % n;
+        // (a message is symmetric up to rounding: take the mean of the two triangles)
+        L[i] = 0.5 * ((double)src[r * s_r + c * s_c] + (double)src[c * s_r + r * s_c]);
+    }
+    __syncthreads();
+    double logsum = 0.0;
+    for (int64_t j = 0; j < n; ++j) {
+        if (tid == 0) pivot = sqrt(L[j * n + j]);
+        __syncthreads();
+        const double d = pivot;
+        if (tid == 0) {
+            logsum += log(d);
+            L[j * n + j] = d;
+        }
+        for (int64_t i = j + 1 + tid; i < n; i += nt) L[i * n + j] /= d;
+        __syncthreads();
+        const int64_t m = n - j - 1;
+        for (int64_t t = tid; t < m * m; t += nt) {
+            const int64_t i = j + 1 + t / m, k = j + 1 + t % m;
+            if (k <= i) L[i * n + k] -= L[i * n + j] * L[k * n + j];
+        }
+        __syncthreads();
+    }
+    // column c of L^-1 (lower triangular): x_c = 1 / L_cc, x_i = -(sum_{k=c..i-1} L_ik x_k) / L_ii
+    for (int64_t c = tid; c < n; c += nt) {
+        for (int64_t i = 0; i < c; ++i) Li[i * n + c] = 0.0;
+        Li[c * n + c] = 1.0 / L[c * n + c];
+        for (int64_t i = c + 1; i < n; ++i) {
+            double acc = 0.0;
+            for (int64_t k = c; k < i; ++k) acc += L[i * n + k] * Li[k * n + c];
+            Li[i * n + c] = -acc / L[i * n + i];
+        }
+    }
+    __syncthreads();
+    T* dst = out + b * n * n;
+    for (int64_t t = tid; t < n * n; t += nt) {
+        const int64_t i = t / n, j = t % n;
+        double acc = 0.0;
+        for (int64_t k = (i > j ? i : j); k < n; ++k) acc += Li[k * n + i] * Li[k * n + j];
+        dst[t] = (T)acc;
+    }
+    if (tid == 0 && logdet) logdet[b] = (T)(2.0 * logsum);
+}
+
 int fill_dims(Dims& d, int rank, const int64_t* shape, int64_t* total, const char* who) {
     BSC_REQUIRE(rank >= 0 && rank <= MAXR, "%s: rank %d exceeds %d", who, rank, MAXR);
     d.rank = rank;
@@ -354,6 +413,27 @@ int bsc_logdet_spd(bsc_ctx* ctx, int dtype, int64_t batch, int64_t n, const void
     else
         hipLaunchKernelGGL(logdet_spd_kernel<double>, dim3((unsigned)batch), dim3(1024), 0,
                            ctx->stream, (const double*)A, n, s_b, s_r, s_c, (double*)ws, (double*)out);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_inverse_spd(bsc_ctx* ctx, int dtype, int64_t batch, int64_t n, const void* A, int64_t s_b, int64_t s_r,
+                    int64_t s_c, void* out, void* logdet) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(dtype == BSC_F32 || dtype == BSC_F64, "bsc_inverse_spd: unknown dtype %d", dtype);
+    BSC_REQUIRE(batch >= 0 && n >= 0 && (out || batch * n == 0), "bsc_inverse_spd: bad arguments");
+    if (batch == 0 || n == 0) return BSC_OK;
+    BSC_REQUIRE(A, "bsc_inverse_spd: A is null");
+    void* ws = nullptr;
+    int rc = bsc_workspace(ctx, (size_t)batch * 2 * n * n * sizeof(double) + 8, &ws);
+    if (rc != BSC_OK) return rc;
+    ctx->slab_rows = 0;
+    if (dtype == BSC_F32)
+        hipLaunchKernelGGL(inverse_spd_kernel<float>, dim3((unsigned)batch), dim3(1024), 0, ctx->stream, (const float*)A, n,
+                           s_b, s_r, s_c, (double*)ws, (float*)out, (float*)logdet);
+    else
+        hipLaunchKernelGGL(inverse_spd_kernel<double>, dim3((unsigned)batch), dim3(1024), 0, ctx->stream, (const double*)A,
+                           n, s_b, s_r, s_c, (double*)ws, (double*)out, (double*)logdet);
     BSC_LAUNCH_CHECK();
     return BSC_OK;
 }

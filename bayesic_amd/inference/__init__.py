@@ -5,8 +5,12 @@ from .conjugacy import (NotConjugate, conjugate_coefficients, depends_on, expand
 from .bbvi import ScoreFunctionVI
 from .reparam import ReparamVI
 from .vmp import (CategoricalNode, DirichletNode, GammaNode, InverseGammaNode, MeanFieldVMP,
-                  MVNormalNode, NormalGammaNode, NormalNode, WishartNode)
+                  MVNormalNode, NormalGammaNode, NormalNode, WishartNode, ResidentDirichletNode,
+                  ResidentGammaNode, ResidentInverseGammaNode, ResidentMVNormalNode, ResidentNormalGammaNode,
+                  ResidentNormalNode, ResidentWishartNode)
 
 __all__ = ["NotConjugate", "conjugate_coefficients", "depends_on", "expand_terms",
            "MeanFieldVMP", "NormalNode", "GammaNode", "DirichletNode", "CategoricalNode", "MVNormalNode", "InverseGammaNode", "WishartNode", "NormalGammaNode",
+           "ResidentDirichletNode", "ResidentGammaNode", "ResidentInverseGammaNode", "ResidentMVNormalNode",
+           "ResidentNormalGammaNode", "ResidentNormalNode", "ResidentWishartNode",
            "ScoreFunctionVI", "ReparamVI"]

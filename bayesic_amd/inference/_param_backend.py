@@ -126,3 +126,6 @@ class ParameterBackend(Backend):
 
     def broadcast_to(self, g, shape):
         return np.broadcast_to(np.asarray(g, np.float64), tuple(shape))
+
+    def inverse_spd(self, x):
+        return np.linalg.inv(self._small(x))

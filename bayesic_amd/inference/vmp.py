@@ -423,27 +423,34 @@ class _ResidentGlobal(object):
     the device backend (the host-side nodes keep float64)."""
     resident = True
 
+    def _eta_shapes(self):
+        """Shape of each natural parameter (element-wise families: one common shape)."""
+        common = tuple(np.broadcast_shapes(*[np.shape(e) for e in self.eta]))
+        return [common] * len(self.eta)
+
     def bind(self, backend):
         self._backend = backend
-        self._shape = tuple(np.broadcast_shapes(*[np.shape(e) for e in self.eta]))
+        self._shapes = [tuple(sh) for sh in self._eta_shapes()]
+        self._shape = self._shapes[0]
         # (float64 handed over: a float64 backend keeps it, the device backend stores float32)
-        self.eta = [backend.from_host(np.ascontiguousarray(np.broadcast_to(np.asarray(e, np.float64), self._shape)),
-                                      "float32", len(self._shape))
-                    for e in self.eta]
+        # (np.ascontiguousarray would turn a scalar factor's 0-d parameter into shape (1,))
+        self.eta = [backend.from_host(np.array(np.broadcast_to(np.asarray(e, np.float64), sh), order="C"),
+                                      "float32", len(sh))
+                    for e, sh in zip(self.eta, self._shapes)]
         self._exp = None
 
     def set_eta(self, j, value):
         b = self._backend
         value = b.materialize(value)
-        if tuple(np.shape(value)) != self._shape:
+        if tuple(np.shape(value)) != self._shapes[j]:
             # a coefficient that does not depend on one of the statistic's axes comes back with that
             # axis broadcast (extent 1): sum_d LT_kd inside a term gives c_kd = c_k
-            value = b.materialize(b.elemwise("add", b.broadcast_to(value, self._shape), b.constant(0.0)))
+            value = b.materialize(b.elemwise("add", b.broadcast_to(value, self._shapes[j]), b.constant(0.0)))
         self.eta[j] = value
         self._exp = None
 
     def host_eta(self):
-        return [np.asarray(self._backend.to_host(e), np.float64).reshape(self._shape) for e in self.eta]
+        return [np.asarray(self._backend.to_host(e), np.float64).reshape(sh) for e, sh in zip(self.eta, self._shapes)]
 
     def expectations(self):
         return [np.asarray(self._backend.to_host(e), np.float64) for e in self.expectations_backend()]
@@ -495,6 +502,117 @@ class ResidentNormalGammaNode(_ResidentGlobal, NormalGammaNode):
         kappa = -2.0 * e2
         m = e1 / kappa
         return NormalGammaNode(*self._vars, m=m, kappa=kappa, a=e3 + 0.5, b=-e4 - 0.5 * kappa * m * m)
+
+
+class ResidentNormalNode(_ResidentGlobal, NormalNode):
+    def expectations_backend(self):
+        if self._exp is None:
+            b = self._backend
+            c = b.constant
+            var = b.materialize(b.mul(c(-0.5), b.elemwise("pow", self.eta[1], c(-1.0))))
+            mean = b.materialize(b.mul(self.eta[0], var))
+            self._exp = [mean, b.materialize(b.elemwise("add", b.mul(mean, mean), var))]
+        return self._exp
+
+    def host_copy(self):
+        e1, e2 = self.host_eta()
+        return NormalNode(self.var, mean=e1 * (-0.5 / e2), variance=-0.5 / e2)
+
+
+class ResidentGammaNode(_ResidentGlobal, GammaNode):
+    def expectations_backend(self):
+        if self._exp is None:
+            b = self._backend
+            c = b.constant
+            a = b.materialize(b.elemwise("add", self.eta[0], c(1.0)))
+            rate = b.materialize(b.mul(c(-1.0), self.eta[1]))
+            self._exp = [b.materialize(b.elemwise("add", b.elemwise("digamma", a),
+                                                  b.mul(c(-1.0), b.elemwise("log", rate)))),
+                         b.materialize(b.mul(a, b.elemwise("pow", rate, c(-1.0))))]
+        return self._exp
+
+    def host_copy(self):
+        e1, e2 = self.host_eta()
+        return GammaNode(self.var, shape=e1 + 1.0, rate=-e2)
+
+
+class ResidentInverseGammaNode(_ResidentGlobal, InverseGammaNode):
+    def expectations_backend(self):
+        if self._exp is None:
+            b = self._backend
+            c = b.constant
+            a = b.materialize(b.elemwise("add", b.mul(c(-1.0), self.eta[0]), c(-1.0)))
+            scale = b.materialize(b.mul(c(-1.0), self.eta[1]))
+            self._exp = [b.materialize(b.elemwise("add", b.elemwise("log", scale),
+                                                  b.mul(c(-1.0), b.elemwise("digamma", a)))),
+                         b.materialize(b.mul(a, b.elemwise("pow", scale, c(-1.0))))]
+        return self._exp
+
+    def host_copy(self):
+        e1, e2 = self.host_eta()
+        return InverseGammaNode(self.var, shape=-e1 - 1.0, scale=-e2)
+
+
+class ResidentMVNormalNode(_ResidentGlobal, MVNormalNode):
+    """(E[w], E[w w^T]) = (Sigma eta_1, Sigma + m m^T), Sigma = (-2 eta_2)^-1 by the backend's SPD inverse
+    (``bsc_inverse_spd``): the D x D precision message of a regression never leaves the device."""
+
+    def _eta_shapes(self):
+        return [np.shape(self.eta[0]), np.shape(self.eta[1])]
+
+    def expectations_backend(self):
+        if self._exp is None:
+            b = self._backend
+            c = b.constant
+            r = len(self._shapes[0])                  # axes of w: lead..., D
+            lead = list(range(r - 1))
+            swapped = b.dimshuffle(self.eta[1], lead + [r, r - 1])
+            cov = b.materialize(b.inverse_spd(b.materialize(b.mul(c(-1.0), b.elemwise("add", self.eta[1], swapped)))))
+            eta1_row = b.dimshuffle(self.eta[0], lead + ["x", r - 1])
+            mean = b.materialize(b.sum(b.mul(cov, eta1_row), [r]))
+            outer = b.mul(b.dimshuffle(mean, lead + [r - 1, "x"]), b.dimshuffle(mean, lead + ["x", r - 1]))
+            self._exp = [mean, b.materialize(b.elemwise("add", cov, outer))]
+        return self._exp
+
+    def host_copy(self):
+        e1, e2 = self.host_eta()
+        lam = -(e2 + np.swapaxes(e2, -1, -2))
+        cov = np.linalg.inv(lam)
+        return MVNormalNode(self.var, self.second, mean=np.einsum("...ij,...j->...i", cov, e1), covariance=cov)
+
+
+class ResidentWishartNode(_ResidentGlobal, WishartNode):
+    """(E[log det Lambda], E[Lambda]) = (sum_i psi((nu - i) / 2) + D log 2 - log det(-2 eta_2), nu (-2 eta_2)^-1)."""
+
+    def _eta_shapes(self):
+        return [np.shape(self.eta[0]), np.shape(self.eta[1])]
+
+    def expectations_backend(self):
+        if self._exp is None:
+            b = self._backend
+            c = b.constant
+            d = self.dim
+            r = len(self._shapes[0])                  # leading axes
+            lead = list(range(r))
+            # (a message is symmetric only in what it says about the symmetric Lambda: sum(Lam * outer(sx, mu)) carries
+            # sx mu^T, not its symmetric part)
+            swapped = b.dimshuffle(self.eta[1], lead + [r + 1, r])
+            vinv = b.materialize(b.mul(c(-1.0), b.elemwise("add", self.eta[1], swapped)))
+            V = b.materialize(b.inverse_spd(vinv))
+            nu = b.materialize(b.elemwise("add", b.mul(c(2.0), self.eta[0]), c(d + 1.0)))
+            steps = b.from_host(np.arange(d, dtype=np.float64).reshape([1] * r + [d]) * -0.5, "float32", r + 1)
+            half = b.elemwise("add", b.mul(c(0.5), b.dimshuffle(nu, lead + ["x"])), steps)
+            psi_sum = b.sum(b.elemwise("digamma", half), [r])
+            # (from_host, not constant: a float64 backend then keeps all of D log 2)
+            elogdet = b.materialize(b.elemwise("add", psi_sum, b.from_host(np.asarray(d * math.log(2.0)), "float32", 0),
+                                               b.mul(c(-1.0), b.logdet(vinv))))
+            self._exp = [elogdet, b.materialize(b.mul(b.dimshuffle(nu, lead + ["x", "x"]), V))]
+        return self._exp
+
+    def host_copy(self):
+        e1, e2 = self.host_eta()
+        inv = -(e2 + np.swapaxes(e2, -1, -2))
+        return WishartNode(self.var, dof=2.0 * e1 + self.dim + 1.0, scale=np.linalg.inv(inv))
 
 
 class MeanFieldVMP(object):

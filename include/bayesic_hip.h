@@ -575,6 +575,14 @@ int bsc_stream_plan(int64_t tiles, int32_t n_kt, int64_t slots, int32_t out[6]);
 int bsc_logdet_spd(bsc_ctx* ctx, int dtype, int64_t batch, int64_t n, const void* A, int64_t s_b,
                    int64_t s_r, int64_t s_c, void* out);
 
+/* out[b] (n x n, contiguous) = the inverse of the symmetric positive-definite A[b] (strides in elements; the mean of
+ * the two triangles is taken), by float64 Cholesky; logdet[b] = log det A[b] when logdet is not null.  What turns the
+ * natural parameters of a multivariate-normal or Wishart factor (precision, V^-1) into its expectations on the
+ * device: the variational-message-passing update of README.md:36 for the (t(x) = (x, x x^T)) family of
+ * bayesic/distribution/core.py:41-56, whose host-side form calls numpy.linalg.inv.  NaN when not SPD. */
+int bsc_inverse_spd(bsc_ctx* ctx, int dtype, int64_t batch, int64_t n, const void* A, int64_t s_b, int64_t s_r,
+                    int64_t s_c, void* out, void* logdet);
+
 /* out[n,n] = identity, contiguous. */
 int bsc_eye(bsc_ctx* ctx, int dtype, void* out, int64_t n);
 

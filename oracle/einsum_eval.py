@@ -123,6 +123,10 @@ class NumpyBackend(Backend):
         sign, value = np.linalg.slogdet(np.asarray(x, dtype=np.float64))
         return value.astype(x.dtype)
 
+    def inverse_spd(self, x):
+        x = np.asarray(x)
+        return np.linalg.inv(0.5 * (x + np.swapaxes(x, -1, -2)).astype(np.float64)).astype(x.dtype)
+
     def softmax_rows(self, x):
         x = np.asarray(x)
         m = x.max(axis=-1, keepdims=True)
