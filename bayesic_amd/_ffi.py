@@ -155,6 +155,11 @@ SIGNATURES = {
                                   c_void_p, c_int64, c_int64, c_int64,
                                   c_void_p, c_int64, c_int64, c_int64,
                                   c_int, c_double, c_void_p, c_int64, c_int64, c_int64]),
+    "bsc_gemm_fused": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64,
+                               c_void_p, c_int64, c_int64, c_int64, c_int,
+                               c_void_p, c_int64, c_int64, c_int64, c_int,
+                               c_void_p, c_int64, c_int64, c_int64,
+                               c_int, c_double, c_void_p, c_int64, c_int64, c_int64, POINTER(c_int32)]),
     "bsc_eye": (c_int, [c_void_p, c_int, c_void_p, c_int64]),
     "bsc_logdet_spd": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                c_int64, c_void_p]),

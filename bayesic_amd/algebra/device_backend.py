@@ -93,11 +93,14 @@ class LazyGemm(object):
     ``B * dot(X, Y)`` and ``C / dot(X, Y)`` (bayesic/algebra.py:741-765, 1419-1432); Theano's graph
     optimiser would have fused them, here the executor does."""
 
-    __slots__ = ("gemm", "shape", "dtype", "power", "scale", "E")
+    __slots__ = ("gemm", "shape", "dtype", "power", "scale", "E", "pre")
 
-    def __init__(self, gemm, shape, dtype, power=1, scale=1.0, E=None):
+    def __init__(self, gemm, shape, dtype, power=1, scale=1.0, E=None, pre=None):
         self.gemm, self.shape, self.dtype = gemm, tuple(shape), dtype
         self.power, self.scale, self.E = power, scale, E
+        # pre = (code_x, code_y): element-wise producers of the operands folded into the product's fragment reads
+        # (bsc_gemm_fused; 1 square, 2 exp, 3 abs) -- `gemm` then holds the producers' SOURCE tensors
+        self.pre = pre
 
     @property
     def ndim(self):
@@ -661,6 +664,25 @@ class DeviceBackend(Backend):
             return self._force(self.tensordot(g.outer_x, q, x_dot, y_dot, [], []))
         xb, m, n, k, x, sxb, sxm, sxk, y, syb, syk, syn = g.gemm
         out = self._empty(g.shape, g.dtype)
+        if g.pre is not None:
+            E = g.E
+            se_m = se_n = 0
+            if E is not None:
+                se_m = 0 if E.shape[0] == 1 else E.stride(0)
+                se_n = 0 if E.shape[1] == 1 else E.stride(1)
+            plain = g.power == 1 and E is None and g.scale == 1.0
+            handled = ctypes.c_int32(0)
+            self.ctx.call("bsc_gemm_fused", _DT[g.dtype], xb, m, n, k, _ffi.ptr(x), sxb, sxm, sxk, g.pre[0],
+                          _ffi.ptr(y), syb, syk, syn, g.pre[1], _ffi.ptr(out), m * n, n, 1,
+                          0 if plain else int(g.power), float(g.scale), _ffi.ptr(E) if E is not None else None,
+                          0, se_m, se_n, ctypes.byref(handled))
+            if handled.value:
+                return out
+            # the shape takes a kernel without prologues: the producers are launched after all (same strides:
+            # an element-wise value has its source's layout)
+            x = self._apply_pre(x, g.pre[0])
+            y = self._apply_pre(y, g.pre[1])
+            (sxb, sxm, sxk), (syb, syk, syn) = self._restride(g.gemm[4], x, sxb, sxm, sxk), self._restride(g.gemm[8], y, syb, syk, syn)
         if g.power == 1 and g.E is None and g.scale == 1.0:
             self.ctx.call("bsc_gemm_strided_batched", _DT[g.dtype], xb, m, n, k,
                           _ffi.ptr(x), sxb, sxm, sxk, _ffi.ptr(y), syb, syk, syn,
@@ -677,13 +699,51 @@ class DeviceBackend(Backend):
                       _ffi.ptr(E) if E is not None else None, 0, se_m, se_n)
         return out
 
+    _PRE_CODES = {1: ("pow", 2.0), 2: ("exp", 0.0), 3: ("abs_", 0.0)}
+
+    def _apply_pre(self, t, code):
+        if not code:
+            return t
+        op, arg = self._PRE_CODES[code]
+        return self._launch(Lazy("mul", [(t, op, arg)], t.shape, t.dtype))
+
+    @staticmethod
+    def _restride(src, new, s_b, s_m, s_k):
+        """Strides of the merged (batch, free, contracted) axis groups of `src`, for `new` = an element-wise
+        value of it: the same when the layouts agree (they do for a dense source), else not representable."""
+        if new is src or tuple(new.stride()) == tuple(src.stride()):
+            return s_b, s_m, s_k
+        raise ValueError("prologue fallback: the materialised operand does not have its source's layout")
+
+    def _prologue_of(self, v):
+        """(source tensor, code, scale) when `v` is an element-wise producer the GEMM can apply to its fragments:
+        exp(T), abs(T), T ** 2, T * T (times a host scalar), T a dense float32 tensor of v's shape that is not a
+        constant of the model (a constant's X * X is computed once and cached instead: _const_cache)."""
+        if not (self.fuse and isinstance(v, Lazy)) or v.post is not None or v.shift != 0.0 or v.combine != "mul" \
+                or v.dtype != torch.float32:
+            return None
+        terms = v.terms
+        code = None
+        if len(terms) == 1:
+            t, op, arg = terms[0]
+            code = {"exp": 2, "abs_": 3}.get(op) if op in ("exp", "abs_") else (1 if op == "pow" and float(arg) == 2.0 else None)
+        elif len(terms) == 2 and terms[0][1] is None and terms[1][1] is None:
+            t, u = terms[0][0], terms[1][0]
+            if t.data_ptr() == u.data_ptr() and tuple(t.shape) == tuple(u.shape) and tuple(t.stride()) == tuple(u.stride()):
+                code = 1
+        if code is None:
+            return None
+        if tuple(t.shape) != tuple(v.shape) or t.dtype != torch.float32 or not t.is_contiguous() or self._is_const(t):
+            return None
+        return t, code, float(v.scale)
+
     def _unary(self, op_name, x, arg=0.0):
         if isinstance(x, LazyLda):
             x = self._force(x)
         if isinstance(x, LazyGemm):
             if self.fuse and op_name == "pow" and float(arg) in (1.0, -1.0) and x.E is None and \
                     x.power == 1 and x.scale == 1.0:
-                return LazyGemm(x.gemm, x.shape, x.dtype, power=int(arg))
+                return LazyGemm(x.gemm, x.shape, x.dtype, power=int(arg), pre=x.pre)
             x = self._force(x)
         if isinstance(x, Lazy):
             if x.post is None and self.fuse:
@@ -781,7 +841,7 @@ class DeviceBackend(Backend):
         m, n = g0.shape
         for g in gemms:
             xb, gm, gn, k, x, sxb, sxm, sxk, y, syb, syk, syn = g.gemm
-            if g.power != 1 or g.E is not None or xb != 1 or (gm, gn) != (m, n) or g.dtype != torch.float32 \
+            if g.power != 1 or g.E is not None or g.pre is not None or xb != 1 or (gm, gn) != (m, n) or g.dtype != torch.float32 \
                     or sxk != 1 or sxm < k or not self._is_const(x) or self._keep is not None:
                 return None
         rows = []
@@ -889,7 +949,7 @@ class DeviceBackend(Backend):
 
     def _lda_pattern(self, x, y, x_dot, y_dot):
         """x = Th^T (a view), y = C / dot(Th, Bt) still deferred: a LazyLda, or None."""
-        if not (isinstance(x, torch.Tensor) and x.dim() == 2 and x.dtype == torch.float32 and y.scale == 1.0
+        if not (isinstance(x, torch.Tensor) and x.dim() == 2 and x.dtype == torch.float32 and y.scale == 1.0 and y.pre is None
                 and y.dtype == torch.float32 and len(y.shape) == 2 and list(y_dot) == [0] and len(x_dot) == 1):
             return None
         xb, docs, V, K, Th, sxb, ldth, sxk, Bt, syb, ldb, syn = y.gemm
@@ -939,7 +999,7 @@ class DeviceBackend(Backend):
             if not isinstance(E, torch.Tensor) or E.dim() != 2 or E.dtype != torch.float32 or \
                     any(E.shape[a] not in (1, g.shape[a]) for a in range(2)):
                 return None
-        return LazyGemm(g.gemm, g.shape, g.dtype, power=g.power, scale=g.scale * math.prod(host), E=E)
+        return LazyGemm(g.gemm, g.shape, g.dtype, power=g.power, scale=g.scale * math.prod(host), E=E, pre=g.pre)
 
     def _plan_for(self, expr):
         """The buffers the previous evaluation of ``expr`` left behind -- or, while a graph is being
@@ -1079,7 +1139,7 @@ class DeviceBackend(Backend):
             g = root if (isinstance(root, LazyGemm) and not isinstance(root, LazyLda)) else None
             if g is not None and self._keep is None:
                 xb, m, n, k, x, sxb, sxm, sxk, y, syb, syk, syn = g.gemm
-                if g.power == 1 and g.E is None and xb == 1 and sxk == 1 and k % 8 == 0 \
+                if g.power == 1 and g.E is None and g.pre is None and xb == 1 and sxk == 1 and k % 8 == 0 \
                         and k <= 64 and n <= 64 and n % 4 == 0 and sxm % 4 == 0 and x.data_ptr() % 16 == 0 \
                         and g.dtype == torch.float32 and len(g.shape) == 2:
                     wkey = next((key for key, t in self._const_cache.items() if t is x and key[0] == "kcat"), None) \
@@ -1287,6 +1347,16 @@ class DeviceBackend(Backend):
                 out = self._weighted_outer(x, y, x_dot, y_dot)
                 if out is not None:
                     return out
+        pre = None
+        if self.fuse and self._plan is not None and not x_batch and not y_batch and free_x >= 1 and free_y >= 1:
+            # an element-wise producer of a matrix-matrix product's operand goes into the product (bsc_gemm_fused)
+            px, py = self._prologue_of(x), self._prologue_of(y)
+            if (px or py) and not (px and py and px[1] == 2 and py[1] == 2) and \
+                    (px or not isinstance(x, (Lazy, LazyGemm, DeferredSoftmax))) and \
+                    (py or not isinstance(y, (Lazy, LazyGemm, DeferredSoftmax))):
+                pre = (px[1] if px else 0, py[1] if py else 0, (px[2] if px else 1.0) * (py[2] if py else 1.0))
+                x = px[0] if px else x
+                y = py[0] if py else y
         x, y = self._force(x), self._force(y)
         (x, y), dtype, _ = self._common([x, y]) if x.dtype != y.dtype else ((x, y), x.dtype, 0)
         x_other = [a for a in range(x.dim()) if a not in x_dot and a not in x_batch]
@@ -1320,7 +1390,14 @@ class DeviceBackend(Backend):
                 and k > 0 and self._plan is not None:
             # deferred: a _mul / pow(., -1) consumer folds into the store (inside evaluate() only --
             # a value handed to the caller is always a tensor)
-            return LazyGemm((xb, m, n, k, x, sxb, sxm, sxk, y, syb, syk, syn), out_shape, dtype)
+            return LazyGemm((xb, m, n, k, x, sxb, sxm, sxk, y, syb, syk, syn), out_shape, dtype,
+                            scale=pre[2] if pre else 1.0, pre=pre[:2] if pre else None)
+        if pre is not None:      # (not a deferred product after all: the producers are launched)
+            x2, y2 = self._apply_pre(x, pre[0]), self._apply_pre(y, pre[1])
+            (sxb, sxm, sxk), (syb, syk, syn) = self._restride(x, x2, sxb, sxm, sxk), self._restride(y, y2, syb, syk, syn)
+            x, y = x2, y2
+            if pre[2] != 1.0:
+                x = self._force(self._combine("mul", [HostScalar(pre[2]), x]))
         out = self._empty(out_shape, dtype)
         self.ctx.call("bsc_gemm_strided_batched", _DT[dtype], xb, m, n, k,
                       _ffi.ptr(x), sxb, sxm, sxk, _ffi.ptr(y), syb, syk, syn,

@@ -63,6 +63,11 @@ struct GemmArgs {
     int ksplit;
     int fix_lanes;     // stream_fixup_kernel: piece lists per element quad (4 or 64)
     float* slab;       // [2 n_wg][128 n][128 m] partial tiles
+    // prologue (bsc_gemm_fused, stream kernel only): an element-wise producer applied to the operand's fragments between
+    // their LDS read and the MFMAs -- dot(exp(X), Y), dot(X * X, A.T) without the intermediate: 0 none, 1 square,
+    // 2 exp, 3 abs.  Operand bytes that lie outside the matrix arrive as zeros; f(0) != 0 (exp) is allowed on ONE
+    // side only, the other side's zeros then still cancel the padded products.
+    int pre_a, pre_b;
 };
 
 __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int64_t b, int64_t row, int64_t col) {
@@ -643,7 +648,18 @@ __device__ __forceinline__ void stream_read_fragments(float (&f)[2][4], unsigned
 // contraction shorter than a k-tile): MFMA blocks that lie wholly outside the matrix and 8-deep
 // k-groups past the end of K are skipped (uniform branches in the k-loop, which the instantiation
 // for large matrices does without -- its few edge tiles multiply their zero padding).
-template <bool A_M_CONTIG, bool B_N_CONTIG, bool EDGE>
+__device__ __forceinline__ void gemm_prologue(int op, float (&f)[2][4]) {
+    if (op == 0) return;           // (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float v = f[i][t];
+            f[i][t] = op == 1 ? v * v : op == 2 ? __builtin_amdgcn_exp2f(v * 1.4426950408889634f) : __builtin_fabsf(v);
+        }
+}
+
+template <bool A_M_CONTIG, bool B_N_CONTIG, bool EDGE, bool PRE = false>
 __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * DMA_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -663,6 +679,7 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
     // what the k-loop itself needs of the arguments
     const int64_t step_a = (int64_t)BK * g.sa_k, step_b = (int64_t)BK * g.sb_k;
     const int last_kt = g.n_kt - 1, k_tail = (int)(g.K - (int64_t)last_kt * BK);   // extent of a tile's last k-tile, 1..32
+    const int pre_a = PRE ? g.pre_a : 0, pre_b = PRE ? g.pre_b : 0;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -868,6 +885,10 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
                 if (u + 2 < n_units) issue(u & 1);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (PRE) {     // (fragment set `set` landed before this group's wait; the other set is in flight)
+                gemm_prologue(pre_a, oa[set]);
+                gemm_prologue(pre_b, ob[set]);
+            }
             if (!EDGE) mfmas(set);
             else if (G < k_groups && (!ksplit || G == wave)) mfmas_masked(set, blk_mask);
             __builtin_amdgcn_sched_barrier(0);
@@ -1230,6 +1251,8 @@ struct Epilogue {
     float scale = 1.f;
     const float* E = nullptr;
     int64_t se_b = 0, se_m = 0, se_n = 0;
+    int pre_a = 0, pre_b = 0;     // operand prologues (bsc_gemm_fused); *handled = 0 when the shape takes a path without them
+    int* handled = nullptr;
 };
 
 static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t N,
@@ -1256,6 +1279,9 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
         }
         return BSC_OK;
     }
+    const bool pre = epi.pre_a != 0 || epi.pre_b != 0;
+    if (epi.handled) *epi.handled = 0;
+    if (pre && (dtype == BSC_F64 || K == 0 || batch > 65535)) return BSC_OK;       // (not handled)
     if (epi.pow && (dtype == BSC_F64 || K == 0))
         return bsc_fail(BSC_ERR_UNSUPPORTED, "bsc_gemm_epilogue: float32 products with K > 0 only");
     if (dtype == BSC_F64 || K == 0) {
@@ -1271,7 +1297,7 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
         BSC_LAUNCH_CHECK();
         return BSC_OK;
     }
-    if (batch == 1 && (N == 1 || M == 1) && K >= 64 && !epi.pow) {
+    if (batch == 1 && (N == 1 || M == 1) && K >= 64 && !epi.pow && !pre) {
         // matrix-vector: orient so that the matrix is "A[m,k]" and the vector "x[k]"
         GemvArgs v;
         if (N == 1) {
@@ -1324,7 +1350,7 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
         }
         return BSC_OK;
     }
-    if (batch == 1 && !epi.pow) {
+    if (batch == 1 && !epi.pow && !pre) {
         // one tiny extent, the large operand streamed once by LDS-DMA (csrc/bsc_skinny.hip)
         int handled = 0;
         int rc = bsc_gemm_skinny(ctx, M, N, K, (const float*)A, sa_m, sa_k, (const float*)B, sb_k, sb_n,
@@ -1342,6 +1368,7 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
         s.C = (float*)C; s.sc_b = sc_b; s.sc_m = swap ? sc_n : sc_m; s.sc_n = swap ? sc_m : sc_n;
         s.E = epi.E; s.se_b = epi.se_b; s.se_m = swap ? epi.se_n : epi.se_m; s.se_n = swap ? epi.se_m : epi.se_n;
         s.epi_scale = epi.scale; s.epi_pow = epi.pow;
+        s.pre_a = swap ? epi.pre_b : epi.pre_a; s.pre_b = swap ? epi.pre_a : epi.pre_b;
         s.splits = 1; s.k_chunk = 0; s.vec_a = s.vec_b = s.fast = 0;
         const bool a_m = s.sa_m == 1, b_n = s.sb_n == 1;
         auto dma_ok = [&](const void* p, bool mn, int64_t ext_mn, int64_t s_mn, int64_t s_k, int64_t s_b) {
@@ -1361,14 +1388,14 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
             // tile costs is its 64 KiB of stores, and one tile per workgroup (the hardware's dispatcher dealing
             // them, LDS-staged 512-byte rows) does that 7 % better than the persistent schedule -- config 4's
             // dot(Th, Bt), K = 128: 1.45 against 1.57 ms (profiles/r02_ab_gemm_stream_vs_tile_b64.txt)
-            const bool short_k_plain = K > 32 && K <= 6 * BK && !(epi.pow && epi.E) &&
+            const bool short_k_plain = !pre && K > 32 && K <= 6 * BK && !(epi.pow && epi.E) &&
                                        (int64_t)s.tiles_pb * batch >= 8 * (int64_t)ctx->cu_count && s.M >= 2 * BM && s.N >= 2 * BN;
             if (!short_k_plain) {
             // X^T X: the same matrix on both sides, transposed -- half the tiles (plus the diagonal)
             s.ksplit = 0;
             s.fix_lanes = 4;
             s.sym = ctx->gemm_sym && s.A == s.B && s.M == s.N && s.sa_m == s.sb_n && s.sa_k == s.sb_k && s.sa_b == s.sb_b &&
-                    !(epi.pow && epi.E) && s.tiles_m > 1;
+                    !(epi.pow && epi.E) && s.tiles_m > 1 && s.pre_a == s.pre_b;
             if (s.sym) s.tiles_pb = s.tiles_m * (s.tiles_m + 1) / 2;
             s.group = 8;
             s.group_log2 = 3;
@@ -1399,7 +1426,13 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
                 const bool edge = (s.tiles_m == 1 && s.M <= 96) || (s.tiles_n == 1 && s.N <= 96) || K <= 24;
 #define BSC_GEMM_STREAM(AM, BN_)                                                                                          \
     do {                                                                                                                  \
-        if (edge)                                                                                                         \
+        if (pre && edge)                                                                                                  \
+            hipLaunchKernelGGL((gemm_f32_stream_kernel<AM, BN_, true, true>), dim3((unsigned)s.n_wg), dim3(GEMM_BLOCK), 0, \
+                               ctx->stream, s);                                                                           \
+        else if (pre)                                                                                                     \
+            hipLaunchKernelGGL((gemm_f32_stream_kernel<AM, BN_, false, true>), dim3((unsigned)s.n_wg), dim3(GEMM_BLOCK), 0, \
+                               ctx->stream, s);                                                                           \
+        else if (edge)                                                                                                    \
             hipLaunchKernelGGL((gemm_f32_stream_kernel<AM, BN_, true>), dim3((unsigned)s.n_wg), dim3(GEMM_BLOCK), 0,      \
                                ctx->stream, s);                                                                           \
         else                                                                                                              \
@@ -1420,10 +1453,12 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
                                    ctx->stream, s);
                 BSC_LAUNCH_CHECK();
             }
+            if (pre && epi.handled) *epi.handled = 1;
             return BSC_OK;
             }   // !short_k_plain
         }
     }
+    if (pre) return BSC_OK;      // (not handled: the kernels below take their operands as they are)
     GemmArgs g;
     g.A = (const float*)A; g.B = (const float*)B;
     g.M = M; g.N = N; g.K = K;
@@ -1574,6 +1609,29 @@ int bsc_gemm_epilogue(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t
     e.E = (const float*)E;
     e.se_b = se_b; e.se_m = se_m; e.se_n = se_n;
     return gemm_impl(ctx, dtype, batch, M, N, K, A, sa_b, sa_m, sa_k, B, sb_b, sb_k, sb_n, C, sc_b, sc_m, sc_n, e);
+}
+
+int bsc_gemm_fused(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t N, int64_t K, const void* A, int64_t sa_b,
+                   int64_t sa_m, int64_t sa_k, int pre_a, const void* B, int64_t sb_b, int64_t sb_k, int64_t sb_n, int pre_b,
+                   void* C, int64_t sc_b, int64_t sc_m, int64_t sc_n, int power, double scale, const void* E, int64_t se_b,
+                   int64_t se_m, int64_t se_n, int32_t* handled) {
+    BSC_REQUIRE(handled, "bsc_gemm_fused: handled is null");
+    *handled = 0;
+    BSC_REQUIRE(pre_a >= 0 && pre_a <= 3 && pre_b >= 0 && pre_b <= 3, "bsc_gemm_fused: prologue %d / %d (0..3)", pre_a, pre_b);
+    BSC_REQUIRE(power == 0 || power == 1 || power == -1, "bsc_gemm_fused: power must be 0, 1 or -1 (got %d)", power);
+    if ((pre_a == 0 && pre_b == 0) || (pre_a == 2 && pre_b == 2)) return BSC_OK;   // nothing to fuse / exp(0) on both sides
+    Epilogue e;
+    e.pow = power;
+    e.scale = (float)scale;
+    e.E = (const float*)E;
+    e.se_b = se_b; e.se_m = se_m; e.se_n = se_n;
+    if (power == 0 && scale != 1.0) e.pow = 1;
+    e.pre_a = pre_a; e.pre_b = pre_b;
+    int h = 0;
+    e.handled = &h;
+    const int rc = gemm_impl(ctx, dtype, batch, M, N, K, A, sa_b, sa_m, sa_k, B, sb_b, sb_k, sb_n, C, sc_b, sc_m, sc_n, e);
+    *handled = h;
+    return rc;
 }
 
 }  // extern "C"

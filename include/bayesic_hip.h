@@ -563,6 +563,18 @@ int bsc_gemm_epilogue(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t
                       int64_t sa_b, int64_t sa_m, int64_t sa_k, const void* B, int64_t sb_b, int64_t sb_k,
                       int64_t sb_n, void* C, int64_t sc_b, int64_t sc_m, int64_t sc_n, int power, double scale,
                       const void* E, int64_t se_b, int64_t se_m, int64_t se_n);
+/* bsc_gemm_epilogue with an element-wise PRODUCER folded into the operand fragments as well:
+ *   C = scale * dot(pre_a(A), pre_b(B))^power * E,   pre = 0 none | 1 square | 2 exp | 3 abs   (power 0: no epilogue)
+ * -- `_mul` / `elemwise` feeding `_tensordot` (bayesic/algebra.py:741-765, 1297-1309 -> :1347) without the
+ * intermediate array: dot(exp(X), Y), dot(X * X, A.T).  Only the persistent stream kernel applies prologues; when the
+ * shape takes another path (matrix-vector, skinny, float64, short contractions), or both sides ask for exp (padded
+ * zeros would no longer cancel), NOTHING is launched and *handled = 0: the caller materialises the operand and calls
+ * bsc_gemm_strided_batched / bsc_gemm_epilogue.  *handled = 1: C is written. */
+int bsc_gemm_fused(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t N, int64_t K, const void* A, int64_t sa_b,
+                   int64_t sa_m, int64_t sa_k, int pre_a, const void* B, int64_t sb_b, int64_t sb_k, int64_t sb_n, int pre_b,
+                   void* C, int64_t sc_b, int64_t sc_m, int64_t sc_n, int power, double scale, const void* E, int64_t se_b,
+                   int64_t se_m, int64_t se_n, int32_t* handled);
+
 /* Host-only: the schedule the persistent kernels (GEMM, LDA statistic) use for `tiles` tiles of `n_kt`
  * units on `slots` resident workgroups; out = {n_wg, rounds, tail_tiles, sk_stream, sk_q, sk_r} --
  * workgroup w takes tiles w, w + n_wg, ... of `rounds` rounds, then units [u(w), u(w + 1)) of the

@@ -427,7 +427,8 @@ def test_sums_of_products_over_constant_rows_become_one_product(ctx, n_rows, d, 
     tol = dict(rtol=2e-5, atol=2e-5 * np.abs(want).max())
     with Counting(ctx) as c:
         plain = be.to_host(f(X=Xd, Am=Ad, Bm=Bd, cv=cd, ev=ed))
-    assert c.count("bsc_gemm_strided_batched") + c.count("bsc_gemm_epilogue") == 2
+    # (unmarked X: the X * X of the second product may be formed inside it -- bsc_gemm_fused)
+    assert c.count("bsc_gemm_strided_batched") + c.count("bsc_gemm_epilogue") + c.count("bsc_gemm_fused") >= 2
     npt.assert_allclose(plain, want, **tol)
     be.mark_constant(Xd)
     be.to_host(f(X=Xd, Am=Ad, Bm=Bd, cv=cd, ev=ed))          # builds [X | X^2 | 1] once
@@ -442,7 +443,8 @@ def test_sums_of_products_over_constant_rows_become_one_product(ctx, n_rows, d, 
     be.forget_constants()
     with Counting(ctx) as c:
         back = be.to_host(f(X=Xd, Am=Ad, Bm=Bd, cv=cd, ev=ed))
-    assert c.count("bsc_gemm_strided_batched") + c.count("bsc_gemm_epilogue") == 2
+    # (unmarked X: the X * X of the second product may be formed inside it -- bsc_gemm_fused)
+    assert c.count("bsc_gemm_strided_batched") + c.count("bsc_gemm_epilogue") + c.count("bsc_gemm_fused") >= 2
     npt.assert_allclose(back, want, **tol)
 
 
@@ -527,3 +529,66 @@ def test_dropping_a_constant_drops_what_was_built_from_it(ctx):
     npt.assert_allclose(be.to_host(logits(X=Xd, Am=Ad)), 2 * (x64 @ A_.T.astype(np.float64))
                         + 2.0 * (x64 * x64) @ A_.T.astype(np.float64), rtol=2e-5, atol=1e-4)
     npt.assert_allclose(be.to_host(stat(R=Rd, X=Xd)), 4 * want_s, rtol=2e-5, atol=1e-3)
+
+
+# ---- an element-wise PRODUCER of a product's operand goes into the product (bsc_gemm_fused) -------
+
+@pytest.mark.parametrize("M,N,K", [(300, 260, 4096), (128, 128, 64), (1000, 96, 777 * 4), (256, 256, 40000)])
+def test_producers_fold_into_the_operand_reads(dev, M, N, K):
+    """dot(exp(X), Y), dot(X * X, A.T), dot(abs(X), Y * Y) and a consumer folded into the same launch's store: ONE
+    launch each, no element-wise launch, against float64 numpy."""
+    X, Y, Am, E = var("X", ndim=2), var("Y", ndim=2), var("Am", ndim=2), var("E", ndim=2)
+    X_ = (RNG.standard_normal((M, K)) * 0.5).astype(np.float32)
+    Y_ = RNG.standard_normal((K, N)).astype(np.float32)
+    A_ = RNG.standard_normal((N, K)).astype(np.float32)
+    E_ = (RNG.rand(M, N) + 0.5).astype(np.float32)
+    X64, Y64, A64 = X_.astype(np.float64), Y_.astype(np.float64), A_.astype(np.float64)
+    cases = [
+        (dot(exp(X), Y), np.exp(X64) @ Y64),
+        (dot(X * X, Am.T), (X64 * X64) @ A64.T),
+        (dot(abs_(X), Y * Y), np.abs(X64) @ (Y64 * Y64)),
+        (dot(2.0 * (X * X), Y), 2.0 * (X64 * X64) @ Y64),
+        (E * dot(X ** 2, Y), E_ * ((X64 ** 2) @ Y64)),
+        (dot(exp(Am), Y), np.exp(A64) @ Y64),            # the producer on the LEFT operand of a [N, K] x [K, N] product
+    ]
+    for expr, want in cases:
+        f = expr.compile(dev)
+        with Counting(dev.ctx) as c:
+            got = f(X=X_, Y=Y_, Am=A_, E=E_)
+        assert c.count("bsc_gemm_fused") == 1, (repr(expr), c.calls)
+        assert c.count("bsc_map_reduce") + c.count("bsc_elemwise") + c.count("bsc_gemm_strided_batched") \
+            + c.count("bsc_gemm_epilogue") == 0, (repr(expr), c.calls)
+        scale = np.abs(want).max()
+        npt.assert_allclose(got, want, rtol=2e-4, atol=2e-5 * scale, err_msg=repr(expr))
+
+
+def test_producers_fall_back_when_the_shape_takes_another_kernel(dev):
+    """A matrix-vector product (fused map-reduce), a skinny product (bsc_gemm_skinny: no prologue there -> handled = 0
+    and the producer is launched), exp on both sides (padded zeros would not cancel): right values whatever the path."""
+    X, Y, v = var("X", ndim=2), var("Y", ndim=2), var("v", ndim=1)
+    X_ = (RNG.standard_normal((5000, 256)) * 0.5).astype(np.float32)
+    Y_ = (RNG.standard_normal((256, 8)) * 0.5).astype(np.float32)
+    v_ = RNG.standard_normal(256).astype(np.float32)
+    X64, Y64 = X_.astype(np.float64), Y_.astype(np.float64)
+    for expr, want in [(dot(exp(X), v), np.exp(X64) @ v_), (dot(exp(X), Y), np.exp(X64) @ Y64),
+                       (dot(exp(X), exp(Y)), np.exp(X64) @ np.exp(Y64)), (dot(X * X, Y), (X64 * X64) @ Y64)]:
+        got = expr.compile(dev)(X=X_, Y=Y_, v=v_)
+        npt.assert_allclose(got, want, rtol=2e-4, atol=2e-4)
+
+
+def test_constant_operands_keep_their_cached_producers(dev):
+    """X marked constant (a model's data): X * X is computed once and cached, not recomputed inside every product."""
+    X, Y = var("X", ndim=2), var("Y", ndim=2)
+    X_ = RNG.standard_normal((512, 2048)).astype(np.float32)
+    Y_ = RNG.standard_normal((2048, 256)).astype(np.float32)
+    Xd = dev.from_host(X_, "float32", 2)
+    dev.mark_constant(Xd)
+    try:
+        f = dot(X * X, Y).compile(dev)
+        for _ in range(2):
+            with Counting(dev.ctx) as c:
+                got = f.device_fn(X=Xd, Y=dev.from_host(Y_, "float32", 2))
+        assert c.count("bsc_gemm_fused") == 0
+        npt.assert_allclose(dev.to_host(got), (X_.astype(np.float64) ** 2) @ Y_, rtol=2e-4, atol=1e-3)
+    finally:
+        dev.unmark_constant(Xd)

@@ -88,7 +88,15 @@ case("sum(X * v[None,:], axis=1) %dx256" % rows, asum(X * dimshuffle(vrow, "x", 
      dict(X=Xd, v=vd), 4 * n, 20)
 case("sum(exp(X) * u[:,None], axis=0) %dx256" % rows, asum(exp(X) * dimshuffle(ucol, 0, "x"), axis=0),
      dict(X=Xd, u=ud), 4 * n, 20)
-del Xd, Yd
+# an element-wise producer of a product's operand, formed inside the product (bsc_gemm_fused)
+W = var("W", ndim=2)
+Wd = torch.randn((256, 256), generator=g, device=dev) / 16
+Yn = torch.randn((rows, 128), generator=g, device=dev)
+Xs = (Xd * 0.25).contiguous()
+case("dot(X * X, W) %dx256 . 256x256" % rows, dot(X * X, W), dict(X=Xd, W=Wd), 8 * n, 10)
+case("dot(exp(X), W) %dx256 . 256x256" % rows, dot(exp(X), W), dict(X=Xs, W=Wd), 8 * n, 10)
+case("dot((X * X).T, Y) 256x%d . %dx128" % (rows, rows), dot((X * X).T, Y), dict(X=Xd, Y=Yn), 4 * n + 4 * rows * 128, 10)
+del Xd, Yd, Xs, Yn
 
 if no_lda:
     sys.exit(0)
