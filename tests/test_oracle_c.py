@@ -11,6 +11,20 @@ import pytest
 from oracle import svi
 
 needs_gcc = pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not available")
+# the MFMA-bound configs also on the operand-split bf16 route (bsc_ctx_set_mfma_split 2): the same
+# comparisons at the same tolerances
+both_routes = pytest.mark.parametrize("terms", [0, 2])
+
+
+class _split(object):
+    def __init__(self, ctx, terms):
+        self.ctx, self.terms = ctx, terms
+
+    def __enter__(self):
+        self.ctx.call("bsc_ctx_set_mfma_split", self.terms)
+
+    def __exit__(self, *exc):
+        self.ctx.call("bsc_ctx_set_mfma_split", 0)
 rs = np.random.RandomState(8)
 
 
@@ -78,9 +92,10 @@ def test_cfg2_full_size_against_c_oracle(ctx):
     assert (np.abs(G.cpu().numpy() - g_ref) <= 2e-5 * scale).all()
 
 
+@both_routes
 @needs_gcc
 @pytest.mark.gpu
-def test_cfg5_full_size_against_c_oracle(ctx):
+def test_cfg5_full_size_against_c_oracle(ctx, terms):
     """1M x 256, G = 1000, S = 64."""
     import torch
     from oracle import cbuild
@@ -92,16 +107,18 @@ def test_cfg5_full_size_against_c_oracle(ctx):
     Wz = torch.randn((S, D), generator=g, device=ctx.device) / 16
     Bz = torch.randn((G, S), generator=g, device=ctx.device)
     ell = ctx.zeros(S, torch.float64)
-    ctx.call("bsc_logreg_bbvi_loglik", X, D, y, grp, N, D, G, Wz, Bz, S, ell)
-    ctx.sync()
+    with _split(ctx, terms):
+        ctx.call("bsc_logreg_bbvi_loglik", X, D, y, grp, N, D, G, Wz, Bz, S, ell)
+        ctx.sync()
     want = cbuild.logreg_loglik(X.cpu().numpy(), y.cpu().numpy(), grp.cpu().numpy(),
                                 Wz.cpu().numpy(), Bz.cpu().numpy())
     npt.assert_allclose(ell.cpu().numpy(), want, rtol=2e-6)
 
 
+@both_routes
 @needs_gcc
 @pytest.mark.gpu
-def test_cfg3_full_size_against_c_oracle(ctx):
+def test_cfg3_full_size_against_c_oracle(ctx, terms):
     """10M x 16, K = 64."""
     import torch
     from oracle import cbuild
@@ -115,8 +132,9 @@ def test_cfg3_full_size_against_c_oracle(ctx):
     c = (-0.5 * (T * cen ** 2).sum(1)).contiguous()
     stats = ctx.zeros((K, 1 + 2 * D), torch.float64)
     lse = ctx.zeros(1, torch.float64)
-    ctx.call("bsc_mog_estep", X, D, N, D, K, Wmat, c, stats, lse)
-    ctx.sync()
+    with _split(ctx, terms):
+        ctx.call("bsc_mog_estep", X, D, N, D, K, Wmat, c, stats, lse)
+        ctx.sync()
     Xh = X.cpu().numpy()
     s_ref, l_ref = cbuild.mog_estep(Xh, Wmat.cpu().numpy(), c.cpu().numpy())
     X64 = np.abs(Xh.astype(np.float64))
@@ -125,9 +143,10 @@ def test_cfg3_full_size_against_c_oracle(ctx):
     npt.assert_allclose(lse.item(), l_ref, rtol=2e-6)
 
 
+@both_routes
 @needs_gcc
 @pytest.mark.gpu
-def test_cfg4_full_size_against_c_oracle(ctx):
+def test_cfg4_full_size_against_c_oracle(ctx, terms):
     """6250 x 100 000 counts (one GPU's shard of config 4), K = 128: the dense MFMA kernel and
     the sparse (CSC) kernel against the C oracle."""
     import scipy.sparse as sp
@@ -139,8 +158,9 @@ def test_cfg4_full_size_against_c_oracle(ctx):
     Th = torch.rand((docs, K), generator=g, device=ctx.device) + 0.1
     Bt = torch.rand((K, V), generator=g, device=ctx.device) + 0.1
     dense = ctx.zeros((K, V), torch.float32)
-    ctx.call("bsc_lda_sstats", C, V, docs, V, K, Th, K, Bt, V, dense, V)
-    ctx.sync()
+    with _split(ctx, terms):
+        ctx.call("bsc_lda_sstats", C, V, docs, V, K, Th, K, Bt, V, dense, V)
+        ctx.sync()
     Ch = C.cpu().numpy()
     want = cbuild.lda_sstats(Ch, Th.cpu().numpy(), Bt.cpu().numpy())
     # a sum of ~300 positive float32 terms per output
@@ -175,9 +195,10 @@ def test_weighted_second_moment_full_size_against_c_oracle(ctx):
     assert (np.abs(out.cpu().numpy() - want) <= 2e-5 * bound).all()
 
 
+@both_routes
 @needs_gcc
 @pytest.mark.gpu
-def test_cfg3_full_size_elbo_against_c_oracle(ctx):
+def test_cfg3_full_size_elbo_against_c_oracle(ctx, terms):
     """10M x 16, K = 64: model.elbo of the fused driver = oracle.svi.mog_elbo with the local term from the C oracle's
     pass over the very same data (the numpy oracle takes minutes at this size)."""
     import torch
@@ -193,16 +214,18 @@ def test_cfg3_full_size_elbo_against_c_oracle(ctx):
         stats, lse = cbuild.mog_estep(X, Wmat, c)
         want = svi.mog_elbo(eta, eta0, lse, 4.0, K, D)
         rho = (t + 1.0) ** -0.6
-        model.step(rho)
-        ctx.sync()
+        with _split(ctx, terms):
+            model.step(rho)
+            ctx.sync()
         npt.assert_allclose(model.elbo.item(), want, rtol=2e-6)
         eta = svi.natgrad_update(eta, eta0, svi.mog_message(stats, K, D), 4.0, rho)
         model.eta.copy_(torch.as_tensor(eta, dtype=torch.float64))
 
 
+@both_routes
 @needs_gcc
 @pytest.mark.gpu
-def test_cfg4_full_size_elbo_against_c_oracle(ctx):
+def test_cfg4_full_size_elbo_against_c_oracle(ctx, terms):
     """6250 x 100 000 counts, K = 128 (one GPU's shard of config 4): the words' term taken inside the statistic kernel
     (dense persistent kernel and sparse kernel) against the C oracle; the topics' and documents' terms against the
     float64 numpy oracle (parameter-sized); model.elbo of the driver against their combination."""
@@ -224,8 +247,9 @@ def test_cfg4_full_size_elbo_against_c_oracle(ctx):
         + float(svi.dirichlet_neg_kl(lh, eta_prior).sum())
     for counts in (C, sp.csr_matrix(Ch)):
         model = LDAFixedGammaSVI(counts, gamma, lam, eta=eta_prior, docs_total=docs_total, ctx=ctx, alpha=alpha)
-        model.step()
-        ctx.sync()
+        with _split(ctx, terms):
+            model.step()
+            ctx.sync()
         # (the device forms Th, Bt in float32 from float64 digammas exactly as the oracle does; the words' term sums
         # 31 M float32 products)
         npt.assert_allclose(model._ll.item(), words, rtol=3e-6)
