@@ -82,6 +82,7 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
         const int v = atoi(e);
         if (v >= 1 && v <= 64) ctx->fused_map_blocks_per_cu = v;
     }
+    if (const char* e = getenv("BSC_FUSED_MAP_FLAT")) ctx->fused_map_flat = atoi(e) != 0;
     if (const char* e = getenv("BSC_FUSED_MAP_UNROLL")) ctx->fused_map_unroll = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("BSC_GEMM_PIPE")) ctx->gemm_pipe = atoi(e) != 0;
     if (const char* e = getenv("BSC_GEMM_SKINNY")) ctx->gemm_skinny = atoi(e) != 0;

@@ -246,6 +246,95 @@ __global__ __launch_bounds__(256) void map_dense_f32_kernel(MapArgs a, int64_t n
     }
 }
 
+// The flat map (round 3): a contiguous float32 result of n4 float4 -- a flat array, or a row-major [R, C] with
+// C % 4 == 0 -- whose operands are each dense like the result, ONE value, a C-vector repeated down the rows
+// (dimshuffle(v, 'x', 0): float4 index i % C4) or one value per row (dimshuffle(u, 0, 'x'): row i / C4).
+// Not persistent: a thread owns U float4, 4 KiB apart (a block's pieces are whole 4-KiB runs), every load of
+// every operand issued before the first use; operand count and "all unary ops are cheap" are template parameters,
+// so there is no loop over absent operands and no switch per element.  What the generic kernels above reached on
+// 1M x 256 (profiles/r03_bench_map_vs_torch.txt): X * v[None, :] 3.7 TB/s, X / Y 4.9, X * 2 5.1 of read + write,
+// where a tuned element-wise kernel reaches 6.0-6.3 on the same box.
+struct FlatArgs {
+    const float* in[4];
+    float* out;
+    unsigned n4, c4;           // float4 count; float4 per row (kinds 2, 3)
+    int kind[4];               // 0 dense, 1 one value, 2 row vector (period c4), 3 one value per row
+    int op[4];                 // pre op (LINEAR: copy / scale / pow -1 / pow 2 / pow 1 only)
+    float arg[4];
+    int combine, post_op, nt_store;
+    float scale, shift, post_arg;
+};
+
+template <bool LINEAR>
+__device__ __forceinline__ float flat_unary(int op, float x, float arg) {
+    if (LINEAR) {      // (uniform selects; the compiler turns them into scalar branches around one instruction)
+        if (op == BSC_OP_SCALE) return x * arg;
+        if (op == BSC_OP_POW) return arg == 2.0f ? x * x : arg == -1.0f ? 1.0f / x : x;
+        return x;
+    }
+    return apply_unary<float>(op, x, (double)arg);
+}
+
+template <int NIN, bool LINEAR>
+__global__ __launch_bounds__(256) void map_flat_f32_kernel(FlatArgs a) {
+    constexpr int U = 4;
+    const unsigned base = (blockIdx.x * U) * 256u + threadIdx.x;
+    const float id = a.combine == BSC_OP_MUL ? 1.f : 0.f;
+    f32x4 u[NIN][U];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+        const int kind = a.kind[k];
+        if (kind == 1) {
+            const float sv = a.in[k][0];
+#pragma unroll
+            for (int j = 0; j < U; ++j) u[k][j] = f32x4{sv, sv, sv, sv};
+        } else {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                unsigned i = base + 256u * j;
+                i = i < a.n4 ? i : a.n4 - 1;
+                if (kind == 0) {
+                    u[k][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.in[k]) + i);
+                } else {
+                    const unsigned r = i / a.c4;
+                    if (kind == 2) {
+                        u[k][j] = reinterpret_cast<const f32x4*>(a.in[k])[i - r * a.c4];
+                    } else {
+                        const float sv = a.in[k][r];
+                        u[k][j] = f32x4{sv, sv, sv, sv};
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        f32x4 v = {id, id, id, id};
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            const int op = a.op[k];
+            const float arg = a.arg[k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = flat_unary<LINEAR>(op, u[k][j][e], arg);
+                v[e] = a.combine == BSC_OP_MUL ? v[e] * x : v[e] + x;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float w = v[e];
+            if (a.scale != 1.0f) w *= a.scale;
+            if (a.shift != 0.0f) w += a.shift;
+            v[e] = LINEAR ? w : apply_unary<float>(a.post_op, w, (double)a.post_arg);
+        }
+        const unsigned i = base + 256u * j;
+        if (i < a.n4) {
+            if (a.nt_store) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out) + i);
+            else reinterpret_cast<f32x4*>(a.out)[i] = v;
+        }
+    }
+}
+
 // Two kept axes [R, C], every operand either dense along C (16-byte loads) or constant
 // along it (one scalar per row, splat) -- column scalings, row weights, biases: the
 // broadcasts of dimshuffle('x', ...).  A wave takes rows (interleaved over the grid: one
@@ -811,6 +900,55 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
 
     if (rank_red == 0) {
         // ---- pure map ----
+        // the flat kernel: contiguous float32 result, operands dense / one value / row vector / one value per row
+        if (!special && dtype == BSC_F32 && n_in <= 4 && n_out >= 4096 && n_out % 4 == 0 && n_out / 4 < ((int64_t)1 << 31) &&
+            (((uintptr_t)out) & 15) == 0 && ctx->fused_map_flat &&
+            (keep.rank == 1 ? m.out_strides[0] == 1
+                            : keep.rank == 2 && m.out_strides[1] == 1 && m.out_strides[0] == keep.shape[1] && keep.shape[1] % 4 == 0)) {
+            FlatArgs f{};
+            const int64_t C = keep.rank == 2 ? keep.shape[1] : n_out;
+            bool ok = true, linear = post_op == BSC_OP_COPY;
+            for (int k = 0; k < n_in && ok; ++k) {
+                const int64_t s0 = keep.rank == 2 ? m.keep_strides[k][0] : 0, s1 = m.keep_strides[k][keep.rank - 1];
+                int kind = -1;
+                if (keep.rank == 1) kind = s1 == 1 ? 0 : s1 == 0 ? 1 : -1;
+                else if (s0 == C && s1 == 1) kind = 0;
+                else if (s0 == 0 && s1 == 0) kind = 1;
+                else if (s0 == 0 && s1 == 1) kind = 2;
+                else if (s0 == 1 && s1 == 0) kind = 3;
+                if (kind < 0 || ((kind == 0 || kind == 2) && (((uintptr_t)m.in[k]) & 15) != 0)) ok = false;
+                f.in[k] = (const float*)m.in[k];
+                f.kind[k] = kind;
+                f.op[k] = m.pre_op[k];
+                f.arg[k] = (float)m.pre_arg[k];
+                const int op = m.pre_op[k];
+                if (!(op == BSC_OP_COPY || op == BSC_OP_SCALE ||
+                      (op == BSC_OP_POW && (m.pre_arg[k] == 2.0 || m.pre_arg[k] == -1.0 || m.pre_arg[k] == 1.0))))
+                    linear = false;
+            }
+            if (ok) {
+                f.out = (float*)out;
+                f.n4 = (unsigned)(n_out / 4);
+                f.c4 = (unsigned)(C / 4);
+                f.combine = combine; f.post_op = post_op; f.nt_store = m.nt_store;
+                f.scale = (float)scale; f.shift = (float)shift; f.post_arg = (float)post_arg;
+                const unsigned blocks = (f.n4 + 1023u) / 1024u;
+#define BSC_FLAT(N_)                                                                                                   \
+    do {                                                                                                               \
+        if (linear) hipLaunchKernelGGL((map_flat_f32_kernel<N_, true>), dim3(blocks), dim3(256), 0, ctx->stream, f);   \
+        else hipLaunchKernelGGL((map_flat_f32_kernel<N_, false>), dim3(blocks), dim3(256), 0, ctx->stream, f);         \
+    } while (0)
+                switch (n_in) {
+                    case 1: BSC_FLAT(1); break;
+                    case 2: BSC_FLAT(2); break;
+                    case 3: BSC_FLAT(3); break;
+                    default: BSC_FLAT(4); break;
+                }
+#undef BSC_FLAT
+                BSC_LAUNCH_CHECK();
+                return BSC_OK;
+            }
+        }
         bool dense = !special && dtype == BSC_F32 && keep.rank <= 1 && (n_out % 4) == 0 &&
                      (((uintptr_t)out) & 15) == 0 && (keep.rank == 0 || m.out_strides[0] == 1);
         int scalar_mask = 0;
