@@ -509,6 +509,74 @@ __global__ __launch_bounds__(256) void map_reduce_wave_dense_f32_kernel(MapArgs 
     }
 }
 
+// Row sums of a matrix with SHORT rows (n_red <= 1024: sum(X * Y, axis=1) at 1M x 256): the kernel above gives every
+// row a wave of its own -- a million waves that each live for one 1-KiB load, and the dispatcher, not HBM, sets the
+// pace (4.1 TB/s).  Here the waves are persistent and take U rows per step, every load before the first use.
+template <int N, bool LINEAR>
+__global__ __launch_bounds__(256) void map_reduce_rows_f32_kernel(MapArgs a) {
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63;
+    const int64_t gwave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    const int c4 = (int)(a.n_red / 4);
+    const float id = a.combine == BSC_OP_MUL ? 1.f : 0.f;
+    const float scale = (float)a.scale, shift = (float)a.shift;
+    for (int64_t r0 = gwave * U; r0 < a.n_out; r0 += n_waves * U) {
+        double acc[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) acc[j] = 0.0;
+        for (int c = lane; c < c4; c += 64) {
+            f32x4 u[N][U];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int64_t r = r0 + j < a.n_out ? r0 + j : a.n_out - 1;
+                    const float* p = static_cast<const float*>(a.in[k]) + r * a.keep_strides[k][0];
+                    if ((a.bcast >> k) & 1) {
+                        const float sv = p[0];
+                        u[k][j] = f32x4{sv, sv, sv, sv};
+                    } else {
+                        u[k][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + c);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                f32x4 v = {id, id, id, id};
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    const int op = a.pre_op[k];
+                    const float arg = (float)a.pre_arg[k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = LINEAR ? flat_unary<true>(op, u[k][j][e], arg) : apply_unary<float>(op, u[k][j][e], a.pre_arg[k]);
+                        v[e] = a.combine == BSC_OP_MUL ? v[e] * x : v[e] + x;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float w = v[e];
+                    if (LINEAR) {
+                        if (scale != 1.0f) w *= scale;
+                        if (shift != 0.0f) w += shift;
+                    } else {
+                        w = finish_value<float>(a, w);
+                    }
+                    acc[j] += (double)w;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) acc[j] = wave_allsum_f64(acc[j]);
+        if (lane < U && r0 + lane < a.n_out) {
+            double mine = acc[0];
+#pragma unroll
+            for (int j = 1; j < U; ++j) mine = lane == j ? acc[j] : mine;
+            static_cast<float*>(a.out)[(r0 + lane) * a.out_strides[0]] = (float)mine;
+        }
+    }
+}
+
 // Variant B, dense: one kept axis and one reduce axis, every operand dense along
 // the kept axis and 16-byte aligned there.  Lane <-> 4 consecutive
 // outputs, a wave covers 256 outputs per row; the four waves of a block and
@@ -1156,7 +1224,26 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
     } else {
         // the wave kernels run four (output, split) jobs per block
         const int64_t blocks = (n_out * splits + 3) / 4;
-        if (dense_wave) {
+        if (dense_wave && splits == 1 && keep.rank == 1 && n_red <= 1024 && n_out >= 4096 && ctx->fused_map_flat) {
+            // many short rows: persistent waves, four rows per step
+            bool linear = post_op == BSC_OP_COPY;
+            for (int k = 0; k < n_in; ++k) {
+                const int op = m.pre_op[k];
+                if (!(op == BSC_OP_COPY || op == BSC_OP_SCALE ||
+                      (op == BSC_OP_POW && (m.pre_arg[k] == 2.0 || m.pre_arg[k] == -1.0 || m.pre_arg[k] == 1.0))))
+                    linear = false;
+            }
+            int64_t rblocks = (n_out + 15) / 16;
+            const int64_t cap = (int64_t)ctx->cu_count * 8;
+            if (rblocks > cap) rblocks = cap;
+#define BSC_ROWS(NV)                                                                                                  \
+    case NV:                                                                                                          \
+        if (linear) hipLaunchKernelGGL((map_reduce_rows_f32_kernel<NV, true>), dim3((unsigned)rblocks), dim3(256), 0, ctx->stream, m);  \
+        else hipLaunchKernelGGL((map_reduce_rows_f32_kernel<NV, false>), dim3((unsigned)rblocks), dim3(256), 0, ctx->stream, m);        \
+        break;
+            switch (n_in) { BSC_ROWS(1) BSC_ROWS(2) BSC_ROWS(3) }
+#undef BSC_ROWS
+        } else if (dense_wave) {
 #define BSC_WAVE_CASE(NV)                                                                        \
     case NV:                                                                                     \
         if (n_red <= 256 * splits)                                                               \
