@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void map_reduce_rows_f32_kernel(MapArgs a) {
 // the kept axis and 16-byte aligned there.  Lane <-> 4 consecutive
 // outputs, a wave covers 256 outputs per row; the four waves of a block and
 // `splits` blocks divide the reduce range, 4 rows in flight per lane.
-template <int N>
+template <int N, bool LINEAR = false>
 __global__ __launch_bounds__(256) void map_reduce_lane_dense_f32_kernel(MapArgs a) {
     __shared__ double red[4][64][4];
     const int lane = threadIdx.x & 63;
@@ -621,18 +621,24 @@ __global__ __launch_bounds__(256) void map_reduce_lane_dense_f32_kernel(MapArgs 
                 for (int k = 0; k < N; ++k) {
                     const int op = a.pre_op[k];
                     const double arg = a.pre_arg[k];
-                    const float x0 = apply_unary<float>(op, u[k][j].x, arg);
-                    const float x1 = apply_unary<float>(op, u[k][j].y, arg);
-                    const float x2 = apply_unary<float>(op, u[k][j].z, arg);
-                    const float x3 = apply_unary<float>(op, u[k][j].w, arg);
+                    const float x0 = LINEAR ? flat_unary<true>(op, u[k][j].x, (float)arg) : apply_unary<float>(op, u[k][j].x, arg);
+                    const float x1 = LINEAR ? flat_unary<true>(op, u[k][j].y, (float)arg) : apply_unary<float>(op, u[k][j].y, arg);
+                    const float x2 = LINEAR ? flat_unary<true>(op, u[k][j].z, (float)arg) : apply_unary<float>(op, u[k][j].z, arg);
+                    const float x3 = LINEAR ? flat_unary<true>(op, u[k][j].w, (float)arg) : apply_unary<float>(op, u[k][j].w, arg);
                     if (a.combine == BSC_OP_MUL) { v.x *= x0; v.y *= x1; v.z *= x2; v.w *= x3; }
                     else { v.x += x0; v.y += x1; v.z += x2; v.w += x3; }
                 }
                 if (rb + 4 * j < r1) {
-                    acc[0] += (double)finish_value<float>(a, v.x);
-                    acc[1] += (double)finish_value<float>(a, v.y);
-                    acc[2] += (double)finish_value<float>(a, v.z);
-                    acc[3] += (double)finish_value<float>(a, v.w);
+                    if (LINEAR) {       // (post op is a copy: scale and shift only)
+                        const float sc = (float)a.scale, sh = (float)a.shift;
+                        acc[0] += (double)(v.x * sc + sh); acc[1] += (double)(v.y * sc + sh);
+                        acc[2] += (double)(v.z * sc + sh); acc[3] += (double)(v.w * sc + sh);
+                    } else {
+                        acc[0] += (double)finish_value<float>(a, v.x);
+                        acc[1] += (double)finish_value<float>(a, v.y);
+                        acc[2] += (double)finish_value<float>(a, v.z);
+                        acc[3] += (double)finish_value<float>(a, v.w);
+                    }
                 }
             }
         }
@@ -1211,10 +1217,19 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
             switch (n_in) { BSC_NARROW(1) BSC_NARROW(2) BSC_NARROW(3) }
 #undef BSC_NARROW
         } else if (dense_lane) {
+            bool lin = post_op == BSC_OP_COPY && ctx->fused_map_flat;
+            for (int k = 0; k < n_in; ++k) {
+                const int op = m.pre_op[k];
+                if (!(op == BSC_OP_COPY || op == BSC_OP_SCALE ||
+                      (op == BSC_OP_POW && (m.pre_arg[k] == 2.0 || m.pre_arg[k] == -1.0 || m.pre_arg[k] == 1.0))))
+                    lin = false;
+            }
 #define BSC_LANE(NV)                                                                             \
     case NV:                                                                                     \
-        hipLaunchKernelGGL(map_reduce_lane_dense_f32_kernel<NV>, dim3((unsigned)blocks), dim3(256), \
-                           0, ctx->stream, m);                                                   \
+        if (lin) hipLaunchKernelGGL((map_reduce_lane_dense_f32_kernel<NV, true>), dim3((unsigned)blocks), dim3(256), \
+                                    0, ctx->stream, m);                                           \
+        else hipLaunchKernelGGL((map_reduce_lane_dense_f32_kernel<NV, false>), dim3((unsigned)blocks), dim3(256), \
+                                0, ctx->stream, m);                                               \
         break;
             switch (n_in) { BSC_LANE(1) BSC_LANE(2) BSC_LANE(3) }
 #undef BSC_LANE
