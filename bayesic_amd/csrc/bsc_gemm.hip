@@ -1246,6 +1246,9 @@ __global__ void gemm_naive_kernel(int64_t M, int64_t N, int64_t K, const T* A, i
 
 }  // namespace
 
+int bsc_gram_split(bsc_ctx* ctx, const float* X, int64_t ldx, int64_t N, int64_t D, float* C, int64_t sc_m, int64_t sc_n,
+                   float scale, int* handled);      // csrc/bsc_gram.hip
+
 struct Epilogue {
     int pow = 0;            // 0: none
     float scale = 1.f;
@@ -1355,6 +1358,13 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
         int handled = 0;
         int rc = bsc_gemm_skinny(ctx, M, N, K, (const float*)A, sa_m, sa_k, (const float*)B, sb_k, sb_n,
                                  (float*)C, sc_m, sc_n, &handled);
+        if (rc != BSC_OK || handled) return rc;
+    }
+    if (ctx->mfma_split == 2 && batch == 1 && !pre && A == B && M == N && sa_m == 1 && sb_n == 1 && sa_k == sb_k &&
+        !(epi.pow && epi.E) && epi.pow >= 0) {
+        // X^T X of a row-major X with the operands as two bf16 terms (csrc/bsc_gram.hip): bound by the read of X
+        int handled = 0;
+        const int rc = bsc_gram_split(ctx, (const float*)A, sa_k, K, M, (float*)C, sc_m, sc_n, epi.pow ? epi.scale : 1.0f, &handled);
         if (rc != BSC_OK || handled) return rc;
     }
     if (ctx->gemm_dma >= 2) {

@@ -39,6 +39,7 @@ KERNELS = {
     "cfg5": ("logreg_loglik_dma_kernel", "bsc_bbvi.hip", 4.0 * 1_000_000 * 256 + 8.0 * 1_000_000),
     "wouter": ("weighted_outer_kernel", "bsc_wouter.hip", 4.0 * 10_000_000 * (64 + 16)),
     "gram": ("gemm_f32_stream_kernel", "bsc_gemm.hip", 4.0 * 1_000_000 * 256),
+    "gramx": ("gram256_bx_kernel", "bsc_gram.hip", 4.0 * 1_000_000 * 256),
     "lda1": ("gemm_f32_stream_kernel", "bsc_gemm.hip", 4.0 * 6250 * 100_000 + 4.0 * 128 * 106_250),
     "lda1e": ("gemm_f32_stream_kernel", "bsc_gemm.hip", 8.0 * 6250 * 100_000 + 4.0 * 128 * 106_250),
     "lda2": ("gemm_f32_stream_kernel", "bsc_gemm.hip", 4.0 * 6250 * 100_000 + 4.0 * 128 * 206_250),

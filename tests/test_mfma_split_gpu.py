@@ -209,3 +209,38 @@ def test_mog_driver_on_split_operands_tracks_the_oracle(ctx, split_ctx):
         npt.assert_allclose(model.elbo.item(), want, rtol=2e-6)
         npt.assert_allclose(model.eta.cpu().numpy(), eta, rtol=2e-4, atol=1e-6)
         model.eta.copy_(torch.as_tensor(eta, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("N,D,ld", [(5000, 256, 256), (4096, 32, 32), (100000, 96, 100), (7001, 160, 160), (300000, 256, 256)])
+def test_gram_statistic_on_split_operands(ctx, split_ctx, N, D, ld):
+    """dot(X.T, X) -- the summed second-moment statistic -- with X as two bf16 terms (csrc/bsc_gram.hip): through the
+    C ABI's product entry and through the executor, against float64; symmetric to the bit."""
+    from bayesic_amd import algebra as A
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    rs = np.random.RandomState(N + D)
+    Xp = (rs.standard_normal((N, ld)) + 0.3).astype(np.float32)
+    X_ = Xp[:, :D]
+    Xd = ctx.to_device(Xp)
+    want = X_.astype(np.float64).T @ X_.astype(np.float64)
+    n2 = np.sqrt((X_.astype(np.float64) ** 2).sum(0))
+    scale = n2[:, None] * n2[None, :]
+    f32 = ctx.zeros((D, D), torch.float32)
+    ctx.call("bsc_gemm_strided_batched", 0, 1, D, D, N, Xd, 0, 1, ld, Xd, 0, ld, 1, f32, 0, D, 1)
+    split_ctx(2)
+    out = torch.full((D, D), float("nan"), dtype=torch.float32, device=ctx.device)
+    ctx.call("bsc_gemm_strided_batched", 0, 1, D, D, N, Xd, 0, 1, ld, Xd, 0, ld, 1, out, 0, D, 1)
+    ctx.sync()
+    got = out.cpu().numpy()
+    assert (np.abs(got - want) <= 2e-5 * scale).all(), (np.abs(got - want) / scale).max()
+    npt.assert_array_equal(got, got.T)
+    out2 = torch.full((D, D), float("nan"), dtype=torch.float32, device=ctx.device)
+    ctx.call("bsc_gemm_strided_batched", 0, 1, D, D, N, Xd, 0, 1, ld, Xd, 0, ld, 1, out2, 0, D, 1)
+    ctx.sync()
+    npt.assert_array_equal(got, out2.cpu().numpy())            # run-to-run identical
+    assert not np.array_equal(got, f32.cpu().numpy())
+    if ld == D:
+        Xv = A.var("X", 2)
+        ex = A.dot(Xv.T, Xv).compile(DeviceBackend(ctx))(X=X_)
+        npt.assert_array_equal(ex, got)
+        ex2 = (A.dot(Xv.T, Xv) * 0.5).compile(DeviceBackend(ctx))(X=X_)
+        npt.assert_allclose(ex2, 0.5 * got, rtol=1e-6)

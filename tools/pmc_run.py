@@ -150,6 +150,12 @@ def main():
         X = torch.randn((N, D), generator=g, device=dev)
         C = torch.empty((D, D), device=dev)
         fn = lambda: ctx.call("bsc_gemm_strided_batched", 0, 1, D, D, N, X, 0, 1, D, X, 0, D, 1, C, 0, D, 1)
+    elif which == "gramx":
+        N, D = 1_000_000, 256
+        X = torch.randn((N, D), generator=g, device=dev)
+        C = torch.empty((D, D), device=dev)
+        ctx.call("bsc_ctx_set_mfma_split", 2)
+        fn = lambda: ctx.call("bsc_gemm_strided_batched", 0, 1, D, D, N, X, 0, 1, D, X, 0, D, 1, C, 0, D, 1)
     elif which == "skinny":
         N, D, S = 1_000_000, 256, 8
         X = torch.randn((N, D), generator=g, device=dev)

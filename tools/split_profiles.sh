@@ -19,9 +19,10 @@ done
 timeout -k 10 200 python3 $R/tools/bench_lda_split.py > $O/bench_lda_split.txt 2>&1
 timeout -k 10 200 python3 $R/tools/bench_logreg_split.py > $O/bench_logreg_split.txt 2>&1
 timeout -k 10 200 python3 $R/tools/bench_mog_split.py > $O/bench_mog_split.txt 2>&1
+timeout -k 10 200 python3 $R/tools/bench_gram_split.py > $O/bench_gram_split.txt 2>&1
 timeout -k 10 60 $R/tools/check_bf16_maps > $O/check_bf16_maps.txt 2>&1
 echo "tools done" >> $O/progress.txt
 cd $R
-timeout -k 10 600 bash tools/pmc_collect.sh $O/pmc cfg3x cfg4x2 cfg5x2 > $O/pmc.log 2>&1
+timeout -k 10 600 bash tools/pmc_collect.sh $O/pmc cfg3x cfg4x2 cfg5x2 gramx > $O/pmc.log 2>&1
 python3 profiles/summarize_pmc.py --all $O/pmc > $O/pmc_kernels.txt 2>&1
 ls $O
