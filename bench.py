@@ -613,7 +613,8 @@ class Cfg4(Workload):
 
     def roofline(self, avg_s):
         split = self.mfma_split
-        kernel = "lda_sstats_bx%d_bound_kernel" % split if split else "lda_sstats_stream_kernel"
+        # (the driver takes the words' term of the bound in the same pass: the ..._bound_kernel instantiations)
+        kernel = "lda_sstats_bx%d_bound_kernel" % split if split else "lda_sstats_stream_bound_kernel"
         return _mfma_roofline(kernel, 4.0 * self.docs * self.V * self.K, 4.0 * self.docs * self.V, avg_s,
                               pmc_traffic(kernel, self.docs == 6250), split=split)
 
