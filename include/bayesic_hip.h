@@ -87,7 +87,9 @@ int bsc_memset(bsc_ctx* ctx, void* dst, int value, size_t bytes);
  * accumulated in f32: relative error per product <= ~2^-17 resp. ~2^-23 (the f32 class).  Honoured by
  * bsc_lda_sstats / bsc_lda_sstats_bound at K = 128 (2 and 3), bsc_logreg_bbvi_loglik for 36 <= S <= 64, S % 4 == 0
  * (2; with 3 it computes as with 0) and bsc_mog_estep (either value: its forward product -- differences of large
- * terms -- always takes three terms, its backward two); every other entry computes as with 0.  Environment:
+ * terms -- always takes three terms, its backward two) and by bsc_gemm_strided_batched / bsc_gemm_epilogue when both
+ * operands are the SAME row-major matrix of <= 256 columns, a multiple of 32 (X^T X: 2); every other entry computes as
+ * with 0.  Environment:
  * BSC_MFMA_SPLIT at bsc_ctx_create.  Replaces nothing in the reference (bayesic/algebra.py:1347-1383
  * contracts in the dtype of its operands); SURVEY.md 8(d) config 4 leaves the operand-split variant open. */
 int bsc_ctx_set_mfma_split(bsc_ctx* ctx, int terms);
