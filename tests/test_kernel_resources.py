@@ -36,11 +36,22 @@ LIMITS = {
         "map_reduce_lane_narrow_f32_kernelILi3E": (128, 0),
         "map_reduce_wave_kernelIfLb0E": (128, 0),
         "map_strided_kernelIfLb0E": (96, 0),
+        "map_flat_f32_kernelILi2ELb1E": (96, 0),
+        "map_flat_f32_kernelILi4ELb0E": (128, 0),
+        "map_reduce_rows_f32_kernelILi2ELb1E": (128, 0),
     },
     "bsc_lda.hip": {
         "lda_sstats_kernelILi4E": (256, 0),
         "lda_sstats_stream_kernel": (256, 32),       # (spills at the block boundaries, not in a step)
         "lda_sstats_csc_kernelILi8ELb1E": (96, 0),
+        # the split-operand route: two workgroups of 80 KiB a CU with two bf16 terms (<= 256 registers, nothing in
+        # scratch: a spilled Bt fragment was reloaded in every step once); three terms run one workgroup a CU
+        "lda_sstats_bx2_kernel": (240, 0),
+        "lda_sstats_bx2_bound_kernel": (240, 0),
+        "lda_sstats_bx3_bound_kernel": (384, 0),
+    },
+    "bsc_gram.hip": {
+        "gram256_bx_kernel": (256, 0),                  # eight waves a CU = two per SIMD
     },
     "bsc_gemm.hip": {
         "gemm_f32_mfma_kernelILb1ELb1ELb1E": (256, 0),
@@ -48,7 +59,8 @@ LIMITS = {
         "gemm_f32_dma_kernel": (144, 0),
         # two workgroups per CU: <= 256; the few scratch bytes are spills in the guarded edge-tile
         # store path, outside the k-loop (the loop's own budget is checked in the ISA: DESIGN 12)
-        "gemm_f32_stream_kernel": (256, 96),
+        # (100 bytes in the instantiation with operand prologues AND partial tiles, bsc_gemm_fused)
+        "gemm_f32_stream_kernel": (256, 112),
     },
     "bsc_skinny.hip": {
         "gemm_skinny_tn_kernel": (128, 0),
@@ -56,10 +68,12 @@ LIMITS = {
     },
     "bsc_mog.hip": {
         "mog_estep_kernel": (256, 0),
+        "mog_estep_bx_kernel": (256, 0),
     },
     "bsc_bbvi.hip": {
         "logreg_loglik_kernel": (256, 0),
         "logreg_loglik_dma_kernelILb1ELi4ELi0E": (192, 0),
+        "logreg_loglik_dma_bx_kernel": (200, 0),
         "bbvi_update_kernel": (96, 0),
     },
     "bsc_wouter.hip": {
