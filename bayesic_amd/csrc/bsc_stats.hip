@@ -360,18 +360,25 @@ __global__ __launch_bounds__(256) void softmax_rows_vec4_kernel(const float* __r
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-    for (int64_t r0 = wave * 2 * RPW; r0 < rows; r0 += n_waves * 2 * RPW) {
-        float4 x[2];
-        bool live[2];
+    // (round 3: four row groups in flight instead of two, streaming loads and stores -- 3.0 -> see DESIGN 4)
+    constexpr int U = 4;
+    typedef float sm_f32x4 __attribute__((ext_vector_type(4)));
+    for (int64_t r0 = wave * U * RPW; r0 < rows; r0 += n_waves * U * RPW) {
+        float4 x[U];
+        bool live[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int64_t r = r0 + u * RPW + sub;
             live[u] = r < rows && c < cols;
-            x[u] = live[u] ? *reinterpret_cast<const float4*>(in + r * ld_in + c)
-                           : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            if (live[u]) {
+                const sm_f32x4 w = __builtin_nontemporal_load(reinterpret_cast<const sm_f32x4*>(in + r * ld_in + c));
+                x[u] = make_float4(w.x, w.y, w.z, w.w);
+            } else {
+                x[u] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int64_t r = r0 + u * RPW + sub;
             float4 v = make_float4(x[u].x * LOG2E, x[u].y * LOG2E, x[u].z * LOG2E, x[u].w * LOG2E);
             float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
@@ -385,8 +392,10 @@ __global__ __launch_bounds__(256) void softmax_rows_vec4_kernel(const float* __r
 #pragma unroll
             for (int off = 1; off < L; off <<= 1) z += __shfl_xor(z, off);
             const float rz = __builtin_amdgcn_rcpf(z), inv = rz * (2.0f - z * rz);
-            if (live[u])
-                *reinterpret_cast<float4*>(out + r * ld_out + c) = make_float4(e.x * inv, e.y * inv, e.z * inv, e.w * inv);
+            if (live[u]) {
+                const sm_f32x4 w = {e.x * inv, e.y * inv, e.z * inv, e.w * inv};
+                __builtin_nontemporal_store(w, reinterpret_cast<sm_f32x4*>(out + r * ld_out + c));
+            }
             if (lse && r < rows && c == 0) lse[r] = (m + __builtin_amdgcn_logf(z)) * LN2;
         }
     }
@@ -469,7 +478,7 @@ int bsc_softmax_rows(bsc_ctx* ctx, const float* in, int64_t rows, int64_t cols, 
                       (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
     if (vec4) {
         const int l = cols <= 8 ? 2 : cols <= 16 ? 4 : cols <= 32 ? 8 : cols <= 64 ? 16 : cols <= 128 ? 32 : 64;
-        int64_t vb = (rows + 8 * (64 / l) - 1) / (8 * (64 / l));
+        int64_t vb = (rows + 16 * (64 / l) - 1) / (16 * (64 / l));
         if (vb > 16 * (int64_t)ctx->cu_count) vb = 16 * (int64_t)ctx->cu_count;
 #define BSC_SM4(L_) hipLaunchKernelGGL(softmax_rows_vec4_kernel<L_>, dim3((unsigned)vb), dim3(256), 0, ctx->stream, \
                                        in, rows, (int)cols, ld_in, out, ld_out, lse)
