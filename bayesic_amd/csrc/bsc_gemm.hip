@@ -68,6 +68,7 @@ struct GemmArgs {
     // 2 exp, 3 abs.  Operand bytes that lie outside the matrix arrive as zeros; f(0) != 0 (exp) is allowed on ONE
     // side only, the other side's zeros then still cancel the padded products.
     int pre_a, pre_b;
+    int nt_c;          // whole-tile stores of C non-temporal (a result far larger than the caches, written once)
 };
 
 __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int64_t b, int64_t row, int64_t col) {
@@ -919,7 +920,7 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
             } else if (fast) {
                 const int sc_n = (int)gc->sc_n, epi_pow = gc->epi_pow, dbg = gc->dbg;
                 const float epi_scale = gc->epi_scale;
-                const bool has_e = gc->E != nullptr;
+                const bool has_e = gc->E != nullptr, nt_c = gc->nt_c != 0;
                 float* c_tile = gc->C + cb * gc->sc_b + cn0 * sc_n + cm0;
                 const unsigned c_lane = (unsigned)((wn * 64 + lane_n) * sc_n + wm * 64 + lane_m) * 4u;
 #pragma unroll
@@ -949,7 +950,8 @@ __global__ __launch_bounds__(GEMM_BLOCK, 2) void gemm_f32_stream_kernel(GemmArgs
                         }
                         char* base = reinterpret_cast<char*>(c_tile + (int64_t)(j * BLK_N) * sc_n + piece_m(p8));
                         if (!(dbg & 1) && (interior || (lane_m + piece_m(p8) < m_left && lane_n + j * BLK_N < n_left))) {
-                            *reinterpret_cast<gemm_f32x4*>(base + c_lane) = v;
+                            if (nt_c) __builtin_nontemporal_store(v, reinterpret_cast<gemm_f32x4*>(base + c_lane));
+                            else *reinterpret_cast<gemm_f32x4*>(base + c_lane) = v;
                             if (mirror) {                // C[n][m] = C[m][n]: the quad's rows become columns
                                 float* mt = gc->C + cb * gc->sc_b + (cm0 + wm * 64 + lane_m + piece_m(p8)) * sc_n +
                                             (cn0 + wn * 64 + lane_n + j * BLK_N);
@@ -1379,6 +1381,7 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
         s.E = epi.E; s.se_b = epi.se_b; s.se_m = swap ? epi.se_n : epi.se_m; s.se_n = swap ? epi.se_m : epi.se_n;
         s.epi_scale = epi.scale; s.epi_pow = epi.pow;
         s.pre_a = swap ? epi.pre_b : epi.pre_a; s.pre_b = swap ? epi.pre_a : epi.pre_b;
+        s.nt_c = ctx->gemm_nt_c && (double)M * (double)N * (double)batch * 4.0 >= 128.0 * 1024.0 * 1024.0;
         s.splits = 1; s.k_chunk = 0; s.vec_a = s.vec_b = s.fast = 0;
         const bool a_m = s.sa_m == 1, b_n = s.sb_n == 1;
         auto dma_ok = [&](const void* p, bool mn, int64_t ext_mn, int64_t s_mn, int64_t s_k, int64_t s_b) {
