@@ -270,6 +270,7 @@ __device__ __forceinline__ float flat_unary(int op, float x, float arg) {
     if (LINEAR) {      // (uniform selects; the compiler turns them into scalar branches around one instruction)
         if (op == BSC_OP_SCALE) return x * arg;
         if (op == BSC_OP_POW) return arg == 2.0f ? x * x : arg == -1.0f ? 1.0f / x : x;
+        if (op == BSC_OP_ABS) return __builtin_fabsf(x);
         return x;
     }
     return apply_unary<float>(op, x, (double)arg);
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(256) void map_reduce_wave_kernel(MapArgs a) {
 
 // Variant A, dense: every operand is a dense run along the single reduce axis and
 // 16-byte aligned there; 16 B per lane per load.
-template <int N, int U>
+template <int N, int U, bool LINEAR = false>
 __global__ __launch_bounds__(256) void map_reduce_wave_dense_f32_kernel(MapArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t job = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -487,18 +488,24 @@ __global__ __launch_bounds__(256) void map_reduce_wave_dense_f32_kernel(MapArgs 
             for (int k = 0; k < N; ++k) {
                 const int op = a.pre_op[k];
                 const double arg = a.pre_arg[k];
-                const float x0 = apply_unary<float>(op, u[k][j].x, arg);
-                const float x1 = apply_unary<float>(op, u[k][j].y, arg);
-                const float x2 = apply_unary<float>(op, u[k][j].z, arg);
-                const float x3 = apply_unary<float>(op, u[k][j].w, arg);
+                const float x0 = LINEAR ? flat_unary<true>(op, u[k][j].x, (float)arg) : apply_unary<float>(op, u[k][j].x, arg);
+                const float x1 = LINEAR ? flat_unary<true>(op, u[k][j].y, (float)arg) : apply_unary<float>(op, u[k][j].y, arg);
+                const float x2 = LINEAR ? flat_unary<true>(op, u[k][j].z, (float)arg) : apply_unary<float>(op, u[k][j].z, arg);
+                const float x3 = LINEAR ? flat_unary<true>(op, u[k][j].w, (float)arg) : apply_unary<float>(op, u[k][j].w, arg);
                 if (a.combine == BSC_OP_MUL) { v.x *= x0; v.y *= x1; v.z *= x2; v.w *= x3; }
                 else { v.x += x0; v.y += x1; v.z += x2; v.w += x3; }
             }
             if (rb + 64 * j < r1) {
-                acc += (double)finish_value<float>(a, v.x);
-                acc += (double)finish_value<float>(a, v.y);
-                acc += (double)finish_value<float>(a, v.z);
-                acc += (double)finish_value<float>(a, v.w);
+                if (LINEAR) {
+                    const float sc = (float)a.scale, sh = (float)a.shift;
+                    acc += (double)(v.x * sc + sh); acc += (double)(v.y * sc + sh);
+                    acc += (double)(v.z * sc + sh); acc += (double)(v.w * sc + sh);
+                } else {
+                    acc += (double)finish_value<float>(a, v.x);
+                    acc += (double)finish_value<float>(a, v.y);
+                    acc += (double)finish_value<float>(a, v.z);
+                    acc += (double)finish_value<float>(a, v.w);
+                }
             }
         }
     }
@@ -996,7 +1003,7 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
                 f.op[k] = m.pre_op[k];
                 f.arg[k] = (float)m.pre_arg[k];
                 const int op = m.pre_op[k];
-                if (!(op == BSC_OP_COPY || op == BSC_OP_SCALE ||
+                if (!(op == BSC_OP_COPY || op == BSC_OP_SCALE || op == BSC_OP_ABS ||
                       (op == BSC_OP_POW && (m.pre_arg[k] == 2.0 || m.pre_arg[k] == -1.0 || m.pre_arg[k] == 1.0))))
                     linear = false;
             }
@@ -1220,7 +1227,7 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
             bool lin = post_op == BSC_OP_COPY && ctx->fused_map_flat;
             for (int k = 0; k < n_in; ++k) {
                 const int op = m.pre_op[k];
-                if (!(op == BSC_OP_COPY || op == BSC_OP_SCALE ||
+                if (!(op == BSC_OP_COPY || op == BSC_OP_SCALE || op == BSC_OP_ABS ||
                       (op == BSC_OP_POW && (m.pre_arg[k] == 2.0 || m.pre_arg[k] == -1.0 || m.pre_arg[k] == 1.0))))
                     lin = false;
             }
@@ -1244,7 +1251,7 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
             bool linear = post_op == BSC_OP_COPY;
             for (int k = 0; k < n_in; ++k) {
                 const int op = m.pre_op[k];
-                if (!(op == BSC_OP_COPY || op == BSC_OP_SCALE ||
+                if (!(op == BSC_OP_COPY || op == BSC_OP_SCALE || op == BSC_OP_ABS ||
                       (op == BSC_OP_POW && (m.pre_arg[k] == 2.0 || m.pre_arg[k] == -1.0 || m.pre_arg[k] == 1.0))))
                     linear = false;
             }
@@ -1259,10 +1266,20 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
             switch (n_in) { BSC_ROWS(1) BSC_ROWS(2) BSC_ROWS(3) }
 #undef BSC_ROWS
         } else if (dense_wave) {
+            bool wlin = post_op == BSC_OP_COPY && ctx->fused_map_flat;
+            for (int k = 0; k < n_in; ++k) {
+                const int op = m.pre_op[k];
+                if (!(op == BSC_OP_COPY || op == BSC_OP_SCALE || op == BSC_OP_ABS ||
+                      (op == BSC_OP_POW && (m.pre_arg[k] == 2.0 || m.pre_arg[k] == -1.0 || m.pre_arg[k] == 1.0))))
+                    wlin = false;
+            }
 #define BSC_WAVE_CASE(NV)                                                                        \
     case NV:                                                                                     \
         if (n_red <= 256 * splits)                                                               \
             hipLaunchKernelGGL((map_reduce_wave_dense_f32_kernel<NV, 1>), dim3((unsigned)blocks), \
+                               dim3(256), 0, ctx->stream, m);                                    \
+        else if (wlin)                                                                           \
+            hipLaunchKernelGGL((map_reduce_wave_dense_f32_kernel<NV, 4, true>), dim3((unsigned)blocks), \
                                dim3(256), 0, ctx->stream, m);                                    \
         else                                                                                     \
             hipLaunchKernelGGL((map_reduce_wave_dense_f32_kernel<NV, 4>), dim3((unsigned)blocks), \
