@@ -214,7 +214,12 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, f32x16 (&acc)
                 const float sc = g.epi_scale;
                 v.x *= ev.x * sc; v.y *= ev.y * sc; v.z *= ev.z * sc; v.w *= ev.w * sc;
             }
-            *reinterpret_cast<float4*>(C + (m0 + row) * sm + n0 + c4) = v;
+            if (g.nt_c) {
+                typedef float st_f32x4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(st_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<st_f32x4*>(C + (m0 + row) * sm + n0 + c4));
+            } else {
+                *reinterpret_cast<float4*>(C + (m0 + row) * sm + n0 + c4) = v;
+            }
         }
         return;
     }
@@ -1483,6 +1488,8 @@ static int gemm_impl(bsc_ctx* ctx, int dtype, int64_t batch, int64_t M, int64_t 
     g.n_kt = 0; g.sk_q = 0; g.sk_r = 0; g.sk_stream = 0; g.n_wg = 0; g.rounds = 0; g.tail_tiles = 0; g.tiles_pb = 0;
     g.group = 1; g.dbg = 0; g.slab = nullptr;
     g.mg_pb = g.mg_strip = g.mg_last = 0; g.sh_pb = g.sh_strip = g.sh_last = g.group_log2 = 0; g.sym = 0; g.ksplit = 0; g.fix_lanes = 4;
+    g.pre_a = g.pre_b = 0;
+    g.nt_c = ctx->gemm_nt_c && (double)M * (double)N * (double)batch * 4.0 >= 128.0 * 1024.0 * 1024.0;
     g.tiles_m = (int)((M + BM - 1) / BM);
     g.tiles_n = (int)((N + BN - 1) / BN);
     const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * batch;
