@@ -244,3 +244,32 @@ def test_gram_statistic_on_split_operands(ctx, split_ctx, N, D, ld):
         npt.assert_array_equal(ex, got)
         ex2 = (A.dot(Xv.T, Xv) * 0.5).compile(DeviceBackend(ctx))(X=X_)
         npt.assert_allclose(ex2, 0.5 * got, rtol=1e-6)
+
+
+def test_plugin_surface_honours_the_split_option(ctx, split_ctx):
+    """Config 3's SYMBOLIC model (inference/mixture.py) is recognised and runs the fused kernels; with the context's
+    split option on, those are the bf16 ones: the oracle's update and bound at the f32 route's tolerances."""
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from bayesic_amd.inference.mixture import DiagonalMixtureVMP
+    n, d, k = 50_000, 16, 64
+    X, _, _ = svi.make_cfg3(n, d, k)
+    prior = dict(alpha0=1.5, m0=0.1, kappa0=0.05, a0=2.0, b0=0.7)
+    eta0 = svi.mog_prior_eta(k, d, **prior)
+    eta = svi.mog_init_eta(X[:500], k, d, seed=2)
+    alpha, m, kappa, a, b = svi.mog_unpack(eta, k, d)
+    plain = DiagonalMixtureVMP(X, k, n_total=10.0 * n, init=(alpha, m, kappa, a, b), backend=DeviceBackend(ctx), **prior)
+    plain.step(0.5)
+    plain_eta = plain.eta_fused_layout()
+    split_ctx(2)
+    model = DiagonalMixtureVMP(X, k, n_total=10.0 * n, init=(alpha, m, kappa, a, b), backend=DeviceBackend(ctx), **prior)
+    assert model.route.startswith("fused"), model.route
+    Wmat, c = svi.mog_expected_params(eta, k, d)
+    _, lse = svi.mog_local_step(X, Wmat, c)
+    want_elbo = svi.mog_elbo(eta, eta0, lse, 10.0, k, d)
+    model.step(0.5)
+    want, _, _ = svi.mog_svi_step(eta, eta0, X, 10.0 * n, 0.5, k, d)
+    npt.assert_allclose(model.elbo(), want_elbo, rtol=2e-6)
+    got = model.eta_fused_layout()
+    scale = np.maximum(np.abs(want), 1.0)
+    assert (np.abs(got - want) <= 1e-3 * scale).all()
+    assert not np.array_equal(got, plain_eta)
