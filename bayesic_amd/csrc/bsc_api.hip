@@ -90,6 +90,7 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
     if (const char* e = getenv("BSC_GEMM_DMA")) ctx->gemm_dma = atoi(e);
     if (const char* e = getenv("BSC_GEMM_DBG")) ctx->gemm_dbg = atoi(e);
     if (const char* e = getenv("BSC_GEMM_NT_C")) ctx->gemm_nt_c = atoi(e) != 0;
+    if (const char* e = getenv("BSC_SKINNY_NT_WG")) { const int v = atoi(e); if (v == 1 || v == 2) ctx->skinny_nt_wg_per_cu = v; }
     if (const char* e = getenv("BSC_GEMM_SYM")) ctx->gemm_sym = atoi(e) != 0;
     if (const char* e = getenv("BSC_LDA_STREAM")) ctx->lda_stream = atoi(e) != 0;
     if (const char* e = getenv("BSC_FUSED_NT_STORE")) ctx->fused_nt_store = atoi(e) != 0;

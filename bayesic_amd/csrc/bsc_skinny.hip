@@ -271,7 +271,7 @@ __global__ __launch_bounds__(64) void skinny_tn_finish_kernel(const double* __re
 int launch_nt(bsc_ctx* ctx, const NtArgs& a) {
     const int64_t n_tiles = (a.N + ST - 1) / ST;
     int n_blocks = (int)((n_tiles + NTW - 1) / NTW);
-    if (n_blocks > ctx->cu_count) n_blocks = ctx->cu_count;
+    if (n_blocks > ctx->skinny_nt_wg_per_cu * ctx->cu_count) n_blocks = ctx->skinny_nt_wg_per_cu * ctx->cu_count;
     const int nsb = a.M <= 16 ? 1 : 2;
     const int ks = a.K <= 64 ? 4 : a.K <= 128 ? 8 : a.K <= 192 ? 12 : 16;
     bsc_prof_scope prof(ctx);
