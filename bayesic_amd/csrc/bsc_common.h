@@ -22,6 +22,7 @@ struct bsc_ctx {
     int blr_tile_rows = 16;      // 16: forward on the MFMA pipe when D == 256 (else 8-row VALU tiles); 8 | 4: VALU variants
     int blr_waves_per_simd = 0;  // tuning: cap resident waves per SIMD (0 = kernel's own limit)
     int fused_map_blocks_per_cu = 8;  // bsc_map_reduce, pure map: grid cap (256-thread blocks)
+    int skinny_nt_dbg = 0;            // deletion builds of gemm_skinny_nt_kernel (BSC_SKINNY_NT_DBG + BSC_PROFILING_BUILDS): WRONG results
     int skinny_nt_wg_per_cu = 1;      // gemm_skinny_nt_kernel: resident workgroups (4 waves, 64 KiB of rings each) per CU (BSC_SKINNY_NT_WG)
     int gemm_nt_c = 1;                // stream GEMM: results of 128 MiB and more leave by non-temporal stores (BSC_GEMM_NT_C=0 for A/B)
     int fused_map_flat = 1;           // pure maps with a contiguous float32 result: map_flat_f32_kernel (BSC_FUSED_MAP_FLAT=0: the round-1/2 kernels, for A/B)

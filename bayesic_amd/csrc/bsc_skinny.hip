@@ -30,10 +30,18 @@ constexpr int SR = 16;         // ring slots (1 KiB each) per wave: a whole tile
 #define BSC_LDS_B32(DST, ADDR, OFF) \
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
 
-// ---- NT: the large operand is B[n, k] (rows = n), KS strips of 16 columns ----------------------
-// Lane (i16, kq) of strip j holds B[row i16][16 j + 4 kq .. +3] as the MFMA A operand; the small
-// matrix is the B operand, A[m = 16 sb + i16][16 j + 4 kq + r] in 16 NSB registers per strip.
-// Result layout: acc[sb][r] = C[m = 16 sb + i16][n = row0 + 4 kq + r].
+// ---- NT: the large operand is B[n, k] (rows = n), 16-row tiles --------------------------------
+// v_mfma_f32_16x16x4_f32 with the SMALL matrix as the A operand: lane (i16, kq) holds A[m = 16 sb + i16][16 j + 4 kq + r]
+// (16 NSB registers per strip j of 16 columns) and, as the B operand, B[row i16 of the tile][the same column]; the
+// result acc[sb][r] = C[m = 16 sb + 4 kq + r][n = row0 + i16] has the LONG axis on adjacent lanes, so a store
+// instruction writes 64-byte runs (with the operands the other way round a lane held four consecutive n of one m and a
+// store instruction was 64 separate 16-byte pieces: 54 of 226 us at 8 x 1M x 256, tools/ab_skinny_nt.py).
+//
+// The tile arrives by LDS-DMA in WHOLE 128-byte lines: piece s = 2 c + sp is rows 8 sp .. + 7 x columns 32 c .. + 31
+// (8 x 128 bytes; pieces of 16 rows x 64 bytes read 23 % slower, same tool), lane l of the DMA = (row l >> 3, 16-byte
+// position l & 7).  The 16-byte chunks of a row are XOR-permuted -- on the GLOBAL side, the fill stays lane-linear --
+// by f = (row >> 1) | (sp << 2), which makes the operand read (ds_read_b128, lane (i16, kq) <- row i16, chunk kq + 4 t
+// of column block c) free of bank conflicts in each of the instruction's four 16-lane groups.
 struct NtArgs {
     const float* A; int64_t sa_m, sa_k;     // small [M, K]
     const float* B; int64_t ldb;            // large [N, K], k-contiguous
@@ -42,13 +50,16 @@ struct NtArgs {
     int M, K;
 };
 
-template <int NSB, int KS>
+// DBG (timing only, results wrong; BSC_SKINNY_NT_DBG behind BSC_PROFILING_BUILDS): bit 0 no MFMAs, bit 2 no stores
+template <int NSB, int KS, int DBG = 0>
 __global__ __launch_bounds__(64 * NTW, 2) void gemm_skinny_nt_kernel(NtArgs a) {
+    static_assert(KS % 2 == 0 && KS <= SR, "two strips per column block, one ring slot per strip");
     __shared__ __attribute__((aligned(16))) char ring[NTW * SR * 1024];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
     const int K = a.K;
+    constexpr int NCB = KS / 2;             // column blocks of 32
 
     f32x4 wreg[NSB][KS];
 #pragma unroll
@@ -66,23 +77,30 @@ __global__ __launch_bounds__(64 * NTW, 2) void gemm_skinny_nt_kernel(NtArgs a) {
     const int64_t n_waves = (int64_t)gridDim.x * NTW;
     int64_t tile = (int64_t)blockIdx.x * NTW + wave;
     const int64_t n_tiles = (a.N + ST - 1) / ST;
-    const int voff = i16 * (int)(a.ldb * 4) + 16 * kq;
     char* const my = ring + wave * SR * 1024;
-    const unsigned addr_lane = (unsigned)(uintptr_t)(bsc_lds_ptr)my + 16u * lane;
-    auto dma = [&](decltype(bsc_rows_rsrc(a.B, a.ldb, K, a.N, 0)) rs, int j) {      // strip j -> slot j
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (bsc_lds_ptr)(my + j * 1024), 16, voff, 64 * j, 0, 2);
+    // the DMA's side: row ra of the piece, position rp; the chunk fetched there is rp ^ f
+    const int ra = lane >> 3, rp = lane & 7;
+    const int row_bytes = (int)(a.ldb * 4);
+    const int voff0 = ra * row_bytes + 16 * (rp ^ (ra >> 1));
+    const int voff1 = ra * row_bytes + 16 * (rp ^ ((ra >> 1) | 4));
+    auto dma = [&](decltype(bsc_rows_rsrc(a.B, a.ldb, K, a.N, 0)) rs, int s) {      // piece s -> slot s
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (bsc_lds_ptr)(my + s * 1024), 16, (s & 1) ? voff1 : voff0,
+                                                 (s & 1) * 8 * row_bytes + 128 * (s >> 1), 0, 2);
     };
-    const bool vec_store = a.sc_n == 1 && (a.sc_m % 4) == 0 && (((uintptr_t)a.C) & 15) == 0;
+    // the reader's side: row i16 = (sp, a), chunk kq + 4 t: strip j = 2 c + t is at addr_t + 2048 c
+    const int sp = i16 >> 3, ar = i16 & 7;
+    const unsigned addr0 = (unsigned)(uintptr_t)(bsc_lds_ptr)my + 1024u * sp + 128u * ar + 16u * (kq ^ ((ar >> 1) | (sp << 2)));
+    const unsigned addr1 = addr0 ^ 64u;
 
     if (tile < n_tiles) {
         const auto rs = bsc_rows_rsrc(a.B, a.ldb, K, a.N, tile * ST);
 #pragma unroll
-        for (int j = 0; j < KS; ++j) dma(rs, j);
+        for (int s = 0; s < KS; ++s) dma(rs, s);
     }
     __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
     asm volatile("" ::: "memory");
     f32x4 an;
-    BSC_LDS_B128(an, addr_lane, 0);
+    BSC_LDS_B128(an, addr0, 0);
 
     for (; tile < n_tiles; tile += n_waves) {
         const int64_t row0 = tile * ST;
@@ -90,45 +108,56 @@ __global__ __launch_bounds__(64 * NTW, 2) void gemm_skinny_nt_kernel(NtArgs a) {
         f32x4 acc[NSB];
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) acc[sb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto multiply = [&](const f32x4& x, int j) {
+            if (DBG & 1) {
 #pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            __builtin_amdgcn_s_waitcnt(BSC_LGKMCNT0);          // `an` was read a strip ago
+                for (int sb = 0; sb < NSB; ++sb) acc[sb] += x * wreg[sb][j];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int sb = 0; sb < NSB; ++sb)
+                        acc[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[sb][j][r], x[r], acc[sb], 0, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            // strip 2 c (read a strip ago); strip 2 c + 1 sits in the same two slots
+            __builtin_amdgcn_s_waitcnt(BSC_LGKMCNT0);
             __builtin_amdgcn_sched_barrier(0);
             f32x4 x = an;
-            if (16 * j + 4 * kq >= K) x = f32x4{0.f, 0.f, 0.f, 0.f};     // columns past K (K % 16 != 0, or padded strips)
-            // strip j+1 (of the next tile for the last strip) must have landed: every strip of a tile
-            // is issued during the previous tile, so the operations issued after strip j+1 are the
-            // KS-2-j strips behind it, this tile's j strips -- and the previous tile's stores, which
-            // are NOT counted here: a smaller count only waits for a few younger strips as well
-            __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(KS - 2));
+            if (32 * c + 4 * kq >= K) x = f32x4{0.f, 0.f, 0.f, 0.f};     // columns past K (K % 32 != 0, or padded strips)
+            BSC_LDS_B128(an, addr1, c * 2048);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(x, 2 * c);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(BSC_LGKMCNT0);
+            __builtin_amdgcn_sched_barrier(0);
+            x = an;
+            if (32 * c + 16 + 4 * kq >= K) x = f32x4{0.f, 0.f, 0.f, 0.f};
+            // column block c + 1 (block 0 of the next tile after the last) must have landed: every piece of a tile is
+            // issued during the previous tile, two per column block, so the loads issued after block c + 1's are the
+            // KS - 4 - 2 c pieces behind it and this tile's 2 c -- and the previous tile's stores, which are NOT
+            // counted here: a smaller count only waits for a few younger pieces as well, whatever order stores retire in
+            __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(KS - 4));
             asm volatile("" ::: "memory");
-            if (j + 1 < KS) BSC_LDS_B128(an, addr_lane, ((j + 1) % KS) * 1024);
-            else BSC_LDS_B128(an, addr_lane, 0);
+            BSC_LDS_B128(an, addr0, ((c + 1) % NCB) * 2048);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int sb = 0; sb < NSB; ++sb)
-                    acc[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[r], wreg[sb][j][r], acc[sb], 0, 0, 0);
-            dma(rs_next, j);            // slot j is free (its strip is in `x`): the next tile's strip j
+            multiply(x, 2 * c + 1);
+            dma(rs_next, 2 * c);            // both strips of the block are in registers: its two slots are free
+            dma(rs_next, 2 * c + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // C[m][row0 + 4 kq + r]
-        const bool whole = row0 + ST <= a.N;
+        // C[m = 16 sb + 4 kq + r][row0 + i16]
+        const int64_t n = row0 + i16;
 #pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) {
-            const int m = 16 * sb + i16;
-            if (m < a.M) {
-                float* c = a.C + (int64_t)m * a.sc_m + (row0 + 4 * kq) * a.sc_n;
-                if (whole && vec_store) {
-                    *reinterpret_cast<f32x4*>(c) = acc[sb];
-                } else {
+        for (int sb = 0; sb < NSB; ++sb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (row0 + 4 * kq + r < a.N) c[r * a.sc_n] = acc[sb][r];
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int m = 16 * sb + 4 * kq + r;
+                if ((DBG & 4) && acc[sb][r] != 12345.678f) continue;
+                if (m < a.M && n < a.N) a.C[(int64_t)m * a.sc_m + n * a.sc_n] = acc[sb][r];
             }
-        }
     }
     // no LDS-DMA of this wave may still be in flight when the workgroup's LDS is released
     __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
@@ -275,6 +304,13 @@ int launch_nt(bsc_ctx* ctx, const NtArgs& a) {
     const int nsb = a.M <= 16 ? 1 : 2;
     const int ks = a.K <= 64 ? 4 : a.K <= 128 ? 8 : a.K <= 192 ? 12 : 16;
     bsc_prof_scope prof(ctx);
+    if (ctx->skinny_nt_dbg && nsb == 1 && ks == 16) {
+#define BSC_NTD(DBG) case DBG: hipLaunchKernelGGL((gemm_skinny_nt_kernel<1, 16, DBG>), dim3(n_blocks), dim3(64 * NTW), 0, ctx->stream, a); break;
+        switch (ctx->skinny_nt_dbg) { BSC_NTD(1) BSC_NTD(4) BSC_NTD(5) default: return bsc_fail(BSC_ERR_INVALID, "BSC_SKINNY_NT_DBG: 1, 4 or 5"); }
+#undef BSC_NTD
+        BSC_LAUNCH_CHECK();
+        return BSC_OK;
+    }
 #define BSC_NT(NSB, KS) hipLaunchKernelGGL((gemm_skinny_nt_kernel<NSB, KS>), dim3(n_blocks), dim3(64 * NTW), 0, ctx->stream, a)
     if (nsb == 1) {
         if (ks == 4) BSC_NT(1, 4); else if (ks == 8) BSC_NT(1, 8); else if (ks == 12) BSC_NT(1, 12); else BSC_NT(1, 16);
