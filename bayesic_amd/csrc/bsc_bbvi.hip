@@ -484,9 +484,10 @@ __global__ __launch_bounds__(64 * XW, 2) void logreg_loglik_xreg_kernel(
 
 // ---- X by LDS-DMA (NSB <= 4: the default up to S = 64) ------------------------------------------
 // Nothing a tile needs passes through a VGPR-returning load.  Each wave owns in LDS
-//   * a ring of XR 1-KiB slots: strip j of a tile (16 rows x 64 B = the A-operand block of
-//     k-group j: lane l's 16 bytes land at slot + 16 l) is DMA'd XR strips ahead of its use and
-//     read back with one conflict-free ds_read_b128;
+//   * a ring of XR 1-KiB slots: the tile arrives in pieces of 8 rows x 128 bytes (whole lines: pieces
+//     shaped like one strip of A operands, 16 rows x 64 bytes, read 23 % slower -- tools/ab_skinny_nt.py),
+//     two per block of 32 columns, DMA'd XR pieces ahead of their use into an XOR-permuted image from
+//     which strip j of a tile (the A-operand block of k-group j) is one conflict-free ds_read_b128;
 //   * y and the group ids of the next tiles (a 256-B dword DMA each: lane l <- row0 + l);
 //   * the 4-KiB block of intercepts b[g_row, NSB i16 ..] of the next tile, gathered by four
 //     dwordx4 DMAs whose per-lane offsets come from the ids, read back as the MFMA's C input.
@@ -535,14 +536,23 @@ __global__ __launch_bounds__(64 * XW, 2) void logreg_loglik_dma_kernel(
 
     const int64_t n_waves = (int64_t)gridDim.x * XW;
     int64_t tile = (int64_t)blockIdx.x * XW + wave;
-    const int x_voff = i16 * (int)(ldx * 4) + 16 * kq;
+    // X arrives in WHOLE 128-byte lines (pieces of 16 rows x 64 bytes read 23 % slower: tools/ab_skinny_nt.py, and see
+    // csrc/bsc_skinny.hip): piece s = 2 c + sp is rows 8 sp .. + 7 x columns 32 c .. + 31, DMA lane l = (row l >> 3,
+    // 16-byte position l & 7); the chunk fetched into position p of row a is p ^ f, f = (a >> 1) | (sp << 2), which
+    // keeps the operand read (lane (i16, kq) <- row i16, chunk kq + 4 t of block c = strip 2 c + t) conflict-free
+    const int x_row_bytes = (int)(ldx * 4);
+    const int x_voff0 = (lane >> 3) * x_row_bytes + 16 * ((lane & 7) ^ (lane >> 4));
+    const int x_voff1 = (lane >> 3) * x_row_bytes + 16 * ((lane & 7) ^ ((lane >> 4) | 4));
     char* const my = dma + wave * DMA_WAVE_BYTES;                       // this wave's DMA region
     const unsigned my_addr = (unsigned)(uintptr_t)(lds_ptr)my;
+    const unsigned addr_x0 = my_addr + 1024u * (i16 >> 3) + 128u * (i16 & 7) + 16u * (kq ^ (((i16 & 7) >> 1) | ((i16 >> 3) << 2)));
+    const unsigned addr_x1 = addr_x0 ^ 64u;
     constexpr int BZ_OFF = XR * 1024, Y_OFF = BZ_OFF + 4096, G_OFF = Y_OFF + 512;
 
     // ---- the DMAs (every one counts in vmcnt, in this order) ----
-    auto x_dma = [&](decltype(x_tile_rsrc(X, ldx, D, N, 0)) rs, int j) {            // strip j -> slot j % XR
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(my + (j % XR) * 1024), 16, x_voff, 64 * j, 0, 2);
+    auto x_dma = [&](decltype(x_tile_rsrc(X, ldx, D, N, 0)) rs, int s) {            // piece s -> slot s % XR
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(my + (s % XR) * 1024), 16, (s & 1) ? x_voff1 : x_voff0,
+                                                 (s & 1) * 8 * x_row_bytes + 128 * (s >> 1), 0, 2);
     };
     auto row_dma = [&](const void* base, int64_t row0, int lds_off) {              // lane l <- 4 bytes of row0 + l
         __builtin_amdgcn_raw_ptr_buffer_load_lds(row_vec_rsrc(base, N, row0), (lds_ptr)(my + lds_off), 4, 4 * lane, 0, 0, 0);
@@ -560,9 +570,10 @@ __global__ __launch_bounds__(64 * XW, 2) void logreg_loglik_dma_kernel(
     const unsigned addr_lane = my_addr + 16u * lane;     // lane l's 16 bytes of a 1-KiB block
     const unsigned addr_kq = my_addr + 16u * kq;         // the 4 rows 4 kq .. 4 kq + 3 of a row vector
 #define BSC_LDS_B128(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
-    auto a_read = [&](int j) {
+    auto a_read = [&](int j) {          // strip j = 2 c + t: both of its pieces sit in slots (2 c) % XR, + 1
         f32x4 f;
-        BSC_LDS_B128(f, addr_lane, (j % XR) * 1024);
+        if (j & 1) BSC_LDS_B128(f, addr_x1, ((j & ~1) % XR) * 1024);
+        else BSC_LDS_B128(f, addr_x0, ((j & ~1) % XR) * 1024);
         return f;
     };
 
@@ -665,11 +676,15 @@ __global__ __launch_bounds__(64 * XW, 2) void logreg_loglik_dma_kernel(
             // in issue order, so "at most as many outstanding as were issued after it": a strip issued
             // in the previous tile (j+1 < XR) is followed by the rest of that batch, this tile's side
             // DMAs and this tile's j strips = XR - 2 + DMA_SIDE; one issued in this tile by XR - 2.
+            // (pieces: strip j + 1 of an even j lies in the block that strip j was read from; behind an odd j = 2 c + 1
+            // block c + 1 is followed by XR / 2 - 2 blocks of two pieces = XR - 4)
             if (DBG & 16) {
                 // profiling only: no strip wait at all (reads race the DMAs; the time shows what the
                 // waits cost)
-            } else if (j + 1 < XR) __builtin_amdgcn_s_waitcnt(vmcnt_only(XR - 2 + ((DBG & 8) ? 0 : DMA_SIDE)));
-            else __builtin_amdgcn_s_waitcnt(vmcnt_only(XR - 2));
+            } else if (j & 1) {
+                if ((j + 1) / 2 < XR / 2) __builtin_amdgcn_s_waitcnt(vmcnt_only(XR - 4 + ((DBG & 8) ? 0 : DMA_SIDE)));
+                else __builtin_amdgcn_s_waitcnt(vmcnt_only(XR - 4));
+            }
             asm volatile("" ::: "memory");
             if (!(DBG & 4)) an = a_read((j + 1) % 16);
             // MFMAs have no memory semantics and would float above the asm read (and the next group's
@@ -680,10 +695,15 @@ __global__ __launch_bounds__(64 * XW, 2) void logreg_loglik_dma_kernel(
 #pragma unroll
                 for (int sb = 0; sb < NSB; ++sb)
                     acc[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[sb][r], acc[sb], 0, 0, 0);
-            // slot j % XR is free (its strip is in `a`): strip j + XR
-            if (!(DBG & 1)) {
-                if (j + XR < 16) x_dma(rs_cur, j + XR);
-                else x_dma(rs_next, j + XR - 16);
+            // behind an odd strip both slots of its block are free (strips j - 1 and j are in registers): pieces
+            // j - 1 + XR, j + XR
+            if (!(DBG & 1) && (j & 1)) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int p = j - 1 + e;
+                    if (p + XR < 16) x_dma(rs_cur, p + XR);
+                    else x_dma(rs_next, p + XR - 16);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -755,14 +775,23 @@ __global__ __launch_bounds__(64 * XW, 2) void logreg_loglik_dma_bx_kernel(
 
     const int64_t n_waves = (int64_t)gridDim.x * XW;
     int64_t tile = (int64_t)blockIdx.x * XW + wave;
-    const int x_voff = i16 * (int)(ldx * 4) + 16 * kq;
+    // X arrives in WHOLE 128-byte lines (pieces of 16 rows x 64 bytes read 23 % slower: tools/ab_skinny_nt.py, and see
+    // csrc/bsc_skinny.hip): piece s = 2 c + sp is rows 8 sp .. + 7 x columns 32 c .. + 31, DMA lane l = (row l >> 3,
+    // 16-byte position l & 7); the chunk fetched into position p of row a is p ^ f, f = (a >> 1) | (sp << 2), which
+    // keeps the operand read (lane (i16, kq) <- row i16, chunk kq + 4 t of block c = strip 2 c + t) conflict-free
+    const int x_row_bytes = (int)(ldx * 4);
+    const int x_voff0 = (lane >> 3) * x_row_bytes + 16 * ((lane & 7) ^ (lane >> 4));
+    const int x_voff1 = (lane >> 3) * x_row_bytes + 16 * ((lane & 7) ^ ((lane >> 4) | 4));
     char* const my = dma + wave * DMA_WAVE_BYTES;                       // this wave's DMA region
     const unsigned my_addr = (unsigned)(uintptr_t)(lds_ptr)my;
+    const unsigned addr_x0 = my_addr + 1024u * (i16 >> 3) + 128u * (i16 & 7) + 16u * (kq ^ (((i16 & 7) >> 1) | ((i16 >> 3) << 2)));
+    const unsigned addr_x1 = addr_x0 ^ 64u;
     constexpr int BZ_OFF = XR * 1024, Y_OFF = BZ_OFF + 4096, G_OFF = Y_OFF + 512;
 
     // ---- the DMAs (every one counts in vmcnt, in this order) ----
-    auto x_dma = [&](decltype(x_tile_rsrc(X, ldx, D, N, 0)) rs, int j) {            // strip j -> slot j % XR
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(my + (j % XR) * 1024), 16, x_voff, 64 * j, 0, 2);
+    auto x_dma = [&](decltype(x_tile_rsrc(X, ldx, D, N, 0)) rs, int s) {            // piece s -> slot s % XR
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(my + (s % XR) * 1024), 16, (s & 1) ? x_voff1 : x_voff0,
+                                                 (s & 1) * 8 * x_row_bytes + 128 * (s >> 1), 0, 2);
     };
     auto row_dma = [&](const void* base, int64_t row0, int lds_off) {              // lane l <- 4 bytes of row0 + l
         __builtin_amdgcn_raw_ptr_buffer_load_lds(row_vec_rsrc(base, N, row0), (lds_ptr)(my + lds_off), 4, 4 * lane, 0, 0, 0);
@@ -780,9 +809,10 @@ __global__ __launch_bounds__(64 * XW, 2) void logreg_loglik_dma_bx_kernel(
     const unsigned addr_lane = my_addr + 16u * lane;     // lane l's 16 bytes of a 1-KiB block
     const unsigned addr_kq = my_addr + 16u * kq;         // the 4 rows 4 kq .. 4 kq + 3 of a row vector
 #define BSC_LDS_B128(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
-    auto a_read = [&](int j) {
+    auto a_read = [&](int j) {          // strip j = 2 c + t: both of its pieces sit in slots (2 c) % XR, + 1
         f32x4 f;
-        BSC_LDS_B128(f, addr_lane, (j % XR) * 1024);
+        if (j & 1) BSC_LDS_B128(f, addr_x1, ((j & ~1) % XR) * 1024);
+        else BSC_LDS_B128(f, addr_x0, ((j & ~1) % XR) * 1024);
         return f;
     };
 
