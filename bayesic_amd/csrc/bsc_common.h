@@ -22,6 +22,8 @@ struct bsc_ctx {
     int blr_tile_rows = 16;      // 16: forward on the MFMA pipe when D == 256 (else 8-row VALU tiles); 8 | 4: VALU variants
     int blr_waves_per_simd = 0;  // tuning: cap resident waves per SIMD (0 = kernel's own limit)
     int fused_map_blocks_per_cu = 8;  // bsc_map_reduce, pure map: grid cap (256-thread blocks)
+    int rows_dbg = 0;                 // deletion builds of map_reduce_rows_f32_kernel (BSC_ROWS_DBG + BSC_PROFILING_BUILDS): WRONG results
+    int rows_wg_per_cu = 64;          // map_reduce_rows_f32_kernel: workgroups per CU in the grid, eight of them resident (BSC_ROWS_WG; 0 = one step per wave)
     int skinny_nt_dbg = 0;            // deletion builds of gemm_skinny_nt_kernel (BSC_SKINNY_NT_DBG + BSC_PROFILING_BUILDS): WRONG results
     int skinny_nt_wg_per_cu = 1;      // gemm_skinny_nt_kernel: resident workgroups (4 waves, 64 KiB of rings each) per CU (BSC_SKINNY_NT_WG)
     int gemm_nt_c = 1;                // stream GEMM: results of 128 MiB and more leave by non-temporal stores (BSC_GEMM_NT_C=0 for A/B)
@@ -201,10 +203,46 @@ __device__ __forceinline__ float wave_allsum(float v) {
     return v;
 }
 
+
+// FOUR 64-lane float64 sums at once, without the LDS crossbar: the 16 lanes of DPP row q end with the sum of a_q over
+// the wave.  v_permlane32_swap / v_permlane16_swap halve the lanes a value occupies while two values share a register
+// pair (lanes 0..31 fold a0 resp. a1 over (l, l + 32), lanes 32..63 a2 resp. a3; then rows 0..3 fold (l, l + 16)),
+// the last four steps are DPP rotations inside a row: 21 vector instructions for four sums, where four butterflies
+// of __shfl_xor are 48 ds_bpermute_b32 in chains of six LDS round trips.  Fixed order: reproducible.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double swap_add32_f64(double a, double b) {
+    auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double swap_add16_f64(double a, double b) {
+    auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// One 64-lane float64 sum, result in every lane: DPP inside the rows, then the rows by the two swaps (a value swapped
+// with itself: rows 0 / 1 and 2 / 3 exchange, then the halves) -- 22 vector instructions and no LDS round trip where
+// six steps of __shfl_xor were twelve ds_bpermute_b32 in a dependent chain.
 __device__ __forceinline__ double wave_allsum_f64(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    v += dpp_f64<DPP_QUAD_XOR1>(v);
+    v += dpp_f64<DPP_QUAD_XOR2>(v);
+    v += dpp_f64<DPP_ROW_ROR4>(v);
+    v += dpp_f64<DPP_ROW_ROR8>(v);
+    v = swap_add16_f64(v, v);
+    return swap_add32_f64(v, v);
+}
+__device__ __forceinline__ double wave_allsum4_f64(double a0, double a1, double a2, double a3) {
+    double t = swap_add16_f64(swap_add32_f64(a0, a2), swap_add32_f64(a1, a3));
+    t += dpp_f64<DPP_QUAD_XOR1>(t);
+    t += dpp_f64<DPP_QUAD_XOR2>(t);
+    t += dpp_f64<DPP_ROW_ROR4>(t);
+    t += dpp_f64<DPP_ROW_ROR8>(t);
+    return t;
 }
 
 // Orders this wave's LDS writes before its later LDS reads of other lanes' data

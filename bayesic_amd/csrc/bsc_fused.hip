@@ -519,7 +519,9 @@ __global__ __launch_bounds__(256) void map_reduce_wave_dense_f32_kernel(MapArgs 
 // Row sums of a matrix with SHORT rows (n_red <= 1024: sum(X * Y, axis=1) at 1M x 256): the kernel above gives every
 // row a wave of its own -- a million waves that each live for one 1-KiB load, and the dispatcher, not HBM, sets the
 // pace (4.1 TB/s).  Here the waves are persistent and take U rows per step, every load before the first use.
-template <int N, bool LINEAR>
+// DBG (timing only, BSC_ROWS_DBG behind BSC_PROFILING_BUILDS): bit 0 float32 lane sums, bit 1 no sums across lanes,
+// bit 2 plain loads, bit 3 the four ds_bpermute butterflies this kernel had before wave_allsum4_f64 (results right)
+template <int N, bool LINEAR, int DBG = 0>
 __global__ __launch_bounds__(256) void map_reduce_rows_f32_kernel(MapArgs a) {
     constexpr int U = 4;      // (eight rows in flight: 776 us instead of 407 -- the float64 butterflies of eight rows at once)
     const int lane = threadIdx.x & 63;
@@ -543,7 +545,8 @@ __global__ __launch_bounds__(256) void map_reduce_rows_f32_kernel(MapArgs a) {
                         const float sv = p[0];
                         u[k][j] = f32x4{sv, sv, sv, sv};
                     } else {
-                        u[k][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + c);
+                        u[k][j] = (DBG & 4) ? reinterpret_cast<const f32x4*>(p)[c]
+                                            : __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + c);
                     }
                 }
             }
@@ -569,17 +572,29 @@ __global__ __launch_bounds__(256) void map_reduce_rows_f32_kernel(MapArgs a) {
                     } else {
                         w = finish_value<float>(a, w);
                     }
-                    acc[j] += (double)w;
+                    if (DBG & 1) acc[j] = (double)((float)acc[j] + w);
+                    else acc[j] += (double)w;
                 }
             }
         }
+        if (DBG & 2) {
+            if (lane < U && r0 + lane < a.n_out) static_cast<float*>(a.out)[(r0 + lane) * a.out_strides[0]] = (float)acc[0];
+        } else if (DBG & 8) {      // the round-3 form: four butterflies through the LDS crossbar
 #pragma unroll
-        for (int j = 0; j < U; ++j) acc[j] = wave_allsum_f64(acc[j]);
-        if (lane < U && r0 + lane < a.n_out) {
-            double mine = acc[0];
+            for (int j = 0; j < U; ++j)
 #pragma unroll
-            for (int j = 1; j < U; ++j) mine = lane == j ? acc[j] : mine;
-            static_cast<float*>(a.out)[(r0 + lane) * a.out_strides[0]] = (float)mine;
+                for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_xor(acc[j], off);
+            if (lane < U && r0 + lane < a.n_out) {
+                double mine = acc[0];
+#pragma unroll
+                for (int j = 1; j < U; ++j) mine = lane == j ? acc[j] : mine;
+                static_cast<float*>(a.out)[(r0 + lane) * a.out_strides[0]] = (float)mine;
+            }
+        } else {
+            static_assert(U == 4, "wave_allsum4_f64 folds four rows");
+            const double mine = wave_allsum4_f64(acc[0], acc[1], acc[2], acc[3]);     // row (lane >> 4)'s sum
+            const int64_t r = r0 + (lane >> 4);
+            if ((lane & 15) == 0 && r < a.n_out) static_cast<float*>(a.out)[r * a.out_strides[0]] = (float)mine;
         }
     }
 }
@@ -1256,8 +1271,15 @@ int bsc_map_reduce(bsc_ctx* ctx, int dtype, int combine, int rank_keep,
                     linear = false;
             }
             int64_t rblocks = (n_out + 15) / 16;
-            const int64_t cap = (int64_t)ctx->cu_count * 8;
-            if (rblocks > cap) rblocks = cap;
+            const int64_t cap = (int64_t)ctx->cu_count * ctx->rows_wg_per_cu;        // (0: one step per wave, not persistent)
+            if (cap > 0 && rblocks > cap) rblocks = cap;
+            if (ctx->rows_dbg && n_in == 2 && linear) {
+#define BSC_ROWSD(DBG) case DBG: hipLaunchKernelGGL((map_reduce_rows_f32_kernel<2, true, DBG>), dim3((unsigned)rblocks), dim3(256), 0, ctx->stream, m); break;
+                switch (ctx->rows_dbg) { BSC_ROWSD(2) BSC_ROWSD(3) BSC_ROWSD(4) BSC_ROWSD(8) default: return bsc_fail(BSC_ERR_INVALID, "BSC_ROWS_DBG: 2, 3, 4 or 8"); }
+#undef BSC_ROWSD
+                BSC_LAUNCH_CHECK();
+                return BSC_OK;
+            }
 #define BSC_ROWS(NV)                                                                                                  \
     case NV:                                                                                                          \
         if (linear) hipLaunchKernelGGL((map_reduce_rows_f32_kernel<NV, true>), dim3((unsigned)rblocks), dim3(256), 0, ctx->stream, m);  \
