@@ -340,11 +340,8 @@ __global__ __launch_bounds__(256) void map_flat_f32_kernel(FlatArgs a) {
             }
         }
     }
-    if (!LINEAR) {
-#pragma unroll
-        for (int k = 0; k < NIN; ++k) apply_unary_step(a.op[k], (double)a.arg[k], u[k]);
-    }
-    f32x4 vv[U];
+    // (values are consumed and stored load by load -- the waits count down with the loads still in flight; one op
+    // dispatch per 16 bytes, not per value: apply_unary_step)
 #pragma unroll
     for (int j = 0; j < U; ++j) {
         f32x4 v = {id, id, id, id};
@@ -352,9 +349,11 @@ __global__ __launch_bounds__(256) void map_flat_f32_kernel(FlatArgs a) {
         for (int k = 0; k < NIN; ++k) {
             const int op = a.op[k];
             const float arg = a.arg[k];
+            f32x4 x1[1] = {u[k][j]};
+            if (!LINEAR) apply_unary_step(op, (double)arg, x1);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float x = LINEAR ? flat_unary<true>(op, u[k][j][e], arg) : u[k][j][e];
+                const float x = LINEAR ? flat_unary<true>(op, x1[0][e], arg) : x1[0][e];
                 v[e] = a.combine == BSC_OP_MUL ? v[e] * x : v[e] + x;
             }
         }
@@ -365,15 +364,12 @@ __global__ __launch_bounds__(256) void map_flat_f32_kernel(FlatArgs a) {
             if (a.shift != 0.0f) w += a.shift;
             v[e] = w;
         }
-        vv[j] = v;
-    }
-    if (!LINEAR) apply_unary_step(a.post_op, (double)a.post_arg, vv);
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
+        f32x4 v1[1] = {v};
+        if (!LINEAR) apply_unary_step(a.post_op, (double)a.post_arg, v1);
         const unsigned i = base + 256u * j;
         if (i < a.n4) {
-            if (a.nt_store) __builtin_nontemporal_store(vv[j], reinterpret_cast<f32x4*>(a.out) + i);
-            else reinterpret_cast<f32x4*>(a.out)[i] = vv[j];
+            if (a.nt_store) __builtin_nontemporal_store(v1[0], reinterpret_cast<f32x4*>(a.out) + i);
+            else reinterpret_cast<f32x4*>(a.out)[i] = v1[0];
         }
     }
 }
