@@ -64,10 +64,17 @@ class ReparamVI(object):
                   are written into fixed device buffers, one graph launch, two results read back.
                   Needs a context on a stream of its own (``Context.set_stream``); falls back to the
                   eager walk otherwise.
+    resident    : device backend only, general route.  The state (lam, Adam moments), the draws, z = mu + e^rho eps,
+                  the ELBO estimate, the pathwise gradient and the Adam step all stay on the device -- the
+                  parameter-sized arithmetic as compiled algebra expressions in float64, the update by
+                  ``bsc_adam_ascent`` -- so a step contains NO host synchronisation: ``step()`` returns None and
+                  the walk of the next step overlaps the device's work on this one; ``elbo`` / ``grad`` / ``lam``
+                  read back on access (as on the fused route).  Without it every step waits for the device twice
+                  (the draws come back, the gradient comes back) and the host does the update in numpy.
     """
 
     def __init__(self, log_joint, latents, data, n_samples, seed=0, lr=1e-2, backend=None,
-                 lam0=None, noise=None, graph=False, route="auto"):
+                 lam0=None, noise=None, graph=False, route="auto", resident=False):
         from ..algebra.backend import resolve_backend
         self.backend = resolve_backend(backend)
         if log_joint.ndim != 1:
@@ -109,6 +116,87 @@ class ReparamVI(object):
             why = self._try_fused_route()
             if why is not None and route == "fused":
                 raise ValueError("route='fused': %s" % why)
+        self._resident = None
+        if resident and self._fused is None and self._pass_plan is None:
+            if self._noise is not None or not hasattr(self.backend, "ctx"):
+                raise ValueError("resident=True needs the MI355X backend and its own device-side noise")
+            self._init_resident()
+
+    # -- the general route with its state on the device (class docstring, `resident`) -------------
+    def _init_resident(self):
+        import torch
+        from .. import algebra as A
+        b, S, P = self.backend, self.S, self.P
+        dev = b.ctx.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        st = {"lam": torch.from_numpy(np.asarray(self._lam, np.float64)).to(dev),
+              "m1": torch.zeros(2 * P, **f64), "m2": torch.zeros(2 * P, **f64),
+              "eps": torch.zeros((S, P), **f64), "elbo": None, "gmu": None, "grho": None}
+        if len(self.latents) > 1:
+            st["g"] = torch.zeros((S, P), dtype=torch.float32, device=dev)
+        EPS, MU, RHO, G, F = A.var("eps", 2), A.var("mu", 1), A.var("rho", 1), A.var("g", 2), A.var("f", 1)
+        sigma = A.dimshuffle(A.exp(RHO), "x", 0)
+        st["z_fn"] = (A.dimshuffle(MU, "x", 0) + sigma * EPS).compile(b).device_fn
+        st["gmu_fn"] = (A.sum(G, axis=0) * (1.0 / S)).compile(b).device_fn
+        st["grho_fn"] = (A.sum(G * EPS, axis=0) * A.exp(RHO) * (1.0 / S) + 1.0).compile(b).device_fn
+        st["elbo_fn"] = (A.sum(F) * (1.0 / S) + A.sum(RHO) + 0.5 * P * (1.0 + _LOG_2PI)).compile(b).device_fn
+        self._resident = st
+        self.route = "general, state resident on the device"
+
+    def _step_resident(self):
+        import torch
+        from ..algebra.device_backend import _DT, _i64
+        b, st, S, P = self.backend, self._resident, self.S, self.P
+        ctx = b.ctx
+        self._t += 1
+        ctx.call("bsc_philox_normal", self.seed, 2, int(self._t - 1), S, P, st["eps"])
+        mu, rho = st["lam"][:P], st["lam"][P:]
+        z = b.materialize(st["z_fn"](eps=st["eps"], mu=mu, rho=rho))                  # float64 [S, P]
+        inputs, offset = dict(self._data), 0
+        names = [v.name for v, _ in self.latents]
+        if self._graph:
+            # fixed buffers for the draws: the walk (forward, then the tape backwards) is recorded once and replayed
+            if self._z_dev is None:
+                self._z_dev = {v.name: b.from_host(np.zeros((S, n), self._types[v.name][0]), *self._types[v.name])
+                               for v, n in self.latents}
+            for v, n in self.latents:
+                zb = self._z_dev[v.name]
+                ctx.call("bsc_convert", _DT[z.dtype], _DT[zb.dtype], 2, _i64(zb.shape), z[:, offset:offset + n],
+                         _i64((z.stride(0), 1)), zb, _i64(zb.stride()))
+                inputs[v.name] = zb
+                offset += n
+
+            def walk():
+                out, grads = value_and_grad(b, self.log_joint, inputs, names)
+                return [out] + [grads[name] for name in names]
+            res = b.graph_call(("reparam", id(self)), walk, [self._z_dev[name] for name in names] + list(self._data.values()))
+            f, gs = res[0], list(res[1:])
+        else:
+            for v, n in self.latents:
+                want = torch.float64 if str(np.dtype(self._types[v.name][0])) == "float64" else torch.float32
+                inputs[v.name] = b._convert(z[:, offset:offset + n], want)
+                offset += n
+            out, grads = value_and_grad(b, self.log_joint, inputs, names)
+            f, gs = b.materialize(out), [b.materialize(grads[name]) for name in names]
+        if len(self.latents) == 1:
+            g = gs[0]
+        else:
+            g, offset = st["g"], 0
+            for (v, n), gv in zip(self.latents, gs):
+                g[:, offset:offset + n].copy_(gv)
+                offset += n
+        gmu = b.materialize(st["gmu_fn"](g=g))
+        if gmu.dtype != torch.float64:
+            gmu = b._convert(gmu, torch.float64)
+        grho = b.materialize(st["grho_fn"](g=g, eps=st["eps"], rho=rho))
+        if grho.dtype != torch.float64:
+            grho = b._convert(grho, torch.float64)
+        st["elbo"] = b.materialize(st["elbo_fn"](f=f, rho=rho))
+        st["gmu"], st["grho"] = gmu, grho
+        for lo, grad in ((0, gmu), (P, grho)):          # (element-wise: two calls on the halves are the one step)
+            ctx.call("bsc_adam_ascent", st["lam"][lo:lo + P], grad, st["m1"][lo:lo + P], st["m2"][lo:lo + P], P,
+                     int(self._t), self.lr, 0.9, 0.999, 1e-8)
+        return None
 
     # -- the fused route (module docstring) ------------------------------------------------------
     def _try_fused_route(self):
@@ -171,6 +259,8 @@ class ReparamVI(object):
     def lam(self):
         if self._fused is not None:
             return self._from_blr_layout(self._fused.lam.cpu().numpy())
+        if getattr(self, "_resident", None) is not None:
+            return self._resident["lam"].cpu().numpy()
         return self._lam
 
     @lam.setter
@@ -178,6 +268,10 @@ class ReparamVI(object):
         if self._fused is not None:
             raise AttributeError("on the fused route the variational parameters live on the device; build the "
                                  "engine with lam0=")
+        if getattr(self, "_resident", None) is not None:
+            import torch
+            self._resident["lam"].copy_(torch.from_numpy(np.asarray(value, np.float64)))
+            return
         self._lam = value
 
     @property
@@ -193,6 +287,9 @@ class ReparamVI(object):
         """Monte-Carlo ELBO estimate of the last step (fused route: reads the device scalar, synchronises)."""
         if self._fused is not None:
             return float(self._fused.elbo.item()) if self._fused.t else None
+        if getattr(self, "_resident", None) is not None:
+            e = self._resident["elbo"]
+            return None if e is None else float(e.reshape(-1)[0].item())
         return self._elbo
 
     @elbo.setter
@@ -203,6 +300,9 @@ class ReparamVI(object):
     def grad(self):
         if self._fused is not None:
             return self._from_blr_layout(self._fused.grad.cpu().numpy()) if self._fused.t else None
+        if getattr(self, "_resident", None) is not None:
+            st = self._resident
+            return None if st["gmu"] is None else np.concatenate([st["gmu"].cpu().numpy(), st["grho"].cpu().numpy()])
         return self._grad
 
     @grad.setter
@@ -322,6 +422,8 @@ class ReparamVI(object):
         if self._fused is not None:
             self._fused.step()          # asynchronous: pass + fused finish on the context's stream
             return None
+        if self._resident is not None:
+            return self._step_resident()
         self.t += 1
         self.elbo, self.grad = self.estimate(self.t - 1)
         b1, b2, eps = 0.9, 0.999, 1e-8

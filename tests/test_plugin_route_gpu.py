@@ -268,3 +268,80 @@ def test_config5_plugin_route_runs_at_the_fused_drivers_speed(ctx):
     t_eng = min(per_step(eng) for _ in range(2))
     print("config 5: plugin route %.1f us per update, hand-written driver %.1f us" % (t_eng * 1e6, t_ref * 1e6))
     assert t_eng <= 1.3 * t_ref, (t_eng, t_ref)
+
+
+@pytest.mark.parametrize("two_latents", [False, True])
+def test_general_reparam_engine_with_its_state_on_the_device(two_latents):
+    """ReparamVI(route="general", resident=True): draws, z, the ELBO estimate, the pathwise gradient and the Adam
+    step stay on the device (no host synchronisation inside step()); same seed -> the host-side engine's
+    parameters, ELBO and gradient to float32 rounding of the [S, N] work, over several steps."""
+    from bayesic_amd import algebra as A
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from bayesic_amd.device import Context
+    from bayesic_amd.inference import ReparamVI
+    rs = np.random.RandomState(4)
+    N, D, S = 30000, 24, 8
+    Xs = rs.standard_normal((N, D)).astype(np.float32)
+    ys = (Xs @ (rs.standard_normal(D) / 4) + 0.7 + 0.5 * rs.standard_normal(N)).astype(np.float32)
+    X, y, W, c = A.var("X", 2), A.var("y", 1), A.var("W", 2), A.var("c", 2)
+    mean = A.dot(W, X.T)
+    if two_latents:
+        mean = mean + c                                 # [S, 1] intercept, broadcast over the rows
+    r = A.dimshuffle(y, "x", 0) - mean
+    lj = A.sum(r * r, axis=1) * (-0.5 / 0.25) + A.sum(W * W, axis=1) * (-0.5)
+    latents = [(W, D)]
+    if two_latents:
+        lj = lj + A.sum(c * c, axis=1) * (-0.005)
+        latents.append((c, 1))
+    ctx = Context(0)
+    engines = [ReparamVI(lj, latents, dict(X=Xs, y=ys), n_samples=S, seed=9, backend=DeviceBackend(ctx), lr=0.02,
+                         route="general", resident=resident) for resident in (False, True)]
+    assert "resident" in engines[1].route
+    crossings = []
+    b1 = engines[1].backend
+    real_to_host, real_sync = b1.to_host, ctx.sync
+    b1.to_host = lambda value: (crossings.append("to_host"), real_to_host(value))[1]
+    for step in range(8):
+        host = engines[0].step()
+        ctx.sync = lambda: (crossings.append("sync"), real_sync())[1]
+        assert engines[1].step() is None
+        ctx.sync = real_sync
+        assert crossings == [], crossings            # nothing read back, nothing waited for
+        assert abs(engines[1].elbo - host) <= 2e-6 * abs(host), (step, host, engines[1].elbo)
+        scale = np.abs(engines[0].grad).max()
+        npt.assert_allclose(engines[1].grad, engines[0].grad, rtol=0, atol=2e-5 * scale)
+    npt.assert_allclose(engines[1].lam, engines[0].lam, rtol=0, atol=2e-4)
+    assert engines[1].t == engines[0].t == 8
+
+
+def test_resident_reparam_engine_with_its_walk_recorded_as_a_graph():
+    """resident=True and graph=True together: the draws are converted into fixed buffers, the walk is recorded on the
+    third step and replayed; bit for bit the eager resident engine."""
+    from bayesic_amd import algebra as A
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from bayesic_amd.device import Context
+    from bayesic_amd.inference import ReparamVI
+    rs = np.random.RandomState(6)
+    N, D, S = 20000, 24, 8
+    Xs = rs.standard_normal((N, D)).astype(np.float32)
+    ys = (Xs @ (rs.standard_normal(D) / 4) + 0.5 * rs.standard_normal(N)).astype(np.float32)
+    X, y, W = A.var("X", 2), A.var("y", 1), A.var("W", 2)
+    r = A.dimshuffle(y, "x", 0) - A.dot(W, X.T)
+    lj = A.sum(r * r, axis=1) * (-0.5 / 0.25) + A.sum(W * W, axis=1) * (-0.5)
+    prev = torch.cuda.current_stream()
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.Stream(ctx.device))
+    try:
+        engines = [ReparamVI(lj, [(W, D)], dict(X=Xs, y=ys), n_samples=S, seed=5, backend=DeviceBackend(ctx), lr=0.02,
+                             route="general", resident=True, graph=graph) for graph in (False, True)]
+        for step in range(10):
+            engines[0].step()
+            engines[1].step()
+            assert engines[0].elbo == engines[1].elbo, step
+            npt.assert_array_equal(engines[0].lam, engines[1].lam)
+        entry = engines[1].backend._graphs[("reparam", id(engines[1]))]
+        assert entry["graph"] is not None and not entry["dead"]         # it really was recorded
+    finally:
+        ctx.sync()
+        torch.cuda.set_stream(prev)
+        ctx.close()

@@ -27,9 +27,10 @@ def main():
     lj = A.sum(r * r, axis=1) * (-0.5 / s2) + A.sum(W * W, axis=1) * (-0.5)
     ctx.set_stream(torch.cuda.Stream(ctx.device))          # a stream of its own: what a graph capture needs
     data = dict(X=Xd, y=yd)
-    for graph, route in ((False, "general"), (True, "general"), (False, "auto")):
+    for graph, route, resident in ((False, "general", False), (True, "general", False), (False, "general", True),
+                                   (True, "general", True), (False, "auto", False)):
         eng = ReparamVI(lj, [(W, D)], data, n_samples=S, seed=1, backend=DeviceBackend(ctx), lr=1e-3, graph=graph,
-                        route=route)
+                        route=route, resident=resident)
         for _ in range(5):
             eng.step()
         ctx.sync()
