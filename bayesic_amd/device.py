@@ -62,8 +62,11 @@ class Context:
     def _check_stream(self):
         """Allocations made through this context must come from the context's stream (see
         set_stream); inside `with torch.cuda.stream(other):` that is not the case."""
-        cur = torch.cuda.current_stream(self.device)
-        if cur.cuda_stream != self._stream.cuda_stream:
+        # (called for every intermediate an engine's walk allocates: the raw handle, not a Stream object -- 0.3 us
+        # instead of 5)
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        cur = raw(self.device_index) if raw is not None else torch.cuda.current_stream(self.device).cuda_stream
+        if cur != self._stream.cuda_stream:
             raise _ffi.BayesicHipError(
                 "torch's current stream on %s is not the context's stream: allocate and launch on "
                 "one stream (Context.set_stream(s) switches both)" % (self.device,))
