@@ -90,6 +90,7 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
     if (const char* e = getenv("BSC_GEMM_DMA")) ctx->gemm_dma = atoi(e);
     if (const char* e = getenv("BSC_GEMM_DBG")) ctx->gemm_dbg = atoi(e);
     if (const char* e = getenv("BSC_GEMM_NT_C")) ctx->gemm_nt_c = atoi(e) != 0;
+    if (const char* e = getenv("BSC_GRAM_DBG")) ctx->gram_dbg = atoi(e) & 7;
     if (const char* e = getenv("BSC_ROWS_DBG")) ctx->rows_dbg = atoi(e) & 15;
     if (const char* e = getenv("BSC_ROWS_WG")) { const int v = atoi(e); if (v >= 0 && v <= 64) ctx->rows_wg_per_cu = v; }
     if (const char* e = getenv("BSC_SKINNY_NT_DBG")) ctx->skinny_nt_dbg = atoi(e) & 7;
@@ -115,13 +116,13 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
     // BSC_BLR_MX=4, BSC_GEMM_DBG and BSC_BBVI_DBG select profiling-only builds whose RESULTS ARE WRONG
     // (deletion builds: a kernel without its stores, a pass that re-reads one window ...).  They exist
     // for tools/ab_*.py; a process gets them only by also saying BSC_PROFILING_BUILDS=1, and then loudly.
-    if (ctx->blr_mx == 4 || ctx->gemm_dbg != 0 || ctx->bbvi_dbg != 0 || ctx->lda_dbg != 0 || ctx->skinny_nt_dbg != 0 || ctx->rows_dbg != 0) {
+    if (ctx->blr_mx == 4 || ctx->gemm_dbg != 0 || ctx->bbvi_dbg != 0 || ctx->lda_dbg != 0 || ctx->skinny_nt_dbg != 0 || ctx->rows_dbg != 0 || ctx->gram_dbg != 0) {
         const char* allow = getenv("BSC_PROFILING_BUILDS");
         if (!allow || atoi(allow) != 1) {
-            const int mx = ctx->blr_mx, gd = ctx->gemm_dbg, bd = ctx->bbvi_dbg, ld = ctx->lda_dbg + 100 * ctx->skinny_nt_dbg + 1000 * ctx->rows_dbg;
+            const int mx = ctx->blr_mx, gd = ctx->gemm_dbg, bd = ctx->bbvi_dbg, ld = ctx->lda_dbg + 100 * ctx->skinny_nt_dbg + 1000 * ctx->rows_dbg + 10000 * ctx->gram_dbg;
             delete ctx;
             return bsc_fail(BSC_ERR_INVALID,
-                            "bsc_ctx_create: BSC_BLR_MX=%d / BSC_GEMM_DBG=%d / BSC_BBVI_DBG=%d / BSC_LDA_DBG + 100 BSC_SKINNY_NT_DBG + 1000 BSC_ROWS_DBG=%d select "
+                            "bsc_ctx_create: BSC_BLR_MX=%d / BSC_GEMM_DBG=%d / BSC_BBVI_DBG=%d / BSC_LDA_DBG + 100 BSC_SKINNY_NT_DBG + 1000 BSC_ROWS_DBG + 10000 BSC_GRAM_DBG=%d select "
                             "profiling-only kernels that compute WRONG results; set BSC_PROFILING_BUILDS=1 as well if "
                             "that is what you want", mx, gd, bd, ld);
         }

@@ -204,6 +204,9 @@ constexpr int GR_IMG_SET = 8 * 2 * GB_IMG;    // one set of bf16 images: [column
 constexpr int GR_IMG_BYTES = 2 * GR_IMG_SET;  // two sets: step i + 1 is converted while step i is multiplied (one barrier a step,
                                               // and the conversion's vector instructions run beside the other wave's MFMAs)
 
+// DBG (timing only, results wrong; BSC_GRAM_DBG behind BSC_PROFILING_BUILDS): bit 0 no conversion (raw reads, splits, image
+// writes), bit 1 no MFMAs, bit 2 no DMAs after the prologue's
+template <int DBG = 0>
 __global__ __launch_bounds__(512, 1) void gram256_bx_kernel(const float* __restrict__ X, int64_t ldx, int64_t N,
                                                             float* __restrict__ slab, int n_steps_total) {
     constexpr int DB = 8, NB = 36;
@@ -273,11 +276,17 @@ __global__ __launch_bounds__(512, 1) void gram256_bx_kernel(const float* __restr
             fr[f][0] = bsc_u32x4{raw[f][0][0], raw[f][0][1], raw[f][1][0], raw[f][1][1]};
             fr[f][1] = bsc_u32x4{raw[f][2][0], raw[f][2][1], raw[f][3][0], raw[f][3][1]};
         }
+        if (DBG & 2) {
+#pragma unroll
+            for (int f = 0; f < P.n_frag; ++f) acc[0][f] += __uint_as_float(fr[f][0][0] ^ fr[f][1][3]);
+            return;
+        }
 #pragma unroll
         for (int b = 0; b < P.n_blk; ++b) acc[b] = bsc_mfma_split<2>(fr[P.blk[b][0]], fr[P.blk[b][1]], acc[b]);
     };
     // convert step i: this lane's 16 floats of row l31 -> two bf16 terms -> this wave's column-block images of set i & 1
     auto convert = [&](int i) __attribute__((always_inline)) {
+        if (DBG & 1) return;
         f32x4_t nx[4];
         const unsigned soff = (unsigned)((i % GR_STAGES) * GR_RAW);
 #pragma unroll
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(512, 1) void gram256_bx_kernel(const float* __restr
         // step i - 1 and the raw tile of step i
         __syncthreads();
         asm volatile("" ::: "memory");
-        if (i + GR_STAGES < my_steps) issue(i + GR_STAGES);      // into the raw stage of step i
+        if (!(DBG & 4) && i + GR_STAGES < my_steps) issue(i + GR_STAGES);      // into the raw stage of step i
         const unsigned set = (unsigned)((i & 1) * GR_IMG_SET);
         auto work = [&](auto wc) __attribute__((always_inline)) {
             bsc_u32x2 f0[4][4], f1[4][4];
@@ -433,7 +442,11 @@ int bsc_gram_split(bsc_ctx* ctx, const float* X, int64_t ldx, int64_t N, int64_t
     {
         bsc_prof_scope prof(ctx);
 #define BSC_GRAM(DB_) case DB_: hipLaunchKernelGGL(gram_bx_kernel<DB_>, dim3((unsigned)n_wg), dim3(GB_BLOCK), 0, ctx->stream, X, ldx, N, (int)D, (float*)ws, (int)steps); break;
-        if (DB == 8) hipLaunchKernelGGL(gram256_bx_kernel, dim3((unsigned)n_wg), dim3(512), 0, ctx->stream, X, ldx, N, (float*)ws, (int)steps);
+        if (DB == 8 && ctx->gram_dbg) {
+#define BSC_GRAMD(DBG) case DBG: hipLaunchKernelGGL(gram256_bx_kernel<DBG>, dim3((unsigned)n_wg), dim3(512), 0, ctx->stream, X, ldx, N, (float*)ws, (int)steps); break;
+            switch (ctx->gram_dbg) { BSC_GRAMD(1) BSC_GRAMD(2) BSC_GRAMD(3) BSC_GRAMD(4) BSC_GRAMD(5) BSC_GRAMD(6) BSC_GRAMD(7) default: break; }
+#undef BSC_GRAMD
+        } else if (DB == 8) hipLaunchKernelGGL(gram256_bx_kernel<0>, dim3((unsigned)n_wg), dim3(512), 0, ctx->stream, X, ldx, N, (float*)ws, (int)steps);
         else switch (DB) {
             BSC_GRAM(1) BSC_GRAM(2) BSC_GRAM(3) BSC_GRAM(4) BSC_GRAM(5) BSC_GRAM(6) BSC_GRAM(7)
         }
