@@ -766,24 +766,27 @@ __global__ __launch_bounds__(256) void map_reduce_lane_narrow_f32_kernel(MapArgs
                 }
             }
 #pragma unroll
+            for (int k = 0; k < N; ++k) apply_unary_step(a.pre_op[k], a.pre_arg[k], u[k]);      // one dispatch per step
+#pragma unroll
             for (int j = 0; j < U; ++j) {
                 float4 v = make_float4(id, id, id, id);
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
-                    const int op = a.pre_op[k];
-                    const double arg = a.pre_arg[k];
-                    const float x0 = apply_unary<float>(op, u[k][j].x, arg);
-                    const float x1 = apply_unary<float>(op, u[k][j].y, arg);
-                    const float x2 = apply_unary<float>(op, u[k][j].z, arg);
-                    const float x3 = apply_unary<float>(op, u[k][j].w, arg);
+                    const float x0 = u[k][j].x, x1 = u[k][j].y, x2 = u[k][j].z, x3 = u[k][j].w;
                     if (a.combine == BSC_OP_MUL) { v.x *= x0; v.y *= x1; v.z *= x2; v.w *= x3; }
                     else { v.x += x0; v.y += x1; v.z += x2; v.w += x3; }
                 }
                 if (rb + (int64_t)(4 * j + wave) * R + sub < r1) {
-                    acc[0] += (double)finish_value<float>(a, v.x);
-                    acc[1] += (double)finish_value<float>(a, v.y);
-                    acc[2] += (double)finish_value<float>(a, v.z);
-                    acc[3] += (double)finish_value<float>(a, v.w);
+                    if (post_is_plain(a)) {
+                        const float sc = (float)a.scale, sh = (float)a.shift;
+                        acc[0] += (double)(v.x * sc + sh); acc[1] += (double)(v.y * sc + sh);
+                        acc[2] += (double)(v.z * sc + sh); acc[3] += (double)(v.w * sc + sh);
+                    } else {
+                        acc[0] += (double)finish_value<float>(a, v.x);
+                        acc[1] += (double)finish_value<float>(a, v.y);
+                        acc[2] += (double)finish_value<float>(a, v.z);
+                        acc[3] += (double)finish_value<float>(a, v.w);
+                    }
                 }
             }
         }
