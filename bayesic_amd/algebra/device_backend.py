@@ -801,6 +801,20 @@ class DeviceBackend(Backend):
                     continue
                 a = self._force(a)
             terms.append((a, None, 0.0))
+        if mul and len(terms) >= 2:
+            # x * x: ONE operand with the pre-op pow 2 -- the same tensor as two operands is two load instructions per
+            # value (sum(R * R, axis=0) at 10M x 64: 820 us against 475 for sum(R, axis=0))
+            merged, seen = [], {}
+            for t, op, arg in terms:
+                key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype) if op is None else None
+                at = seen.get(key) if key is not None else None
+                if at is not None and merged[at][1] is None:
+                    merged[at] = (t, "pow", 2.0)
+                    continue
+                if key is not None and at is None:
+                    seen[key] = len(merged)
+                merged.append((t, op, arg))
+            terms = merged
         terms = [(t if t.dtype == dtype else self._convert(t, dtype), op, arg)
                  for t, op, arg in terms]
         while len(terms) > 8:                         # the kernel takes up to 8 operands
