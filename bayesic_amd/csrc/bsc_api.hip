@@ -385,6 +385,26 @@ __global__ __launch_bounds__(256) void read_probe_kernel(const float4* __restric
     }
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = 1.f;   // never true; keeps the loads
 }
+// The same stream by LDS-DMA (buffer_load ... lds: whole 1-KiB runs into a ring per wave, never read back) -- how the
+// passes of csrc/bsc_skinny.hip / bsc_bbvi.hip fetch their operand; on this part it reads faster than loads that return
+// to registers (the deletion builds of tools/ab_skinny_nt.py: 6.7-6.9 TB/s), so it belongs in the ceiling.
+__global__ __launch_bounds__(256) void read_probe_dma_kernel(const void* x, unsigned bytes, unsigned n_tiles) {
+    __shared__ __attribute__((aligned(16))) char ring[4 * 16 * 1024];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(x), 0, bytes, 0x00020000);
+    char* const my = ring + wave * 16 * 1024;
+    const unsigned n_waves = gridDim.x * 4;
+    for (unsigned tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += n_waves) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(15));       // the DMA that last filled this slot has landed
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (bsc_lds_ptr)(my + j * 1024), 16, 16 * lane,
+                                                     tile * 16384u + 1024u * j, 0, 2);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+}
 }  // namespace
 
 extern "C" {
@@ -403,20 +423,29 @@ int bsc_hbm_read_probe(bsc_ctx* ctx, const void* buf, size_t bytes, int reps, do
     BSC_HIP(hipEventCreate(&e0));
     BSC_HIP(hipEventCreate(&e1));
     double best = 0.0;
-    for (int variant = 0; variant < 2; ++variant) {
+    // (the DMA variants address the buffer through a 32-bit descriptor: its first 4 GiB - 16 KiB at most)
+    const size_t dma_bytes = bytes < 0xFFFFC000ull ? bytes : 0xFFFFC000ull;
+    const unsigned dma_tiles = (unsigned)(dma_bytes / 16384);
+    for (int variant = 0; variant < 4; ++variant) {
         for (int r = 0; r < reps + 2; ++r) {
             BSC_HIP(hipEventRecord(e0, ctx->stream));
+            double moved = (double)(n4 * 16);
             if (variant == 0)   // 4 workgroups per CU, one load in flight per lane
                 hipLaunchKernelGGL(read_probe_kernel<1>, dim3(4 * ctx->cu_count), dim3(256), 0,
                                    ctx->stream, (const float4*)buf, n4, (float*)ws);
-            else                // 1 workgroup per CU, eight loads in flight per lane
+            else if (variant == 1)  // 1 workgroup per CU, eight loads in flight per lane
                 hipLaunchKernelGGL(read_probe_kernel<8>, dim3(ctx->cu_count), dim3(256), 0,
                                    ctx->stream, (const float4*)buf, n4, (float*)ws);
+            else {              // LDS-DMA, 16 KiB in flight per wave: one resp. two workgroups of four waves per CU
+                hipLaunchKernelGGL(read_probe_dma_kernel, dim3((variant - 1) * ctx->cu_count), dim3(256), 0, ctx->stream,
+                                   buf, (unsigned)(dma_tiles * 16384ull), dma_tiles);
+                moved = (double)dma_tiles * 16384.0;
+            }
             BSC_HIP(hipEventRecord(e1, ctx->stream));
             BSC_HIP(hipEventSynchronize(e1));
             float ms = 0.f;
             BSC_HIP(hipEventElapsedTime(&ms, e0, e1));
-            const double gbps = (double)(n4 * 16) / (ms * 1e-3) / 1e9;
+            const double gbps = moved / (ms * 1e-3) / 1e9;
             if (r >= 2 && gbps > best) best = gbps;     // the first two launches warm up
         }
     }

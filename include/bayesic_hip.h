@@ -136,9 +136,10 @@ int bsc_allreduce_max(bsc_ctx* ctx, void* buf, int64_t n, int dtype);
 
 /* hipEvent wrappers so a ctypes caller can time the ctx stream. */
 /* Measurement aid: best pure streaming-read rate (GB/s) over `buf` on this device, from
- * a kernel that does nothing but 16-byte loads (two launch shapes, best of `reps` timed
- * launches each).  Synchronises.  bench.py quotes the data pass against this as well as
- * against the spec-sheet peak. */
+ * kernels that do nothing but read it: 16-byte loads into registers (two launch shapes) and
+ * LDS-DMA of whole 1-KiB runs (one and two workgroups per CU; the first 4 GiB of `buf`) --
+ * best of `reps` timed launches each.  Synchronises.  bench.py quotes the data pass against
+ * this as well as against the spec-sheet peak. */
 int bsc_hbm_read_probe(bsc_ctx* ctx, const void* buf, size_t bytes, int reps, double* host_gbps);
 
 /* ---- mini-batch streaming: host memory -> HBM slots on a copy stream --------------
