@@ -90,6 +90,7 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
     if (const char* e = getenv("BSC_GEMM_DMA")) ctx->gemm_dma = atoi(e);
     if (const char* e = getenv("BSC_GEMM_DBG")) ctx->gemm_dbg = atoi(e);
     if (const char* e = getenv("BSC_GEMM_NT_C")) ctx->gemm_nt_c = atoi(e) != 0;
+    if (const char* e = getenv("BSC_BLR_DMA")) ctx->blr_dma = atoi(e) != 0;
     if (const char* e = getenv("BSC_GRAM_DBG")) ctx->gram_dbg = atoi(e) & 7;
     if (const char* e = getenv("BSC_ROWS_DBG")) ctx->rows_dbg = atoi(e) & 15;
     if (const char* e = getenv("BSC_ROWS_WG")) { const int v = atoi(e); if (v >= 0 && v <= 64) ctx->rows_wg_per_cu = v; }

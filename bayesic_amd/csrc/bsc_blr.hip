@@ -468,6 +468,171 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_mfma_kernel(
     }
 }
 
+// ---- the same pass with the tile brought by LDS-DMA: the default since the end of round 3 (BSC_BLR_DMA=0: the kernel
+// above).  166 -> 161 us per 1M x 256 pass in alternating runs on one box (tools/ab_blr_dma.sh) -----------------------
+// buffer_load ... lds writes a row's 1 KiB straight into the wave's LDS tile: no 64 staging registers, no sixteen
+// ds_write_b128 a tile, and on this part a pure read by LDS-DMA reaches 6.9 TB/s where loads into registers reach 6.4
+// (bsc_hbm_read_probe).  One tile buffer per wave as before: the backward reads ALL sixteen rows into registers first
+// (the registers the prefetched tile used to occupy), which frees the buffer, issues the next tile's sixteen DMAs, and
+// only then does its rank-1 updates from the registers -- so the DMAs have the whole backward and the other wave's turn
+// to land, and no LDS read of the tile follows a DMA in flight (the compiler answers such a read with vmcnt(0): the
+// residuals, which ARE read during the backward, come by inline asm with their own lgkmcnt waits).
+template <int AUX>
+__device__ __forceinline__ void dma_mtile(float* __restrict__ tl, const float* __restrict__ X, int64_t ldx,
+                                          const float* __restrict__ y, int64_t row0, int64_t B, int lane, float4& yv) {
+    const int64_t rem = row0 < 0 ? 0 : B - row0;
+    uint64_t xbytes = 0, ybytes = 0;
+    if (rem > 0) {
+        xbytes = ((uint64_t)(rem - 1) * (uint64_t)ldx + (uint64_t)GCOLS) * 4u;
+        ybytes = (uint64_t)rem * 4u;
+    }
+    const unsigned xrec = xbytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)xbytes;
+    const unsigned yrec = ybytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)ybytes;
+    const int64_t safe0 = rem > 0 ? row0 : 0;
+    auto xs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + safe0 * ldx), 0, xrec, 0x00020000);
+    auto ys = __builtin_amdgcn_make_buffer_rsrc((void*)(y + safe0), 0, yrec, 0x00020000);
+    const int row_bytes = (int)(ldx * 4);
+#pragma unroll
+    for (int r = 0; r < MT_ROWS; ++r)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (bsc_lds_ptr)(tl + r * MT_RS), 16, 16 * lane, r * row_bytes, 0, AUX);
+    auto v = __builtin_amdgcn_raw_buffer_load_b128(ys, 16 * (lane >> 4), 0, 0);
+    yv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+
+template <int AUX>
+__device__ __forceinline__ void dma_tile_step(float4& yv_cur, float* __restrict__ tl, float* __restrict__ rb,
+                                              const float (&wreg)[GCOLS / 4], float4 (&acc)[SG], float& qacc,
+                                              const float* __restrict__ X, int64_t ldx, const float* __restrict__ y,
+                                              int64_t next_row0, int64_t B, int lane) {
+    const int i16 = lane & 15, kq = lane >> 4;
+    const bool live = i16 < SG;
+    // the tile's DMAs (issued a step ago) and its y have landed
+    __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+    asm volatile("" ::: "memory");
+    const float4 yv = yv_cur;
+    mfma_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+    const float* arow = tl + i16 * MT_RS + 64 * kq;
+#pragma unroll
+    for (int j = 0; j < GCOLS / 16; j += 2) {
+        const float4 a0 = *reinterpret_cast<const float4*>(arow + 4 * j);
+        const float4 a1 = *reinterpret_cast<const float4*>(arow + 4 * j + 4);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wreg[4 * j + 0], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wreg[4 * j + 4], d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wreg[4 * j + 1], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wreg[4 * j + 5], d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wreg[4 * j + 2], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wreg[4 * j + 6], d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wreg[4 * j + 3], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wreg[4 * j + 7], d1, 0, 0, 0);
+    }
+    if (live) {
+        const float r0 = yv.x - (d0[0] + d1[0]), r1 = yv.y - (d0[1] + d1[1]);
+        const float r2 = yv.z - (d0[2] + d1[2]), r3 = yv.w - (d0[3] + d1[3]);
+        qacc = fmaf(r0, r0, qacc); qacc = fmaf(r1, r1, qacc);
+        qacc = fmaf(r2, r2, qacc); qacc = fmaf(r3, r3, qacc);
+        float* dst = rb + (4 * kq) * SG + i16;
+        dst[0] = r0; dst[SG] = r1; dst[2 * SG] = r2; dst[3 * SG] = r3;
+    }
+    // every row into registers, then the buffer belongs to the next tile
+    float4 x4[MT_ROWS];
+#pragma unroll
+    for (int r = 0; r < MT_ROWS; ++r) x4[r] = *reinterpret_cast<const float4*>(tl + r * MT_RS + 4 * lane);
+    wave_lds_sync();            // (the residual writes before the asm reads below; the row reads before the DMAs)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    dma_mtile<AUX>(tl, X, ldx, y, next_row0, B, lane, yv_cur);
+    // backward from the registers; residuals by LDS broadcast, read by asm (see the header)
+    const unsigned rb_addr = (unsigned)(uintptr_t)(bsc_lds_ptr)rb;
+#define BSC_BLR_GROUP(G4)                                                                                          \
+    {                                                                                                             \
+        mfma_f32x4 c0[4], c1[4];                                                                                  \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c0[0]) : "v"(rb_addr), "n"((4 * G4 + 0) * 32) : "memory");      \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c1[0]) : "v"(rb_addr), "n"((4 * G4 + 0) * 32 + 16) : "memory"); \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c0[1]) : "v"(rb_addr), "n"((4 * G4 + 1) * 32) : "memory");      \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c1[1]) : "v"(rb_addr), "n"((4 * G4 + 1) * 32 + 16) : "memory"); \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c0[2]) : "v"(rb_addr), "n"((4 * G4 + 2) * 32) : "memory");      \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c1[2]) : "v"(rb_addr), "n"((4 * G4 + 2) * 32 + 16) : "memory"); \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c0[3]) : "v"(rb_addr), "n"((4 * G4 + 3) * 32) : "memory");      \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c1[3]) : "v"(rb_addr), "n"((4 * G4 + 3) * 32 + 16) : "memory"); \
+        asm volatile("s_waitcnt lgkmcnt(0)"                                                                       \
+                     : "+v"(c0[0]), "+v"(c1[0]), "+v"(c0[1]), "+v"(c1[1]), "+v"(c0[2]), "+v"(c1[2]), "+v"(c0[3]), "+v"(c1[3])); \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                           \
+            const float4 xr = x4[4 * G4 + k];                                                                     \
+            axpy4_pk(acc[0], c0[k][0], xr); axpy4_pk(acc[1], c0[k][1], xr);                                       \
+            axpy4_pk(acc[2], c0[k][2], xr); axpy4_pk(acc[3], c0[k][3], xr);                                       \
+            axpy4_pk(acc[4], c1[k][0], xr); axpy4_pk(acc[5], c1[k][1], xr);                                       \
+            axpy4_pk(acc[6], c1[k][2], xr); axpy4_pk(acc[7], c1[k][3], xr);                                       \
+        }                                                                                                         \
+    }
+    BSC_BLR_GROUP(0) BSC_BLR_GROUP(1) BSC_BLR_GROUP(2) BSC_BLR_GROUP(3)
+#undef BSC_BLR_GROUP
+    // (the asm reads of the residuals are done: the next step's forward may overwrite rb after its own barrier)
+    wave_lds_sync();
+}
+
+template <bool NT>
+__global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_dma_kernel(
+    const float* __restrict__ X, int64_t ldx, const float* __restrict__ y, int64_t B,
+    const float* __restrict__ W, int S, float* __restrict__ slab, int n_iter, int rev, int keep) {
+    constexpr int LDS_FLOATS = PASS_WAVES * (MT_WAVE_LDS > SLAB_STRIDE ? MT_WAVE_LDS : SLAB_STRIDE);
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    float* tl = lds + wave * MT_WAVE_LDS;
+    float* rb = tl + MT_ROWS * MT_RS;
+    float wreg[GCOLS / 4];
+#pragma unroll
+    for (int j = 0; j < GCOLS / 16; ++j) {
+        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i16 < S) w4 = *reinterpret_cast<const float4*>(W + (int64_t)i16 * GCOLS + 64 * kq + 4 * j);
+        wreg[4 * j + 0] = w4.x; wreg[4 * j + 1] = w4.y;
+        wreg[4 * j + 2] = w4.z; wreg[4 * j + 3] = w4.w;
+    }
+    float4 acc[SG];
+#pragma unroll
+    for (int s = 0; s < SG; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float qacc = 0.f;
+    const bool live = i16 < SG;
+    const int64_t stride0 = (int64_t)gridDim.x * PASS_WAVES;
+    const int64_t stride = rev ? -stride0 : stride0;
+    int64_t tile = (int64_t)blockIdx.x * PASS_WAVES + wave + (rev ? (int64_t)(n_iter - 1) * stride0 : 0);
+    if (!NT) keep = n_iter;
+    const int n_stream = n_iter - keep > 0 ? n_iter - keep : 0;
+    float4 yv;
+    if (n_stream > 0) dma_mtile<2>(tl, X, ldx, y, n_iter > 0 ? tile * MT_ROWS : B, B, lane, yv);
+    else dma_mtile<0>(tl, X, ldx, y, n_iter > 0 ? tile * MT_ROWS : B, B, lane, yv);
+    int k = 0;
+    for (; k + 1 < n_stream; ++k) {
+        tile += stride;
+        dma_tile_step<2>(yv, tl, rb, wreg, acc, qacc, X, ldx, y, tile * MT_ROWS, B, lane);
+    }
+    for (; k < n_iter; ++k) {
+        tile += stride;
+        dma_tile_step<0>(yv, tl, rb, wreg, acc, qacc, X, ldx, y, k + 1 < n_iter ? tile * MT_ROWS : B, B, lane);
+    }
+    // no LDS-DMA of this wave may still be in flight when the tile region is reused for the block reduction
+    __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+    __syncthreads();
+    float* ep = lds + wave * SLAB_STRIDE;
+#pragma unroll
+    for (int s = 0; s < SG; ++s)
+        *reinterpret_cast<float4*>(ep + s * GCOLS + 4 * lane) = acc[s];
+    float qv = live ? qacc : 0.f;
+    qv += __shfl_xor(qv, 16);
+    qv += __shfl_xor(qv, 32);
+    if (lane < SG) ep[SLAB_G + lane] = qv;
+    __syncthreads();
+    float* out = slab + (int64_t)blockIdx.x * SLAB_STRIDE;
+    for (int i = tid; i < SLAB_STRIDE; i += PASS_BLOCK) {
+        const int src = i < SLAB_G ? (i & 7) * GCOLS + (i >> 3) : i;
+        float v = lds[src];
+#pragma unroll
+        for (int kk = 1; kk < PASS_WAVES; ++kk) v += lds[kk * SLAB_STRIDE + src];
+        out[i] = v;
+    }
+}
+
 // ---- both contractions on the MFMA pipe (D == 256) ------------------------------------------
 //
 // With every load served from the caches blr_pass_mfma_kernel still takes ~150 us per 1M x 256
@@ -1315,6 +1480,11 @@ void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int6
             else if (nt) BSC_PASS_MX(true, 2);
             else BSC_PASS_MX(false, 2);
 #undef BSC_PASS_MX
+        } else if (ctx->blr_dma && ctx->blr_pk) {
+            if (nt) hipLaunchKernelGGL((blr_pass_dma_kernel<true>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0, ctx->stream, X, ldx,
+                                       y, B, W, sg, slab, g.n_iter, rev, keep);
+            else hipLaunchKernelGGL((blr_pass_dma_kernel<false>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0, ctx->stream, X, ldx,
+                                    y, B, W, sg, slab, g.n_iter, rev, keep);
         } else if (nt && ctx->blr_pk) BSC_PASS_MFMA(true, true);
         else if (nt) BSC_PASS_MFMA(true, false);
         else if (ctx->blr_pk) BSC_PASS_MFMA(false, true);

@@ -47,6 +47,7 @@ struct bsc_ctx {
     int mog_nt = 0;              // bsc_mog_estep: 1 = non-temporal loads of X (BSC_MOG_NT).  Default 0: both half-waves read the same rows and the L2 keeps a row for the second one -- 1.01 x the algorithmic bytes instead of 1.19 x, same time (profiles/r03_pmc_kernels.txt)
     int wo_wg_per_cu = 2;        // bsc_weighted_outer: resident workgroups per CU the grid is sized for
     int fused_waves_per_cu = 16; // bsc_map_reduce: reduce splits target this many waves per CU
+    int blr_dma = 1;             // blr_pass_dma_kernel (the tile by LDS-DMA: 166 -> 161 us at 1M x 256) -- BSC_BLR_DMA=0: blr_pass_mfma_kernel (tile through registers), for A/B
     int blr_pk = 1;              // MFMA pass: backward rank-1 updates as packed FMAs (BSC_BLR_PK=0: scalar; +0.4 % in-process A/B, same bits)
     int blr_finish_block = 1024; // threads per workgroup of blr_fused_update_kernel (BSC_BLR_FINISH_BLOCK = 256 | 512 | 1024)
     int blr_nt_loads = 1;        // non-temporal loads of X (read once per pass): +9% measured

@@ -316,8 +316,8 @@ class Cfg2(Workload):
 
     def roofline(self, avg_s):
         algo = 4.0 * self.rows * self.D + 4.0 * self.rows      # X and y read once per launch
-        kernel = "blr_pass_mfma_kernel" if self.D == 256 and \
-            os.environ.get("BSC_BLR_TILE_ROWS", "16") == "16" else "blr_pass_kernel"
+        kernel = ("blr_pass_dma_kernel" if os.environ.get("BSC_BLR_DMA", "1") != "0" else "blr_pass_mfma_kernel") \
+            if self.D == 256 and os.environ.get("BSC_BLR_TILE_ROWS", "16") == "16" else "blr_pass_kernel"
         achieved = algo / avg_s / 1e9
         return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
