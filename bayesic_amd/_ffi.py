@@ -30,6 +30,9 @@ SIGNATURES = {
     "bsc_graph_launch": (c_int, [c_void_p, c_void_p]),
     "bsc_graph_destroy": (c_int, [c_void_p]),
     "bsc_ctx_set_mfma_split": (c_int, [c_void_p, c_int]),
+    "bsc_ctx_set_option": (c_int, [c_void_p, c_char_p, c_int64]),
+    "bsc_ctx_get_option": (c_int, [c_void_p, c_char_p, POINTER(c_int64)]),
+    "bsc_ctx_option_name": (c_int, [c_int32, POINTER(c_char_p)]),
     "bsc_ctx_profile": (c_int, [c_void_p, c_int]),
     "bsc_ctx_profile_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
     "bsc_ctx_profile_read_slot": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int64)]),
@@ -63,6 +66,7 @@ SIGNATURES = {
                                         c_void_p, c_int32, c_void_p, c_void_p, c_int32]),
     "bsc_blr_data_pass_partial_sweep": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                                 c_int32, c_void_p, c_int32, c_int32]),
+    "bsc_blr_read_stamps": (c_int, [c_void_p, c_void_p, c_int32, POINTER(c_int32)]),
     "bsc_blr_pass_count": (c_int, [c_void_p, c_void_p, c_int32, c_int32, POINTER(c_int32)]),
     "bsc_blr_fused_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,

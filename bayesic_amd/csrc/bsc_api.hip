@@ -38,6 +38,82 @@ int bsc_workspace(bsc_ctx* ctx, size_t bytes, void** out) {
     return BSC_OK;
 }
 
+
+// ---- kernel-selection options (bsc_ctx_set_option) -------------------------------------------------
+// Every tuning / A-B switch of the library is a named integer option of the CONTEXT, set by an explicit
+// call: the library reads no environment variable.  `dbg` options select deletion builds whose results are
+// WRONG by construction (timing only); a non-zero value is refused until the caller has set the option
+// "profiling_builds" to 1 on the same context, which prints a warning once.
+namespace {
+struct bsc_option {
+    const char* key;
+    int bsc_ctx::*field;
+    int lo, hi;            // accepted range (inclusive)
+    const char* allowed;   // when non-null: the accepted values, comma separated (a subset of [lo, hi])
+    bool dbg;              // a non-zero value selects a profiling-only build
+};
+const bsc_option OPTIONS[] = {
+    {"blr_tile_rows", &bsc_ctx::blr_tile_rows, 4, 16, "4,8,16", false},
+    {"blr_waves_per_simd", &bsc_ctx::blr_waves_per_simd, 0, 8, nullptr, false},
+    {"blr_nt", &bsc_ctx::blr_nt_loads, 0, 1, nullptr, false},
+    {"blr_finish_block", &bsc_ctx::blr_finish_block, 256, 1024, "256,512,1024", false},
+    {"blr_pk", &bsc_ctx::blr_pk, 0, 1, nullptr, false},
+    {"blr_keep", &bsc_ctx::blr_keep, -1, 1 << 20, nullptr, false},
+    {"blr_mx", &bsc_ctx::blr_mx, 0, 4, "0,1,2,4", false},           // 4 is a deletion build: checked apart
+    {"blr_wide", &bsc_ctx::blr_wide, 0, 1, nullptr, false},
+    {"blr_rot", &bsc_ctx::blr_rot, 0, 15, nullptr, false},
+    {"blr_dma", &bsc_ctx::blr_dma, 0, 1, nullptr, false},
+    {"blr_q", &bsc_ctx::blr_q, 0, 1, nullptr, false},
+    {"blr_q_dbg", &bsc_ctx::blr_q_dbg, 0, 3, nullptr, true},
+    {"blr_q_bias", &bsc_ctx::blr_q_bias, 0, 400, nullptr, false},
+    {"blr_stamps", &bsc_ctx::blr_stamps, 0, 1, nullptr, false},
+    {"fused_map_blocks_per_cu", &bsc_ctx::fused_map_blocks_per_cu, 1, 64, nullptr, false},
+    {"fused_map_flat", &bsc_ctx::fused_map_flat, 0, 1, nullptr, false},
+    {"fused_map_unroll", &bsc_ctx::fused_map_unroll, 1, 2, nullptr, false},
+    {"fused_nt_store", &bsc_ctx::fused_nt_store, 0, 1, nullptr, false},
+    {"fused_waves_per_cu", &bsc_ctx::fused_waves_per_cu, 1, 64, nullptr, false},
+    {"gemm_pipe", &bsc_ctx::gemm_pipe, 0, 1, nullptr, false},
+    {"gemm_skinny", &bsc_ctx::gemm_skinny, 0, 1, nullptr, false},
+    {"gemm_fast", &bsc_ctx::gemm_fast, 0, 1, nullptr, false},
+    {"gemm_dma", &bsc_ctx::gemm_dma, 0, 2, nullptr, false},
+    {"gemm_dbg", &bsc_ctx::gemm_dbg, 0, 15, nullptr, true},
+    {"gemm_nt_c", &bsc_ctx::gemm_nt_c, 0, 1, nullptr, false},
+    {"gemm_sym", &bsc_ctx::gemm_sym, 0, 1, nullptr, false},
+    {"gram_dbg", &bsc_ctx::gram_dbg, 0, 7, nullptr, true},
+    {"rows_dbg", &bsc_ctx::rows_dbg, 0, 15, nullptr, true},
+    {"rows_wg", &bsc_ctx::rows_wg_per_cu, 0, 64, nullptr, false},
+    {"skinny_nt_dbg", &bsc_ctx::skinny_nt_dbg, 0, 7, nullptr, true},
+    {"skinny_nt_wg", &bsc_ctx::skinny_nt_wg_per_cu, 1, 2, nullptr, false},
+    {"lda_stream", &bsc_ctx::lda_stream, 0, 1, nullptr, false},
+    {"lda_dbg", &bsc_ctx::lda_dbg, 0, 15, nullptr, true},
+    {"bbvi_waves", &bsc_ctx::bbvi_waves, 4, 8, "4,8", false},
+    {"bbvi_kernel", &bsc_ctx::bbvi_kernel, 0, 2, nullptr, false},
+    {"bbvi_dbg", &bsc_ctx::bbvi_dbg, 0, 15, nullptr, true},
+    {"csc_fast", &bsc_ctx::csc_fast, 0, 1, nullptr, false},
+    {"mog_nt", &bsc_ctx::mog_nt, 0, 1, nullptr, false},
+    {"mfma_split", &bsc_ctx::mfma_split, 0, 3, "0,2,3", false},
+    {"wo_wg_per_cu", &bsc_ctx::wo_wg_per_cu, 1, 8, nullptr, false},
+    {"profiling_builds", &bsc_ctx::profiling_builds, 0, 1, nullptr, false},
+};
+const bsc_option* find_option(const char* key) {
+    if (!key) return nullptr;
+    for (const bsc_option& o : OPTIONS)
+        if (strcmp(o.key, key) == 0) return &o;
+    return nullptr;
+}
+bool value_allowed(const bsc_option& o, int64_t v) {
+    if (v < o.lo || v > o.hi) return false;
+    if (!o.allowed) return true;
+    for (const char* p = o.allowed; *p;) {
+        char* end = nullptr;
+        const long a = strtol(p, &end, 10);
+        if (a == v) return true;
+        p = *end == ',' ? end + 1 : end;
+    }
+    return false;
+}
+}  // namespace
+
 extern "C" {
 
 const char* bsc_last_error(void) { return g_last_error; }
@@ -62,75 +138,6 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
     ctx->device = device;
     ctx->stream = (hipStream_t)stream;
     ctx->cu_count = prop.multiProcessorCount;
-    // tuning knob for A/B runs in one process; not part of the ABI contract
-    if (const char* e = getenv("BSC_BLR_TILE_ROWS")) {
-        const int v = atoi(e);
-        ctx->blr_tile_rows = (v == 4 || v == 16) ? v : 8;
-    }
-    if (const char* e = getenv("BSC_BLR_WAVES_PER_SIMD")) ctx->blr_waves_per_simd = atoi(e);
-    if (const char* e = getenv("BSC_BLR_NT")) ctx->blr_nt_loads = atoi(e);
-    if (const char* e = getenv("BSC_BLR_FINISH_BLOCK")) {
-        const int v = atoi(e);
-        ctx->blr_finish_block = (v == 256 || v == 512) ? v : 1024;
-    }
-    if (const char* e = getenv("BSC_BLR_PK")) ctx->blr_pk = atoi(e) != 0;
-    if (const char* e = getenv("BSC_BLR_KEEP")) ctx->blr_keep = atoi(e);
-    if (const char* e = getenv("BSC_BLR_MX")) ctx->blr_mx = atoi(e);
-    if (const char* e = getenv("BSC_BLR_WIDE")) ctx->blr_wide = atoi(e) != 0;
-    if (const char* e = getenv("BSC_BLR_ROT")) ctx->blr_rot = atoi(e) & 15;
-    if (const char* e = getenv("BSC_FUSED_MAP_BLOCKS_PER_CU")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= 64) ctx->fused_map_blocks_per_cu = v;
-    }
-    if (const char* e = getenv("BSC_FUSED_MAP_FLAT")) ctx->fused_map_flat = atoi(e) != 0;
-    if (const char* e = getenv("BSC_FUSED_MAP_UNROLL")) ctx->fused_map_unroll = atoi(e) == 1 ? 1 : 2;
-    if (const char* e = getenv("BSC_GEMM_PIPE")) ctx->gemm_pipe = atoi(e) != 0;
-    if (const char* e = getenv("BSC_GEMM_SKINNY")) ctx->gemm_skinny = atoi(e) != 0;
-    if (const char* e = getenv("BSC_GEMM_FAST")) ctx->gemm_fast = atoi(e) != 0;
-    if (const char* e = getenv("BSC_GEMM_DMA")) ctx->gemm_dma = atoi(e);
-    if (const char* e = getenv("BSC_GEMM_DBG")) ctx->gemm_dbg = atoi(e);
-    if (const char* e = getenv("BSC_GEMM_NT_C")) ctx->gemm_nt_c = atoi(e) != 0;
-    if (const char* e = getenv("BSC_BLR_DMA")) ctx->blr_dma = atoi(e) != 0;
-    if (const char* e = getenv("BSC_GRAM_DBG")) ctx->gram_dbg = atoi(e) & 7;
-    if (const char* e = getenv("BSC_ROWS_DBG")) ctx->rows_dbg = atoi(e) & 15;
-    if (const char* e = getenv("BSC_ROWS_WG")) { const int v = atoi(e); if (v >= 0 && v <= 64) ctx->rows_wg_per_cu = v; }
-    if (const char* e = getenv("BSC_SKINNY_NT_DBG")) ctx->skinny_nt_dbg = atoi(e) & 7;
-    if (const char* e = getenv("BSC_SKINNY_NT_WG")) { const int v = atoi(e); if (v == 1 || v == 2) ctx->skinny_nt_wg_per_cu = v; }
-    if (const char* e = getenv("BSC_GEMM_SYM")) ctx->gemm_sym = atoi(e) != 0;
-    if (const char* e = getenv("BSC_LDA_STREAM")) ctx->lda_stream = atoi(e) != 0;
-    if (const char* e = getenv("BSC_FUSED_NT_STORE")) ctx->fused_nt_store = atoi(e) != 0;
-    if (const char* e = getenv("BSC_FUSED_WAVES_PER_CU")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= 64) ctx->fused_waves_per_cu = v;
-    }
-    if (const char* e = getenv("BSC_BBVI_WAVES")) ctx->bbvi_waves = atoi(e) == 8 ? 8 : 4;
-    if (const char* e = getenv("BSC_BBVI_KERNEL")) ctx->bbvi_kernel = atoi(e);
-    if (const char* e = getenv("BSC_BBVI_DBG")) ctx->bbvi_dbg = atoi(e);
-    if (const char* e = getenv("BSC_LDA_DBG")) ctx->lda_dbg = atoi(e);
-    if (const char* e = getenv("BSC_CSC_FAST")) ctx->csc_fast = atoi(e) != 0;
-    if (const char* e = getenv("BSC_MOG_NT")) ctx->mog_nt = atoi(e) != 0;
-    if (const char* e = getenv("BSC_MFMA_SPLIT")) { const int v = atoi(e); ctx->mfma_split = v == 2 || v == 3 ? v : 0; }
-    if (const char* e = getenv("BSC_WO_WG_PER_CU")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= 8) ctx->wo_wg_per_cu = v;
-    }
-    // BSC_BLR_MX=4, BSC_GEMM_DBG and BSC_BBVI_DBG select profiling-only builds whose RESULTS ARE WRONG
-    // (deletion builds: a kernel without its stores, a pass that re-reads one window ...).  They exist
-    // for tools/ab_*.py; a process gets them only by also saying BSC_PROFILING_BUILDS=1, and then loudly.
-    if (ctx->blr_mx == 4 || ctx->gemm_dbg != 0 || ctx->bbvi_dbg != 0 || ctx->lda_dbg != 0 || ctx->skinny_nt_dbg != 0 || ctx->rows_dbg != 0 || ctx->gram_dbg != 0) {
-        const char* allow = getenv("BSC_PROFILING_BUILDS");
-        if (!allow || atoi(allow) != 1) {
-            const int mx = ctx->blr_mx, gd = ctx->gemm_dbg, bd = ctx->bbvi_dbg, ld = ctx->lda_dbg + 100 * ctx->skinny_nt_dbg + 1000 * ctx->rows_dbg + 10000 * ctx->gram_dbg;
-            delete ctx;
-            return bsc_fail(BSC_ERR_INVALID,
-                            "bsc_ctx_create: BSC_BLR_MX=%d / BSC_GEMM_DBG=%d / BSC_BBVI_DBG=%d / BSC_LDA_DBG + 100 BSC_SKINNY_NT_DBG + 1000 BSC_ROWS_DBG + 10000 BSC_GRAM_DBG=%d select "
-                            "profiling-only kernels that compute WRONG results; set BSC_PROFILING_BUILDS=1 as well if "
-                            "that is what you want", mx, gd, bd, ld);
-        }
-        fprintf(stderr, "libbayesic_hip: WARNING -- profiling-only kernels selected (BSC_BLR_MX=%d BSC_GEMM_DBG=%d "
-                        "BSC_BBVI_DBG=%d BSC_LDA_DBG=%d): results of this context are WRONG by construction\n",
-                ctx->blr_mx, ctx->gemm_dbg, ctx->bbvi_dbg, ctx->lda_dbg);
-    }
     *out = ctx;
     return BSC_OK;
 }
@@ -140,6 +147,7 @@ int bsc_ctx_destroy(bsc_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->workspace) (void)hipFree(ctx->workspace);
+    if (ctx->stamps) (void)hipFree(ctx->stamps);
     (void)bsc_comm_destroy(ctx);
     for (auto* v : {&ctx->prof_events[0], &ctx->prof_events[1], &ctx->prof_events[2], &ctx->prof_pool})
         for (auto& ev : *v) {
@@ -160,6 +168,39 @@ int bsc_ctx_reserve(bsc_ctx* ctx, size_t bytes) {
     BSC_CHECK_CTX(ctx);
     void* p;
     return bsc_workspace(ctx, bytes, &p);
+}
+
+int bsc_ctx_set_option(bsc_ctx* ctx, const char* key, int64_t value) {
+    BSC_CHECK_CTX(ctx);
+    const bsc_option* o = find_option(key);
+    BSC_REQUIRE(o != nullptr, "bsc_ctx_set_option: unknown option '%s'", key ? key : "(null)");
+    BSC_REQUIRE(value_allowed(*o, value), "bsc_ctx_set_option: %s=%lld is not accepted (%s%s, range [%d, %d])", key,
+                (long long)value, o->allowed ? "one of " : "", o->allowed ? o->allowed : "any integer", o->lo, o->hi);
+    const bool wrong = (o->dbg && value != 0) || (o->field == &bsc_ctx::blr_mx && value == 4);
+    if (wrong && !ctx->profiling_builds)
+        return bsc_fail(BSC_ERR_INVALID,
+                        "bsc_ctx_set_option: %s=%lld selects a profiling-only kernel that computes WRONG results; set the "
+                        "option profiling_builds to 1 on this context first if that is what you want", key, (long long)value);
+    if (wrong)
+        fprintf(stderr, "libbayesic_hip: WARNING -- profiling-only kernel selected (%s=%lld): results of this context are "
+                        "WRONG by construction\n", key, (long long)value);
+    ctx->*(o->field) = (int)value;
+    return BSC_OK;
+}
+
+int bsc_ctx_get_option(bsc_ctx* ctx, const char* key, int64_t* host_value) {
+    BSC_CHECK_CTX(ctx);
+    const bsc_option* o = find_option(key);
+    BSC_REQUIRE(o != nullptr && host_value != nullptr, "bsc_ctx_get_option: unknown option '%s' or null result", key ? key : "(null)");
+    *host_value = ctx->*(o->field);
+    return BSC_OK;
+}
+
+int bsc_ctx_option_name(int32_t index, const char** host_key) {
+    BSC_REQUIRE(host_key != nullptr, "bsc_ctx_option_name: null result");
+    const int n = (int)(sizeof(OPTIONS) / sizeof(OPTIONS[0]));
+    *host_key = (index >= 0 && index < n) ? OPTIONS[index].key : nullptr;
+    return BSC_OK;
 }
 
 int bsc_ctx_set_mfma_split(bsc_ctx* ctx, int terms) {

@@ -633,6 +633,233 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_dma_kernel(
     }
 }
 
+// ---- round 4: BOTH contractions on v_mfma_f32_4x4x1_16B_f32, the tile by LDS-DMA (D == 256, S <= 8) -----------------
+//
+// The counters of blr_pass_dma_kernel (profiles/r03_pmc_blr_pass_dma.txt) say what holds it at 0.80 of the peak: a
+// 16-row tile costs a SIMD 64 v_mfma_f32_16x16x4 of 32 cycles (half of each idle: eight draws in sixteen columns) plus
+// ~310 vector instructions at ~4.6 matrix-pipe cycles apiece (fp32 MFMA and VALU do not overlap on a SIMD:
+// profiles/r01_ubench_mfma_valu_mix.txt) -- ~3 500 issue cycles a tile, ~0.75 of the time HBM takes to deliver it.
+// v_mfma_f32_4x4x1 is sixteen independent 4 x 4 outer products (K = 1) in 8 cycles and has no idle half:
+//
+//   forward   block b = lane / 4 = (k8 = lane >> 3, sb = (lane >> 2) & 1) contracts the 32 columns
+//             {128 h + 16 k8 + c : h < 2, c < 16} for the draws 4 sb .. 4 sb + 3: A = x[4 g + lane % 4][col] (the
+//             rows of row group g, read from the LDS tile: eight ds_read_b128 a group, conflict-free because the four
+//             k8 of a ds_read_b128 lane group start 16 floats apart), B = w[4 sb + lane % 4][col] (32 registers, loaded
+//             once), and register i of accumulator g is the partial dot product (row 4 g + i, draw lane % 8) over
+//             the lane's columns.  The eight column blocks are folded by two halving swaps (v_permlane32_swap,
+//             v_permlane16_swap: each also halves the values a lane carries, 16 -> 8 -> 4) and one DPP rotation:
+//             28 vector instructions a tile, after which lane (kq = lane >> 4, draw = lane % 8) holds the dot
+//             products of rows 4 kq .. 4 kq + 3 -- the rows whose y it loaded.  128 MFMAs of 8 cycles.
+//   backward  as blr_pass_mx_kernel: A = r[n][4 sb + lane % 4] (LDS broadcast), B = x[n][4 lane + q], register i of
+//             accumulator (sb, q) is G[4 sb + i][4 lane + q].  128 MFMAs of 8 cycles.
+//
+// ~2 050 matrix-pipe cycles and ~45 vector instructions a tile.  The feed is blr_pass_dma_kernel's: one 16-row buffer
+// per wave; every operand of the backward (sixteen rows, the residuals) goes to registers before the next tile's
+// sixteen DMAs are issued, so those have the backward and the other wave's turn to land.
+constexpr int QW = 32;   // forward B operand: registers per lane
+
+// DBG (profiling only, WRONG results; BSC_BLR_Q_DBG + BSC_PROFILING_BUILDS): 1 = no arithmetic at all (the feed's own
+// ceiling: DMAs, waits, LDS reads), 2 = forward only, 3 = backward only
+// `next_row0()` is called once, right before the next tile's DMAs are issued, `after_dma()` right behind them.
+template <int AUX, int DBG, typename NextRow, typename AfterDma>
+__device__ __forceinline__ void q_tile_step(float4& yv_cur, float* __restrict__ tl, float* __restrict__ rb,
+                                            const float (&wreg)[QW], mfma_f32x4 (&acc)[2][4], float& qacc,
+                                            const float* __restrict__ X, int64_t ldx, const float* __restrict__ y,
+                                            NextRow next_row0, AfterDma after_dma, int64_t B, int lane) {
+    const int kq = lane >> 4;
+    // the tile's DMAs (issued a step ago) and its y have landed
+    __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+    asm volatile("" ::: "memory");
+    const float4 yv = yv_cur;
+    if (DBG == 0 || DBG == 2) {
+        mfma_f32x4 d[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) d[g] = mfma_f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* abase = tl + (lane & 3) * MT_RS + 16 * (lane >> 3);
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+            float4 a[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                a[g] = *reinterpret_cast<const float4*>(abase + 4 * g * MT_RS + 128 * (c8 >> 2) + 4 * (c8 & 3));
+#pragma unroll
+            for (int g = 0; g < 4; ++g) d[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[g].x, wreg[4 * c8 + 0], d[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) d[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[g].y, wreg[4 * c8 + 1], d[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) d[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[g].z, wreg[4 * c8 + 2], d[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) d[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[g].w, wreg[4 * c8 + 3], d[g], 0, 0, 0);
+        }
+        // fold the eight column blocks (lane bits 5, 4, 3); lanes l and l ^ 8 end with the same four values
+        float u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t0 = swap_add32(d[0][i], d[2][i]);    // lanes 0..31: row group 0, lanes 32..63: row group 2
+            const float t1 = swap_add32(d[1][i], d[3][i]);    //              row group 1               row group 3
+            float v = swap_add16(t0, t1);                     // DPP rows 0, 2 keep t0, rows 1, 3 t1: row group kq
+            v += dpp_f32<DPP_ROW_ROR8>(v);
+            u[i] = v;
+        }
+        const float r0 = yv.x - u[0], r1 = yv.y - u[1], r2 = yv.z - u[2], r3 = yv.w - u[3];
+        qacc = fmaf(r0, r0, qacc); qacc = fmaf(r1, r1, qacc);
+        qacc = fmaf(r2, r2, qacc); qacc = fmaf(r3, r3, qacc);
+        // rb[draw][row]; both lanes of a pair (l, l ^ 8) store the same sixteen bytes
+        *reinterpret_cast<float4*>(rb + (lane & 7) * MT_ROWS + 4 * kq) = make_float4(r0, r1, r2, r3);
+    }
+    wave_lds_sync();
+    // every operand of the backward into registers, then the buffer belongs to the next tile
+    float4 x4[MT_ROWS];
+#pragma unroll
+    for (int r = 0; r < MT_ROWS; ++r) x4[r] = *reinterpret_cast<const float4*>(tl + r * MT_RS + 4 * lane);
+    float4 ra[2][4];
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            ra[sb][g] = *reinterpret_cast<const float4*>(rb + (4 * sb + (lane & 3)) * MT_ROWS + 4 * g);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wave_lds_sync();
+    dma_mtile<AUX>(tl, X, ldx, y, next_row0(), B, lane, yv_cur);
+    after_dma();
+    if (DBG == 0 || DBG == 3) {
+#pragma unroll
+        for (int r = 0; r < MT_ROWS; ++r) {
+            const float4 xr = x4[r];
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                const float4 rr = ra[sb][r >> 2];
+                const float a = (r & 3) == 0 ? rr.x : (r & 3) == 1 ? rr.y : (r & 3) == 2 ? rr.z : rr.w;
+                acc[sb][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, xr.x, acc[sb][0], 0, 0, 0);
+                acc[sb][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, xr.y, acc[sb][1], 0, 0, 0);
+                acc[sb][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, xr.z, acc[sb][2], 0, 0, 0);
+                acc[sb][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, xr.w, acc[sb][3], 0, 0, 0);
+            }
+        }
+    } else {
+        // keep the loads of a deletion build alive
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < MT_ROWS; ++r) s += x4[r].x;
+        if (s == 12345.678f) qacc += ra[0][0].x + ra[1][3].w;
+    }
+}
+
+// Which tiles a wave of blr_pass_q_kernel reads.
+//
+// STATIC (reproducible: a wave's tiles and their order are a function of the launch geometry alone).  Window w < n_all
+// is one contiguous run of (workgroups x 4) tiles, tile = w * w_all + slot, as in every pass kernel of this file.  The
+// workgroups with an EVEN blockIdx then take `n_a - n_all` further windows of (even workgroups x 4) tiles among
+// themselves: on this part the XCDs 0, 2, 4, 6 stream 7-15 % faster than 1, 3, 5, 7 (tools/ubench_dma_inflight: the
+// same 3 GiB split evenly ends after 390 us on the even XCDs and 450 us on the odd ones), workgroups are dealt to the XCDs
+// round-robin, and a pass that gives every workgroup the same share ends when the slow half does.  The placement is an
+// observation used for speed only: any placement computes the same sums.
+//
+// (Measured and dropped: tiles popped from eight atomic queues, one per XCD, with stealing -- every workgroup then ends
+// within 0.2 us of every other, but 62 500 returning atomics on eight words take 226 us where the static schedule takes
+// 160, profiles/r04_ab_pass_q_schedules.txt; and the sums would no longer be reproducible in the last bits.)
+struct QSched {
+    int n_all, n_mine, rev, keep;
+    int64_t w_all, w_a, slot, slot_a, B;
+    __device__ __forceinline__ int64_t row0(int p) const {        // p-th tile of this wave's walk; p >= n_mine: the empty tile
+        if (p >= n_mine) return B;
+        const int w = rev ? n_mine - 1 - p : p;
+        const int64_t tile = w < n_all ? (int64_t)w * w_all + slot
+                                       : (int64_t)n_all * w_all + (int64_t)(w - n_all) * w_a + slot_a;
+        return tile * MT_ROWS;
+    }
+};
+
+template <bool NT, int DBG>
+__global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_q_kernel(
+    const float* __restrict__ X, int64_t ldx, const float* __restrict__ y, int64_t B,
+    const float* __restrict__ W, int S, float* __restrict__ slab, int n_all, int n_a, int rev, int keep,
+    unsigned long long* __restrict__ stamps) {
+    constexpr int LDS_FLOATS = PASS_WAVES * (MT_WAVE_LDS > SLAB_STRIDE ? MT_WAVE_LDS : SLAB_STRIDE);
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long t_start = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    float* tl = lds + wave * MT_WAVE_LDS;
+    float* rb = tl + MT_ROWS * MT_RS;          // residuals [draw][row]
+    mfma_f32x4 acc[2][4];                      // [draw group][column component]: register i = draw 4 sb + i
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[sb][q] = mfma_f32x4{0.f, 0.f, 0.f, 0.f};
+    float qacc = 0.f;
+    float4 yv;
+    float wreg[QW];
+    // forward B operand: w[draw lane % 8][128 h + 16 k8 + 4 m + c], register 4 (4 h + m) + c; draws >= S are zero
+    auto load_w = [&]() {
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+            float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((lane & 7) < S)
+                w4 = *reinterpret_cast<const float4*>(W + (int64_t)(lane & 7) * GCOLS + 128 * (c8 >> 2) + 16 * (lane >> 3) +
+                                                      4 * (c8 & 3));
+            wreg[4 * c8 + 0] = w4.x; wreg[4 * c8 + 1] = w4.y;
+            wreg[4 * c8 + 2] = w4.z; wreg[4 * c8 + 3] = w4.w;
+        }
+    };
+    {
+        QSched sc;
+        sc.n_all = n_all; sc.rev = rev; sc.B = B;
+        sc.n_mine = (blockIdx.x & 1) ? n_all : n_a;
+        sc.w_all = (int64_t)gridDim.x * PASS_WAVES;
+        sc.w_a = (int64_t)((gridDim.x + 1) >> 1) * PASS_WAVES;
+        sc.slot = (int64_t)blockIdx.x * PASS_WAVES + wave;
+        sc.slot_a = (int64_t)(blockIdx.x >> 1) * PASS_WAVES + wave;
+        const int n_mine = sc.n_mine;
+        if (!NT) keep = n_mine;
+        const int n_stream = n_mine - keep > 0 ? n_mine - keep : 0;   // tiles read non-temporal; the last `keep` allocate
+        // the first tile's DMAs go out before anything else: W (L2 hits) loads behind them
+        if (n_stream > 0) dma_mtile<2>(tl, X, ldx, y, sc.row0(0), B, lane, yv);
+        else dma_mtile<0>(tl, X, ldx, y, sc.row0(0), B, lane, yv);
+        load_w();
+        int k = 0;
+        for (; k + 1 < n_stream; ++k)
+            q_tile_step<2, DBG>(yv, tl, rb, wreg, acc, qacc, X, ldx, y, [&] { return sc.row0(k + 1); }, [] {}, B, lane);
+        for (; k < n_mine; ++k)
+            q_tile_step<0, DBG>(yv, tl, rb, wreg, acc, qacc, X, ldx, y, [&] { return sc.row0(k + 1); }, [] {}, B, lane);
+    }
+    // no LDS-DMA of this wave may still be in flight when the tile region is reused for the block reduction
+    __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+    __syncthreads();
+    float* ep = lds + wave * SLAB_STRIDE;
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(ep + (4 * sb + i) * GCOLS + 4 * lane) =
+                make_float4(acc[sb][0][i], acc[sb][1][i], acc[sb][2][i], acc[sb][3][i]);
+    float qv = (lane & 8) ? 0.f : qacc;        // lane (draw lane % 8, kq): rows 4 kq .. of that draw; lanes l ^ 8 repeat them
+    qv += __shfl_xor(qv, 16);
+    qv += __shfl_xor(qv, 32);
+    if (lane < SG) ep[SLAB_G + lane] = qv;
+    __syncthreads();
+    float* out = slab + (int64_t)blockIdx.x * SLAB_STRIDE;
+    for (int i = tid; i < SLAB_STRIDE; i += PASS_BLOCK) {
+        const int src = i < SLAB_G ? (i & 7) * GCOLS + (i >> 3) : i;
+        float v = lds[src];
+#pragma unroll
+        for (int kk = 1; kk < PASS_WAVES; ++kk) v += lds[kk * SLAB_STRIDE + src];
+        out[i] = v;
+    }
+    if (stamps) {
+        // measurement aid (option blr_stamps): when did this workgroup start and end, and on which XCD did it run
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long* st = stamps + 4 * (int64_t)blockIdx.x;
+            st[0] = t_start;
+            st[1] = __builtin_amdgcn_s_memrealtime();
+            st[2] = __builtin_amdgcn_s_getreg((3 << 11) | 20);     // HW_REG_XCC_ID[3:0]
+            st[3] = __builtin_amdgcn_s_getreg((15 << 11) | 4);     // HW_REG_HW_ID[15:0]
+        }
+    }
+}
+
 // ---- both contractions on the MFMA pipe (D == 256) ------------------------------------------
 //
 // With every load served from the caches blr_pass_mfma_kernel still takes ~150 us per 1M x 256
@@ -1457,9 +1684,9 @@ int keep_windows(const bsc_ctx* ctx, int64_t ldx, PassGrid g) {
 // and 8-row kernels (D != 256) always stream forward.
 void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B, int D,
                  const float* W, int sg, PassGrid g, float* slab, int sweep, bool wide = false) {
-    bsc_prof_scope prof(ctx);  // times the pass kernel alone
     const bool nt = ctx->blr_nt_loads != 0;
     const int rows = pass_rows(ctx, D, y);
+    bsc_prof_scope prof(ctx);  // times the pass kernel alone
     if (rows == 16) {
         const int rev = sweep == BSC_SWEEP_BACKWARD_KEEP ? 1 : 0;
         const int keep = sweep == BSC_SWEEP_STREAM ? 0 : keep_windows(ctx, ldx, g);
@@ -1480,6 +1707,33 @@ void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int6
             else if (nt) BSC_PASS_MX(true, 2);
             else BSC_PASS_MX(false, 2);
 #undef BSC_PASS_MX
+        } else if (ctx->blr_q) {
+            // both contractions on v_mfma_f32_4x4x1, the tile by LDS-DMA (round 4; option blr_q = 0: the kernels below)
+            unsigned long long* stamps = nullptr;
+            if (ctx->blr_stamps && !ctx->capturing) {
+                if (!ctx->stamps && hipMalloc(&ctx->stamps, (size_t)MAX_SLAB_ROWS * 32) != hipSuccess) ctx->stamps = nullptr;
+                stamps = (unsigned long long*)ctx->stamps;
+                ctx->stamp_rows = g.n_blocks <= MAX_SLAB_ROWS ? g.n_blocks : 0;
+                if (!ctx->stamp_rows) stamps = nullptr;
+            }
+            // windows of every workgroup / of the even ones (QSched): `blr_q_bias` per mille more for the even ones
+            const int64_t n_tiles = (B + MT_ROWS - 1) / MT_ROWS;
+            const int64_t w_all = (int64_t)g.n_blocks * PASS_WAVES, w_a = (int64_t)((g.n_blocks + 1) / 2) * PASS_WAVES;
+            int extra = (int)((int64_t)g.n_iter * ctx->blr_q_bias + 500) / 1000;
+            if (g.n_blocks < 2 || sweep != BSC_SWEEP_STREAM) extra = 0;
+            int64_t rest = n_tiles - (int64_t)extra * w_a;
+            if (rest < 0) { rest = n_tiles; extra = 0; }
+            const int n_all = extra ? (int)((rest + w_all - 1) / w_all) : g.n_iter;
+            const int n_a = n_all + extra;
+#define BSC_PASS_Q(NT_, DBG_)                                                                      \
+    hipLaunchKernelGGL((blr_pass_q_kernel<NT_, DBG_>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0,     \
+                       ctx->stream, X, ldx, y, B, W, sg, slab, n_all, n_a, rev, keep, stamps)
+            if (ctx->blr_q_dbg == 1) BSC_PASS_Q(true, 1);
+            else if (ctx->blr_q_dbg == 2) BSC_PASS_Q(true, 2);
+            else if (ctx->blr_q_dbg == 3) BSC_PASS_Q(true, 3);
+            else if (nt) BSC_PASS_Q(true, 0);
+            else BSC_PASS_Q(false, 0);
+#undef BSC_PASS_Q
         } else if (ctx->blr_dma && ctx->blr_pk) {
             if (nt) hipLaunchKernelGGL((blr_pass_dma_kernel<true>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0, ctx->stream, X, ldx,
                                        y, B, W, sg, slab, g.n_iter, rev, keep);
@@ -1542,7 +1796,7 @@ int data_pass_partial_impl(bsc_ctx* ctx, const float* X, int64_t ldx, const floa
     BSC_REQUIRE(sweep >= 0 && sweep <= 2, "bsc_blr_data_pass_partial: sweep=%d (0, 1 or 2)", sweep);
     const PassGrid g = pass_grid(ctx, B, pass_rows(ctx, D, y));
     void* ws = nullptr;
-    rc = bsc_workspace(ctx, (size_t)g.n_blocks * SLAB_STRIDE * sizeof(float), &ws);
+    rc = bsc_workspace(ctx, (size_t)2 * g.n_blocks * SLAB_STRIDE * sizeof(float), &ws);
     if (rc != BSC_OK) return rc;
     launch_pass(ctx, X, ldx, y, B, (int)D, W, (int)S, g, (float*)ws, sweep);
     BSC_LAUNCH_CHECK();
@@ -1564,6 +1818,16 @@ int bsc_blr_pass_count(bsc_ctx* ctx, const float* y, int32_t D, int32_t S, int32
         s0 += (S - s0 < cap) ? (S - s0) : cap;
     }
     *count = n;
+    return BSC_OK;
+}
+
+int bsc_blr_read_stamps(bsc_ctx* ctx, uint64_t* host_stamps, int32_t capacity_rows, int32_t* host_rows) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(host_stamps && host_rows && capacity_rows >= 0, "bsc_blr_read_stamps: bad arguments");
+    BSC_HIP(hipStreamSynchronize(ctx->stream));
+    const int n = ctx->stamps ? (ctx->stamp_rows < capacity_rows ? ctx->stamp_rows : capacity_rows) : 0;
+    if (n > 0) BSC_HIP(hipMemcpy(host_stamps, ctx->stamps, (size_t)n * 32, hipMemcpyDeviceToHost));
+    *host_rows = n;
     return BSC_OK;
 }
 

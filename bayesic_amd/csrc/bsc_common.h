@@ -48,6 +48,13 @@ struct bsc_ctx {
     int wo_wg_per_cu = 2;        // bsc_weighted_outer: resident workgroups per CU the grid is sized for
     int fused_waves_per_cu = 16; // bsc_map_reduce: reduce splits target this many waves per CU
     int blr_dma = 1;             // blr_pass_dma_kernel (the tile by LDS-DMA: 166 -> 161 us at 1M x 256) -- BSC_BLR_DMA=0: blr_pass_mfma_kernel (tile through registers), for A/B
+    int blr_q = 1;               // blr_pass_q_kernel (both contractions on v_mfma_f32_4x4x1, the tile by LDS-DMA; round 4) -- BSC_BLR_Q=0: blr_pass_dma_kernel, for A/B
+    int blr_q_dbg = 0;           // deletion builds of blr_pass_q_kernel (BSC_BLR_Q_DBG + BSC_PROFILING_BUILDS): WRONG results
+    int blr_q_bias = 70;         // blr_pass_q_kernel, static schedule: per mille of further windows for the workgroups with an even blockIdx (QSched)
+    int blr_stamps = 0;          // blr_pass_q_kernel: every workgroup leaves start / end s_memrealtime stamps and its XCD (bsc_blr_read_stamps)
+    void* stamps = nullptr;      // 32 bytes per workgroup, allocated when blr_stamps is first used
+    int stamp_rows = 0;          // workgroups of the last stamped launch
+    int profiling_builds = 0;    // 1: the deletion builds (options marked dbg) may be selected -- WRONG results, timing only
     int blr_pk = 1;              // MFMA pass: backward rank-1 updates as packed FMAs (BSC_BLR_PK=0: scalar; +0.4 % in-process A/B, same bits)
     int blr_finish_block = 1024; // threads per workgroup of blr_fused_update_kernel (BSC_BLR_FINISH_BLOCK = 256 | 512 | 1024)
     int blr_nt_loads = 1;        // non-temporal loads of X (read once per pass): +9% measured

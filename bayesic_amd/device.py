@@ -5,6 +5,7 @@ stream; every compute call goes through the C ABI.  Creating a ``Context``
 without a visible gfx950 GPU raises -- there is no CPU path.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -12,8 +13,26 @@ import torch
 from . import _ffi
 
 
+def option_names(lib=None):
+    """The kernel-selection options of the library (bsc_ctx_option_name), in its order."""
+    lib = lib or _ffi.load_library()
+    names, i = [], 0
+    while True:
+        key = ctypes.c_char_p()
+        _ffi.check(lib.bsc_ctx_option_name(i, ctypes.byref(key)), "bsc_ctx_option_name")
+        if key.value is None:
+            return names
+        names.append(key.value.decode())
+        i += 1
+
+
 class Context:
-    def __init__(self, device=None, stream=None):
+    """`options`: {name: int} handed to bsc_ctx_set_option after creation (kernel selection is a property of the
+    context; the LIBRARY reads no environment variable).  For A/B runs of whole programs (tools/ab_*.py, bench.py
+    under a profiler) this class -- not the library -- also honours BSC_<NAME> environment variables, but only in a
+    process that says BSC_PROFILING_BUILDS=1; explicit `options` win over them."""
+
+    def __init__(self, device=None, stream=None, options=None):
         if not torch.cuda.is_available():
             raise _ffi.BayesicHipError(
                 "bayesic_amd needs a gfx950 (MI355X) GPU: torch.cuda.is_available() is False "
@@ -28,6 +47,26 @@ class Context:
         _ffi.check(self.lib.bsc_ctx_create(self.device_index, self._stream.cuda_stream,
                                            ctypes.byref(handle)), "bsc_ctx_create")
         self.handle = handle
+        merged = {}
+        if os.environ.get("BSC_PROFILING_BUILDS") == "1":
+            merged["profiling_builds"] = 1
+            for name in option_names(self.lib):
+                v = os.environ.get("BSC_" + name.upper())
+                if v is not None and name != "profiling_builds":
+                    merged[name] = int(v)
+        if options:
+            first = {k: v for k, v in options.items() if k == "profiling_builds"}
+            merged.update(first)
+            merged.update({k: v for k, v in options.items() if k != "profiling_builds"})
+        try:
+            if "profiling_builds" in merged:
+                self.set_option("profiling_builds", merged.pop("profiling_builds"))
+            for k, v in merged.items():
+                self.set_option(k, v)
+        except Exception:
+            self.lib.bsc_ctx_destroy(self.handle)
+            self.handle = None
+            raise
         self.has_comm = False   # an RCCL communicator (comm_init), even of one rank
         self._graphs = weakref.WeakSet()   # live Graph objects recorded on this context
 
@@ -88,6 +127,24 @@ class Context:
         h = ctypes.c_void_p()
         _ffi.check(self.lib.bsc_capture_end(self.handle, ctypes.byref(h)), "bsc_capture_end")
         return Graph(self, h, list(keep))
+
+    def set_option(self, name, value):
+        _ffi.check(self.lib.bsc_ctx_set_option(self.handle, name.encode(), int(value)), "bsc_ctx_set_option")
+
+    def get_option(self, name):
+        out = ctypes.c_int64()
+        _ffi.check(self.lib.bsc_ctx_get_option(self.handle, name.encode(), ctypes.byref(out)), "bsc_ctx_get_option")
+        return int(out.value)
+
+    def read_stamps(self):
+        """Option blr_stamps: (rows, 4) uint64 array {start tick, end tick, XCD, HW_ID} per workgroup of the last
+        D = 256, S <= 8 pass (100 MHz ticks); syncs."""
+        import numpy as np
+        buf = np.zeros((2048, 4), np.uint64)
+        n = ctypes.c_int32()
+        _ffi.check(self.lib.bsc_blr_read_stamps(self.handle, buf.ctypes.data, 2048, ctypes.byref(n)),
+                   "bsc_blr_read_stamps")
+        return buf[:n.value]
 
     def reserve(self, nbytes):
         _ffi.check(self.lib.bsc_ctx_reserve(self.handle, nbytes), "bsc_ctx_reserve")

@@ -316,8 +316,15 @@ class Cfg2(Workload):
 
     def roofline(self, avg_s):
         algo = 4.0 * self.rows * self.D + 4.0 * self.rows      # X and y read once per launch
-        kernel = ("blr_pass_dma_kernel" if os.environ.get("BSC_BLR_DMA", "1") != "0" else "blr_pass_mfma_kernel") \
-            if self.D == 256 and os.environ.get("BSC_BLR_TILE_ROWS", "16") == "16" else "blr_pass_kernel"
+        # which pass kernel the context's options select (csrc/bsc_blr.hip launch_pass), asked of the library
+        opt = self.ctx.get_option
+        if self.D == 256 and opt("blr_tile_rows") == 16 and min(self.S, 8) == self.S:
+            kernel = ("blr_pass_mx_kernel" if opt("blr_mx") else "blr_pass_q_kernel" if opt("blr_q") else
+                      "blr_pass_dma_kernel" if opt("blr_dma") and opt("blr_pk") else "blr_pass_mfma_kernel")
+        elif self.D == 256 and opt("blr_tile_rows") == 16:
+            kernel = "blr_pass_mx_kernel"
+        else:
+            kernel = "blr_pass_kernel"
         achieved = algo / avg_s / 1e9
         return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

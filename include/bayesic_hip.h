@@ -89,10 +89,22 @@ int bsc_memset(bsc_ctx* ctx, void* dst, int value, size_t bytes);
  * (2; with 3 it computes as with 0) and bsc_mog_estep (either value: its forward product -- differences of large
  * terms -- always takes three terms, its backward two) and by bsc_gemm_strided_batched / bsc_gemm_epilogue when both
  * operands are the SAME row-major matrix of <= 256 columns, a multiple of 32 (X^T X: 2); every other entry computes as
- * with 0.  Environment:
- * BSC_MFMA_SPLIT at bsc_ctx_create.  Replaces nothing in the reference (bayesic/algebra.py:1347-1383
+ * with 0.  Also the option
+ * "mfma_split" of bsc_ctx_set_option.  Replaces nothing in the reference (bayesic/algebra.py:1347-1383
  * contracts in the dtype of its operands); SURVEY.md 8(d) config 4 leaves the operand-split variant open. */
 int bsc_ctx_set_mfma_split(bsc_ctx* ctx, int terms);
+
+/* Kernel selection is a property of the CONTEXT, set by explicit calls: the library reads no environment
+ * variable.  Every A/B switch and tuning knob is a named integer option (csrc/bsc_api.hip OPTIONS: "blr_q",
+ * "gemm_dma", "lda_stream", "mfma_split", ...; bsc_ctx_option_name enumerates them, *host_key = NULL past the
+ * last); a value outside an option's accepted set is an error, nothing is coerced.  Options that select
+ * deletion builds (kernels with parts removed, for timing: their RESULTS ARE WRONG) are refused until the
+ * option "profiling_builds" has been set to 1 on the same context, and then warn on stderr.  Defaults are the
+ * measured best; a drop-in caller never needs these.  (The reference has no counterpart: its one backend
+ * switch is Theano's own configuration, bayesic/algebra.py:54.) */
+int bsc_ctx_set_option(bsc_ctx* ctx, const char* key, int64_t value);
+int bsc_ctx_get_option(bsc_ctx* ctx, const char* key, int64_t* host_value);
+int bsc_ctx_option_name(int32_t index, const char** host_key);
 
 /* Per-kernel timing of the dominant kernel of each entry point, with hipEvents
  * recorded on the ctx stream immediately around that one launch.  enable = 0: off
@@ -238,6 +250,12 @@ int bsc_blr_data_pass_sweep(bsc_ctx* ctx, const float* X, int64_t ldx, const flo
 int bsc_blr_data_pass_partial_sweep(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y,
                                     int64_t B, int32_t D, const float* W, int32_t S,
                                     int32_t sweep);
+
+/* Measurement aid (option "blr_stamps" = 1): the D = 256, S <= 8 pass leaves per workgroup
+ * {start, end} in s_memrealtime ticks (100 MHz), the XCD it ran on and its HW_ID; this copies the
+ * stamps of the LAST such launch to host_stamps[4 * rows] (synchronises).  Shows how evenly a static
+ * partition of the mini-batch finishes (tools/ab_q.py). */
+int bsc_blr_read_stamps(bsc_ctx* ctx, uint64_t* host_stamps, int32_t capacity_rows, int32_t* host_rows);
 
 /* How many launches of the pass kernel bsc_blr_data_pass[_sweep] makes for S draws (eight per pass, or
  * sixteen while more than eight are left at D = 256): what a caller that alternates sweep directions

@@ -23,9 +23,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # config directory -> (kernel-name substring, source file, algorithmic bytes per launch)
 KERNELS = {
-    "cfg2": ("blr_pass_dma_kernel", "bsc_blr.hip", 4.0 * 1_000_000 * 256 + 4.0 * 1_000_000),
-    "cfg2stream": ("blr_pass_dma_kernel", "bsc_blr.hip", 4.0 * 1_000_000 * 256 + 4.0 * 1_000_000),
-    "cfg2rot": ("blr_pass_dma_kernel", "bsc_blr.hip", 4.0 * 1_000_000 * 256 + 4.0 * 1_000_000),
+    "cfg2": ("blr_pass_q_kernel", "bsc_blr.hip", 4.0 * 1_000_000 * 256 + 4.0 * 1_000_000),
+    "cfg2stream": ("blr_pass_q_kernel", "bsc_blr.hip", 4.0 * 1_000_000 * 256 + 4.0 * 1_000_000),
+    "cfg2rot": ("blr_pass_q_kernel", "bsc_blr.hip", 4.0 * 1_000_000 * 256 + 4.0 * 1_000_000),
     "cfg3": ("mog_estep_kernel", "bsc_mog.hip", 4.0 * 10_000_000 * 16),
     "cfg3l2": ("mog_estep_kernel", "bsc_mog.hip", 4.0 * 10_000_000 * 16),
     "cfg3x": ("mog_estep_bx_kernel", "bsc_mog.hip", 4.0 * 10_000_000 * 16),

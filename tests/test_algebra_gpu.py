@@ -217,11 +217,7 @@ def test_skinny_products_one_tiny_extent_nt(dev, M, N, K):
     assert (np.abs(got - want) <= 1e-5 * bound + 1e-12).all(), np.abs(got - want).max()
     got_t = run(dev, dot(X, W.T), W=W_, X=X_)                # C^T: strided stores
     assert (np.abs(got_t - want.T) <= 1e-5 * bound.T + 1e-12).all()
-    os.environ["BSC_GEMM_SKINNY"] = "0"
-    try:
-        plain = DeviceBackend(Context(0))
-    finally:
-        del os.environ["BSC_GEMM_SKINNY"]
+    plain = DeviceBackend(Context(0, options=dict(gemm_skinny=0)))
     ref = dot(W, X.T).compile(plain)(W=W_, X=X_)
     # both are k-ordered fp32 fma chains over different groupings: equal to rounding, not bitwise
     assert (np.abs(got - ref) <= 2e-5 * bound + 1e-12).all()
@@ -262,11 +258,7 @@ def test_gemm_operands_by_lds_dma_all_layouts(ctx, M, N, K, batch):
     import os
     import torch
     from bayesic_amd.device import Context
-    os.environ["BSC_GEMM_DMA"] = "0"
-    try:
-        staged = Context(0)
-    finally:
-        del os.environ["BSC_GEMM_DMA"]
+    staged = Context(0, options=dict(gemm_dma=0))
     rs = np.random.RandomState(M + 3 * N + 7 * K)
     A_ = rs.standard_normal((batch, M, K)).astype(np.float32)
     B_ = rs.standard_normal((batch, K, N)).astype(np.float32)
@@ -325,15 +317,11 @@ def test_sums_over_the_rows_of_a_narrow_matrix(dev, rows, cols):
 def test_gram_matrix_computes_the_upper_triangle_of_tiles_once(ctx, rows, D, batch):
     """dot(X.T, X): the same matrix on both sides -- the GEMM computes the tiles on and above the
     diagonal and stores each off-diagonal one twice.  Against float64, against the full schedule
-    (BSC_GEMM_SYM=0), exactly symmetric, run-to-run identical; both operand layouts."""
+    (option gemm_sym = 0), exactly symmetric, run-to-run identical; both operand layouts."""
     import os
     import torch
     from bayesic_amd.device import Context
-    os.environ["BSC_GEMM_SYM"] = "0"
-    try:
-        full = Context(0)
-    finally:
-        del os.environ["BSC_GEMM_SYM"]
+    full = Context(0, options=dict(gemm_sym=0))
     g = torch.Generator(device=ctx.device).manual_seed(rows + D)
     ld = D + 4
     X = torch.randn((batch, rows, ld), generator=g, device=ctx.device)

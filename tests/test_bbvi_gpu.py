@@ -138,14 +138,10 @@ def test_loglik_any_sample_count(ctx, S, N, D, G):
 
 
 def test_first_generation_kernel_still_agrees(ctx):
-    """BSC_BBVI_KERNEL=0 keeps the LDS-staged kernel for in-process A/B runs; same oracle."""
+    """option bbvi_kernel = 0 keeps the LDS-staged kernel for in-process A/B runs; same oracle."""
     import os
     from bayesic_amd.device import Context
-    os.environ["BSC_BBVI_KERNEL"] = "0"
-    try:
-        old = Context(0)
-    finally:
-        del os.environ["BSC_BBVI_KERNEL"]
+    old = Context(0, options=dict(bbvi_kernel=0))
     rs = np.random.RandomState(5)
     N, D, G = 3001, 256, 19
     X = rs.standard_normal((N, D)).astype(np.float32)

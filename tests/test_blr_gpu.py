@@ -412,12 +412,11 @@ def test_sweep_orders_agree_with_the_oracle_and_are_deterministic(ctx, B, S):
 
 @pytest.mark.parametrize("keep", ["0", "1", "3", "100"])
 def test_sweep_keep_window_counts(keep, monkeypatch):
-    """BSC_BLR_KEEP = windows a keeping sweep reads with the allocating policy: 0 (none), fewer
+    """Option blr_keep = windows a keeping sweep reads with the allocating policy: 0 (none), fewer
     than the sweep has, and more than it has all give the streaming pass's bits (forward) and the
     oracle's sums (backward)."""
     from bayesic_amd.device import Context
-    monkeypatch.setenv("BSC_BLR_KEEP", keep)
-    ctx = Context(0)
+    ctx = Context(0, options=dict(blr_keep=int(keep)))
     rng = np.random.RandomState(int(keep))
     B, D, S = 100_001, 256, 8
     X = rng.standard_normal((B, D)).astype(np.float32)
@@ -465,13 +464,11 @@ def test_alternating_driver_tracks_the_streaming_driver(ctx):
 
 @pytest.mark.parametrize("mx", ["1", "2"])
 def test_all_mfma_pass_variant_matches_oracle(mx, monkeypatch):
-    """BSC_BLR_MX selects blr_pass_mx_kernel (backward rank-1 updates on v_mfma_f32_4x4x1; 1 = with the
+    """Option blr_mx selects blr_pass_mx_kernel (backward rank-1 updates on v_mfma_f32_4x4x1; 1 = with the
     rotated cached-zone schedule for keeping sweeps, 2 = plain sweep orders).  Not the default (DESIGN.md
     section 12: same speed at the read ceiling) but kept selectable, so it is held to the same tolerance."""
     from bayesic_amd.device import Context
-    monkeypatch.setenv("BSC_BLR_MX", mx)
-    monkeypatch.setenv("BSC_BLR_KEEP", "2")
-    ctx = Context(0)
+    ctx = Context(0, options=dict(blr_mx=int(mx), blr_keep=2))
     for B, S in [(0, 8), (5, 8), (4099, 3), (130_003, 8), (70_000, 20)]:
         rng = np.random.RandomState(B + S)
         D = 256
@@ -491,8 +488,8 @@ def test_all_mfma_pass_variant_matches_oracle(mx, monkeypatch):
 
 
 def test_sixteen_draws_per_pass_equals_eight_per_pass(monkeypatch):
-    """S > 8 at D = 256 runs sixteen draws per pass by default (BSC_BLR_WIDE=1); eight per pass
-    (BSC_BLR_WIDE=0) reads X twice as often and must agree to the float32 summation order."""
+    """S > 8 at D = 256 runs sixteen draws per pass by default (option blr_wide = 1); eight per pass
+    (blr_wide = 0) reads X twice as often and must agree to the float32 summation order."""
     from bayesic_amd.device import Context
     rng = np.random.RandomState(16)
     B, D, S = 90_001, 256, 24
@@ -501,8 +498,7 @@ def test_sixteen_draws_per_pass_equals_eight_per_pass(monkeypatch):
     W = (rng.standard_normal((S, D)) / 16).astype(np.float32)
     out = {}
     for wide in ("1", "0"):
-        monkeypatch.setenv("BSC_BLR_WIDE", wide)
-        ctx = Context(0)
+        ctx = Context(0, options=dict(blr_wide=int(wide)))
         Xd, yd, Wd = ctx.to_device(X), ctx.to_device(y), ctx.to_device(W)
         out[wide] = [_pass_sweep(ctx, Xd, yd, Wd, sweep) for sweep in (0, 1, 2)]
         again = _pass_sweep(ctx, Xd, yd, Wd, 1)
@@ -516,7 +512,7 @@ def test_sixteen_draws_per_pass_equals_eight_per_pass(monkeypatch):
 
 def test_pass_count_is_the_librarys_answer(ctx, monkeypatch):
     """bsc_blr_pass_count: launches of the pass kernel per update as bsc_blr_data_pass issues them -- eight draws
-    per pass; sixteen while more than eight are left at D = 256 (BSC_BLR_WIDE=0: always eight).  The driver asks
+    per pass; sixteen while more than eight are left at D = 256 (option blr_wide = 0: always eight).  The driver asks
     the library instead of re-deriving the rule from the environment."""
     import ctypes
     from bayesic_amd.device import Context
@@ -531,28 +527,91 @@ def test_pass_count_is_the_librarys_answer(ctx, monkeypatch):
     for S, D, want in [(1, 256, 1), (8, 256, 1), (9, 256, 1), (16, 256, 1), (17, 256, 2), (24, 256, 2),
                        (25, 256, 2), (33, 256, 3), (64, 256, 4), (20, 128, 3), (64, 64, 8)]:
         assert count(ctx, D, S) == want, (S, D)
-    monkeypatch.setenv("BSC_BLR_WIDE", "0")
-    narrow = Context(0)
+    narrow = Context(0, options=dict(blr_wide=0))
     assert count(narrow, 256, 64) == 8
-    monkeypatch.delenv("BSC_BLR_WIDE")
     X = ctx.zeros((64, 256))
     model = BLRReparamSVI(X, y, n_samples=24, ctx=ctx)
     assert model._passes_per_update() == 2
-    # a context that reads BSC_BLR_WIDE=0 and a driver that runs later agree, whatever the environment says by then
+    # a context created with blr_wide = 0 and a driver that runs later agree: the driver asks the library
     model = BLRReparamSVI(X, y, n_samples=64, ctx=narrow)
     assert model._passes_per_update() == 8
 
 
 def test_profiling_only_builds_need_an_explicit_second_switch(monkeypatch):
-    """BSC_BLR_MX=4 / BSC_GEMM_DBG / BSC_BBVI_DBG select kernels with parts deleted (wrong results, for timing):
-    a context refuses them unless BSC_PROFILING_BUILDS=1 is set as well."""
+    """blr_mx = 4 / gemm_dbg / bbvi_dbg / blr_q_dbg select kernels with parts deleted (wrong results, for timing):
+    bsc_ctx_set_option refuses them unless profiling_builds = 1 was set on the same context first.  The LIBRARY reads
+    no environment variable; the Python Context honours BSC_<NAME> only in a process that says BSC_PROFILING_BUILDS=1."""
     from bayesic_amd._ffi import BayesicHipError
     from bayesic_amd.device import Context
-    for name, value in (("BSC_BLR_MX", "4"), ("BSC_GEMM_DBG", "1"), ("BSC_BBVI_DBG", "3")):
-        monkeypatch.setenv(name, value)
+    for name, value in (("blr_mx", 4), ("gemm_dbg", 1), ("bbvi_dbg", 3), ("blr_q_dbg", 1)):
         with pytest.raises(BayesicHipError, match="WRONG results"):
-            Context(0)
+            Context(0, options={name: value})
+        c = Context(0, options={"profiling_builds": 1, name: value})
+        assert c.get_option(name) == value
+        c.close()
+        # the environment alone selects nothing ...
+        monkeypatch.setenv("BSC_" + name.upper(), str(value))
+        c = Context(0)
+        assert c.get_option(name) == 0
+        c.close()
+        # ... unless the process opts in
         monkeypatch.setenv("BSC_PROFILING_BUILDS", "1")
-        Context(0).close()
+        c = Context(0)
+        assert c.get_option(name) == value
+        c.close()
         monkeypatch.delenv("BSC_PROFILING_BUILDS")
-        monkeypatch.delenv(name)
+        monkeypatch.delenv("BSC_" + name.upper())
+    plain = Context(0)
+    with pytest.raises(BayesicHipError, match="unknown option"):
+        plain.set_option("no_such_option", 1)
+    with pytest.raises(BayesicHipError, match="not accepted"):
+        plain.set_option("blr_tile_rows", 5)
+    assert plain.get_option("blr_q") == 1
+
+
+@pytest.mark.parametrize("options", [dict(blr_q=0), dict(blr_q=0, blr_dma=0), dict(blr_q=0, blr_dma=0, blr_pk=0)],
+                         ids=["dma", "mfma-pk", "mfma"])
+def test_earlier_pass_kernels_stay_selectable_and_correct(options):
+    """Round 4 made blr_pass_q_kernel (both contractions on v_mfma_f32_4x4x1) the D = 256, S <= 8 pass; the kernels it
+    replaced stay behind the options blr_q / blr_dma / blr_pk for A/B runs and are held to the same tolerance."""
+    from bayesic_amd.device import Context
+    ctx = Context(0, options=options)
+    for B, S in [(0, 8), (7, 8), (1003, 8), (4099, 3), (130_003, 8)]:
+        rs = np.random.RandomState(B + S)
+        X = rs.standard_normal((B, 256)).astype(np.float32)
+        y = rs.standard_normal(B).astype(np.float32)
+        W = (rs.standard_normal((S, 256)) / 16).astype(np.float32)
+        if B:
+            _check_pass(ctx, X, y, W)
+        else:
+            Q, G = _pass(ctx, X, y, W)
+            assert (Q == 0).all() and (G == 0).all()
+
+
+@pytest.mark.parametrize("options", [dict(blr_q_bias=0), dict(blr_q_bias=130), dict(blr_q_bias=400)],
+                         ids=["bias0", "bias130", "bias400"])
+def test_pass_schedules_cover_every_tile_once(options):
+    """blr_pass_q_kernel's schedule gives the workgroups with an even blockIdx further windows (option blr_q_bias, per
+    mille; default 70): static and reproducible whatever the value.  Exact-integer data (W = 0, y in {0, 1},
+    X in {-1, 0, 1}): a tile read twice or not at all changes an integer; then random data against the oracle at the
+    pass's tolerance."""
+    from bayesic_amd.device import Context
+    ctx = Context(0, options=options)
+    for B in (0, 1, 16, 4099, 130_003, 333_333):
+        D, S = 256, 8
+        n = np.arange(B)[:, None]
+        d = np.arange(D)[None, :]
+        X = ((n * 3 + d * 5) % 3 - 1).astype(np.float32)
+        W = np.zeros((S, D), np.float32)               # residual = y: G = X^T y and Q = y.y in small integers
+        y = ((np.arange(B) * 13) % 17 < 9).astype(np.float32)
+        Q, G = _pass(ctx, X, y, W)
+        if B:
+            np.testing.assert_array_equal(Q, np.full(S, float(y.sum())))
+            np.testing.assert_array_equal(G, np.tile(X.astype(np.float64).T @ y.astype(np.float64), (S, 1)))
+            rs = np.random.RandomState(B)
+            X = rs.standard_normal((B, D)).astype(np.float32)
+            y = rs.standard_normal(B).astype(np.float32)
+            W = (rs.standard_normal((S, D)) / 16).astype(np.float32)
+            _check_pass(ctx, X, y, W)
+        else:
+            assert (Q == 0).all() and (G == 0).all()

@@ -182,15 +182,11 @@ def test_fused_lda_statistics_persistent_kernel_rounds_and_split_blocks(ctx, doc
     """K = 128, 64, 32 through lda_sstats_stream_kernel where the 128-column blocks exceed the resident
     workgroups (a whole round, then left-over blocks split along the documents and added by the
     fix-up pass), with leading dimensions larger than the extents, a ragged last block and a short
-    last document step -- against the one-block-per-workgroup kernel (BSC_LDA_STREAM=0) on the same
+    last document step -- against the one-block-per-workgroup kernel (option lda_stream = 0) on the same
     operands and against the float64 oracle on a sample of columns."""
     import os
     from bayesic_amd.device import Context
-    os.environ["BSC_LDA_STREAM"] = "0"
-    try:
-        plain = Context(0)
-    finally:
-        del os.environ["BSC_LDA_STREAM"]
+    plain = Context(0, options=dict(lda_stream=0))
     g = torch.Generator(device=ctx.device).manual_seed(docs + V + K)
     ldc, ldth, ldb, ldo = V + 8, K + 4, V + 4, V + 12
     C = torch.poisson(torch.full((docs, ldc), 0.3, device=ctx.device), generator=g)
@@ -251,11 +247,7 @@ def test_words_term_of_the_bound_inside_the_statistic_kernels(ctx, docs, V, K):
     import os
     import scipy.sparse as sparse
     from bayesic_amd.device import Context
-    os.environ["BSC_LDA_STREAM"] = "0"
-    try:
-        plain = Context(0)
-    finally:
-        del os.environ["BSC_LDA_STREAM"]
+    plain = Context(0, options=dict(lda_stream=0))
     rs = np.random.RandomState(docs + V + K)
     C = rs.poisson(0.3, (docs, V)).astype(np.float32)
     Th = (rs.rand(docs, K) + 0.05).astype(np.float32)

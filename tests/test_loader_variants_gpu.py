@@ -1,7 +1,7 @@
 """The uniform-base ("fast") loaders against the general ones they replace for interior tiles.
 
-A context reads its tuning knobs from the environment when it is created, so two contexts in one
-process give both code paths on the same device buffers.  The GEMM variants do the same arithmetic
+Kernel selection is a property of the context (bsc_ctx_set_option), so two contexts in one process give
+both code paths on the same device buffers.  The GEMM variants do the same arithmetic
 in the same order: their results must be bit-identical.  The sparse LDA variants differ in the
 division (v_rcp_f32 vs IEEE): 1e-6 relative."""
 import os
@@ -13,19 +13,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _context_with(monkeypatch, **env):
+def _context_with(monkeypatch, **options):
     from bayesic_amd.device import Context
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    return Context(0)
+    return Context(0, options={k: int(v) for k, v in options.items()})
 
 
 @pytest.mark.parametrize("m,n,k,a_m_contig", [(512, 384, 1024, False), (512, 384, 1024, True),
                                               (300, 260, 777, False), (1024, 256, 4096, True)])
 def test_gemm_fast_loader_is_bit_identical(monkeypatch, m, n, k, a_m_contig):
     import torch
-    fast = _context_with(monkeypatch, BSC_GEMM_FAST="1")
-    slow = _context_with(monkeypatch, BSC_GEMM_FAST="0")
+    fast = _context_with(monkeypatch, gemm_fast=1)
+    slow = _context_with(monkeypatch, gemm_fast=0)
     g = torch.Generator(device=fast.device).manual_seed(m + n + k)
     if a_m_contig:
         A = torch.randn((k, m), generator=g, device=fast.device)       # stored [k][m]
@@ -48,8 +46,8 @@ def test_gemm_fast_loader_is_bit_identical(monkeypatch, m, n, k, a_m_contig):
 def test_sparse_lda_fast_gathers_match_the_general_path(monkeypatch):
     import scipy.sparse as sp
     import torch
-    fast = _context_with(monkeypatch, BSC_CSC_FAST="1")
-    slow = _context_with(monkeypatch, BSC_CSC_FAST="0")
+    fast = _context_with(monkeypatch, csc_fast=1)
+    slow = _context_with(monkeypatch, csc_fast=0)
     rs = np.random.RandomState(12)
     docs, V, K = 700, 1500, 128
     C = rs.poisson(0.08, (docs, V)).astype(np.float32)
@@ -72,10 +70,11 @@ def test_sparse_lda_fast_gathers_match_the_general_path(monkeypatch):
 
 
 def test_pass_packed_backward_gives_the_same_bits(monkeypatch):
-    """BSC_BLR_PK: v_pk_fma_f32 is two fused multiply-adds -- the statistics must not change."""
+    """Option blr_pk (the register-fed MFMA pass, blr_q = blr_dma = 0): v_pk_fma_f32 is two fused multiply-adds --
+    the statistics must not change."""
     import torch
-    pk = _context_with(monkeypatch, BSC_BLR_PK="1")
-    scalar = _context_with(monkeypatch, BSC_BLR_PK="0")
+    pk = _context_with(monkeypatch, blr_q=0, blr_dma=0, blr_pk=1)
+    scalar = _context_with(monkeypatch, blr_q=0, blr_dma=0, blr_pk=0)
     g = torch.Generator(device=pk.device).manual_seed(5)
     B, D, S = 50_000, 256, 8
     X = torch.randn((B, D), generator=g, device=pk.device)

@@ -18,10 +18,11 @@ from bayesic_amd.device import Context
 def main():
     which = sys.argv[1]
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-    if which == "cfg3l2":             # config 3's E-step with X through the default cache policy (BSC_MOG_NT=0)
-        os.environ["BSC_MOG_NT"] = "0"
+    options = {}
+    if which == "cfg3l2":             # config 3's E-step with X through the default cache policy (option mog_nt = 0)
+        options["mog_nt"] = 0
         which = "cfg3"
-    ctx = Context(0)
+    ctx = Context(0, options=options)
     dev = ctx.device
     g = torch.Generator(device=dev).manual_seed(0)
     ctx.reserve(64 << 20)
