@@ -427,7 +427,11 @@ __global__ __launch_bounds__(256) void gram_bx_reduce_kernel(const double* __res
 int bsc_gram_split(bsc_ctx* ctx, const float* X, int64_t ldx, int64_t N, int64_t D, float* C, int64_t sc_m, int64_t sc_n,
                    float scale, int* handled) {
     *handled = 0;
-    if (D < 32 || D > 256 || D % 32 != 0 || N < 4096 || ldx % 4 != 0 || (((uintptr_t)X) & 15) != 0) return BSC_OK;
+    // (the kernels address a step's rows through 32-bit byte offsets, row * ldx * 4 with row < 32: a leading dimension of
+    // 2^25 floats or more would wrap them -- such a view is declined here and takes the general product)
+    if (D < 32 || D > 256 || D % 32 != 0 || N < 4096 || ldx % 4 != 0 || ldx < D || ldx >= ((int64_t)1 << 25) ||
+        (((uintptr_t)X) & 15) != 0)
+        return BSC_OK;
     const int DB = (int)(D / 32), NB = DB * (DB + 1) / 2;
     const int64_t steps = (N + 31) / 32;
     int64_t n_wg = (DB == 8 ? 1 : 2) * (int64_t)ctx->cu_count;

@@ -86,8 +86,11 @@ class ScoreFunctionVI(object):
         if route not in ("auto", "general", "fused"):
             raise ValueError("route must be 'auto', 'general' or 'fused'")
         self.route, self.plan = "general", None
+        self.route_reason = None        # why route="auto" did not take the fused route (None: it did, or was not asked)
         if route != "general":
-            why = self._try_fused_route(log_joint)
+            from .recognise import guarded_route
+            why = guarded_route(lambda: self._try_fused_route(log_joint), strict=route == "fused")
+            self.route_reason = why
             if why is not None and route == "fused":
                 raise ValueError("route='fused': %s" % why)
 
@@ -96,9 +99,11 @@ class ScoreFunctionVI(object):
         import torch
         from . import recognise
         shapes = {n: tuple(int(k) for k in v.shape) for n, v in self._data.items()}
-        plan = recognise.logistic_hierarchy(log_joint, self.latents, shapes, self.S)
+        said = []
+        plan = recognise.logistic_hierarchy(log_joint, self.latents, shapes, self.S, why=said)
         if plan is None:
-            return "the log-joint is not config 5's hierarchical logistic regression in any parameterisation"
+            return ("the log-joint is not config 5's hierarchical logistic regression in any parameterisation: %s"
+                    % (said[-1] if said else "no reason recorded"))
         self.plan = plan
         X, y, Gm = self._data[plan.X], self._data[plan.y], self._data[plan.onehot]
         if not all(isinstance(t, torch.Tensor) and t.dtype == torch.float32 for t in (X, y, Gm)):
@@ -181,13 +186,14 @@ class ScoreFunctionVI(object):
 
     def set_data(self, **arrays):
         """Replace data inputs (the next mini-batch; write the data term times N / B)."""
-        for name, value in arrays.items():
-            if name not in self._types or name in {v.name for v, _ in self.latents}:
-                raise TypeError("%s is not a data input of the log-joint" % name)
-            self._data[name] = self.backend.from_host(value, *self._types[name])
-        if self._fused is not None:
+        if self._fused is not None:         # (before anything is touched: the engine stays as it was)
             raise NotImplementedError("set_data on the fused route: build a new engine for another mini-batch "
                                       "(the one-hot group matrix is converted to an index vector at construction)")
+        for name in arrays:
+            if name not in self._types or name in {v.name for v, _ in self.latents}:
+                raise TypeError("%s is not a data input of the log-joint" % name)
+        for name, value in arrays.items():
+            self._data[name] = self.backend.from_host(value, *self._types[name])
 
     def draw(self, step):
         """eps [S, P] for Philox step `step` (device draw, downloaded: parameter-sized)."""

@@ -73,8 +73,11 @@ class DiagonalMixtureVMP(object):
         if route not in ("auto", "derived", "fused"):
             raise ValueError("route must be 'auto', 'derived' or 'fused'")
         self.route, self._fused = "derived", None
+        self.route_reason = None        # why route="auto" stayed on the derived route (None: it did not, or was not asked)
         if route != "derived":
-            why = self._try_fused_route(lj, Z, pi, (TM, TM2, LT, T), init)
+            from .recognise import guarded_route
+            why = guarded_route(lambda: self._try_fused_route(lj, Z, pi, (TM, TM2, LT, T), init), strict=route == "fused")
+            self.route_reason = why
             if why is not None and route == "fused":
                 raise ValueError("route='fused': %s" % why)
 
@@ -87,9 +90,11 @@ class DiagonalMixtureVMP(object):
         X = self.vmp._data["X"]
         if not (isinstance(X, torch.Tensor) and X.dtype == torch.float32 and X.stride(1) == 1):
             return "the fused E-step streams row-major float32 data"
-        eta0 = recognise.diagonal_mixture(lj, Z, pi, ng_vars, "X", self.K, self.D, self.scale)
+        said = []
+        eta0 = recognise.diagonal_mixture(lj, Z, pi, ng_vars, "X", self.K, self.D, self.scale, why=said)
         if eta0 is None:
-            return "the derived update rules are not those of a diagonal Gaussian mixture with Dirichlet / Normal-Gamma factors"
+            return ("the derived update rules are not those of a diagonal Gaussian mixture with Dirichlet / Normal-Gamma "
+                    "factors: %s" % (said[-1] if said else "no reason recorded"))
         from ..svi.mog import MoGNatGradSVI
         alpha, m, kappa, a, b = (np.asarray(v, np.float64) for v in init)
         shape = (self.K, self.D)

@@ -31,6 +31,37 @@ from .conjugacy import _carried_axes, expand_terms
 
 _PROBE = ParameterBackend()
 
+# What "this is not the model I compute" looks like when it surfaces as an exception: a term that is not linear in a
+# statistic (conjugacy.NotConjugate, a ValueError), shapes that do not fit, an input the probe cannot evaluate, a fit
+# that divides by zero.  ANYTHING ELSE raised inside a recogniser is a bug in the recogniser or in the derived-update
+# code beneath it and propagates: the engines turn it into a RuntimeWarning under route="auto" (the model still runs,
+# on the general route, and says why) and re-raise it under route="fused".
+NOT_THIS_MODEL = (ValueError, KeyError, TypeError, IndexError, ZeroDivisionError, FloatingPointError, np.linalg.LinAlgError)
+
+
+def guarded_route(try_route, strict):
+    """Run an engine's ``_try_fused_route`` (returns None = routed, or the reason it was not).  A recogniser declines by
+    returning; an exception out of it is a bug.  ``strict`` (route="fused"): it propagates.  Otherwise (route="auto")
+    the model still runs on its general route, but not silently: a RuntimeWarning names the exception, and the
+    engine's ``route_reason`` keeps it."""
+    if strict:
+        return try_route()
+    try:
+        return try_route()
+    except Exception as e:      # noqa: BLE001 -- reported (warning + route_reason), not swallowed
+        import warnings
+        reason = "recognition FAILED with %s: %s -- a bug, not a verdict on the model" % (type(e).__name__, e)
+        warnings.warn("bayesic_amd: route='auto' falls back to the general route because %s" % reason, RuntimeWarning,
+                      stacklevel=3)
+        return reason
+
+
+def _say(why, message):
+    """Record why a recogniser declined (``why``: a list the caller passed, or None)."""
+    if why is not None:
+        why.append(message)
+    return None
+
 
 # ---- small tree utilities ------------------------------------------------------------------------
 
@@ -170,26 +201,33 @@ def _evaluate(expr, latents, S, rng, extra=None):
     return np.asarray(_PROBE.evaluate(expr, inputs), np.float64), inputs
 
 
-def gaussian_linear(log_joint, latents, data_shapes, n_samples):
+def gaussian_linear(log_joint, latents, data_shapes, n_samples, why=None):
     """``log_joint``: expression of ndim 1 (one value per draw); ``latents``: [(var [S, size], size)];
     ``data_shapes``: {data input name: shape}.  Returns a ``GaussianLinear`` or None -- None means "not
-    this structure", never an error: the caller then evaluates the expression as written."""
-    latent_names = {v.name for v, _ in latents}
+    this structure": the caller then evaluates the expression as written, and ``why`` (a list, optional)
+    receives the reason.  Exceptions outside ``NOT_THIS_MODEL`` are bugs and propagate."""
+    try:
+        return _gaussian_linear(log_joint, latents, data_shapes, n_samples, why)
+    except NOT_THIS_MODEL as e:
+        return _say(why, "%s while reading the log-joint: %s" % (type(e).__name__, e))
+
+
+def _gaussian_linear(log_joint, latents, data_shapes, n_samples, why):
     shapes = dict(data_shapes)
     shapes.update({v.name: (n_samples, n) for v, n in latents})
-    try:
-        # (distributing over an add can introduce extents of its own -- shape nodes -- for summands that
-        # were broadcast inside it: resolved again afterwards)
-        terms = [_without_shapes(t, shapes) for t in expand_terms(normalise(log_joint, shapes))]
-    except (ValueError, KeyError, TypeError):
-        return None
+    # (distributing over an add can introduce extents of its own -- shape nodes -- for summands that
+    # were broadcast inside it: resolved again afterwards)
+    terms = [_without_shapes(t, shapes) for t in expand_terms(normalise(log_joint, shapes))]
     data_names = set(data_shapes)
     data_terms = [t for t in terms if _names(t) & data_names]
     rest = [t for t in terms if not (_names(t) & data_names)]
-    if not data_terms or any(t.ndim != 1 for t in terms):
-        return None
+    if not data_terms:
+        return _say(why, "no term of the log-joint mentions a data input")
+    if any(t.ndim != 1 for t in terms):
+        return _say(why, "a term of the expanded log-joint is not one value per draw (ndim 1)")
     types = log_joint.input_types
     rng = np.random.RandomState(20240)
+    reason = "no (matrix [N, D], vector [N], latent [S, D]) triple among the inputs"
     for Xn in sorted(n for n in data_names if types.get(n, (None, 0))[1] == 2):
         for yn in sorted(n for n in data_names if types.get(n, (None, 0))[1] == 1
                          and data_shapes[n][0] == data_shapes[Xn][0]):
@@ -207,9 +245,14 @@ def gaussian_linear(log_joint, latents, data_shapes, n_samples):
                             found[which].append(c)
                             break
                     else:
+                        reason = ("the data term %r is none of sum_nd y X W, sum_nde X W X W, sum_n y^2 times a "
+                                  "parameter-sized coefficient (X = %s, y = %s, W = %s)" % (term, Xn, yn, Wv.name))
                         break
                 else:
                     if not all(found):
+                        names = ("sum_nd y_n X_nd W_sd", "sum_nde X_nd W_sd X_ne W_se", "sum_n y_n^2")
+                        reason = "the log-joint has no term in %s (X = %s, y = %s, W = %s)" % (
+                            ", ".join(n for n, f in zip(names, found) if not f), Xn, yn, Wv.name)
                         continue
                     c1, c2, c3 = (cs[0] if len(cs) == 1 else add(*cs) for cs in found)
                     others = [(v, n) for v, n in latents if v.name != Wv.name]
@@ -223,11 +266,13 @@ def gaussian_linear(log_joint, latents, data_shapes, n_samples):
                                 and np.all(v2 <= 0.0)):
                             ok = False
                     if not ok:
+                        reason = ("the coefficients of the three data contractions do not stand in the ratio -2 : 1 : 1 "
+                                  "with a negative quadratic one: not a multiple of sum_n (y_n - x_n . w_s)^2")
                         continue
                     plan = GaussianLinear(Xn, yn, Wv.name, c2, rest)
                     plan.family = _fit_family(plan, Wv, width, others, rng)
                     return plan
-    return None
+    return _say(why, reason)
 
 
 def _fit_family(plan, Wv, D, others, rng):
@@ -285,7 +330,7 @@ def _mog_message_fused(R, X, K, D):
     return np.concatenate([Rk, (R.T @ X).ravel(), Rkd.ravel(), Rkd.ravel(), (R.T @ (X * X)).ravel()])
 
 
-def diagonal_mixture(log_joint, Z, pi, ng_vars, X_name, K, D, scale, dtype="float64"):
+def diagonal_mixture(log_joint, Z, pi, ng_vars, X_name, K, D, scale, dtype="float64", why=None):
     """Is the mean-field update DERIVED from ``log_joint`` (conjugacy.conjugate_coefficients: every message a
     coefficient ``match`` pulled out of a term) the update csrc/bsc_mog.hip computes -- a Categorical local
     latent ``Z`` [N, K] whose logits are E[log pi_k] + sum_d (E[tau mu] x - E[tau] x^2 / 2 + E[log tau] / 2 -
@@ -320,7 +365,7 @@ def diagonal_mixture(log_joint, Z, pi, ng_vars, X_name, K, D, scale, dtype="floa
             if eta0 is None:
                 eta0 = prior
             elif not np.allclose(prior, eta0, rtol=1e-9, atol=1e-9):
-                return None                 # not "prior + scale * statistics" with a fixed prior
+                return _say(why, "the global factors' messages are not a fixed prior + %g * [sum r | R^T X | R^T X^2]" % scale)
             # the local latent's logits (up to a constant per row, which the softmax does not see)
             (logits,) = vmp.message(Z.name)
             T = a / b
@@ -330,12 +375,13 @@ def diagonal_mixture(log_joint, Z, pi, ng_vars, X_name, K, D, scale, dtype="floa
             d1 = logits - logits[:, :1]
             d2 = want - want[:, :1]
             if not np.allclose(d1, d2, rtol=1e-9, atol=1e-9 * np.abs(d2).max()):
-                return None
-    except Exception:       # not conjugate, other node types, shapes that do not fit ...: not this model
-        return None
+                return _say(why, "the assignments' logits are not E[log pi_k] + sum_d (E[tau mu] x - E[tau] x^2 / 2 + "
+                                 "E[log tau] / 2 - E[tau mu^2] / 2) times %g" % scale)
+    except NOT_THIS_MODEL as e:       # not conjugate, other node types, shapes that do not fit ...: not this model
+        return _say(why, "%s while deriving the update rules: %s" % (type(e).__name__, e))
     kappa0 = eta0[K + K * D:K + 2 * K * D]
     if not (np.all(kappa0 > 0.0) and np.all(eta0[:K] > -1.0)):
-        return None
+        return _say(why, "the recovered prior is improper (kappa0 <= 0 or alpha0 <= 0)")
     return eta0
 
 
@@ -352,22 +398,23 @@ class LogisticHierarchy(object):
         self.scale, self.a0, self.b0, self.offset = scale, a0, b0, offset
 
 
-def logistic_hierarchy(log_joint, latents, data_shapes, n_samples):
+def logistic_hierarchy(log_joint, latents, data_shapes, n_samples, why=None):
     """Identity testing by evaluation on a seven-row instance (host float64): the log-joint must be the closed
     form above for SOME (scale, a0, b0, offset), whatever way it was written.  Returns a ``LogisticHierarchy``
     or None."""
     import math
     types = log_joint.input_types
     if len(latents) != 3:
-        return None
+        return _say(why, "config 5 has three latent blocks (weights, group intercepts, log precision); got %d" % len(latents))
     # explicit extents (a log-normaliser times the number of rows) keep the REAL data's value; the sums over the
     # rows are then taken over the instance's rows
     shapes = dict(data_shapes)
     shapes.update({v.name: (n_samples, size) for v, size in latents})
     try:
         log_joint = _without_shapes(log_joint, shapes)
-    except (ValueError, KeyError):
-        return None
+    except NOT_THIS_MODEL as e:
+        return _say(why, "%s while resolving the extents of the log-joint: %s" % (type(e).__name__, e))
+    reason = "no (design matrix [N, D], one-hot group matrix [N, G], targets [N]) triple whose widths match the latents"
     two_d = [n for n in data_shapes if types.get(n, (None, 0))[1] == 2]
     one_d = [n for n in data_shapes if types.get(n, (None, 0))[1] == 1]
     rng = np.random.RandomState(31)
@@ -412,6 +459,8 @@ def logistic_hierarchy(log_joint, latents, data_shapes, n_samples):
                     scale_s = (F(d1, w, b, zeta) - F(d2, w, b, zeta)) / de
                     scale = float(scale_s[0])
                     if not (np.isfinite(scale) and scale > 0 and np.allclose(scale_s, scale, rtol=1e-9)):
+                        reason = ("the data do not enter as scale * sum_n [y_n l_ns - softplus(l_ns)], l = X w + b[group] "
+                                  "(X = %s, groups = %s, y = %s)" % (Xn, Gn, yn))
                         continue
                     zero_w, zero_b = np.zeros((1, D)), np.zeros((1, G))
                     r = lambda zt: (F(d1, zero_w, zero_b, np.array([zt])) - scale * ell(d1, zero_w, zero_b))[0]
@@ -423,6 +472,7 @@ def logistic_hierarchy(log_joint, latents, data_shapes, n_samples):
                     a0 = slope - 0.5 * G
                     c = r0 + b0
                     if not (a0 > 0 and b0 > 0 and np.isfinite(c)):
+                        reason = "the log-precision's terms are not those of a Gamma(a0, b0) prior with a0, b0 > 0"
                         continue
                     const = -0.5 * (D + G) * math.log(2 * math.pi) + a0 * math.log(b0) - math.lgamma(a0)
                     ok = True
@@ -436,6 +486,9 @@ def logistic_hierarchy(log_joint, latents, data_shapes, n_samples):
                     if ok:
                         return LogisticHierarchy(Xn, yn, Gn, Wv.name, Bv.name, Zv.name, scale, float(a0), float(b0),
                                                  float(c - const))
-                except Exception:
+                    reason = ("the parameter-sized part is not log N(w | 0, I) + sum_g log N(b_g | 0, e^{-zeta}) + "
+                              "log Gamma(e^{zeta} | a0, b0) + zeta (checked at random points)")
+                except NOT_THIS_MODEL as e:
+                    reason = "%s while evaluating the log-joint on a seven-row instance: %s" % (type(e).__name__, e)
                     continue
-    return None
+    return _say(why, reason)

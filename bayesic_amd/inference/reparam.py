@@ -49,6 +49,25 @@ from ..algebra.autodiff import value_and_grad
 _LOG_2PI = math.log(2.0 * math.pi)
 
 
+def _outside_pass_envelope(X, y, D, S):
+    """None, or why bsc_blr_data_pass would refuse these operands -- the checks of check_pass_args
+    (csrc/bsc_blr.hip) restated, so that route="auto" falls back to the general route instead of raising at
+    the first step."""
+    if D > 256 or S > 64:
+        return "outside the fused pass's envelope (D <= 256, S <= 64)"
+    if D < 4 or D % 4:
+        return "outside the fused pass's envelope (D = %d is not a multiple of 4)" % D
+    if X.dim() != 2 or X.stride(1) != 1 or (X.shape[0] > 1 and (X.stride(0) < D or X.stride(0) % 4)):
+        return "outside the fused pass's envelope (row-major X with a leading dimension >= D that is a multiple of 4)"
+    if X.shape[0] > 1 and X.stride(0) >= 1 << 26:
+        return "outside the fused pass's envelope (leading dimension of X below 2^26)"
+    if X.data_ptr() % 16:
+        return "outside the fused pass's envelope (X 16-byte aligned)"
+    if y.dim() != 1 or (y.shape[0] > 1 and y.stride(0) != 1):
+        return "outside the fused pass's envelope (contiguous y)"
+    return None
+
+
 class ReparamVI(object):
     """log_joint : expression of ndim 1 (one value per Monte-Carlo sample, mini-batch scaling
                    included) over data inputs and the latent vars
@@ -111,9 +130,12 @@ class ReparamVI(object):
         if route not in ("auto", "general", "fused"):
             raise ValueError("route must be 'auto', 'general' or 'fused'")
         self.route = "general"
+        self.route_reason = None        # why route="auto" did not take a fused route (None: it did, or was not asked)
         self.plan = None
         if route != "general":
-            why = self._try_fused_route()
+            from .recognise import guarded_route
+            why = guarded_route(self._try_fused_route, strict=route == "fused")
+            self.route_reason = why
             if why is not None and route == "fused":
                 raise ValueError("route='fused': %s" % why)
         self._resident = None
@@ -208,17 +230,21 @@ class ReparamVI(object):
         if not hasattr(self.backend, "ctx"):
             return "the fused kernels run on the MI355X backend"
         shapes = {n: tuple(int(k) for k in v.shape) for n, v in self._data.items()}
-        plan = recognise.gaussian_linear(self.log_joint, self.latents, shapes, self.S)
+        said = []
+        plan = recognise.gaussian_linear(self.log_joint, self.latents, shapes, self.S, why=said)
         if plan is None:
-            return "the data do not enter the log-joint as coefficient_s * sum_n (y_n - x_n . w_s)^2"
+            return ("the data do not enter the log-joint as coefficient_s * sum_n (y_n - x_n . w_s)^2: %s"
+                    % (said[-1] if said else "no reason recorded"))
         self.plan = plan
         import torch
         X, y = self._data[plan.X], self._data[plan.y]
         D = int(X.shape[1])
         if not (isinstance(X, torch.Tensor) and X.dtype == torch.float32 and y.dtype == torch.float32):
             return "the fused pass streams float32 data"
-        if D > 256 or self.S > 64 or X.stride(1) != 1:
-            return "outside the fused pass's envelope (D <= 256, S <= 64, row-major X)"
+        why = _outside_pass_envelope(X, y, D, self.S)
+        if why is not None:
+            return why
+        self._planned_shape = (int(X.shape[0]), D)
         if plan.family is None:
             # the pass route: data term by the fused pass, the rest by the executor (module docstring)
             self._pass_plan = plan
@@ -311,16 +337,29 @@ class ReparamVI(object):
 
     def set_data(self, **arrays):
         """Replace data inputs (the next mini-batch; write the data term times N / B)."""
-        for name, value in arrays.items():
+        for name in arrays:
             if name not in self._types or name in {v.name for v, _ in self.latents}:
                 raise TypeError("%s is not a data input of the log-joint" % name)
+        previous = {name: self._data[name] for name in arrays if name in self._data}
+        for name, value in arrays.items():
             self._data[name] = self.backend.from_host(value, *self._types[name])     # (a new buffer: a recorded graph is dropped)
-        if self._fused is not None:
+        if self._fused is not None or self._pass_plan is not None:
+            # fused route AND pass route: every shape(X, 0) of the log-joint was resolved to a constant when the model
+            # was recognised (recognise.normalise), so another row count would keep the old N in the normaliser terms
             X, y = self._data[self.plan.X], self._data[self.plan.y]
-            if tuple(X.shape) != (self._fused.B, self._fused.D):
-                raise ValueError("the fused route was planned for mini-batches of %d x %d rows (the mini-batch "
-                                 "extent is part of the recognised coefficients)" % (self._fused.B, self._fused.D))
-            self._fused.set_batch(X, y)
+            if tuple(X.shape) != self._planned_shape or tuple(y.shape) != (self._planned_shape[0],):
+                for name, value in previous.items():
+                    self._data[name] = value
+                raise ValueError("the %s route was planned for mini-batches of %d x %d (the mini-batch extent is part of "
+                                 "the recognised coefficients); build a new engine for another batch size"
+                                 % (("fused" if self._fused is not None else "pass",) + self._planned_shape))
+            why = _outside_pass_envelope(X, y, self._planned_shape[1], self.S)
+            if why is not None:
+                for name, value in previous.items():
+                    self._data[name] = value
+                raise ValueError("set_data: " + why)
+            if self._fused is not None:
+                self._fused.set_batch(X, y)
 
     def draw(self, step):
         if self._noise is not None:

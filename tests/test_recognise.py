@@ -168,3 +168,82 @@ def test_hierarchical_logistic_regression_is_recognised_with_its_hyperparameters
     assert R.logistic_hierarchy(other, latents, shapes, S5) is None
     flat = scale * loglik + A.sum(W * W, axis=1) * (-0.5) + A.sum(Bg * Bg, axis=1) * (-0.5) + a0 * zeta - b0 * tau
     assert R.logistic_hierarchy(flat, latents, shapes, S5) is None
+
+
+# ---- recognition is observable: every "no" comes with its reason, and a bug is not a "no" ------------------------------
+
+def test_every_recogniser_says_why_it_declined():
+    X, y, W, xi = A.var("X", 2), A.var("y", 1), A.var("W", 2), A.var("xi", 2)
+    logits = A.dot(W, X.T)
+    yb = A.dimshuffle(y, "x", 0)
+    # one term away from config 2: the cross term with the wrong weight
+    why = []
+    r2 = A.sum(yb * yb, axis=1) - A.sum(yb * logits, axis=1) * 1.5 + A.sum(logits * logits, axis=1)
+    assert R.gaussian_linear(r2 * (-0.5) + A.sum(W * W, axis=1) * (-0.5), [(W, D)], SHAPES, S, why=why) is None
+    assert "ratio -2 : 1 : 1" in why[-1]
+    # a Bernoulli-logit likelihood: a data term that is none of the three contractions
+    why = []
+    bern = A.sum(yb * logits - A.log(1.0 + A.exp(logits)), axis=1) + A.sum(W * W, axis=1) * (-0.5)
+    assert R.gaussian_linear(bern, [(W, D)], SHAPES, S, why=why) is None
+    assert "none of sum_nd y X W" in why[-1]
+    # no data at all
+    why = []
+    assert R.gaussian_linear(A.sum(W * W, axis=1) * (-0.5), [(W, D)], SHAPES, S, why=why) is None
+    assert "no term of the log-joint mentions a data input" in why[-1]
+
+    from bayesic_amd.inference.mixture import diagonal_mixture_log_joint
+    K, Dm, scale = 4, 3, 2.0
+    Xm, Z, pi, ng = _mixture_vars()
+    lj = diagonal_mixture_log_joint(Xm, Z, pi, *ng, scale, 1.0, 0.0, 0.01, 1.0, 1.0)
+    why = []
+    assert R.diagonal_mixture(lj, Z, pi, ng, "X", K, Dm, 3.0, why=why) is None        # told another scale
+    assert "fixed prior" in why[-1] or "logits" in why[-1]
+    why = []
+    odd = lj + A.sum(Z * A.dot(Xm * Xm * Xm, ng[0].T)) * 0.01
+    assert R.diagonal_mixture(odd, Z, pi, ng, "X", K, Dm, scale, why=why) is None
+    assert why and ("logits" in why[-1] or "prior" in why[-1] or "deriving" in why[-1])
+
+    N5, D5, G5, S5 = 300, 8, 5, 4
+    Xv, yv, Gm = A.var("X", 2), A.var("y", 1), A.var("Gm", 2)
+    Wl, Bg, Zl = A.var("W", 2), A.var("Bg", 2), A.var("Z", 2)
+    L = A.dot(Xv, Wl.T) + A.dot(Gm, Bg.T)
+    zeta = A.sum(Zl, axis=1)
+    tau = A.exp(zeta)
+    shapes = {"X": (N5, D5), "y": (N5,), "Gm": (N5, G5)}
+    latents = [(Wl, D5), (Bg, G5), (Zl, 1)]
+    prior = A.sum(Wl * Wl, axis=1) * (-0.5) + zeta * (0.5 * G5) - 0.5 * (tau * A.sum(Bg * Bg, axis=1)) + 1.5 * zeta - 0.7 * tau
+    why = []
+    other = A.sum(A.dimshuffle(yv, 0, "x") * L - A.log(1 + A.exp(L * 2.0)), axis=0) * 10.0 + prior      # another link
+    assert R.logistic_hierarchy(other, latents, shapes, S5, why=why) is None
+    assert "softplus" in why[-1]
+    why = []
+    assert R.logistic_hierarchy(prior, latents[:2], shapes, S5, why=why) is None
+    assert "three latent blocks" in why[-1]
+
+
+def test_a_bug_inside_a_recogniser_is_not_a_verdict_on_the_model(monkeypatch):
+    """recognise.NOT_THIS_MODEL lists what "not this model" may look like as an exception; anything else propagates
+    out of the recogniser, and ``guarded_route`` turns it into a RuntimeWarning + reason (route="auto") or lets it
+    through (route="fused")."""
+    lj, v = linear_regression_log_joint(1.0, 1.0, 1.0)
+    latents = [(v["W"], D), (v["xi"], 1)]
+
+    def broken(*a, **k):
+        raise AttributeError("'NoneType' object has no attribute 'factors_and_indices'")
+    monkeypatch.setattr(R, "_coefficient", broken)
+    with pytest.raises(AttributeError):
+        R.gaussian_linear(lj, latents, SHAPES, S)
+
+    def try_route():
+        R.gaussian_linear(lj, latents, SHAPES, S)
+        return None
+    with pytest.warns(RuntimeWarning, match="recognition FAILED with AttributeError"):
+        reason = R.guarded_route(try_route, strict=False)
+    assert "a bug, not a verdict on the model" in reason
+    with pytest.raises(AttributeError):
+        R.guarded_route(try_route, strict=True)
+    # a declining recogniser is no warning
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert R.guarded_route(lambda: "not this model", strict=False) == "not this model"

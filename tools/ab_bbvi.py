@@ -4,6 +4,7 @@ S = 64): interleaved bursts after a time-based warm-up, kernel time from hipEven
     python tools/ab_bbvi.py [rounds]
 """
 import os
+os.environ.setdefault("BSC_PROFILING_BUILDS", "1")   # the Context honours BSC_<OPTION> variables only in a process that opts in (device.py)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

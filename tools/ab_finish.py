@@ -5,6 +5,7 @@ the context stream and the finish kernel's own duration from timing slot 2.
     python tools/ab_finish.py [rounds]
 """
 import os
+os.environ.setdefault("BSC_PROFILING_BUILDS", "1")   # the Context honours BSC_<OPTION> variables only in a process that opts in (device.py)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -5,6 +5,7 @@ split-K product counts its reduce), and the two variants' results compared.
     python tools/ab_gemm.py [KNOB [VALUE_A VALUE_B]] [--quick]
 """
 import os, sys
+os.environ.setdefault("BSC_PROFILING_BUILDS", "1")   # the Context honours BSC_<OPTION> variables only in a process that opts in (device.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
