@@ -63,6 +63,123 @@ void oracle_blr_data_pass(const float* X, long ldx, const float* y, long B, int 
     free(part);
 }
 
+/* The same statistics as ONE fused float32 pass, the way a host implementation that wanted to be fast would write
+ * them (bench.py's cpu_baseline.fused_f32: the honest host figure beside the numpy / BLAS leg and the float64 scalar
+ * leg above).  Every thread streams its row block once; per row the S dot products and the S rank-1 updates run on
+ * eight-float vectors (AVX2 + FMA: both this container's Xeon and the GPU box's EPYC run it), eight draws' dot products
+ * as eight independent chains, four rows per accumulator update, against accumulators of S x D floats that stay in
+ * the core's L1 (8 KiB at S = 8, D = 256) and are flushed into float64 totals every 256 rows, which keeps the float32
+ * sums as short as the device's per-wave ones.  Same formula, README.md:51; S <= 16, D <= 1024. */
+#define BLR_F32_MAX_S 16
+#define BLR_F32_MAX_D 1024
+typedef float blr_v8 __attribute__((vector_size(32), aligned(4)));   /* eight floats, unaligned loads allowed */
+
+/* Rows [n0, n1) into acc[S][D] (float32) and qa[S]; NS = S as a compile-time constant keeps the NS dot-product
+ * chains in registers.  Four rows at a time: one load and one store of an accumulator vector per four updates. */
+#define BLR_F32_BLOCK(NS)                                                                                   \
+    static inline __attribute__((always_inline, optimize("O3"), target("avx2,fma")))                          \
+    void blr_f32_block_##NS(const float* X, long ldx, const float* y, long n0, long n1, int D, const float* W, \
+                            float* acc, float* qa) {                                                          \
+        const int D8 = D & ~7;                                                                                \
+        long n = n0;                                                                                          \
+        for (; n + 4 <= n1; n += 4) {                                                                         \
+            float r[4][NS];                                                                                   \
+            for (int k = 0; k < 4; ++k) {                                                                     \
+                const float* x = X + (n + k) * ldx;                                                           \
+                blr_v8 dv[NS];                                                                                \
+                for (int s = 0; s < NS; ++s) dv[s] = (blr_v8){0, 0, 0, 0, 0, 0, 0, 0};                        \
+                for (int d = 0; d < D8; d += 8) {                                                             \
+                    const blr_v8 xv = *(const blr_v8*)(x + d);                                                \
+                    for (int s = 0; s < NS; ++s) dv[s] += xv * *(const blr_v8*)(W + (long)s * D + d);         \
+                }                                                                                             \
+                for (int s = 0; s < NS; ++s) {                                                                \
+                    float dot = ((dv[s][0] + dv[s][4]) + (dv[s][1] + dv[s][5])) +                             \
+                                ((dv[s][2] + dv[s][6]) + (dv[s][3] + dv[s][7]));                              \
+                    for (int d = D8; d < D; ++d) dot += x[d] * W[(long)s * D + d];                            \
+                    r[k][s] = y[n + k] - dot;                                                                 \
+                    qa[s] += r[k][s] * r[k][s];                                                               \
+                }                                                                                             \
+            }                                                                                                 \
+            const float *x0 = X + n * ldx, *x1 = x0 + ldx, *x2 = x1 + ldx, *x3 = x2 + ldx;                    \
+            for (int d = 0; d < D8; d += 8) {                                                                 \
+                const blr_v8 a = *(const blr_v8*)(x0 + d), b = *(const blr_v8*)(x1 + d);                      \
+                const blr_v8 c = *(const blr_v8*)(x2 + d), e = *(const blr_v8*)(x3 + d);                      \
+                for (int s = 0; s < NS; ++s) {                                                                \
+                    blr_v8* as = (blr_v8*)(acc + (long)s * D + d);                                            \
+                    *as += (r[0][s] * a + r[1][s] * b) + (r[2][s] * c + r[3][s] * e);                         \
+                }                                                                                             \
+            }                                                                                                 \
+            for (int d = D8; d < D; ++d)                                                                      \
+                for (int s = 0; s < NS; ++s)                                                                  \
+                    acc[(long)s * D + d] += (r[0][s] * x0[d] + r[1][s] * x1[d]) + (r[2][s] * x2[d] + r[3][s] * x3[d]); \
+        }                                                                                                     \
+        for (; n < n1; ++n) {                                                                                 \
+            const float* x = X + n * ldx;                                                                     \
+            for (int s = 0; s < NS; ++s) {                                                                    \
+                float dot = 0.f;                                                                              \
+                for (int d = 0; d < D; ++d) dot += x[d] * W[(long)s * D + d];                                 \
+                const float rr = y[n] - dot;                                                                  \
+                qa[s] += rr * rr;                                                                             \
+                for (int d = 0; d < D; ++d) acc[(long)s * D + d] += rr * x[d];                                \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+BLR_F32_BLOCK(8)
+BLR_F32_BLOCK(1)
+
+__attribute__((optimize("O3"), target("avx2,fma")))
+int oracle_blr_data_pass_f32(const float* X, long ldx, const float* y, long B, int D, const float* W,
+                             int S, double* Q, double* G) {
+    if (S < 1 || S > BLR_F32_MAX_S || D < 1 || D > BLR_F32_MAX_D) return 1;
+    const int nt = omp_get_max_threads();
+    double* part = (double*)calloc((size_t)nt * (S + (size_t)S * D), sizeof(double));
+    if (!part) return 2;
+#pragma omp parallel num_threads(nt)
+    {
+        const int t = omp_get_thread_num();
+        double* q = part + (size_t)t * (S + (size_t)S * D);
+        double* g = q + S;
+        float* acc = (float*)aligned_alloc(64, sizeof(float) * (size_t)BLR_F32_MAX_S * BLR_F32_MAX_D);
+        float qa[BLR_F32_MAX_S];
+        long lo, hi;
+        row_block(B, t, nt, &lo, &hi);
+        for (long n0 = lo; n0 < hi; n0 += 256) {
+            const long n1 = n0 + 256 < hi ? n0 + 256 : hi;
+            memset(acc, 0, sizeof(float) * (size_t)S * D);
+            for (int s = 0; s < S; ++s) qa[s] = 0.f;
+            int s0 = 0;
+            for (; s0 + 8 <= S; s0 += 8) blr_f32_block_8(X, ldx, y, n0, n1, D, W + (long)s0 * D, acc + (long)s0 * D, qa + s0);
+            for (; s0 < S; ++s0) blr_f32_block_1(X, ldx, y, n0, n1, D, W + (long)s0 * D, acc + (long)s0 * D, qa + s0);
+            for (int s = 0; s < S; ++s) q[s] += (double)qa[s];
+            for (long i = 0; i < (long)S * D; ++i) g[i] += (double)acc[i];
+        }
+        free(acc);
+    }
+    memset(Q, 0, sizeof(double) * S);
+    memset(G, 0, sizeof(double) * (size_t)S * D);
+    for (int t = 0; t < nt; ++t) {
+        const double* q = part + (size_t)t * (S + (size_t)S * D);
+        for (int s = 0; s < S; ++s) Q[s] += q[s];
+        for (long i = 0; i < (long)S * D; ++i) G[i] += q[S + i];
+    }
+    free(part);
+    return 0;
+}
+
+/* Copies `rows` rows of `row_bytes` each with the row blocks (and threads) the passes above use.  Into a freshly mapped
+ * destination this is a parallel FIRST TOUCH: every page lands on the NUMA node of the thread that will stream it, which
+ * is how a host implementation that cared would lay a mini-batch out (bench.py's fused_f32 leg times the pass on such a
+ * copy; the numpy legs read the array as numpy allocated it). */
+void oracle_parallel_copy(void* dst, const void* src, long rows, long row_bytes) {
+    const int nt = omp_get_max_threads();
+#pragma omp parallel num_threads(nt)
+    {
+        long lo, hi;
+        row_block(rows, omp_get_thread_num(), nt, &lo, &hi);
+        if (hi > lo) memcpy((char*)dst + lo * row_bytes, (const char*)src + lo * row_bytes, (size_t)(hi - lo) * row_bytes);
+    }
+}
+
 /* Config 5 (README.md:52, BBVI): ell[s] = sum_n [ y_n l_ns - softplus(l_ns) ],
  *   l_ns = x_n . Wz[s] + Bz[g_n, s]   (Bz is [G, S]). */
 void oracle_logreg_loglik(const float* X, long ldx, const float* y, const int* g, long N, int D,
@@ -238,3 +355,12 @@ void oracle_weighted_outer(const float* R, const float* X, const float* Y, long 
 }
 
 int oracle_threads(void) { return omp_get_max_threads(); }
+/* Threads of the passes above from now on (bench.py: the host's CPU SHARE, not its CPU count -- a container that may
+ * use 16 of 256 logical CPUs runs 128 spinning threads far slower than 16). */
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

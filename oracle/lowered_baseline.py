@@ -25,6 +25,11 @@ def host_facts():
     """What SURVEY 8(d) asks to be recorded beside a CPU number."""
     facts = {"cpu_count": os.cpu_count(), "machine": platform.machine(), "numpy": np.__version__}
     try:
+        from . import cbuild
+        facts["cpu_share"] = cbuild.cpu_share()       # affinity cut down to the cgroup's CPU quota: what the legs can use
+    except Exception:
+        pass
+    try:
         out = subprocess.run(["lscpu"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
                              timeout=10).stdout
         for line in out.splitlines():

@@ -254,3 +254,23 @@ def test_cfg4_full_size_elbo_against_c_oracle(ctx, terms):
         # 31 M float32 products)
         npt.assert_allclose(model._ll.item(), words, rtol=3e-6)
         npt.assert_allclose(model.elbo.item(), want, rtol=3e-6)
+
+
+def test_fused_f32_host_leg_agrees_with_the_numpy_oracle():
+    """oracle_blr_data_pass_f32 (bench.py's cpu_baseline.fused_f32: one fused float32 OpenMP pass, AVX2 vectors, float64
+    across threads) restates the same formula (README.md:51): held to the device pass's tolerance against oracle.svi."""
+    from oracle import cbuild, svi
+    for B, D, S in ((4099, 256, 8), (1003, 252, 5), (777, 36, 11), (5, 8, 1), (130_003, 256, 8)):
+        rs = np.random.RandomState(B + D + S)
+        X = rs.standard_normal((B, D)).astype(np.float32)
+        y = rs.standard_normal(B).astype(np.float32)
+        W = (rs.standard_normal((S, D)) / np.sqrt(D)).astype(np.float32)
+        Q, G = cbuild.blr_data_pass_f32(X, y, W)
+        Qr, Gr = svi.blr_data_pass_chunked(X, y, W)
+        np.testing.assert_allclose(Q, Qr, rtol=2e-5)
+        bound = np.sqrt(Qr)[:, None] * np.sqrt((X.astype(np.float64) ** 2).sum(axis=0))[None, :]
+        assert (np.abs(G - Gr) <= 2e-5 * bound + 1e-12).all()
+        Xc = cbuild.first_touch_copy(X)
+        assert Xc is not X and np.array_equal(Xc, X)
+    with pytest.raises(ValueError, match="envelope"):
+        cbuild.blr_data_pass_f32(np.zeros((4, 8), np.float32), np.zeros(4, np.float32), np.zeros((17, 8), np.float32))
