@@ -42,6 +42,11 @@ SIGNATURES = {
     "bsc_comm_info": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
     "bsc_allreduce_sum": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
     "bsc_allreduce_max": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
+    "bsc_allreduce_sum_begin": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int32]),
+    "bsc_allreduce_sum_end": (c_int, [c_void_p, c_int32]),
+    "bsc_natgrad_update_f32_2d": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_int64, c_int64, c_int64,
+                                          c_float, c_float, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "bsc_lda_sstats_round_columns": (c_int, [c_void_p, c_int32, POINTER(c_int64)]),
     "bsc_device_info": (c_int, [c_void_p, POINTER(c_int64)]),
     "bsc_last_error": (c_char_p, []),
     "bsc_version": (c_int, []),

@@ -252,6 +252,8 @@ class DeviceBackend(Backend):
         self._const_ptrs = {}     # single tensors under the same promise (mark_constant_tensor): address -> tensor
         self._wide = {}           # (ptr, columns, row stride) of a constituent -> (key of its wide operand, column offset)
         self._const_cache = {}    # element-wise values of constants only: computed once, LRU by bytes
+        self._const_gen = 0       # bumped whenever a constant is withdrawn: recorded call lists (replay_call) are then stale
+        self._replays = {}        # key -> recorded C-ABI call list (replay_call)
         self._const_bytes = 0
         self._graphs = {}         # graph_call: key -> recorded hipGraph
         self.ctx = ctx if ctx is not None else default_context()
@@ -336,6 +338,43 @@ class DeviceBackend(Backend):
 
     _CONST_CACHE_BYTES = 8 << 30
 
+    def replay_call(self, key, fn, inputs):
+        """``graph_call`` without a graph: the third call under a ``key`` runs ``fn()`` once more with every C-ABI call
+        RECORDED (``Context.record_begin``: bound function + raw arguments) and every intermediate a fresh allocation
+        owned by the recording; later calls re-issue that list (``Context.replay``) while the inputs keep their
+        addresses, shapes and strides.  What it removes is the host-side walk of the expression -- ~28 us of Python per
+        launch, the whole gap between the general engines and their kernels on short launches -- and what it needs is
+        less than a capture does: no stream of the context's own, nothing that cannot be captured to avoid.  What it does
+        NOT do is what a graph does on the device (one submission, ~1.2 us between kernels): each launch is still an
+        eager one.  Contract as for ``graph_call``: ``fn`` reads ``inputs`` (refreshed in place by the caller), contains
+        no host read-back, and returns device tensors that belong to the recording -- consume them before the next call."""
+        entry = self._replays.get(key)
+        sig = tuple((t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype) for t in inputs)
+        if entry is not None and entry["calls"] is not None:
+            if entry["sig"] == sig and entry["gen"] == self._const_gen:
+                self.ctx.replay(entry["calls"])
+                return entry["outs"]
+            self._replays.pop(key, None)                  # other buffers, or a constant was withdrawn: start over
+            entry = None
+        if entry is None:
+            if len(self._replays) >= self._MAX_GRAPHS:
+                self._replays.pop(next(iter(self._replays)))
+            entry = self._replays[key] = {"n": 0, "calls": None, "outs": None, "keep": None, "sig": sig,
+                                          "gen": self._const_gen}
+        entry["n"] += 1
+        if entry["n"] < 3 or entry["sig"] != sig or self._keep is not None or self.ctx._record is not None:
+            entry["sig"] = sig
+            return [self._force(o) for o in fn()]
+        self._keep = []                   # (evaluate() then allocates every intermediate afresh: _plan_for)
+        self.ctx.record_begin()
+        try:
+            outs = [self._force(o) for o in fn()]
+        finally:
+            calls = self.ctx.record_end()
+            keep, self._keep = self._keep, None
+        entry.update(calls=calls, outs=outs, keep=keep + list(outs) + list(inputs), gen=self._const_gen)
+        return outs
+
     def mark_constant(self, *tensors):
         """A promise that these device tensors (a model's data) are not written while they stay marked:
         an element-wise value of constants only -- ``X * X`` in every message of a Gaussian model --
@@ -357,6 +396,7 @@ class DeviceBackend(Backend):
         return t.untyped_storage().data_ptr() in self._const or t.data_ptr() in self._const_ptrs
 
     def forget_constants(self):
+        self._const_gen += 1
         self._const.clear()
         self._const_ptrs.clear()
         self._const_cache.clear()
@@ -366,6 +406,7 @@ class DeviceBackend(Backend):
     def unmark_constant(self, *tensors):
         """The caller is about to change or release these tensors: cached values computed from them
         are dropped and they are no longer constants (call BEFORE the storage can be reused)."""
+        self._const_gen += 1
         for t in tensors:
             if not isinstance(t, torch.Tensor):
                 continue
@@ -384,6 +425,7 @@ class DeviceBackend(Backend):
         old = self._const_cache.pop(key, None)
         if old is None:
             return
+        self._const_gen += 1
         self._const_bytes -= old.numel() * old.element_size()
         self._const.pop(old.untyped_storage().data_ptr(), None)
         ptr = old.data_ptr()

@@ -113,7 +113,20 @@ int bsc_comm_init_rank(bsc_ctx* ctx, const void* host_id, int32_t rank, int32_t 
 }
 
 int bsc_comm_destroy(bsc_ctx* ctx) {
-    if (!ctx || !ctx->comm) return BSC_OK;
+    if (!ctx) return BSC_OK;
+    if (ctx->comm_stream) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->comm_stream);
+        for (int i = 0; i < BSC_EXCHANGE_SLOTS; ++i) {
+            if (ctx->xch_ready[i]) (void)hipEventDestroy(ctx->xch_ready[i]);
+            if (ctx->xch_done[i]) (void)hipEventDestroy(ctx->xch_done[i]);
+            ctx->xch_ready[i] = ctx->xch_done[i] = nullptr;
+            ctx->xch_pending[i] = 0;
+        }
+        (void)hipStreamDestroy(ctx->comm_stream);
+        ctx->comm_stream = nullptr;
+    }
+    if (!ctx->comm) return BSC_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ncclResult_t r = g_rccl.CommDestroy((ncclComm_t)ctx->comm);
@@ -149,6 +162,50 @@ int bsc_allreduce_sum(bsc_ctx* ctx, void* buf, int64_t n, int dtype) {
     bsc_prof_scope prof(ctx, /*slot=*/1);
     BSC_RCCL(ctx, g_rccl.AllReduce(buf, buf, (size_t)n, dtype == BSC_F64 ? ncclFloat64 : ncclFloat32,
                                    ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+    return BSC_OK;
+}
+
+int bsc_allreduce_sum_begin(bsc_ctx* ctx, void* buf, int64_t n, int dtype, int32_t slot) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(dtype == BSC_F32 || dtype == BSC_F64, "bsc_allreduce_sum_begin: dtype %d", dtype);
+    BSC_REQUIRE(n >= 0 && (buf != nullptr || n == 0), "bsc_allreduce_sum_begin: null buffer");
+    BSC_REQUIRE(slot >= 0 && slot < BSC_EXCHANGE_SLOTS, "bsc_allreduce_sum_begin: slot %d (0 .. %d)", slot,
+                BSC_EXCHANGE_SLOTS - 1);
+    BSC_REQUIRE(!ctx->xch_pending[slot], "bsc_allreduce_sum_begin: slot %d has a collective that was not ended", slot);
+    if (!ctx->comm || n == 0) return BSC_OK;            // a world of one: nothing to wait for either
+    if (ctx->capturing) {
+        // inside a graph capture everything stays on the captured stream (no overlap, same result)
+        bsc_prof_scope prof(ctx, /*slot=*/1);
+        BSC_RCCL(ctx, g_rccl.AllReduce(buf, buf, (size_t)n, dtype == BSC_F64 ? ncclFloat64 : ncclFloat32, ncclSum,
+                                       (ncclComm_t)ctx->comm, ctx->stream));
+        return BSC_OK;
+    }
+    if (!ctx->comm_stream) BSC_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    if (!ctx->xch_ready[slot]) {
+        BSC_HIP(hipEventCreateWithFlags(&ctx->xch_ready[slot], hipEventDisableTiming));
+        BSC_HIP(hipEventCreateWithFlags(&ctx->xch_done[slot], hipEventDisableTiming));
+    }
+    // everything enqueued on the context's stream so far (the kernels that produced `buf`) precedes the collective ...
+    BSC_HIP(hipEventRecord(ctx->xch_ready[slot], ctx->stream));
+    BSC_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->xch_ready[slot], 0));
+    {
+        bsc_prof_scope prof(ctx, /*slot=*/1, ctx->comm_stream);
+        BSC_RCCL(ctx, g_rccl.AllReduce(buf, buf, (size_t)n, dtype == BSC_F64 ? ncclFloat64 : ncclFloat32, ncclSum,
+                                       (ncclComm_t)ctx->comm, ctx->comm_stream));
+    }
+    // ... and bsc_allreduce_sum_end makes the context's stream wait for it
+    BSC_HIP(hipEventRecord(ctx->xch_done[slot], ctx->comm_stream));
+    ctx->xch_pending[slot] = 1;
+    return BSC_OK;
+}
+
+int bsc_allreduce_sum_end(bsc_ctx* ctx, int32_t slot) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(slot >= 0 && slot < BSC_EXCHANGE_SLOTS, "bsc_allreduce_sum_end: slot %d (0 .. %d)", slot,
+                BSC_EXCHANGE_SLOTS - 1);
+    if (!ctx->xch_pending[slot]) return BSC_OK;          // a world of one, an empty buffer, or a capture: already in order
+    BSC_HIP(hipStreamWaitEvent(ctx->stream, ctx->xch_done[slot], 0));
+    ctx->xch_pending[slot] = 0;
     return BSC_OK;
 }
 

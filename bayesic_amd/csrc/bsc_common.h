@@ -12,6 +12,7 @@
 #include "../../include/bayesic_hip.h"
 
 constexpr int BSC_PROF_SLOTS = 3;
+constexpr int BSC_EXCHANGE_SLOTS = 16;
 
 struct bsc_ctx {
     int device = 0;
@@ -74,6 +75,12 @@ struct bsc_ctx {
     void* comm = nullptr;
     int comm_rank = 0;
     int comm_world = 1;
+    // the overlapped exchange (bsc_allreduce_sum_begin / _end): collectives of finished pieces of a statistic run on a
+    // second stream while the kernels of the next piece run on `stream`; one event pair per slot, created on first use
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t xch_ready[BSC_EXCHANGE_SLOTS] = {};
+    hipEvent_t xch_done[BSC_EXCHANGE_SLOTS] = {};
+    int xch_pending[BSC_EXCHANGE_SLOTS] = {};
 };
 
 // Records an event pair around one launch when ctx->profile is on.
@@ -120,7 +127,8 @@ struct bsc_prof_scope {
     bsc_ctx* ctx;
     int slot;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-    explicit bsc_prof_scope(bsc_ctx* c, int slot_ = 0) : ctx(c), slot(slot_) {
+    hipStream_t on;      // the stream the timed launch goes to (the context's own unless said otherwise)
+    explicit bsc_prof_scope(bsc_ctx* c, int slot_ = 0, hipStream_t on_ = nullptr) : ctx(c), slot(slot_), on(on_ ? on_ : c->stream) {
         if (ctx->profile <= 0 || ctx->capturing) return;
         if ((ctx->profile_tick[slot]++ % ctx->profile) != 0) return;
         if (!ctx->prof_pool.empty()) {
@@ -130,11 +138,11 @@ struct bsc_prof_scope {
             (void)hipEventCreate(&ev.first);
             (void)hipEventCreate(&ev.second);
         }
-        (void)hipEventRecord(ev.first, ctx->stream);
+        (void)hipEventRecord(ev.first, on);
     }
     ~bsc_prof_scope() {
         if (!ev.first) return;
-        (void)hipEventRecord(ev.second, ctx->stream);
+        (void)hipEventRecord(ev.second, on);
         ctx->prof_events[slot].push_back(ev);
     }
 };

@@ -1464,6 +1464,16 @@ int lda_sstats_csc_impl(bsc_ctx* ctx, const int64_t* colptr, const int32_t* rowi
 
 extern "C" {
 
+int bsc_lda_sstats_round_columns(bsc_ctx* ctx, int32_t K, int64_t* host_cols) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(host_cols != nullptr, "bsc_lda_sstats_round_columns: null result");
+    // one whole round of the persistent kernel: one 128-column block per resident workgroup (lda_sstats_impl's
+    // stream_plan: two workgroups a CU; one with three split terms at K = 128)
+    const int split = K == 128 ? ctx->mfma_split : 0;
+    *host_cols = (int64_t)(split == 3 ? 1 : 2) * ctx->cu_count * VT;
+    return BSC_OK;
+}
+
 int bsc_lda_sstats(bsc_ctx* ctx, const float* C, int64_t ldc, int64_t docs, int64_t V, int32_t K,
                    const float* Th, int64_t ldth, const float* Bt, int64_t ldb, float* sstats,
                    int64_t ldo) {

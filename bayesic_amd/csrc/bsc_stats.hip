@@ -315,6 +315,29 @@ __global__ void natgrad_update_f32_kernel(float* __restrict__ eta, float eta0,
         eta[i] = (1.0f - rho) * eta[i] + rho * (eta0 + scale * message[i]);
 }
 
+// The same step on a [rows, cols] block of eta and a message with leading dimensions of their own: the piece of lambda a
+// finished piece of the statistic belongs to (svi/lda.py: the statistic is taken and all-reduced in column ranges, each
+// staged contiguously).  `n_ll` words' terms are added in index order into the bound.
+__global__ void natgrad_update_f32_2d_kernel(float* __restrict__ eta, int64_t ld_eta, float eta0,
+                                             const float* __restrict__ message, int64_t ld_msg, int64_t rows,
+                                             int64_t cols, float scale, float rho, const double* __restrict__ ll,
+                                             int n_ll, const double* __restrict__ local_bound,
+                                             const double* __restrict__ global_bound, double scale64,
+                                             double* __restrict__ elbo) {
+    if (elbo && blockIdx.x == 0 && threadIdx.x == 0) {
+        double words = 0.0;
+        for (int i = 0; i < n_ll; ++i) words += ll[i];
+        elbo[0] = scale64 * (words + local_bound[0]) + global_bound[0];
+    }
+    const int64_t n = rows * cols;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / cols, c = i - r * cols;
+        float* e = eta + r * ld_eta + c;
+        *e = (1.0f - rho) * *e + rho * (eta0 + scale * message[r * ld_msg + c]);
+    }
+}
+
 // ---- row softmax: the expectation of a Categorical node (responsibilities) --------------------
 // out[r, :] = softmax(in[r, :]), lse[r] = log sum exp in[r, :]; float32 in/out, the row's max and
 // sum in float32 with exp2 on pre-scaled values.  cols <= 64: a row occupies P = 2^ceil(log2 cols)
@@ -521,6 +544,23 @@ int bsc_natgrad_update_f32_elbo(bsc_ctx* ctx, float* eta, float eta0, const floa
     if (blocks > 8 * (int64_t)ctx->cu_count) blocks = 8 * (int64_t)ctx->cu_count;
     hipLaunchKernelGGL(natgrad_update_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
                        eta, eta0, message, n, scale, rho, ll, local_bound, global_bound, (double)scale, elbo);
+    BSC_LAUNCH_CHECK();
+    return BSC_OK;
+}
+
+int bsc_natgrad_update_f32_2d(bsc_ctx* ctx, float* eta, int64_t ld_eta, float eta0, const float* message,
+                              int64_t ld_msg, int64_t rows, int64_t cols, float scale, float rho, const double* ll,
+                              int32_t n_ll, const double* local_bound, const double* global_bound, double* elbo) {
+    BSC_CHECK_CTX(ctx);
+    BSC_REQUIRE(eta && message && rows > 0 && cols > 0 && ld_eta >= cols && ld_msg >= cols,
+                "bsc_natgrad_update_f32_2d: bad arguments");
+    BSC_REQUIRE(!elbo || (ll && n_ll >= 1 && local_bound && global_bound),
+                "bsc_natgrad_update_f32_2d: the bound needs ll[n_ll], local_bound and global_bound");
+    int64_t blocks = (rows * cols + 255) / 256;
+    if (blocks > 8 * (int64_t)ctx->cu_count) blocks = 8 * (int64_t)ctx->cu_count;
+    hipLaunchKernelGGL(natgrad_update_f32_2d_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, eta, ld_eta, eta0,
+                       message, ld_msg, rows, cols, scale, rho, ll, (int)n_ll, local_bound, global_bound, (double)scale,
+                       elbo);
     BSC_LAUNCH_CHECK();
     return BSC_OK;
 }

@@ -90,10 +90,15 @@ class ReparamVI(object):
                   the walk of the next step overlaps the device's work on this one; ``elbo`` / ``grad`` / ``lam``
                   read back on access (as on the fused route).  Without it every step waits for the device twice
                   (the draws come back, the gradient comes back) and the host does the update in numpy.
+    replay      : resident engines only (default on).  From its third step on the engine re-issues the RECORDED list of
+                  C-ABI calls of a step -- draws to gradient, every launch whose arguments do not change -- instead of
+                  walking the expression again (``DeviceBackend.replay_call``): the walk costs ~28 us of Python per
+                  launch, the list ~2.  Unlike ``graph`` it needs no stream of the context's own; ``graph=True`` wins
+                  when both are set.  ``set_data`` with new buffers records again.
     """
 
     def __init__(self, log_joint, latents, data, n_samples, seed=0, lr=1e-2, backend=None,
-                 lam0=None, noise=None, graph=False, route="auto", resident=False):
+                 lam0=None, noise=None, graph=False, route="auto", resident=False, replay=True):
         from ..algebra.backend import resolve_backend
         self.backend = resolve_backend(backend)
         if log_joint.ndim != 1:
@@ -124,6 +129,7 @@ class ReparamVI(object):
         self._noise = noise
         self._eps_dev = None
         self._graph = bool(graph) and hasattr(self.backend, "graph_call")
+        self._replay = bool(replay) and hasattr(self.backend, "replay_call")     # (used by the resident general route)
         self._z_dev = None
         self._elbo, self._grad = None, None
         self._pass_plan = None
@@ -171,50 +177,65 @@ class ReparamVI(object):
         b, st, S, P = self.backend, self._resident, self.S, self.P
         ctx = b.ctx
         self._t += 1
-        ctx.call("bsc_philox_normal", self.seed, 2, int(self._t - 1), S, P, st["eps"])
+        ctx.call("bsc_philox_normal", self.seed, 2, int(self._t - 1), S, P, st["eps"])      # (its step counter changes)
         mu, rho = st["lam"][:P], st["lam"][P:]
-        z = b.materialize(st["z_fn"](eps=st["eps"], mu=mu, rho=rho))                  # float64 [S, P]
-        inputs, offset = dict(self._data), 0
         names = [v.name for v, _ in self.latents]
-        if self._graph:
+        fixed = self._graph or self._replay
+        if fixed and self._z_dev is None:
             # fixed buffers for the draws: the walk (forward, then the tape backwards) is recorded once and replayed
-            if self._z_dev is None:
-                self._z_dev = {v.name: b.from_host(np.zeros((S, n), self._types[v.name][0]), *self._types[v.name])
-                               for v, n in self.latents}
-            for v, n in self.latents:
-                zb = self._z_dev[v.name]
-                ctx.call("bsc_convert", _DT[z.dtype], _DT[zb.dtype], 2, _i64(zb.shape), z[:, offset:offset + n],
-                         _i64((z.stride(0), 1)), zb, _i64(zb.stride()))
-                inputs[v.name] = zb
-                offset += n
+            self._z_dev = {v.name: b.from_host(np.zeros((S, n), self._types[v.name][0]), *self._types[v.name])
+                           for v, n in self.latents}
 
-            def walk():
-                out, grads = value_and_grad(b, self.log_joint, inputs, names)
-                return [out] + [grads[name] for name in names]
-            res = b.graph_call(("reparam", id(self)), walk, [self._z_dev[name] for name in names] + list(self._data.values()))
-            f, gs = res[0], list(res[1:])
-        else:
+        def draws_to_gradient():
+            """lam, eps -> z -> log p and its gradient -> ELBO estimate and pathwise gradient: every launch of a step
+            whose arguments do not change from step to step."""
+            z = b.materialize(st["z_fn"](eps=st["eps"], mu=mu, rho=rho))                  # float64 [S, P]
+            inputs, offset = dict(self._data), 0
             for v, n in self.latents:
-                want = torch.float64 if str(np.dtype(self._types[v.name][0])) == "float64" else torch.float32
-                inputs[v.name] = b._convert(z[:, offset:offset + n], want)
+                if fixed:
+                    zb = self._z_dev[v.name]
+                    ctx.call("bsc_convert", _DT[z.dtype], _DT[zb.dtype], 2, _i64(zb.shape), z[:, offset:offset + n],
+                             _i64((z.stride(0), 1)), zb, _i64(zb.stride()))
+                    inputs[v.name] = zb
+                else:
+                    want = torch.float64 if str(np.dtype(self._types[v.name][0])) == "float64" else torch.float32
+                    inputs[v.name] = b._convert(z[:, offset:offset + n], want)
                 offset += n
-            out, grads = value_and_grad(b, self.log_joint, inputs, names)
-            f, gs = b.materialize(out), [b.materialize(grads[name]) for name in names]
-        if len(self.latents) == 1:
-            g = gs[0]
+            if self._graph:
+                def walk():
+                    out, grads = value_and_grad(b, self.log_joint, inputs, names)
+                    return [out] + [grads[name] for name in names]
+                res = b.graph_call(("reparam", id(self)), walk,
+                                   [self._z_dev[name] for name in names] + list(self._data.values()))
+                f, gs = res[0], list(res[1:])
+            else:
+                out, grads = value_and_grad(b, self.log_joint, inputs, names)
+                f, gs = b.materialize(out), [b.materialize(grads[name]) for name in names]
+            if len(self.latents) == 1:
+                g = gs[0]
+            else:
+                g, offset = st["g"], 0
+                for (v, n), gv in zip(self.latents, gs):            # (a strided copy through the C ABI: recordable)
+                    ctx.call("bsc_convert", _DT[gv.dtype], _DT[g.dtype], 2, _i64(gv.shape), gv, _i64(gv.stride()),
+                             g[:, offset:offset + n], _i64((g.stride(0), 1)))
+                    offset += n
+            gmu = b.materialize(st["gmu_fn"](g=g))
+            if gmu.dtype != torch.float64:
+                gmu = b._convert(gmu, torch.float64)
+            grho = b.materialize(st["grho_fn"](g=g, eps=st["eps"], rho=rho))
+            if grho.dtype != torch.float64:
+                grho = b._convert(grho, torch.float64)
+            return [b.materialize(st["elbo_fn"](f=f, rho=rho)), gmu, grho]
+
+        if self._replay and not self._graph:
+            # the third step records this region's C-ABI calls, later steps re-issue the list (DeviceBackend.replay_call):
+            # ~2 us of host time per launch instead of the ~28 us of walking the expression again
+            elbo, gmu, grho = b.replay_call(("reparam-step", id(self)), draws_to_gradient,
+                                            [st["eps"], st["lam"]] + [self._z_dev[name] for name in names]
+                                            + list(self._data.values()))
         else:
-            g, offset = st["g"], 0
-            for (v, n), gv in zip(self.latents, gs):
-                g[:, offset:offset + n].copy_(gv)
-                offset += n
-        gmu = b.materialize(st["gmu_fn"](g=g))
-        if gmu.dtype != torch.float64:
-            gmu = b._convert(gmu, torch.float64)
-        grho = b.materialize(st["grho_fn"](g=g, eps=st["eps"], rho=rho))
-        if grho.dtype != torch.float64:
-            grho = b._convert(grho, torch.float64)
-        st["elbo"] = b.materialize(st["elbo_fn"](f=f, rho=rho))
-        st["gmu"], st["grho"] = gmu, grho
+            elbo, gmu, grho = draws_to_gradient()
+        st["elbo"], st["gmu"], st["grho"] = elbo, gmu, grho
         for lo, grad in ((0, gmu), (P, grho)):          # (element-wise: two calls on the halves are the one step)
             ctx.call("bsc_adam_ascent", st["lam"][lo:lo + P], grad, st["m1"][lo:lo + P], st["m2"][lo:lo + P], P,
                      int(self._t), self.lr, 0.9, 0.999, 1e-8)

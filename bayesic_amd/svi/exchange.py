@@ -58,6 +58,29 @@ class Exchange:
             torch.distributed.all_reduce(tensor, group=self.group)
         return tensor
 
+    def begin(self, tensor, slot):
+        """Start the all-reduce of `tensor` (contiguous) so that it OVERLAPS what the caller enqueues next;
+        ``end(slot)`` before anything reads the sum.  RCCL route: a second stream of the context
+        (bsc_allreduce_sum_begin); torch.distributed route: an asynchronous collective."""
+        if self.rccl:
+            self.ctx.allreduce_sum_begin(tensor, slot)
+        elif self.world > 1:
+            self._pending = getattr(self, "_pending", {})
+            self._pending[slot] = torch.distributed.all_reduce(tensor, group=self.group, async_op=True)
+
+    def end(self, slot):
+        if self.rccl:
+            self.ctx.allreduce_sum_end(slot)
+        elif self.world > 1:
+            work = getattr(self, "_pending", {}).pop(slot, None)
+            if work is not None:
+                work.wait()
+
+    @property
+    def active(self):
+        """Whether a collective is actually issued (more than one rank, or a one-rank RCCL communicator)."""
+        return self.rccl or self.world > 1
+
     @property
     def rank(self):
         if self.rccl:

@@ -74,6 +74,9 @@ def parse_args(argv=None):
     ap.add_argument("--dim", type=int, default=256, help="cfg2 / cfg5 columns")
     ap.add_argument("--samples", type=int, default=None, help="Monte-Carlo draws (cfg2: 8, cfg5: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="cfg4 with a communicator: ONE all-reduce after the whole statistic instead of one per finished "
+                         "column range on a second stream (svi/lda.py overlap=False)")
     ap.add_argument("--no-via-plugin", action="store_true",
                     help="cfg2: skip the second timed loop through the plugin surface (value_via_plugin)")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0,
@@ -637,13 +640,17 @@ class Cfg4(Workload):
         self.docs, self.V, self.K = docs, V, K
         self.mfma_split = args.mfma_split
         self.model = LDAFixedGammaSVI(C, gamma, lam, docs_total=float(global_docs), ctx=ctx,
-                                      group=args.exchange_group)
+                                      group=args.exchange_group, overlap=not args.no_overlap)
         self.units_per_step = 1.0 if args.scaling == "strong" else float(world)
         self.describe = ("cfg4: LDA-style Dirichlet-Multinomial, %d docs x %d vocab f32 dense counts %s, "
                          "K=%d, fixed-gamma local step + natural-gradient step (all-reduce of %d x %d f32)"
                          % (docs, V, "per GPU" if args.scaling == "weak" else "block of %d docs" % global_docs,
                             K, K, V))
         self.config = {"docs_per_gpu": docs, "global_docs": global_docs, "vocab": V, "topics": K,
+                       "exchange_pieces": ("the statistic's all-reduce in column ranges of whole kernel rounds, each on a "
+                                           "second stream beside the next range's kernel (allreduce_us = mean per piece)")
+                       if (self.model.overlap and self.model.exchange.active and self.model.via == "kernel") else
+                       "one all-reduce after the whole statistic",
                        "inputs": "counts: torch.poisson(0.05) on the device, generator seed 5 + rank -- NOT the "
                                  "RandomState(5).poisson(0.05) stream SURVEY 8(d) names (2.5 GB a shard is minutes of "
                                  "numpy); same law, other draws.  gamma, lambda: torch.rand + 0.5 on the device",

@@ -145,6 +145,16 @@ int bsc_comm_info(bsc_ctx* ctx, int32_t* host_rank, int32_t* host_world,
                   int32_t* host_rccl_version);
 int bsc_allreduce_sum(bsc_ctx* ctx, void* buf, int64_t n, int dtype);
 int bsc_allreduce_max(bsc_ctx* ctx, void* buf, int64_t n, int dtype);
+/* The same collective OVERLAPPED with the kernels that follow on the context's stream: _begin orders the
+ * all-reduce behind everything enqueued so far (an event) and issues it on a second stream of the context;
+ * kernels enqueued afterwards run beside it; _end(slot) makes the context's stream wait for that collective
+ * (call it before the first kernel that reads `buf`).  slot < 16 names the collective in flight; each _begin
+ * is ended once.  A context without a communicator (a world of one) does nothing in either; inside a graph
+ * capture the collective stays on the captured stream.  Used where a statistic is finished piece by piece
+ * (svi/lda.py: config 4's 51.2 MB all-reduce) -- only the last piece's collective is
+ * exposed.  bsc_ctx_profile's slot 1 times every piece. */
+int bsc_allreduce_sum_begin(bsc_ctx* ctx, void* buf, int64_t n, int dtype, int32_t slot);
+int bsc_allreduce_sum_end(bsc_ctx* ctx, int32_t slot);
 
 /* hipEvent wrappers so a ctypes caller can time the ctx stream. */
 /* Measurement aid: best pure streaming-read rate (GB/s) over `buf` on this device, from
@@ -411,6 +421,17 @@ int bsc_dirichlet_expectation_bound(bsc_ctx* ctx, const float* lam, int64_t rows
 int bsc_natgrad_update_f32_elbo(bsc_ctx* ctx, float* eta, float eta0, const float* message, int64_t n,
                                 float scale, float rho, const double* ll, const double* local_bound,
                                 const double* global_bound, double* elbo);
+/* The same step on a [rows, cols] block: eta with leading dimension ld_eta, the message with ld_msg -- the
+ * piece of lambda [K, V] that one column range of the statistic, staged contiguously for its collective,
+ * belongs to.  elbo != NULL: elbo[0] = scale * (ll[0] + .. + ll[n_ll - 1] + local_bound[0]) + global_bound[0]
+ * first (one words' term per piece).  The same arithmetic per element as bsc_natgrad_update_f32.
+ * bsc_lda_sstats_round_columns: the columns of ONE whole round of the persistent statistic kernel on this
+ * context (128 per resident workgroup); a statistic taken in ranges that start at multiples of it is
+ * bit-identical to the statistic taken in one call (every column block then has the schedule it has there). */
+int bsc_natgrad_update_f32_2d(bsc_ctx* ctx, float* eta, int64_t ld_eta, float eta0, const float* message,
+                              int64_t ld_msg, int64_t rows, int64_t cols, float scale, float rho, const double* ll,
+                              int32_t n_ll, const double* local_bound, const double* global_bound, double* elbo);
+int bsc_lda_sstats_round_columns(bsc_ctx* ctx, int32_t K, int64_t* host_cols);
 
 /* ---- summed sufficient statistics of iid draws ---------------------------
  * ExpFamIndependentObservations.sufficient_statistics,

@@ -167,7 +167,25 @@ class OracleContext:
         out.copy_(torch.from_numpy(svi.dirichlet_expectation(lam.numpy()).astype(np.float32)))
 
     def bsc_lda_sstats(self, C, ldc, docs, V, K, Th, ldth, Bt, ldb, out, ldo):
-        out.copy_(torch.from_numpy(svi.lda_sstats(C.numpy(), Th.numpy(), Bt.numpy()).astype(np.float32)))
+        # (C, Bt: views of V columns; out: [K, V] with leading dimension ldo -- a block of the staging buffer when the
+        # driver takes the statistic in column ranges)
+        res = svi.lda_sstats(C.numpy()[:, :V], Th.numpy(), Bt.numpy()[:, :V]).astype(np.float32)
+        out.view(-1)[:K * ldo].view(K, ldo)[:, :V].copy_(torch.from_numpy(res))
+
+    def bsc_lda_sstats_round_columns(self, K, out):
+        out._obj.value = 16            # (a "round" of 16 columns: 40 columns are taken in three ranges)
+
+    def bsc_natgrad_update_f32_2d(self, eta, ld_eta, eta0, message, ld_msg, rows, cols, scale, rho, ll, n_ll,
+                                  local_bound, global_bound, elbo):
+        if elbo is not None:
+            words = 0.0
+            for i in range(n_ll):
+                words += float(ll[i])
+            elbo[0] = scale * (words + float(local_bound[0])) + float(global_bound[0])
+        e = eta[:, :cols]
+        m = message.view(-1)[:rows * ld_msg].view(rows, ld_msg)[:, :cols]
+        new = (1.0 - rho) * e.numpy().astype(np.float64) + rho * (eta0 + scale * m.numpy().astype(np.float64))
+        e.copy_(torch.from_numpy(new.astype(np.float32)))
 
     def bsc_dirichlet_expectation_bound(self, lam, rows, cols, ld, prior, out, bound):
         self.bsc_dirichlet_expectation(lam, rows, cols, ld, out)
@@ -175,7 +193,7 @@ class OracleContext:
 
     def bsc_lda_sstats_bound(self, C, ldc, docs, V, K, Th, ldth, Bt, ldb, out, ldo, ll):
         self.bsc_lda_sstats(C, ldc, docs, V, K, Th, ldth, Bt, ldb, out, ldo)
-        ll[0] = svi.lda_local_bound(C.numpy(), Th.numpy(), Bt.numpy())
+        ll[0] = svi.lda_local_bound(C.numpy()[:, :V], Th.numpy(), Bt.numpy()[:, :V])
 
     def bsc_natgrad_update_f32_elbo(self, eta, eta0, message, n, scale, rho, ll, local_bound, global_bound, elbo):
         elbo[0] = scale * (float(ll[0]) + float(local_bound[0])) + float(global_bound[0])
@@ -250,8 +268,17 @@ def main():
                            torch.from_numpy(lam4.copy()), eta=0.01, docs_total=900, ctx=OracleContext(),
                            via="kernel")
     assert lda.world == world and lda.batch_docs == 90.0
+    # the same model with ONE collective after the whole statistic (overlap=False): the column ranges of the default
+    # route (three of them here, each all-reduced on its own while the next is computed) must give the same bits
+    mono = LDAFixedGammaSVI(torch.from_numpy(C4[sl].copy()), torch.from_numpy(gamma4[sl].copy()),
+                            torch.from_numpy(lam4.copy()), eta=0.01, docs_total=900, ctx=OracleContext(),
+                            via="kernel", overlap=False)
     for _ in range(2):
         lda.step()
+        mono.step()
+    assert lda._pieces == [(0, 16), (16, 16), (32, 8)] and mono._pieces is None
+    assert torch.equal(lda.lam, mono.lam), "overlapped pieces differ from the one-collective update"
+    np.testing.assert_allclose(lda.elbo.numpy(), mono.elbo.numpy(), rtol=1e-13)
     np.savez(out_path % rank, lam=lam, lam_rep=lam_rep, elbo=model.elbo.numpy(), eta=mog.eta.numpy(),
              lse=mog.lse.numpy(), bbvi_lam=bb.lam.numpy(), bbvi_elbo=bb.elbo.numpy(),
              lda_lam=lda.lam.numpy(), mog_elbo=mog.elbo.numpy(), lda_elbo=lda.elbo.numpy())

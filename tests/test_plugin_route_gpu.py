@@ -371,6 +371,27 @@ def test_general_reparam_engine_with_its_state_on_the_device(two_latents):
         npt.assert_allclose(engines[1].grad, engines[0].grad, rtol=0, atol=2e-5 * scale)
     npt.assert_allclose(engines[1].lam, engines[0].lam, rtol=0, atol=2e-4)
     assert engines[1].t == engines[0].t == 8
+    # from the third step on the resident engine re-issued a RECORDED list of C-ABI calls instead of walking the
+    # expression (DeviceBackend.replay_call): the comparisons above ran on replayed steps
+    (entry,) = [e for k, e in b1._replays.items() if k[0] == "reparam-step"]
+    assert entry["calls"] is not None and len(entry["calls"]) >= 8
+    walked = []
+    real_call = ctx.call
+    ctx.call = lambda name, *a: (walked.append(name), real_call(name, *a))[1]
+    engines[1].step()
+    ctx.call = real_call
+    assert sorted(walked) == ["bsc_adam_ascent", "bsc_adam_ascent", "bsc_philox_normal"], walked   # the rest came from the list
+    engines[0].step()                                # (keep the two engines on the same step counter)
+    # another mini-batch (new buffers): two eager steps, recorded again, and still the host engine's numbers
+    Xs2 = rs.standard_normal((N, D)).astype(np.float32)
+    for e in engines:
+        e.set_data(X=Xs2)
+    for step in range(5):
+        host = engines[0].step()
+        engines[1].step()
+        assert abs(engines[1].elbo - host) <= 2e-6 * abs(host), (step, host, engines[1].elbo)
+    (entry,) = [e for k, e in b1._replays.items() if k[0] == "reparam-step"]
+    assert entry["calls"] is not None
 
 
 def test_resident_reparam_engine_with_its_walk_recorded_as_a_graph():

@@ -95,6 +95,59 @@ def test_update_loop_through_rccl_equals_loop_without(ctx, rccl_ctx):
     npt.assert_array_equal(ma.eta.cpu().numpy(), mb.eta.cpu().numpy())
 
 
+def test_lda_statistic_in_overlapped_pieces_equals_the_one_collective_update(ctx, rccl_ctx):
+    """Config 4: with a communicator the statistic is taken in column ranges -- whole rounds of the
+    persistent kernel -- each staged contiguously and all-reduced on the context's second stream while the next range is
+    computed (bsc_allreduce_sum_begin / _end); the natural-gradient step of a range waits for its own collective only.
+    Bit-identical to the update with ONE collective after the whole statistic, and to the update without a
+    communicator; every piece's collective is timed in slot 1."""
+    from bayesic_amd.svi.lda import LDAFixedGammaSVI
+    docs, V, K = 700, 140_000, 128                   # 1 094 column blocks: two whole rounds of 512 and a tail of 70
+    dev = ctx.device
+    g = torch.Generator(device=dev).manual_seed(4)
+    C = torch.poisson(torch.full((docs, V), 0.05, device=dev), generator=g)
+    gamma = torch.rand((docs, K), generator=g, device=dev) + 0.5
+    lam0 = torch.rand((K, V), generator=g, device=dev) + 0.5
+    models = {
+        "pieces": LDAFixedGammaSVI(C, gamma, lam0, docs_total=7000.0, ctx=rccl_ctx),
+        "one": LDAFixedGammaSVI(C, gamma, lam0, docs_total=7000.0, ctx=rccl_ctx, overlap=False),
+        "alone": LDAFixedGammaSVI(C, gamma, lam0, docs_total=7000.0, ctx=ctx),
+    }
+    assert models["pieces"].exchange.rccl and not models["alone"].exchange.active
+    rccl_ctx.profile(1)
+    for _ in range(3):
+        models["pieces"].step()
+    rccl_ctx.sync()
+    ms, n = rccl_ctx.profile_read(1)
+    rccl_ctx.profile(0)
+    pieces = models["pieces"]._pieces
+    assert [c for _, c in pieces] == [65536, 65536, 140_000 - 2 * 65536], pieces
+    assert n == 3 * (len(pieces) + 1) and ms > 0.0          # three ranges and the bound's two sums, per update
+    for name in ("one", "alone"):
+        for _ in range(3):
+            models[name].step()
+    rccl_ctx.sync()
+    ctx.sync()
+    want = models["alone"].lam.cpu().numpy()
+    npt.assert_array_equal(models["pieces"].lam.cpu().numpy(), want)
+    npt.assert_array_equal(models["one"].lam.cpu().numpy(), want)
+    # (the words' term is summed per range from float32 per-wave partials: another grouping than in one call)
+    npt.assert_allclose(models["pieces"].elbo.item(), models["alone"].elbo.item(), rtol=1e-8)
+    npt.assert_allclose(models["one"].elbo.item(), models["alone"].elbo.item(), rtol=1e-12)
+    # begin / end bookkeeping: a slot cannot be begun twice, an idle slot ends as a no-op
+    from bayesic_amd._ffi import BayesicHipError
+    v = torch.ones(1024, device=rccl_ctx.device)
+    rccl_ctx.allreduce_sum_begin(v, 3)
+    with pytest.raises(BayesicHipError, match="was not ended"):
+        rccl_ctx.allreduce_sum_begin(v, 3)
+    rccl_ctx.allreduce_sum_end(3)
+    rccl_ctx.allreduce_sum_end(3)
+    ctx.allreduce_sum_begin(v.to(ctx.device), 0)           # no communicator: both are no-ops
+    ctx.allreduce_sum_end(0)
+    rccl_ctx.sync()
+    npt.assert_array_equal(v.cpu().numpy(), np.ones(1024, np.float32))
+
+
 def _bench(extra, env_extra=None, timeout=600):
     env = dict(os.environ, **(env_extra or {}))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):

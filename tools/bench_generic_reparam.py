@@ -27,22 +27,38 @@ def main():
     lj = A.sum(r * r, axis=1) * (-0.5 / s2) + A.sum(W * W, axis=1) * (-0.5)
     ctx.set_stream(torch.cuda.Stream(ctx.device))          # a stream of its own: what a graph capture needs
     data = dict(X=Xd, y=yd)
-    for graph, route, resident in ((False, "general", False), (True, "general", False), (False, "general", True),
-                                   (True, "general", True), (False, "auto", False)):
+    for graph, route, resident, replay in ((False, "general", False, False), (True, "general", False, False),
+                                           (False, "general", True, False), (False, "general", True, True),
+                                           (True, "general", True, False), (False, "auto", False, False)):
         eng = ReparamVI(lj, [(W, D)], data, n_samples=S, seed=1, backend=DeviceBackend(ctx), lr=1e-3, graph=graph,
-                        route=route, resident=resident)
+                        route=route, resident=resident, replay=replay)
         for _ in range(5):
             eng.step()
         ctx.sync()
         t0 = time.perf_counter()
-        steps = 20
+        steps = 40
         for _ in range(steps):
             eng.step()
         ctx.sync()
         dt = (time.perf_counter() - t0) / steps
+        how = " (walk recorded as a hipGraph)" if graph else \
+            " (recorded C-ABI call list re-issued: the default of a resident engine)" if (replay and resident) else ""
         print("reparameterisation engine, route = %s%s, %dx%d, S=%d: %.2f ms per update (%.1f updates/s), elbo %.6e; "
-              "the fused config-2 kernels: 0.17 ms"
-              % (eng.route, " (walk recorded as a hipGraph)" if graph else "", N, D, S, dt * 1e3, 1.0 / dt, eng.elbo))
+              "the fused config-2 kernels: 0.17 ms" % (eng.route, how, N, D, S, dt * 1e3, 1.0 / dt, eng.elbo))
+    # the same engine on the context's DEFAULT stream (no stream of its own: a graph capture is not available there)
+    ctx2 = Context(0)
+    for replay in (False, True):
+        eng = ReparamVI(lj, [(W, D)], data, n_samples=S, seed=1, backend=DeviceBackend(ctx2), lr=1e-3, route="general",
+                        resident=True, replay=replay)
+        for _ in range(5):
+            eng.step()
+        ctx2.sync()
+        t0 = time.perf_counter()
+        for _ in range(40):
+            eng.step()
+        ctx2.sync()
+        dt = (time.perf_counter() - t0) / 40
+        print("    default stream, resident, replay=%s: %.2f ms per update" % (replay, dt * 1e3))
 
 
 if __name__ == "__main__":
