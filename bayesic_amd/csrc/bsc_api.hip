@@ -66,6 +66,7 @@ const bsc_option OPTIONS[] = {
     {"blr_q", &bsc_ctx::blr_q, 0, 1, nullptr, false},
     {"blr_q_dbg", &bsc_ctx::blr_q_dbg, 0, 3, nullptr, true},
     {"blr_q_bias", &bsc_ctx::blr_q_bias, 0, 400, nullptr, false},
+    {"blr_q_prio", &bsc_ctx::blr_q_prio, 0, 2, nullptr, false},
     {"blr_stamps", &bsc_ctx::blr_stamps, 0, 1, nullptr, false},
     {"fused_map_blocks_per_cu", &bsc_ctx::fused_map_blocks_per_cu, 1, 64, nullptr, false},
     {"fused_map_flat", &bsc_ctx::fused_map_flat, 0, 1, nullptr, false},

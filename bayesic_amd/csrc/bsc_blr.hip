@@ -661,7 +661,7 @@ constexpr int QW = 32;   // forward B operand: registers per lane
 // DBG (profiling only, WRONG results; BSC_BLR_Q_DBG + BSC_PROFILING_BUILDS): 1 = no arithmetic at all (the feed's own
 // ceiling: DMAs, waits, LDS reads), 2 = forward only, 3 = backward only
 // `next_row0()` is called once, right before the next tile's DMAs are issued, `after_dma()` right behind them.
-template <int AUX, int DBG, typename NextRow, typename AfterDma>
+template <int AUX, int DBG, int PRIO, typename NextRow, typename AfterDma>
 __device__ __forceinline__ void q_tile_step(float4& yv_cur, float* __restrict__ tl, float* __restrict__ rb,
                                             const float (&wreg)[QW], mfma_f32x4 (&acc)[2][4], float& qacc,
                                             const float* __restrict__ X, int64_t ldx, const float* __restrict__ y,
@@ -670,6 +670,11 @@ __device__ __forceinline__ void q_tile_step(float4& yv_cur, float* __restrict__ 
     // the tile's DMAs (issued a step ago) and its y have landed
     __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
     asm volatile("" ::: "memory");
+    // PRIO 1: the stretch from "my tile has landed" to "my next tile's DMAs are out" runs at raised priority -- it is
+    // the latency chain that sets how fast a wave can draw on HBM; the backward, which only has to finish before
+    // the next tile lands, yields to the partner wave's forward.  (PRIO 2: the other way round, for the A/B.)
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+    if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
     const float4 yv = yv_cur;
     if (DBG == 0 || DBG == 2) {
         mfma_f32x4 d[4];
@@ -722,6 +727,8 @@ __device__ __forceinline__ void q_tile_step(float4& yv_cur, float* __restrict__ 
     wave_lds_sync();
     dma_mtile<AUX>(tl, X, ldx, y, next_row0(), B, lane, yv_cur);
     after_dma();
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
     if (DBG == 0 || DBG == 3) {
 #pragma unroll
         for (int r = 0; r < MT_ROWS; ++r) {
@@ -770,7 +777,7 @@ struct QSched {
     }
 };
 
-template <bool NT, int DBG>
+template <bool NT, int DBG, int PRIO>
 __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_q_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ y, int64_t B,
     const float* __restrict__ W, int S, float* __restrict__ slab, int n_all, int n_a, int rev, int keep,
@@ -820,9 +827,9 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_q_kernel(
         load_w();
         int k = 0;
         for (; k + 1 < n_stream; ++k)
-            q_tile_step<2, DBG>(yv, tl, rb, wreg, acc, qacc, X, ldx, y, [&] { return sc.row0(k + 1); }, [] {}, B, lane);
+            q_tile_step<2, DBG, PRIO>(yv, tl, rb, wreg, acc, qacc, X, ldx, y, [&] { return sc.row0(k + 1); }, [] {}, B, lane);
         for (; k < n_mine; ++k)
-            q_tile_step<0, DBG>(yv, tl, rb, wreg, acc, qacc, X, ldx, y, [&] { return sc.row0(k + 1); }, [] {}, B, lane);
+            q_tile_step<0, DBG, PRIO>(yv, tl, rb, wreg, acc, qacc, X, ldx, y, [&] { return sc.row0(k + 1); }, [] {}, B, lane);
     }
     // no LDS-DMA of this wave may still be in flight when the tile region is reused for the block reduction
     __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
@@ -1725,14 +1732,16 @@ void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int6
             if (rest < 0) { rest = n_tiles; extra = 0; }
             const int n_all = extra ? (int)((rest + w_all - 1) / w_all) : g.n_iter;
             const int n_a = n_all + extra;
-#define BSC_PASS_Q(NT_, DBG_)                                                                      \
-    hipLaunchKernelGGL((blr_pass_q_kernel<NT_, DBG_>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0,     \
+#define BSC_PASS_Q(NT_, DBG_, PRIO_)                                                               \
+    hipLaunchKernelGGL((blr_pass_q_kernel<NT_, DBG_, PRIO_>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0, \
                        ctx->stream, X, ldx, y, B, W, sg, slab, n_all, n_a, rev, keep, stamps)
-            if (ctx->blr_q_dbg == 1) BSC_PASS_Q(true, 1);
-            else if (ctx->blr_q_dbg == 2) BSC_PASS_Q(true, 2);
-            else if (ctx->blr_q_dbg == 3) BSC_PASS_Q(true, 3);
-            else if (nt) BSC_PASS_Q(true, 0);
-            else BSC_PASS_Q(false, 0);
+            if (ctx->blr_q_dbg == 1) BSC_PASS_Q(true, 1, 0);
+            else if (ctx->blr_q_dbg == 2) BSC_PASS_Q(true, 2, 0);
+            else if (ctx->blr_q_dbg == 3) BSC_PASS_Q(true, 3, 0);
+            else if (nt && ctx->blr_q_prio == 1) BSC_PASS_Q(true, 0, 1);
+            else if (nt && ctx->blr_q_prio == 2) BSC_PASS_Q(true, 0, 2);
+            else if (nt) BSC_PASS_Q(true, 0, 0);
+            else BSC_PASS_Q(false, 0, 0);
 #undef BSC_PASS_Q
         } else if (ctx->blr_dma && ctx->blr_pk) {
             if (nt) hipLaunchKernelGGL((blr_pass_dma_kernel<true>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0, ctx->stream, X, ldx,

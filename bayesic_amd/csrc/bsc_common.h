@@ -52,6 +52,7 @@ struct bsc_ctx {
     int blr_q = 1;               // blr_pass_q_kernel (both contractions on v_mfma_f32_4x4x1, the tile by LDS-DMA; round 4) -- BSC_BLR_Q=0: blr_pass_dma_kernel, for A/B
     int blr_q_dbg = 0;           // deletion builds of blr_pass_q_kernel (BSC_BLR_Q_DBG + BSC_PROFILING_BUILDS): WRONG results
     int blr_q_bias = 70;         // blr_pass_q_kernel, static schedule: per mille of further windows for the workgroups with an even blockIdx (QSched)
+    int blr_q_prio = 1;          // blr_pass_q_kernel: s_setprio 1 from a tile's landing to the next tile's DMAs (1), or during the backward (2)
     int blr_stamps = 0;          // blr_pass_q_kernel: every workgroup leaves start / end s_memrealtime stamps and its XCD (bsc_blr_read_stamps)
     void* stamps = nullptr;      // 32 bytes per workgroup, allocated when blr_stamps is first used
     int stamp_rows = 0;          // workgroups of the last stamped launch

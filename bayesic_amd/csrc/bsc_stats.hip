@@ -324,17 +324,17 @@ __global__ void natgrad_update_f32_2d_kernel(float* __restrict__ eta, int64_t ld
                                              int n_ll, const double* __restrict__ local_bound,
                                              const double* __restrict__ global_bound, double scale64,
                                              double* __restrict__ elbo) {
-    if (elbo && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (elbo && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         double words = 0.0;
         for (int i = 0; i < n_ll; ++i) words += ll[i];
         elbo[0] = scale64 * (words + local_bound[0]) + global_bound[0];
     }
-    const int64_t n = rows * cols;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int64_t r = i / cols, c = i - r * cols;
-        float* e = eta + r * ld_eta + c;
-        *e = (1.0f - rho) * *e + rho * (eta0 + scale * message[r * ld_msg + c]);
+    // blockIdx.y walks the rows, the x extent of the grid a row's columns: no division per element
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+        float* e = eta + r * ld_eta;
+        const float* m = message + r * ld_msg;
+        for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += (int64_t)gridDim.x * blockDim.x)
+            e[c] = (1.0f - rho) * e[c] + rho * (eta0 + scale * m[c]);
     }
 }
 
@@ -556,9 +556,10 @@ int bsc_natgrad_update_f32_2d(bsc_ctx* ctx, float* eta, int64_t ld_eta, float et
                 "bsc_natgrad_update_f32_2d: bad arguments");
     BSC_REQUIRE(!elbo || (ll && n_ll >= 1 && local_bound && global_bound),
                 "bsc_natgrad_update_f32_2d: the bound needs ll[n_ll], local_bound and global_bound");
-    int64_t blocks = (rows * cols + 255) / 256;
-    if (blocks > 8 * (int64_t)ctx->cu_count) blocks = 8 * (int64_t)ctx->cu_count;
-    hipLaunchKernelGGL(natgrad_update_f32_2d_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, eta, ld_eta, eta0,
+    int64_t bx = (cols + 255) / 256;
+    if (bx > 16) bx = 16;
+    const int64_t by = rows < 65535 ? rows : 65535;
+    hipLaunchKernelGGL(natgrad_update_f32_2d_kernel, dim3((unsigned)bx, (unsigned)by), dim3(256), 0, ctx->stream, eta, ld_eta, eta0,
                        message, ld_msg, rows, cols, scale, rho, ll, (int)n_ll, local_bound, global_bound, (double)scale,
                        elbo);
     BSC_LAUNCH_CHECK();

@@ -21,6 +21,10 @@ VARIANTS = {
     # name: options of the context (bsc_ctx_set_option)
     "dma": dict(blr_q=0),
     "q": dict(blr_q=1),
+    "q-prio1": dict(blr_q=1, blr_q_prio=1),
+    "q-prio2": dict(blr_q=1, blr_q_prio=2),
+    "q-bias40": dict(blr_q=1, blr_q_bias=40),
+    "q-bias100p1": dict(blr_q=1, blr_q_bias=100, blr_q_prio=1),
     "q-bias0": dict(blr_q=1, blr_q_bias=0),
     "q-bias100": dict(blr_q=1, blr_q_bias=100),
     "q-bias130": dict(blr_q=1, blr_q_bias=130),
