@@ -83,6 +83,16 @@ SIGNATURES = {
                                              c_double, c_double, c_double, c_double, c_int64, c_double, c_double,
                                              c_double, c_double, c_uint64, c_uint32, c_void_p, c_int32,
                                              c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bsc_blr_pass_update": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                    c_double, c_double, c_double, c_double, c_int64, c_double, c_double, c_double,
+                                    c_double, c_uint64, c_uint32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
+    "bsc_blr_pass_update_general": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                            c_double, c_double, c_double, c_double, c_double, c_int64, c_double, c_double,
+                                            c_double, c_double, c_uint64, c_uint32, c_void_p, c_int32, c_void_p, c_void_p,
+                                            c_void_p, c_void_p]),
     "bsc_blr_noise": (c_int, [c_void_p, c_int32, c_int32, c_uint64, c_uint32, c_int32, c_void_p]),
     "bsc_blr_elbo_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_int32, c_int32, c_double, c_double, c_double,

@@ -67,6 +67,7 @@ const bsc_option OPTIONS[] = {
     {"blr_q_dbg", &bsc_ctx::blr_q_dbg, 0, 3, nullptr, true},
     {"blr_q_bias", &bsc_ctx::blr_q_bias, 0, 400, nullptr, false},
     {"blr_q_prio", &bsc_ctx::blr_q_prio, 0, 2, nullptr, false},
+    {"blr_fold", &bsc_ctx::blr_fold, 0, 1, nullptr, false},
     {"blr_stamps", &bsc_ctx::blr_stamps, 0, 1, nullptr, false},
     {"fused_map_blocks_per_cu", &bsc_ctx::fused_map_blocks_per_cu, 1, 64, nullptr, false},
     {"fused_map_flat", &bsc_ctx::fused_map_flat, 0, 1, nullptr, false},
@@ -139,6 +140,17 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
     ctx->device = device;
     ctx->stream = (hipStream_t)stream;
     ctx->cu_count = prop.multiProcessorCount;
+    // the arrival counters of the folded finish (csrc/bsc_blr.hip FoldArgs): allocated here, not on first use, so that
+    // a graph capture never meets an allocation
+    if (hipMalloc((void**)&ctx->fold_counters, 256) == hipSuccess) {
+        if (hipMemset(ctx->fold_counters, 0, 256) != hipSuccess) {
+            (void)hipFree(ctx->fold_counters);
+            ctx->fold_counters = nullptr;
+        }
+    } else {
+        ctx->fold_counters = nullptr;
+        (void)hipGetLastError();
+    }
     *out = ctx;
     return BSC_OK;
 }
@@ -149,6 +161,7 @@ int bsc_ctx_destroy(bsc_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->workspace) (void)hipFree(ctx->workspace);
     if (ctx->stamps) (void)hipFree(ctx->stamps);
+    if (ctx->fold_counters) (void)hipFree(ctx->fold_counters);
     (void)bsc_comm_destroy(ctx);
     for (auto* v : {&ctx->prof_events[0], &ctx->prof_events[1], &ctx->prof_events[2], &ctx->prof_pool})
         for (auto& ev : *v) {

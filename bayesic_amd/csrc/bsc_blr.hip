@@ -633,6 +633,65 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_dma_kernel(
     }
 }
 
+// The finish kernel's arguments (blr_fused_update_kernel further down; defined here because the round-4 pass kernel can
+// carry them: FoldArgs).
+struct FusedArgs {
+    const float* slab;     // block partials of the pass kernel, or nullptr
+    int n_slab;            // slab rows
+    const double* stats;   // [Q (S) | G (S*D)] when slab == nullptr
+    const double* lam_in;
+    double* lam_out;
+    double* m1;
+    double* m2;
+    const double* eps;
+    const float* W;
+    const double* xi;
+    double* eps_next;      // nullptr: no next draw
+    int eps_next_ready;    // 1: eps_next already holds the noise of next_step (bsc_blr_noise)
+    float* W_next;
+    double* xi_next;
+    double* elbo;
+    double* grad;
+    int D, S;
+    // the log-joint per draw as a member of the family (bsc_blr_fused_update_general):
+    //   f(w, xi; Q) = c0 + c_xi xi + e^{-xi} (-s_q Q / 2 - k_w |w|^2 / 2 - beta)
+    double c0, c_xi, s_q, k_w, beta;
+    double lr, beta1, beta2, adam_eps, corr1, corr2;
+    uint64_t seed;
+    uint32_t next_step;
+};
+
+// ---- the finish folded into the pass's tail (round 4, option blr_fold) ---------------------------------------------------
+// VERDICT r2 #6 / r3 #2(b).  After its slab row a workgroup takes an arrival ticket; the LAST `n_roles` arrivals do
+// what the finish kernel's workgroups do (mode 1: role r = that kernel's block r -- slab -> float64 -> ELBO, gradient,
+// Adam, next draws; mode 2: the float64 statistics [Q | G] for the all-reduce of the N > 1 structure), once every row
+// has arrived.  One launch per update instead of two: the pass -> finish boundary (~1.7 us) and the finish kernel's
+// own launch and small-operand round trips leave the critical path.
+//
+// Visibility across CUs and XCDs (MI355X_MICROARCH.md, "inter-workgroup visibility"): the slab row is stored
+// write-through (sc1: relaxed agent-scope atomic stores), every storing wave drains (s_waitcnt vmcnt(0)), the
+// workgroup's barrier, then ONE lane adds to the arrival counter (agent scope).  A role workgroup polls that counter
+// with sc1 loads (one lane, s_sleep, bounded), barrier, and reads the slab with sc1 loads only (L1 bypassed; no XCD's L2
+// can hold a slab line of this launch before the rows are complete: nothing reads the slab earlier, and L1 / L2 start
+// a launch invalidated).  The arithmetic of a role is fixed, whichever workgroup performs it: reproducible.  The last
+// role to finish zeroes the counters for the next launch.  The role workgroups spin only for workgroups that are
+// resident (the grid never exceeds two workgroups per CU).
+struct FoldArgs {
+    FusedArgs a;           // mode 1
+    unsigned* counters;    // [0] arrivals, [1] roles done (zero between launches)
+    double* Q;             // mode 2: Q[s_base + s], G[(s_base + s) * D + d]
+    double* G;
+    int mode;              // 0 = no fold (the slab is the kernel's result)
+    int s_base, S_total;
+};
+// `wait()` is called by every thread of the workgroup right before the first access to the slab: the folded finish
+// waits there for the last partial (everything a role can do without the slab happens before it).
+template <int BLOCK, bool COH, typename Wait>
+__device__ void fused_update_role(const FusedArgs& a, int role, Wait wait);
+template <int BLOCK, bool COH, typename Wait>
+__device__ void slab_stats_role(const float* __restrict__ slab, int n_blocks, int D, int S, int s_base,
+                                double* __restrict__ Q, double* __restrict__ G, int role, Wait wait);
+
 // ---- round 4: BOTH contractions on v_mfma_f32_4x4x1_16B_f32, the tile by LDS-DMA (D == 256, S <= 8) -----------------
 //
 // The counters of blr_pass_dma_kernel (profiles/r03_pmc_blr_pass_dma.txt) say what holds it at 0.80 of the peak: a
@@ -781,7 +840,7 @@ template <bool NT, int DBG, int PRIO>
 __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_q_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ y, int64_t B,
     const float* __restrict__ W, int S, float* __restrict__ slab, int n_all, int n_a, int rev, int keep,
-    unsigned long long* __restrict__ stamps) {
+    unsigned long long* __restrict__ stamps, FoldArgs fold) {
     constexpr int LDS_FLOATS = PASS_WAVES * (MT_WAVE_LDS > SLAB_STRIDE ? MT_WAVE_LDS : SLAB_STRIDE);
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     const int tid = threadIdx.x;
@@ -852,13 +911,57 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_q_kernel(
         float v = lds[src];
 #pragma unroll
         for (int kk = 1; kk < PASS_WAVES; ++kk) v += lds[kk * SLAB_STRIDE + src];
-        out[i] = v;
+        // (folded finish: write-through, so that a workgroup on another XCD reads the row from memory)
+        if (fold.mode) __hip_atomic_store(out + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else out[i] = v;
+    }
+    if (fold.mode) {
+        // ---- the finish in the pass's tail (FoldArgs) ----
+        __shared__ unsigned ticket_s;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's slab stores have been written through
+        __syncthreads();                                        // ... and every other wave's of the workgroup
+        if (tid == 0) {
+            if (stamps) stamps[8 * (int64_t)blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();     // slab row written through
+            ticket_s = __hip_atomic_fetch_add(fold.counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (stamps) { stamps[8 * (int64_t)blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime(); stamps[8 * (int64_t)blockIdx.x + 7] = ticket_s; }
+        }
+        __syncthreads();
+        const int n_roles = fold.mode == 1 ? (fold.a.D + 7) / 8 + 1 : (SLAB_STRIDE + BSC_WAVE - 1) / BSC_WAVE;
+        // the LAST arrival takes role 0, the earliest of the last n_roles the highest role (mode 1: the scalar role,
+        // which has the most to do before it needs the slab -- and the longest wait for the last partial)
+        const int role = (int)gridDim.x - 1 - (int)ticket_s;
+        if (role < n_roles) {                                   // one of the last n_roles arrivals
+            auto all_arrived = [&] {
+                if (tid == 0) {
+                    // every row has arrived?  (sc1 poll by one lane; the rows still missing belong to workgroups that
+                    // are computing on resident slots.  Bounded: ~2 s of the 100 MHz clock, then carry on.)
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    while (__hip_atomic_load(fold.counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;
+                    }
+                    if (stamps) stamps[8 * (int64_t)blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();
+                }
+                __syncthreads();
+            };
+            if (fold.mode == 1) fused_update_role<PASS_BLOCK, true>(fold.a, role, all_arrived);
+            else slab_stats_role<PASS_BLOCK, true>(slab, (int)gridDim.x, GCOLS, fold.S_total, fold.s_base, fold.Q, fold.G, role, all_arrived);
+            __syncthreads();
+            if (tid == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned done = __hip_atomic_fetch_add(fold.counters + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (done == (unsigned)n_roles - 1u) {           // the last role: zero the counters for the next launch
+                    __hip_atomic_store(fold.counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(fold.counters + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
     }
     if (stamps) {
         // measurement aid (option blr_stamps): when did this workgroup start and end, and on which XCD did it run
         __syncthreads();
         if (tid == 0) {
-            unsigned long long* st = stamps + 4 * (int64_t)blockIdx.x;
+            unsigned long long* st = stamps + 8 * (int64_t)blockIdx.x;
             st[0] = t_start;
             st[1] = __builtin_amdgcn_s_memrealtime();
             st[2] = __builtin_amdgcn_s_getreg((3 << 11) | 20);     // HW_REG_XCC_ID[3:0]
@@ -1046,7 +1149,8 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_mx_kernel(
 // Loads are issued in batches of 16 before any add: the partials were written by
 // another kernel, so every load is a MALL/HBM round trip (~0.4 us) and a
 // load-add-load-add chain would serialise them.
-template <int BATCH = 16>
+// COH: the rows were written by other workgroups of THIS launch (the folded finish): sc1 loads.
+template <int BATCH = 16, bool COH = false>
 __device__ __forceinline__ double slab_column_sum(const float* __restrict__ p, int first,
                                                   int step, int n_rows) {
     double sum = 0.0;
@@ -1055,7 +1159,8 @@ __device__ __forceinline__ double slab_column_sum(const float* __restrict__ p, i
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
             const int b = b0 + j * step;
-            v[j] = b < n_rows ? p[(int64_t)b * SLAB_STRIDE] : 0.f;
+            if (COH) v[j] = b < n_rows ? __hip_atomic_load(p + (int64_t)b * SLAB_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+            else v[j] = b < n_rows ? p[(int64_t)b * SLAB_STRIDE] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) sum += (double)v[j];
@@ -1073,7 +1178,9 @@ __device__ __forceinline__ double slab_column_sum(const float* __restrict__ p, i
 // 165-us data pass, and straight-line code is fetched at ~0.5 us per 64 bytes -- the 32
 // guarded scalar loads this replaces (1.5 KB of code) cost 10 us before the first load had
 // even been issued (cycle counters, round 1).
-template <int N_WAVES, typename F>
+// JJ: loads in flight per lane and trip (8: the finish kernels' 16 waves cover 512 rows in one trip; 32: four waves do).
+// AUX: cache policy of the loads (16 = sc1, for rows written by other workgroups of this launch).
+template <int N_WAVES, int JJ = 8, int AUX = 0, typename F>
 __device__ __forceinline__ void slab_run_sum(const float* __restrict__ slab, int n_slab, int col0,
                                              int wave, int lane, double (&s4)[4], F between) {
     const uint64_t slab_bytes = (uint64_t)n_slab * SLAB_STRIDE * 4u;
@@ -1083,18 +1190,18 @@ __device__ __forceinline__ void slab_run_sum(const float* __restrict__ slab, int
     const int voff = ((wave + N_WAVES * q4) * SLAB_STRIDE + col0 + 4 * c16) * 4;
     constexpr int BATCH_BYTES = 4 * N_WAVES * SLAB_STRIDE * 4;      // 4 * N_WAVES rows per load
     s4[0] = s4[1] = s4[2] = s4[3] = 0.0;
-    for (int base = 0; base < n_slab; base += 32 * N_WAVES) {       // one trip up to 32 * N_WAVES partials
-        float4 v8[8];
+    for (int base = 0; base < n_slab; base += 4 * JJ * N_WAVES) {   // one trip up to 4 JJ N_WAVES partials
+        float4 v8[JJ];
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
+        for (int jj = 0; jj < JJ; ++jj) {
             auto v = __builtin_amdgcn_raw_buffer_load_b128(
-                rs, voff, base * (SLAB_STRIDE * 4) + jj * BATCH_BYTES, 0);
+                rs, voff, base * (SLAB_STRIDE * 4) + jj * BATCH_BYTES, AUX);
             v8[jj] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
                                  __uint_as_float(v[3]));
         }
         if (base == 0) between();
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
+        for (int jj = 0; jj < JJ; ++jj) {
             s4[0] += (double)v8[jj].x; s4[1] += (double)v8[jj].y;
             s4[2] += (double)v8[jj].z; s4[3] += (double)v8[jj].w;
         }
@@ -1112,16 +1219,18 @@ __device__ __forceinline__ void slab_run_sum(const float* __restrict__ slab, int
 constexpr int RED_BLOCK = 1024;
 constexpr int RED_WAVES = RED_BLOCK / BSC_WAVE;
 
-__global__ __launch_bounds__(RED_BLOCK) void blr_slab_reduce_kernel(
-    const float* __restrict__ slab, int n_blocks, int D, int S, int s_base,
-    double* __restrict__ Q, double* __restrict__ G) {
-    __shared__ double part[RED_WAVES][BSC_WAVE];
+template <int BLOCK, bool COH, typename Wait>
+__device__ void slab_stats_role(const float* __restrict__ slab, int n_blocks, int D, int S, int s_base,
+                                double* __restrict__ Q, double* __restrict__ G, int role, Wait wait) {
+    constexpr int WAVES = BLOCK / BSC_WAVE;
+    __shared__ double part[WAVES][BSC_WAVE];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * BSC_WAVE + lane;
+    const int i = role * BSC_WAVE + lane;
     double s4[4];
-    slab_run_sum<RED_WAVES>(slab, n_blocks, (int)blockIdx.x * BSC_WAVE, wave, lane, s4, [] {});
-    if (lane < 16) {   // (columns past SLAB_STRIDE in the last workgroup are read but never written out)
+    wait();
+    slab_run_sum<WAVES, (WAVES >= 16 ? 8 : 32), (COH ? 16 : 0)>(slab, n_blocks, role * BSC_WAVE, wave, lane, s4, [] {});
+    if (lane < 16) {   // (columns past SLAB_STRIDE in the last role are read but never written out)
 #pragma unroll
         for (int k = 0; k < 4; ++k) part[wave][4 * lane + k] = s4[k];
     }
@@ -1129,7 +1238,7 @@ __global__ __launch_bounds__(RED_BLOCK) void blr_slab_reduce_kernel(
     if (wave == 0 && i < SLAB_STRIDE) {
         double tot = part[0][lane];
 #pragma unroll
-        for (int k = 1; k < RED_WAVES; ++k) tot += part[k][lane];
+        for (int k = 1; k < WAVES; ++k) tot += part[k][lane];
         if (i < SLAB_G) {
             int s = i & 7, d = i >> 3;
             if (s_base + s < S && d < D) G[(int64_t)(s_base + s) * D + d] = tot;
@@ -1138,6 +1247,12 @@ __global__ __launch_bounds__(RED_BLOCK) void blr_slab_reduce_kernel(
             if (s_base + s < S) Q[s_base + s] = tot;
         }
     }
+}
+
+__global__ __launch_bounds__(RED_BLOCK) void blr_slab_reduce_kernel(
+    const float* __restrict__ slab, int n_blocks, int D, int S, int s_base,
+    double* __restrict__ Q, double* __restrict__ G) {
+    slab_stats_role<RED_BLOCK, false>(slab, n_blocks, D, S, s_base, Q, G, (int)blockIdx.x, [] {});
 }
 
 // ---- sampler and ELBO/gradient finish (tiny, float64) ----------------------
@@ -1343,31 +1458,6 @@ __global__ __launch_bounds__(FIN_BLOCK) void blr_elbo_grad_kernel(
 // workgroup owns Q, |w_s|^2, the entropy term, (a, b) and the ELBO.  State is
 // double-buffered by the caller (lam_in/lam_out, cur/next draws) so no
 // workgroup reads what another one writes.
-struct FusedArgs {
-    const float* slab;     // block partials of the pass kernel, or nullptr
-    int n_slab;            // slab rows
-    const double* stats;   // [Q (S) | G (S*D)] when slab == nullptr
-    const double* lam_in;
-    double* lam_out;
-    double* m1;
-    double* m2;
-    const double* eps;
-    const float* W;
-    const double* xi;
-    double* eps_next;      // nullptr: no next draw
-    int eps_next_ready;    // 1: eps_next already holds the noise of next_step (bsc_blr_noise)
-    float* W_next;
-    double* xi_next;
-    double* elbo;
-    double* grad;
-    int D, S;
-    // the log-joint per draw as a member of the family (bsc_blr_fused_update_general):
-    //   f(w, xi; Q) = c0 + c_xi xi + e^{-xi} (-s_q Q / 2 - k_w |w|^2 / 2 - beta)
-    double c0, c_xi, s_q, k_w, beta;
-    double lr, beta1, beta2, adam_eps, corr1, corr2;
-    uint64_t seed;
-    uint32_t next_step;
-};
 
 __device__ __forceinline__ double adam_ascent_one(double lam, double g, double& m1, double& m2,
                                                   const FusedArgs& a) {
@@ -1382,8 +1472,8 @@ __device__ __forceinline__ double adam_ascent_one(double lam, double g, double& 
 
 // BLOCK threads per workgroup (1024 = 16 waves: 32 slab rows per wave at 512 partials; fewer waves
 // launch sooner -- BSC_BLR_FINISH_BLOCK, A/B in tools/ab_pass.py)
-template <int FUSED_BLOCK>
-__global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs a) {
+template <int FUSED_BLOCK, bool COH, typename Wait>
+__device__ void fused_update_role(const FusedArgs& a, int role, Wait wait) {
     constexpr int FUSED_WAVES = FUSED_BLOCK / BSC_WAVE;
     __shared__ double red[FUSED_WAVES][BSC_WAVE];
     __shared__ double sh[2 * FIN_MAX_S + 16];
@@ -1392,9 +1482,9 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
     const int n_chunks = (D + 7) / 8;
     const double inv_S = 1.0 / (double)S;
 
-    if ((int)blockIdx.x < n_chunks) {
+    if (role < n_chunks) {
         // ---------------- column workgroup: columns d0 .. d0+7 ----------------
-        const int d0 = 8 * blockIdx.x;
+        const int d0 = 8 * role;
         const int dl = lane >> 3, sl = lane & 7;  // slab order within the run is [d][s]
         const int d = d0 + dl;
         double gm = 0.0, gr = 0.0;
@@ -1423,7 +1513,15 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
             // float64 exponentials that do not depend on it run while it is in flight
             double s4[4];
             double e_mxs = 0.0;
-            slab_run_sum<FUSED_WAVES>(a.slab, a.n_slab, 64 * (int)blockIdx.x, wave, lane, s4, [&] {
+            if (COH) {              // (the operands above are on their way; the exponentials do not need the slab either)
+                if (wave == 0) {
+                    e_mxs = exp(-xs);
+                    e_rho = exp(p_rho);
+                }
+                wait();
+            }
+            slab_run_sum<FUSED_WAVES, (FUSED_WAVES >= 16 ? 8 : 32), (COH ? 16 : 0)>(a.slab, a.n_slab, 64 * role, wave, lane, s4, [&] {
+                if (COH) return;
                 if (wave == 0) {
                     e_mxs = exp(-xs);
                     e_rho = exp(p_rho);
@@ -1493,7 +1591,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
         } else if (a.eps_next) {
             // two Philox blocks per sample cover the 8 columns
             for (int i = lane; i < 2 * S; i += BSC_WAVE) {
-                const int s = i >> 1, pb = 2 * blockIdx.x + (i & 1);
+                const int s = i >> 1, pb = 2 * role + (i & 1);
                 if (4 * pb < D)
                     blr_draw_block(new_m - d0, new_rho - d0, D, s, pb, a.seed, a.next_step,
                                    a.eps_next, a.W_next);
@@ -1532,8 +1630,44 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
             if (d < D) wpre[j] = a.W[(int64_t)wave * D + d];
         }
     }
+    // folded finish: everything that does not need the slab first -- this role belongs to the EARLIEST of the role
+    // workgroups, which has the longest wait for the last partial (a second draw per wave prefetched too: four
+    // waves here, sixteen in the finish kernel)
+    float wpre2[4] = {0.f, 0.f, 0.f, 0.f};
+    bool sums_done = false;
+    if (COH) {
+        if (FUSED_WAVES < FIN_MAX_S && wave + FUSED_WAVES < S) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = lane + BSC_WAVE * j;
+                if (d < D) wpre2[j] = a.W[(int64_t)(wave + FUSED_WAVES) * D + d];
+            }
+        }
+        for (int s = wave; s < S; s += FUSED_WAVES) {
+            double part = 0.0;
+            int d = lane;
+            if (s == wave || s == wave + FUSED_WAVES) {   // the prefetched columns, same ascending order as the loop below
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float wj = s == wave ? wpre[j] : wpre2[j];
+                    if (d < D) part += (double)wj * (double)wj;
+                    d += BSC_WAVE;
+                }
+            }
+            for (; d < D; d += BSC_WAVE) {
+                const double wv = (double)a.W[(int64_t)s * D + d];
+                part += wv * wv;
+            }
+            part = wave_allsum_f64(part);
+            if (lane == 0) wsq[s] = part;
+        }
+        rho_part = wave_allsum_f64(rho_part);
+        if (lane == 0) red[wave][32] = rho_part;
+        sums_done = true;
+        wait();
+    }
     if (a.slab) {  // S <= 8: thread -> (sample tid&7, slab-row group tid>>3)
-        double part = slab_column_sum<8>(a.slab + SLAB_G + (tid & 7), tid >> 3, FUSED_BLOCK / 8,
+        double part = slab_column_sum<(FUSED_BLOCK >= 1024 ? 8 : 16), COH>(a.slab + SLAB_G + (tid & 7), tid >> 3, FUSED_BLOCK / 8,
                                          a.n_slab);
         // fold the 8 row groups of this wave (lane bits 3-5), then the 16 waves
         part += __shfl_xor(part, 8);
@@ -1543,7 +1677,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
     } else {
         for (int s = tid; s < S; s += FUSED_BLOCK) Qs[s] = a.stats[s];
     }
-    for (int s = wave; s < S; s += FUSED_WAVES) {
+    for (int s = wave; s < S && !sums_done; s += FUSED_WAVES) {
         double part = 0.0;
         int d = lane;
         if (s == wave) {  // the prefetched columns, same ascending order as the loop below
@@ -1560,8 +1694,10 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
         part = wave_allsum_f64(part);
         if (lane == 0) wsq[s] = part;
     }
-    rho_part = wave_allsum_f64(rho_part);
-    if (lane == 0) red[wave][32] = rho_part;  // column 32: clear of the Q staging columns
+    if (!sums_done) {
+        rho_part = wave_allsum_f64(rho_part);
+        if (lane == 0) red[wave][32] = rho_part;  // column 32: clear of the Q staging columns
+    }
     __syncthreads();
     if (a.slab && tid < 8) {
         double t = 0.0;
@@ -1613,6 +1749,11 @@ __global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs
         for (int s = tid; s < S; s += FUSED_BLOCK)
             blr_draw_scale(misc[1], misc[2], D, s, a.seed, a.next_step, a.eps_next, a.xi_next);
     }
+}
+
+template <int FUSED_BLOCK>
+__global__ __launch_bounds__(FUSED_BLOCK) void blr_fused_update_kernel(FusedArgs a) {
+    fused_update_role<FUSED_BLOCK, false>(a, (int)blockIdx.x, [] {});
 }
 
 // Grid and per-wave trip count: fill the resident wave slots, then balance so
@@ -1689,8 +1830,16 @@ int keep_windows(const bsc_ctx* ctx, int64_t ldx, PassGrid g) {
 // sweep: BSC_SWEEP_STREAM (0) forward, every load non-temporal; BSC_SWEEP_FORWARD_KEEP (1) forward,
 // BSC_SWEEP_BACKWARD_KEEP (2) backward, the windows read last left in the Infinity Cache.  The 4-
 // and 8-row kernels (D != 256) always stream forward.
+// Can this pass carry its finish (FoldArgs)?  Only blr_pass_q_kernel does, and only when the grid leaves the role
+// workgroups something to wait for.
+bool pass_can_fold(const bsc_ctx* ctx, int D, const float* y, int sg, PassGrid g) {
+    return ctx->blr_fold && ctx->fold_counters && pass_rows(ctx, D, y) == 16 && ctx->blr_q && !ctx->blr_mx &&
+           !ctx->blr_q_dbg && ctx->blr_nt_loads && sg <= SG && g.n_iter > 0 && g.n_blocks >= 2 * ((SLAB_STRIDE + 63) / 64);
+}
+
 void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B, int D,
-                 const float* W, int sg, PassGrid g, float* slab, int sweep, bool wide = false) {
+                 const float* W, int sg, PassGrid g, float* slab, int sweep, bool wide = false,
+                 const FoldArgs* fold_in = nullptr) {
     const bool nt = ctx->blr_nt_loads != 0;
     const int rows = pass_rows(ctx, D, y);
     bsc_prof_scope prof(ctx);  // times the pass kernel alone
@@ -1718,7 +1867,7 @@ void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int6
             // both contractions on v_mfma_f32_4x4x1, the tile by LDS-DMA (round 4; option blr_q = 0: the kernels below)
             unsigned long long* stamps = nullptr;
             if (ctx->blr_stamps && !ctx->capturing) {
-                if (!ctx->stamps && hipMalloc(&ctx->stamps, (size_t)MAX_SLAB_ROWS * 32) != hipSuccess) ctx->stamps = nullptr;
+                if (!ctx->stamps && hipMalloc(&ctx->stamps, (size_t)MAX_SLAB_ROWS * 64) != hipSuccess) ctx->stamps = nullptr;
                 stamps = (unsigned long long*)ctx->stamps;
                 ctx->stamp_rows = g.n_blocks <= MAX_SLAB_ROWS ? g.n_blocks : 0;
                 if (!ctx->stamp_rows) stamps = nullptr;
@@ -1732,9 +1881,11 @@ void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int6
             if (rest < 0) { rest = n_tiles; extra = 0; }
             const int n_all = extra ? (int)((rest + w_all - 1) / w_all) : g.n_iter;
             const int n_a = n_all + extra;
+            FoldArgs fold{};
+            if (fold_in) fold = *fold_in;
 #define BSC_PASS_Q(NT_, DBG_, PRIO_)                                                               \
     hipLaunchKernelGGL((blr_pass_q_kernel<NT_, DBG_, PRIO_>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0, \
-                       ctx->stream, X, ldx, y, B, W, sg, slab, n_all, n_a, rev, keep, stamps)
+                       ctx->stream, X, ldx, y, B, W, sg, slab, n_all, n_a, rev, keep, stamps, fold)
             if (ctx->blr_q_dbg == 1) BSC_PASS_Q(true, 1, 0);
             else if (ctx->blr_q_dbg == 2) BSC_PASS_Q(true, 2, 0);
             else if (ctx->blr_q_dbg == 3) BSC_PASS_Q(true, 3, 0);
@@ -1781,6 +1932,16 @@ int data_pass_impl(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, in
         const bool wide = wide_ok && S - s0 > SG;
         const int cap = wide ? 2 * SG : SG;
         const int sg = (S - s0 < cap) ? (S - s0) : cap;
+        if (!wide && pass_can_fold(ctx, (int)D, y, sg, g)) {
+            // the float64 statistics come out of the pass's own tail (FoldArgs mode 2): no reduce launch
+            FoldArgs fold{};
+            fold.mode = 2; fold.counters = ctx->fold_counters; fold.Q = Q; fold.G = G; fold.s_base = s0; fold.S_total = (int)S;
+            launch_pass(ctx, X, ldx, y, B, (int)D, W + (int64_t)s0 * D, sg, g, slab, sweep, false, &fold);
+            BSC_LAUNCH_CHECK();
+            s0 += sg;
+            if (sweep != BSC_SWEEP_STREAM) sweep = 3 - sweep;
+            continue;
+        }
         launch_pass(ctx, X, ldx, y, B, (int)D, W + (int64_t)s0 * D, sg, g, slab, sweep, wide);
         BSC_LAUNCH_CHECK();
         hipLaunchKernelGGL(blr_slab_reduce_kernel, rgrid, dim3(RED_BLOCK), 0, ctx->stream, slab,
@@ -1835,7 +1996,7 @@ int bsc_blr_read_stamps(bsc_ctx* ctx, uint64_t* host_stamps, int32_t capacity_ro
     BSC_REQUIRE(host_stamps && host_rows && capacity_rows >= 0, "bsc_blr_read_stamps: bad arguments");
     BSC_HIP(hipStreamSynchronize(ctx->stream));
     const int n = ctx->stamps ? (ctx->stamp_rows < capacity_rows ? ctx->stamp_rows : capacity_rows) : 0;
-    if (n > 0) BSC_HIP(hipMemcpy(host_stamps, ctx->stamps, (size_t)n * 32, hipMemcpyDeviceToHost));
+    if (n > 0) BSC_HIP(hipMemcpy(host_stamps, ctx->stamps, (size_t)n * 64, hipMemcpyDeviceToHost));
     *host_rows = n;
     return BSC_OK;
 }
@@ -1920,7 +2081,7 @@ int fused_update_impl(bsc_ctx* ctx, const char* who, const double* stats, const 
                       int32_t S, double c0, double c_xi, double s_q, double k_w, double beta, int64_t t, double lr,
                       double beta1, double beta2, double adam_eps, uint64_t seed, uint32_t next_step,
                       double* eps_next, int32_t eps_next_ready, float* W_next, double* xi_next, double* elbo,
-                      double* grad) {
+                      double* grad, FusedArgs* out_args = nullptr) {
     BSC_CHECK_CTX(ctx);
     BSC_REQUIRE(lam_in && lam_out && m1 && m2 && eps && W && xi && elbo && grad, "%s: null pointer", who);
     BSC_REQUIRE(lam_in != lam_out, "%s: lam_in and lam_out must differ", who);
@@ -1934,7 +2095,7 @@ int fused_update_impl(bsc_ctx* ctx, const char* who, const double* stats, const 
     a.stats = stats;
     a.slab = nullptr;
     a.n_slab = 0;
-    if (!stats) {
+    if (!stats && !out_args) {
         BSC_REQUIRE(ctx->slab_rows > 0 && ctx->workspace,
                     "%s: stats is null and no bsc_blr_data_pass_partial slab is pending", who);
         BSC_REQUIRE(S <= SG && D <= GCOLS, "%s: slab input needs S<=8, D<=256", who);
@@ -1953,6 +2114,10 @@ int fused_update_impl(bsc_ctx* ctx, const char* who, const double* stats, const 
     a.corr2 = 1.0 - pow(beta2, (double)t);
     a.seed = seed;
     a.next_step = next_step;
+    if (out_args) {             // bsc_blr_pass_update: the pass launches with these (FoldArgs mode 1)
+        *out_args = a;
+        return BSC_OK;
+    }
     {
         bsc_prof_scope prof(ctx, /*slot=*/2);  // the finish kernel, timed apart from the pass
         const dim3 fgrid((D + 7) / 8 + 1);
@@ -1983,6 +2148,72 @@ int bsc_blr_fused_update(bsc_ctx* ctx, const double* stats, const double* lam_in
                              -half * LOG_2PI + alpha0 * log(beta0) - lgamma(alpha0), -half - alpha0, scale, 1.0, beta0,
                              t, lr, beta1, beta2, adam_eps, seed, next_step, eps_next, eps_next_ready, W_next,
                              xi_next, elbo, grad);
+}
+
+namespace {
+// One update = the pass with its finish folded into its tail when the shape allows it (blr_pass_q_kernel: D = 256,
+// S <= 8, a grid of at least 66 workgroups, option blr_fold), else the two launches bsc_blr_data_pass_partial_sweep +
+// bsc_blr_fused_update[_general] make.  Same results either way up to the order of the float64 slab sum.
+int pass_update_impl(bsc_ctx* ctx, const char* who, const float* X, int64_t ldx, const float* y, int64_t B, int32_t D,
+                     int32_t sweep, const double* lam_in, double* lam_out, double* m1, double* m2, const double* eps,
+                     const float* W, const double* xi, int32_t S, double c0, double c_xi, double s_q, double k_w,
+                     double beta, int64_t t, double lr, double beta1, double beta2, double adam_eps, uint64_t seed,
+                     uint32_t next_step, double* eps_next, int32_t eps_next_ready, float* W_next, double* xi_next,
+                     double* elbo, double* grad) {
+    BSC_CHECK_CTX(ctx);
+    int rc = check_pass_args(X, ldx, y, B, D, W, S, SG);
+    if (rc != BSC_OK) return rc;
+    BSC_REQUIRE(sweep >= 0 && sweep <= 2, "%s: sweep=%d (0, 1 or 2)", who, sweep);
+    const PassGrid g = pass_grid(ctx, B, pass_rows(ctx, D, y));
+    if (!pass_can_fold(ctx, (int)D, y, (int)S, g)) {
+        rc = data_pass_partial_impl(ctx, X, ldx, y, B, D, W, S, sweep);
+        if (rc != BSC_OK) return rc;
+        return fused_update_impl(ctx, who, nullptr, lam_in, lam_out, m1, m2, eps, W, xi, D, S, c0, c_xi, s_q, k_w, beta, t,
+                                 lr, beta1, beta2, adam_eps, seed, next_step, eps_next, eps_next_ready, W_next, xi_next,
+                                 elbo, grad);
+    }
+    FoldArgs fold{};
+    rc = fused_update_impl(ctx, who, nullptr, lam_in, lam_out, m1, m2, eps, W, xi, D, S, c0, c_xi, s_q, k_w, beta, t, lr,
+                           beta1, beta2, adam_eps, seed, next_step, eps_next, eps_next_ready, W_next, xi_next, elbo, grad,
+                           &fold.a);
+    if (rc != BSC_OK) return rc;
+    void* ws = nullptr;
+    rc = bsc_workspace(ctx, (size_t)2 * g.n_blocks * SLAB_STRIDE * sizeof(float), &ws);
+    if (rc != BSC_OK) return rc;
+    fold.a.slab = (const float*)ws;
+    fold.a.n_slab = g.n_blocks;
+    fold.mode = 1;
+    fold.counters = ctx->fold_counters;
+    launch_pass(ctx, X, ldx, y, B, (int)D, W, (int)S, g, (float*)ws, sweep, false, &fold);
+    BSC_LAUNCH_CHECK();
+    ctx->slab_rows = 0;      // consumed inside the launch
+    return BSC_OK;
+}
+}  // namespace
+
+int bsc_blr_pass_update(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B, int32_t D, int32_t sweep,
+                        const double* lam_in, double* lam_out, double* m1, double* m2, const double* eps, const float* W,
+                        const double* xi, int32_t S, double batch_rows, double scale, double alpha0, double beta0,
+                        int64_t t, double lr, double beta1, double beta2, double adam_eps, uint64_t seed,
+                        uint32_t next_step, double* eps_next, int32_t eps_next_ready, float* W_next, double* xi_next,
+                        double* elbo, double* grad) {
+    BSC_REQUIRE(alpha0 > 0 && beta0 > 0, "bsc_blr_pass_update: bad hyper-parameters");
+    const double half = 0.5 * (scale * batch_rows + (double)D);       // (config 2 as a member of the family: bsc_blr_fused_update)
+    return pass_update_impl(ctx, "bsc_blr_pass_update", X, ldx, y, B, D, sweep, lam_in, lam_out, m1, m2, eps, W, xi, S,
+                            -half * LOG_2PI + alpha0 * log(beta0) - lgamma(alpha0), -half - alpha0, scale, 1.0, beta0, t, lr,
+                            beta1, beta2, adam_eps, seed, next_step, eps_next, eps_next_ready, W_next, xi_next, elbo, grad);
+}
+
+int bsc_blr_pass_update_general(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B, int32_t D,
+                                int32_t sweep, const double* lam_in, double* lam_out, double* m1, double* m2,
+                                const double* eps, const float* W, const double* xi, int32_t S, double c0, double c_xi,
+                                double s_q, double k_w, double beta, int64_t t, double lr, double beta1, double beta2,
+                                double adam_eps, uint64_t seed, uint32_t next_step, double* eps_next,
+                                int32_t eps_next_ready, float* W_next, double* xi_next, double* elbo, double* grad) {
+    BSC_REQUIRE(s_q >= 0.0 && k_w >= 0.0, "bsc_blr_pass_update_general: s_q=%g k_w=%g must not be negative", s_q, k_w);
+    return pass_update_impl(ctx, "bsc_blr_pass_update_general", X, ldx, y, B, D, sweep, lam_in, lam_out, m1, m2, eps, W, xi,
+                            S, c0, c_xi, s_q, k_w, beta, t, lr, beta1, beta2, adam_eps, seed, next_step, eps_next,
+                            eps_next_ready, W_next, xi_next, elbo, grad);
 }
 
 int bsc_blr_fused_update_general(bsc_ctx* ctx, const double* stats, const double* lam_in, double* lam_out,

@@ -53,6 +53,8 @@ struct bsc_ctx {
     int blr_q_dbg = 0;           // deletion builds of blr_pass_q_kernel (BSC_BLR_Q_DBG + BSC_PROFILING_BUILDS): WRONG results
     int blr_q_bias = 70;         // blr_pass_q_kernel, static schedule: per mille of further windows for the workgroups with an even blockIdx (QSched)
     int blr_q_prio = 1;          // blr_pass_q_kernel: s_setprio 1 from a tile's landing to the next tile's DMAs (1), or during the backward (2)
+    int blr_fold = 0;            // 1: blr_pass_q_kernel carries its finish (or the float64 statistics of the N > 1 structure) in its tail -- one launch per update (FoldArgs).  Built and measured in round 4: break-even (162.9-163.1 vs 162.5-162.9 us per 1M-row update, 36.4 vs 35.3-36.4 at 125k rows, profiles/r04_fold_*.txt), so off by default
+    unsigned* fold_counters = nullptr;   // [arrivals, roles done] of the folded finish: zero between launches
     int blr_stamps = 0;          // blr_pass_q_kernel: every workgroup leaves start / end s_memrealtime stamps and its XCD (bsc_blr_read_stamps)
     void* stamps = nullptr;      // 32 bytes per workgroup, allocated when blr_stamps is first used
     int stamp_rows = 0;          // workgroups of the last stamped launch

@@ -138,10 +138,11 @@ class Context:
         return int(out.value)
 
     def read_stamps(self):
-        """Option blr_stamps: (rows, 4) uint64 array {start tick, end tick, XCD, HW_ID} per workgroup of the last
-        D = 256, S <= 8 pass (100 MHz ticks); syncs."""
+        """Option blr_stamps: (rows, 8) uint64 array {start tick, end tick, XCD, HW_ID, and -- folded finish -- partial
+        written, ticket taken, every row arrived, ticket} per workgroup of the last D = 256, S <= 8 pass (100 MHz
+        ticks); syncs."""
         import numpy as np
-        buf = np.zeros((2048, 4), np.uint64)
+        buf = np.zeros((2048, 8), np.uint64)
         n = ctypes.c_int32()
         _ffi.check(self.lib.bsc_blr_read_stamps(self.handle, buf.ctypes.data, 2048, ctypes.byref(n)),
                    "bsc_blr_read_stamps")

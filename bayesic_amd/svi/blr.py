@@ -81,6 +81,9 @@ class BLRReparamSVI:
         self.batch_rows = self.exchange.global_count(self.B, dev)
         self.n_total = float(n_total) if n_total is not None else self.batch_rows
         self.fused = bool(fused)
+        # one launch per update (bsc_blr_pass_update: the finish in the pass's tail) where the library offers the entry
+        # point; a test double without it, or one_launch = False, takes the two launches
+        self.one_launch = hasattr(getattr(self.ctx, "lib", None), "bsc_blr_pass_update")
         self.reproducible = bool(reproducible)
         if sweep not in ("alternate", "stream"):
             raise ValueError("sweep must be 'alternate' or 'stream'")
@@ -278,14 +281,34 @@ class BLRReparamSVI:
                           self.grad)
         self.t = t
 
+    def _pass_update(self):
+        """bsc_blr_pass_update[_general]: data pass + gradient + Adam + next draw as ONE launch; flips the double buffer."""
+        c, n = self.cur, 1 - self.cur
+        t = self.t + 1                  # Adam step count; Philox step of the NEXT draw
+        self._ensure_noise(t)
+        head = (self._Xarg, self._ldx, self._yarg, self.B, self.D, self._take_sweep(),
+                self._lam[c], self._lam[n], self.m1, self.m2, self._eps[self.t % self._ring], self._W[c], self._xi[c],
+                self.S)
+        tail = (t, self.lr, 0.9, 0.999, 1e-8, self.seed, t, self._eps[t % self._ring], 1, self._W[n], self._xi[n],
+                self.elbo, self.grad)
+        if self.family is None:
+            self.ctx.call("bsc_blr_pass_update", *head, self.batch_rows, self.n_total / self.batch_rows, self.alpha0,
+                          self.beta0, *tail)
+        else:
+            self.ctx.call("bsc_blr_pass_update_general", *head, *self.family, *tail)
+        self.t = t
+
     def step(self):
         """One ELBO-gradient update; asynchronous on the context stream."""
         if not self._drawn:
             self.sample(self.t)  # Philox step index == number of completed updates
         if self.fused and self.world == 1 and not self.exchange.rccl and self.S <= 8 and not self.reproducible:
-            self.ctx.call("bsc_blr_data_pass_partial_sweep", self._Xarg, self._ldx,
-                          self._yarg, self.B, self.D, self.W, self.S, self._take_sweep())
-            self._finish(None)
+            if self.one_launch:
+                self._pass_update()         # the pass with the finish in its tail: one launch (falls back inside the library)
+            else:
+                self.ctx.call("bsc_blr_data_pass_partial_sweep", self._Xarg, self._ldx,
+                              self._yarg, self.B, self.D, self.W, self.S, self._take_sweep())
+                self._finish(None)
         else:
             self.data_pass()
             self.all_reduce()

@@ -263,7 +263,7 @@ int bsc_blr_data_pass_partial_sweep(bsc_ctx* ctx, const float* X, int64_t ldx, c
 
 /* Measurement aid (option "blr_stamps" = 1): the D = 256, S <= 8 pass leaves per workgroup
  * {start, end} in s_memrealtime ticks (100 MHz), the XCD it ran on and its HW_ID; this copies the
- * stamps of the LAST such launch to host_stamps[4 * rows] (synchronises).  Shows how evenly a static
+ * stamps of the LAST such launch to host_stamps[8 * rows] (synchronises; entries 4..7: the folded finish's hand-off).  Shows how evenly a static
  * partition of the mini-batch finishes (tools/ab_q.py). */
 int bsc_blr_read_stamps(bsc_ctx* ctx, uint64_t* host_stamps, int32_t capacity_rows, int32_t* host_rows);
 
@@ -309,6 +309,31 @@ int bsc_blr_fused_update(bsc_ctx* ctx, const double* stats, const double* lam_in
  * bayesic_amd.inference.ReparamVI launches when it recognises such a model written with Distribution nodes
  * and bayesic.algebra expressions (bayesic/distribution/base.py:47-69 decomposition; coefficient extraction
  * with match, bayesic/algebra.py:1037-1063). */
+/* ONE launch per update (round 4): the data pass of bsc_blr_data_pass_partial_sweep with the finish of
+ * bsc_blr_fused_update[_general] (stats = NULL) carried in its tail -- after its block partial a workgroup
+ * takes an arrival ticket, and the last (D + 7) / 8 + 1 arrivals do what the finish kernel's workgroups do once
+ * every partial has been written (csrc/bsc_blr.hip FoldArgs: write-through partials, one arrival counter,
+ * sc1 reads; a role's arithmetic is fixed whichever workgroup performs it, so the update stays reproducible).
+ * Taken when D = 256, S <= 8, the mini-batch gives the grid >= 66 workgroups AND the option "blr_fold" is 1.
+ * Its default is 0: measured on MI355X the fold is break-even with the two launches (the hand-off takes ~1 us,
+ * but 33 role workgroups of four waves take 4-8 us over the slab where the finish kernel's sixteen-wave
+ * workgroups take 6 us behind a 1.7 us boundary; profiles/r04_fold_timeline.txt).  Without the option, and for
+ * any other shape, the entry point issues the two launches, with the same results up to the order of the float64 sum over
+ * the partials.  bsc_blr_data_pass[_sweep] folds its float64 reduction the same way (the N > 1 structure:
+ * pass -> all-reduce -> finish is then two launches and the collective).  Arguments: those of the two entry
+ * points it replaces.  README.md:51, 69-79. */
+int bsc_blr_pass_update(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B, int32_t D, int32_t sweep,
+                        const double* lam_in, double* lam_out, double* m1, double* m2, const double* eps, const float* W,
+                        const double* xi, int32_t S, double batch_rows, double scale, double alpha0, double beta0,
+                        int64_t t, double lr, double beta1, double beta2, double adam_eps, uint64_t seed,
+                        uint32_t next_step, double* eps_next, int32_t eps_next_ready, float* W_next, double* xi_next,
+                        double* elbo, double* grad);
+int bsc_blr_pass_update_general(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int64_t B, int32_t D,
+                                int32_t sweep, const double* lam_in, double* lam_out, double* m1, double* m2,
+                                const double* eps, const float* W, const double* xi, int32_t S, double c0, double c_xi,
+                                double s_q, double k_w, double beta, int64_t t, double lr, double beta1, double beta2,
+                                double adam_eps, uint64_t seed, uint32_t next_step, double* eps_next,
+                                int32_t eps_next_ready, float* W_next, double* xi_next, double* elbo, double* grad);
 int bsc_blr_fused_update_general(bsc_ctx* ctx, const double* stats, const double* lam_in, double* lam_out,
                                  double* m1, double* m2, const double* eps, const float* W, const double* xi,
                                  int32_t D, int32_t S, double c0, double c_xi, double s_q, double k_w, double beta,

@@ -615,3 +615,112 @@ def test_pass_schedules_cover_every_tile_once(options):
             _check_pass(ctx, X, y, W)
         else:
             assert (Q == 0).all() and (G == 0).all()
+
+
+# ---- round 4: the finish folded into the pass's tail (FoldArgs; bsc_blr_pass_update, bsc_blr_data_pass) -------------
+# Built, measured break-even against the two launches (profiles/r04_fold_timeline.txt), hence option blr_fold = 0 by
+# default: these tests switch it on.
+
+@pytest.fixture(scope="module")
+def fold_ctx():
+    from bayesic_amd.device import Context
+    c = Context(0, options=dict(blr_fold=1))
+    yield c
+    c.close()
+
+
+def _svi_pair(ctx, B, n_total, seed, lr, S=8):
+    from bayesic_amd.svi.blr import BLRReparamSVI
+    X, y, _ = svi.make_cfg2(B, 256)
+    Xd, yd = ctx.to_device(X), ctx.to_device(y)
+    one = BLRReparamSVI(Xd, yd, n_total=n_total, n_samples=S, seed=seed, lr=lr, ctx=ctx)
+    two = BLRReparamSVI(Xd, yd, n_total=n_total, n_samples=S, seed=seed, lr=lr, ctx=ctx)
+    two.one_launch = False
+    assert one.one_launch
+    return X, y, one, two
+
+
+@pytest.mark.parametrize("B", [40_000, 130_003, 1_000])
+def test_one_launch_update_equals_the_two_launch_update(fold_ctx, B):
+    """bsc_blr_pass_update: the last (D + 7) / 8 + 1 workgroups to finish their rows do the finish kernel's work inside
+    the pass launch.  Against the two launches it replaces (pass, then bsc_blr_fused_update from the slab): the same
+    parameters, ELBO and gradient -- the float64 sum over the block partials runs in another order (4 waves instead
+    of 16), nothing else differs -- and against the oracle's update.  B = 1 000 gives a grid below 66 workgroups: the
+    entry point then issues the two launches itself."""
+    ctx = fold_ctx
+    X, y, one, two = _svi_pair(ctx, B, 10.0 * B, seed=21, lr=0.02)
+    lam = svi.blr_init_lam(256)
+    m1, m2 = np.zeros_like(lam), np.zeros_like(lam)
+    calls = []
+    real = ctx.call
+    ctx.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+    try:
+        for t in range(1, 6):
+            one.step()
+            two.step()
+            lam, m1, m2, elbo, grad = svi.blr_step(lam, m1, m2, t, X, y, 8, 21, 10.0 * B, 0.02)
+            np.testing.assert_allclose(one.lam.cpu().numpy(), two.lam.cpu().numpy(), rtol=1e-12, atol=1e-14)
+            np.testing.assert_allclose(one.elbo.item(), two.elbo.item(), rtol=1e-12)
+            np.testing.assert_allclose(one.grad.cpu().numpy(), two.grad.cpu().numpy(), rtol=1e-10, atol=1e-10)
+            np.testing.assert_allclose(one.elbo.item(), elbo, rtol=1e-6)
+            np.testing.assert_allclose(one.lam.cpu().numpy(), lam, atol=1e-4)
+    finally:
+        ctx.call = real
+    assert calls.count("bsc_blr_pass_update") == 5 and calls.count("bsc_blr_fused_update") == 5
+    # run to run: bit for bit
+    _, _, again, _ = _svi_pair(ctx, B, 10.0 * B, seed=21, lr=0.02)
+    for _ in range(5):
+        again.step()
+    np.testing.assert_array_equal(again.lam.cpu().numpy(), one.lam.cpu().numpy())
+    np.testing.assert_array_equal(again.elbo.cpu().numpy(), one.elbo.cpu().numpy())
+
+
+def test_folded_finish_under_uneven_load_and_many_launches(fold_ctx):
+    """The hand-off inside the launch (write-through partials -> arrival counter -> sc1 reads) with the chip busy with
+    something else on another stream, for many consecutive launches of changing size (the counters must come back to
+    zero every time): every update equal to the two-launch update's."""
+    ctx = fold_ctx
+    from bayesic_amd.svi.blr import BLRReparamSVI
+    dev = ctx.device
+    hog_a = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    hog_b = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    side = torch.cuda.Stream(dev)
+    engines = []
+    for B in (40_000, 77_777, 250_000):
+        X, y, one, two = _svi_pair(ctx, B, 5.0 * B, seed=B, lr=0.01)
+        engines.append((one, two))
+    for rep in range(40):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                hog_b.copy_(hog_a)              # 256 MiB read + write beside the passes: uneven arrival of the workgroups
+        for one, two in engines:
+            one.step()
+        for one, two in engines:
+            two.step()
+        if rep % 10 == 9:
+            for one, two in engines:
+                np.testing.assert_allclose(one.lam.cpu().numpy(), two.lam.cpu().numpy(), rtol=1e-12, atol=1e-14)
+                np.testing.assert_allclose(one.elbo.item(), two.elbo.item(), rtol=1e-12)
+    side.synchronize()
+    ctx.sync()
+
+
+def test_data_pass_folds_its_float64_reduction(fold_ctx):
+    """bsc_blr_data_pass (the N > 1 structure's pass): with option blr_fold the float64 statistics [Q | G] come out of
+    the pass launch's tail instead of a second launch.  Against a context with blr_fold = 0 and against the oracle."""
+    ctx = fold_ctx
+    from bayesic_amd.device import Context
+    plain = Context(0, options=dict(blr_fold=0))
+    assert ctx.get_option("blr_fold") == 1 and Context(0).get_option("blr_fold") == 0
+    for B, S in ((130_003, 8), (40_000, 5), (1_000, 8)):
+        rs = np.random.RandomState(B + S)
+        X = rs.standard_normal((B, 256)).astype(np.float32)
+        y = rs.standard_normal(B).astype(np.float32)
+        W = (rs.standard_normal((S, 256)) / 16).astype(np.float32)
+        Q, G = _check_pass(ctx, X, y, W)
+        Q0, G0 = _pass(plain, X, y, W)
+        np.testing.assert_allclose(Q, Q0, rtol=1e-13)
+        np.testing.assert_allclose(G, G0, rtol=1e-12, atol=1e-12 * np.abs(G0).max())
+        Q2, G2 = _pass(ctx, X, y, W)
+        assert np.array_equal(Q, Q2) and np.array_equal(G, G2)
+    plain.close()
