@@ -24,7 +24,9 @@ LIMITS = {
         "blr_pass_mx_kernelILb1ELi2E": (232, 0),
         "blr_pass_mx_kernelILb1ELi4E": (256, 0),        # sixteen draws per pass: 64 accumulator registers
         "blr_pass_kernelILb1ELi8ELb1E": (256, 0),
-        "blr_fused_update_kernel": (128, 0),
+        "blr_fused_update_kernelILi1024E": (128, 0),    # the default: sixteen waves = four per SIMD
+        "blr_fused_update_kernelILi512E": (192, 0),     # (A/B variants: eight / four waves, the slab in one trip of
+        "blr_fused_update_kernelILi256E": (192, 0),     #  32 loads per lane, as the folded finish's roles read it)
     },
     "bsc_rowsoftmax.hip": {
         "gemm_softmax_rows_kernelILi20E": (256, 0),     # K = 40 (the derived mixture): 2 waves/SIMD, no scratch
