@@ -36,13 +36,12 @@ __device__ __forceinline__ float bsc_bf16_hi(unsigned pk) { return __uint_as_flo
 // (a, b) -> the packed terms of SPLIT-term sums; t[0] = leading terms
 template <int SPLIT>
 __device__ __forceinline__ void bsc_split_pk(float a, float b, unsigned (&t)[SPLIT]) {
+    bsc_f32x2 ab = {a, b};
 #pragma unroll
     for (int c = 0; c < SPLIT; ++c) {
-        t[c] = bsc_pk_bf16(a, b);
-        if (c + 1 < SPLIT) {
-            a -= bsc_bf16_lo(t[c]);       // exact: the difference of an f32 and its own leading bits
-            b -= bsc_bf16_hi(t[c]);
-        }
+        t[c] = __builtin_bit_cast(unsigned, __builtin_convertvector(ab, bsc_bf16x2));
+        if (c + 1 < SPLIT)      // exact: the difference of an f32 and its own leading bits -- both of the pair in ONE v_pk_add_f32
+            ab -= bsc_f32x2{bsc_bf16_lo(t[c]), bsc_bf16_hi(t[c])};
     }
 }
 

@@ -277,8 +277,8 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_kernel(
 //   * a lane loads HALF a row (x[8 h ..], 32 bytes): element j of its k-step-0 fragment is x[8 h + j], of k-step 1
 //     x[8 h + j]^2 -- the B operand (k = feature, n = row) with no data movement, no row read twice;
 //   * the result has the row on the lane and the components in registers, as before: the softmax is unchanged;
-//   * the backward sums over rows, i.e. over the LANE index of both its operands: e (unnormalised) and the
-//     features / sum go to wave-private LDS as bf16 terms, [row][32 components or features] with 64-byte rows, and
+//   * the backward sums over rows, i.e. over the LANE index of both its operands: the responsibilities r = e / sum
+//     (two terms) and the features (the first two of the forward's three terms) go to wave-private LDS as bf16 terms, [row][32 components or features] with 64-byte rows, and
 //     come back transposed by ds_read_b64_tr_b16 (cdna_hip_programming.md "An accumulator tile as the next MFMA's
 //     operand").  8-byte chunk c of row r sits at chunk c ^ sw(r): sw = (r >> 1) & 7 for the e images (written 8
 //     bytes a lane: two lanes a bank, the floor), 2 ((r >> 1) & 3) for the feature image (written 16 bytes a lane);
@@ -404,6 +404,13 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_bx_kernel(
 #pragma unroll
             for (int c = 0; c < 3; ++c) fb[1][c][t] = pk[c];
         }
+        // the backward's feature operand = the first two of these terms, to the (free: the previous tile's backward ended
+        // with a wave barrier) image right away, so that the fragments die with the forward product
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {       // (fb[.][c][t] packs the columns 2 t, 2 t + 1 of this lane's half row: the image's order)
+            asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(wg0), "v"(fb[0][c]), "n"(c * BX_E_IMG) : "memory");
+            asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(wg1), "v"(fb[1][c]), "n"(c * BX_E_IMG) : "memory");
+        }
         f32x16 logit[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
@@ -418,22 +425,38 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_bx_kernel(
 #pragma unroll
             for (int q = 0; q < 16; q += 2) m = __builtin_fmaxf(__builtin_fmaxf(logit[cb][q], logit[cb][q + 1]), m);
         m = swap32_max(m);
-        float ssum = 0.f;
+        // pairs of values through v_pk_add / v_pk_mul (a packed instruction takes the matrix pipe what a scalar one does:
+        // profiles/r01_ubench_mfma_valu_mix.txt)
+        const f32x2 m2 = {m, m};
+        f32x2 ssum2 = {0.f, 0.f};
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                logit[cb][q] = __builtin_amdgcn_exp2f(logit[cb][q] - m);
-                ssum += logit[cb][q];
+            for (int q = 0; q < 16; q += 2) {
+                const f32x2 d = f32x2{logit[cb][q], logit[cb][q + 1]} - m2;
+                const f32x2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+                logit[cb][q] = e[0];
+                logit[cb][q + 1] = e[1];
+                ssum2 += e;
             }
-        ssum = swap32_sum(ssum);
+        const float ssum = swap32_sum(ssum2[0] + ssum2[1]);
         const float inv = valid ? 1.0f / ssum : 0.f;
         if (valid && half == 0) lse_acc += LN2 * (m + __builtin_amdgcn_logf(ssum));
-        // ---- e (two terms) and the features / sum (two terms) to LDS
+        // ---- the responsibilities r = e / sum (two terms) and the features (the first two of the forward's three terms:
+        // nothing to compute) to LDS.  Round 4: the 1 / sum went from the 16 features of a lane -- where it cost a second
+        // split of x and x^2, 64 vector instructions -- to its 32 responsibilities (16 packed multiplies).
+        const f32x2 inv2 = {inv, inv};
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) rsum[cb][q] = __builtin_fmaf(logit[cb][q], inv, rsum[cb][q]);
+            for (int q = 0; q < 16; q += 2) {
+                const f32x2 r = f32x2{logit[cb][q], logit[cb][q + 1]} * inv2;
+                const f32x2 acc2 = f32x2{rsum[cb][q], rsum[cb][q + 1]} + r;
+                logit[cb][q] = r[0];
+                logit[cb][q + 1] = r[1];
+                rsum[cb][q] = acc2[0];
+                rsum[cb][q + 1] = acc2[1];
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 unsigned p0[2], p1[2];
@@ -445,22 +468,7 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_bx_kernel(
                                  "n"((2 * cb + c) * BX_E_IMG) : "memory");
             }
         }
-        {
-            bsc_u32x4 gx[2], gx2[2];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                unsigned pk[2];
-                bsc_split_pk<2>(cur.x[2 * t] * inv, cur.x[2 * t + 1] * inv, pk);
-                gx[0][t] = pk[0]; gx[1][t] = pk[1];
-                bsc_split_pk<2>(x2[2 * t] * inv, x2[2 * t + 1] * inv, pk);
-                gx2[0][t] = pk[0]; gx2[1][t] = pk[1];
-            }
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(wg0), "v"(gx[c]), "n"(c * BX_E_IMG) : "memory");
-                asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(wg1), "v"(gx2[c]), "n"(c * BX_E_IMG) : "memory");
-            }
-        }
+
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wave_lds_sync();
         // ---- backward: S[comp][feat] += sum over rows e[row][comp] (f[row][feat] / sum[row]), 16 rows a k-step
