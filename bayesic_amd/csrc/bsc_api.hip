@@ -68,6 +68,7 @@ const bsc_option OPTIONS[] = {
     {"blr_q_bias", &bsc_ctx::blr_q_bias, 0, 400, nullptr, false},
     {"blr_q_prio", &bsc_ctx::blr_q_prio, 0, 2, nullptr, false},
     {"blr_fold", &bsc_ctx::blr_fold, 0, 1, nullptr, false},
+    {"blr_steal", &bsc_ctx::blr_steal, 0, 500, nullptr, false},
     {"blr_stamps", &bsc_ctx::blr_stamps, 0, 1, nullptr, false},
     {"fused_map_blocks_per_cu", &bsc_ctx::fused_map_blocks_per_cu, 1, 64, nullptr, false},
     {"fused_map_flat", &bsc_ctx::fused_map_flat, 0, 1, nullptr, false},
@@ -142,10 +143,14 @@ int bsc_ctx_create(int device, void* stream, bsc_ctx** out) {
     ctx->cu_count = prop.multiProcessorCount;
     // the arrival counters of the folded finish (csrc/bsc_blr.hip FoldArgs): allocated here, not on first use, so that
     // a graph capture never meets an allocation
-    if (hipMalloc((void**)&ctx->fold_counters, 256) == hipSuccess) {
-        if (hipMemset(ctx->fold_counters, 0, 256) != hipSuccess) {
+    // ... and behind them the tile queues of blr_pass_q_kernel's stealing tail (StealArgs: 64 heads 256 bytes apart + one counter)
+    constexpr size_t COUNTER_BYTES = 256 + (64 * 64 + 64) * sizeof(unsigned);
+    if (hipMalloc((void**)&ctx->fold_counters, COUNTER_BYTES) == hipSuccess) {
+        if (hipMemset(ctx->fold_counters, 0, COUNTER_BYTES) != hipSuccess) {
             (void)hipFree(ctx->fold_counters);
             ctx->fold_counters = nullptr;
+        } else {
+            ctx->steal_heads = ctx->fold_counters + 64;
         }
     } else {
         ctx->fold_counters = nullptr;

@@ -477,7 +477,10 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_mfma_kernel(
 // only then does its rank-1 updates from the registers -- so the DMAs have the whole backward and the other wave's turn
 // to land, and no LDS read of the tile follows a DMA in flight (the compiler answers such a read with vmcnt(0): the
 // residuals, which ARE read during the backward, come by inline asm with their own lgkmcnt waits).
-template <int AUX>
+// VROW: the row's offset rides in the VECTOR offset (sixteen loop-invariant registers) instead of the scalar one -- for
+// the stealing loop of blr_pass_q_kernel, where the compiler otherwise parks the fifteen scalar products in vector
+// registers and wraps every DMA in a waterfall loop.
+template <int AUX, bool VROW = false>
 __device__ __forceinline__ void dma_mtile(float* __restrict__ tl, const float* __restrict__ X, int64_t ldx,
                                           const float* __restrict__ y, int64_t row0, int64_t B, int lane, float4& yv) {
     const int64_t rem = row0 < 0 ? 0 : B - row0;
@@ -493,8 +496,10 @@ __device__ __forceinline__ void dma_mtile(float* __restrict__ tl, const float* _
     auto ys = __builtin_amdgcn_make_buffer_rsrc((void*)(y + safe0), 0, yrec, 0x00020000);
     const int row_bytes = (int)(ldx * 4);
 #pragma unroll
-    for (int r = 0; r < MT_ROWS; ++r)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (bsc_lds_ptr)(tl + r * MT_RS), 16, 16 * lane, r * row_bytes, 0, AUX);
+    for (int r = 0; r < MT_ROWS; ++r) {
+        if (VROW) __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (bsc_lds_ptr)(tl + r * MT_RS), 16, 16 * lane + r * row_bytes, 0, 0, AUX);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (bsc_lds_ptr)(tl + r * MT_RS), 16, 16 * lane, r * row_bytes, 0, AUX);
+    }
     auto v = __builtin_amdgcn_raw_buffer_load_b128(ys, 16 * (lane >> 4), 0, 0);
     yv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
 }
@@ -720,7 +725,7 @@ constexpr int QW = 32;   // forward B operand: registers per lane
 // DBG (profiling only, WRONG results; BSC_BLR_Q_DBG + BSC_PROFILING_BUILDS): 1 = no arithmetic at all (the feed's own
 // ceiling: DMAs, waits, LDS reads), 2 = forward only, 3 = backward only
 // `next_row0()` is called once, right before the next tile's DMAs are issued, `after_dma()` right behind them.
-template <int AUX, int DBG, int PRIO, typename NextRow, typename AfterDma>
+template <int AUX, int DBG, int PRIO, bool VROW = false, typename NextRow, typename AfterDma>
 __device__ __forceinline__ void q_tile_step(float4& yv_cur, float* __restrict__ tl, float* __restrict__ rb,
                                             const float (&wreg)[QW], mfma_f32x4 (&acc)[2][4], float& qacc,
                                             const float* __restrict__ X, int64_t ldx, const float* __restrict__ y,
@@ -784,7 +789,7 @@ __device__ __forceinline__ void q_tile_step(float4& yv_cur, float* __restrict__ 
             ra[sb][g] = *reinterpret_cast<const float4*>(rb + (4 * sb + (lane & 3)) * MT_ROWS + 4 * g);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wave_lds_sync();
-    dma_mtile<AUX>(tl, X, ldx, y, next_row0(), B, lane, yv_cur);
+    dma_mtile<AUX, VROW>(tl, X, ldx, y, next_row0(), B, lane, yv_cur);
     after_dma();
     if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
     if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
@@ -809,6 +814,54 @@ __device__ __forceinline__ void q_tile_step(float4& yv_cur, float* __restrict__ 
         for (int r = 0; r < MT_ROWS; ++r) s += x4[r].x;
         if (s == 12345.678f) qacc += ra[0][0].x + ra[1][3].w;
     }
+}
+
+// ---- the queued tail of blr_pass_q_kernel (option blr_steal) ---------------------------------------------------------
+//
+// The static schedule below ends when the slowest workgroup does, and the workgroups do not run at one speed: the
+// mean end of a workgroup differs by 8-9 us of ~145 between the XCDs of one part (and WHICH XCDs are slow differs from
+// part to part: tools/stamps_structure.py), with another ~5 us of launch-to-launch noise on top.  So every wave takes
+// only (1000 - blr_steal) per mille of an even share statically and draws the remaining tiles, one at a time, from
+// one of up to 64 queues.  Queue q holds a contiguous run of `per_q` tiles and serves the workgroups with
+// (blockIdx / 8) % nq = q -- workgroups are dealt to the XCDs round-robin, so a queue is shared by one workgroup of
+// every XCD (twice over at 512 workgroups) and the fast XCDs take the tiles the slow ones do not get to.  A wave leaves
+// when its queue is empty; nothing moves between queues.
+//   * The request goes out BEFORE the wait for the current tile's DMAs and is looked at only when the next tile's DMAs
+//     are issued, so its latency is behind a wait the wave has anyway.
+//   * A cache line serves one returning atomic per ~15 ns whatever the address in it (tools/ubench_atomic_queue.hip):
+//     hence 64 heads 256 bytes apart, not one counter -- and no device-wide "who is last" counter either: the
+//     workgroups of a queue count themselves out on the queue's own line and the last one zeroes it.
+//   * (Measured and dropped: waves of an empty queue moving on to other queues.  Finding one takes a look at all 64 heads;
+//     2 048 waves doing that within microseconds of each other, and then falling on the few queues with a tile left,
+//     cost 20-40 us a launch: profiles/r04_ab_pass_q_steal.txt.)
+// Which wave adds which tile into its partial sums now depends on timing: the LAST BITS of the f32 sums differ from
+// launch to launch (blr_steal = 0 keeps the reproducible static schedule).
+constexpr int STEAL_Q = 64, STEAL_STRIDE = 64;      // queues; words between their heads (word 1 of a line: workgroups done)
+struct StealArgs {
+    unsigned* heads;          // nullptr: static schedule only
+    int per_q;                // tiles per queue (the last non-empty one may hold fewer)
+    int nq;                   // queues in use: min(64, whole groups of 8 workgroups)
+    long long t0, n_dyn;      // first queued tile, queued tiles
+};
+__device__ __forceinline__ int steal_len(const StealArgs& s, int q) {
+    const long long r = s.n_dyn - (long long)q * s.per_q;
+    return r <= 0 ? 0 : r < s.per_q ? (int)r : s.per_q;
+}
+// (inline asm: the compiler's atomic optimizer rewrites a one-lane __hip_atomic_fetch_add and waits for the result -- vmcnt(0),
+// so for every DMA in flight as well -- right behind it.  The result is valid after the caller's next vmcnt(0).)
+__device__ __forceinline__ unsigned steal_request(const StealArgs& s, int q, int lane) {
+    unsigned t = 1u;
+    const unsigned off = (unsigned)q * (STEAL_STRIDE * 4u);
+    if (lane == 0) asm volatile("global_atomic_add %0, %1, %0, %2 sc0" : "+v"(t) : "v"(off), "s"(s.heads) : "memory");
+    return t;
+}
+// row0 of the tile the request `pend` on queue q drew, or B: the queue is empty
+__device__ __forceinline__ int64_t steal_resolve(const StealArgs& s, unsigned pend, int q, int64_t B) {
+    // (the value is looked at HERE, not where the request was made; wave-uniform, and said so: or every DMA built on
+    // it sits in a waterfall loop)
+    asm volatile("" : "+v"(pend));
+    const unsigned t = __builtin_amdgcn_readfirstlane(pend);
+    return (long long)t < (long long)steal_len(s, q) ? (s.t0 + (int64_t)q * s.per_q + (int64_t)t) * MT_ROWS : B;
 }
 
 // Which tiles a wave of blr_pass_q_kernel reads.
@@ -836,11 +889,11 @@ struct QSched {
     }
 };
 
-template <bool NT, int DBG, int PRIO>
+template <bool NT, int DBG, int PRIO, bool STEAL = false>
 __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_q_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ y, int64_t B,
     const float* __restrict__ W, int S, float* __restrict__ slab, int n_all, int n_a, int rev, int keep,
-    unsigned long long* __restrict__ stamps, FoldArgs fold) {
+    unsigned long long* __restrict__ stamps, FoldArgs fold, StealArgs steal) {
     constexpr int LDS_FLOATS = PASS_WAVES * (MT_WAVE_LDS > SLAB_STRIDE ? MT_WAVE_LDS : SLAB_STRIDE);
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     const int tid = threadIdx.x;
@@ -885,14 +938,45 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_q_kernel(
         else dma_mtile<0>(tl, X, ldx, y, sc.row0(0), B, lane, yv);
         load_w();
         int k = 0;
-        for (; k + 1 < n_stream; ++k)
-            q_tile_step<2, DBG, PRIO>(yv, tl, rb, wreg, acc, qacc, X, ldx, y, [&] { return sc.row0(k + 1); }, [] {}, B, lane);
-        for (; k < n_mine; ++k)
-            q_tile_step<0, DBG, PRIO>(yv, tl, rb, wreg, acc, qacc, X, ldx, y, [&] { return sc.row0(k + 1); }, [] {}, B, lane);
+        if constexpr (STEAL) {
+            // static share (the host: n_mine >= 1 for every wave, keep = 0), then one queued tile per step until none is left
+            for (; k + 1 < n_mine; ++k)
+                q_tile_step<2, DBG, PRIO, true>(yv, tl, rb, wreg, acc, qacc, X, ldx, y, [&] { return sc.row0(k + 1); }, [] {}, B, lane);
+            const int q = (blockIdx.x >> 3) % steal.nq;
+            if (stamps && tid == 0) stamps[8 * (int64_t)blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();     // wave 0: static share read
+            unsigned long long taken = 0;
+            for (;;) {
+                const unsigned pend = steal_request(steal, q, lane);
+                int64_t next = 0;
+                q_tile_step<2, DBG, PRIO, true>(yv, tl, rb, wreg, acc, qacc, X, ldx, y,
+                                                [&] { next = steal_resolve(steal, pend, q, B); return next; }, [] {}, B, lane);
+                if (next >= B) break;
+                ++taken;
+            }
+            if (stamps && tid == 0) {
+                stamps[8 * (int64_t)blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();     // wave 0: left the queue
+                stamps[8 * (int64_t)blockIdx.x + 6] = taken;                                // ... with this many queued tiles
+            }
+        } else {
+            for (; k + 1 < n_stream; ++k)
+                q_tile_step<2, DBG, PRIO>(yv, tl, rb, wreg, acc, qacc, X, ldx, y, [&] { return sc.row0(k + 1); }, [] {}, B, lane);
+            for (; k < n_mine; ++k)
+                q_tile_step<0, DBG, PRIO>(yv, tl, rb, wreg, acc, qacc, X, ldx, y, [&] { return sc.row0(k + 1); }, [] {}, B, lane);
+        }
     }
     // no LDS-DMA of this wave may still be in flight when the tile region is reused for the block reduction
     __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
     __syncthreads();
+    __shared__ unsigned steal_last_s;
+    if (STEAL && tid == 0) {
+        // every wave of this workgroup has left its queue: count the workgroup out on the queue's line; the last of the
+        // queue's workgroups (groups of 8 with group % nq = q; the last group of the grid may be short) zeroes the line
+        const int q = (blockIdx.x >> 3) % steal.nq;
+        int homes = 0;
+        for (int j = q; 8 * j < (int)gridDim.x; j += steal.nq) homes += (int)gridDim.x - 8 * j < 8 ? (int)gridDim.x - 8 * j : 8;
+        steal_last_s = __hip_atomic_fetch_add(steal.heads + q * STEAL_STRIDE + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                       (unsigned)homes - 1u;
+    }
     float* ep = lds + wave * SLAB_STRIDE;
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb)
@@ -905,6 +989,8 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_q_kernel(
     qv += __shfl_xor(qv, 32);
     if (lane < SG) ep[SLAB_G + lane] = qv;
     __syncthreads();
+    if (STEAL && steal_last_s && tid < 2)      // the queue's last workgroup: head and count back to zero
+        __hip_atomic_store(steal.heads + ((blockIdx.x >> 3) % steal.nq) * STEAL_STRIDE + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float* out = slab + (int64_t)blockIdx.x * SLAB_STRIDE;
     for (int i = tid; i < SLAB_STRIDE; i += PASS_BLOCK) {
         const int src = i < SLAB_G ? (i & 7) * GCOLS + (i >> 3) : i;
@@ -912,10 +998,10 @@ __global__ __launch_bounds__(PASS_BLOCK, 2) void blr_pass_q_kernel(
 #pragma unroll
         for (int kk = 1; kk < PASS_WAVES; ++kk) v += lds[kk * SLAB_STRIDE + src];
         // (folded finish: write-through, so that a workgroup on another XCD reads the row from memory)
-        if (fold.mode) __hip_atomic_store(out + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!STEAL && fold.mode) __hip_atomic_store(out + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else out[i] = v;
     }
-    if (fold.mode) {
+    if (!STEAL && fold.mode) {
         // ---- the finish in the pass's tail (FoldArgs) ----
         __shared__ unsigned ticket_s;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's slab stores have been written through
@@ -1883,12 +1969,31 @@ void launch_pass(bsc_ctx* ctx, const float* X, int64_t ldx, const float* y, int6
             const int n_a = n_all + extra;
             FoldArgs fold{};
             if (fold_in) fold = *fold_in;
+            // the stealing tail (StealArgs): every wave `n_st` tiles of its own, the rest in the queues
+            StealArgs steal{};
+            int n_st = (int)((n_tiles * (1000 - ctx->blr_steal)) / (1000 * w_all));
+            if (ctx->blr_steal > 0 && ctx->steal_heads && nt && sweep == BSC_SWEEP_STREAM && n_st >= 1 && !ctx->blr_q_dbg && !fold.mode) {
+                steal.heads = ctx->steal_heads;
+                steal.t0 = (long long)n_st * w_all;
+                steal.n_dyn = n_tiles - steal.t0;
+                // whole groups of 8 workgroups only: a short last group joins queue (groups - 1) % nq -- a queue of its own
+                // would hold a full share of tiles for an eighth of the waves
+                steal.nq = g.n_blocks / 8 < 1 ? 1 : g.n_blocks / 8 < STEAL_Q ? g.n_blocks / 8 : STEAL_Q;
+                steal.per_q = (int)((steal.n_dyn + steal.nq - 1) / steal.nq);
+            }
+            const int q_all = steal.heads ? n_st : n_all, q_a = steal.heads ? n_st : n_a;
 #define BSC_PASS_Q(NT_, DBG_, PRIO_)                                                               \
     hipLaunchKernelGGL((blr_pass_q_kernel<NT_, DBG_, PRIO_>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0, \
-                       ctx->stream, X, ldx, y, B, W, sg, slab, n_all, n_a, rev, keep, stamps, fold)
+                       ctx->stream, X, ldx, y, B, W, sg, slab, q_all, q_a, rev, keep, stamps, fold, steal)
             if (ctx->blr_q_dbg == 1) BSC_PASS_Q(true, 1, 0);
             else if (ctx->blr_q_dbg == 2) BSC_PASS_Q(true, 2, 0);
             else if (ctx->blr_q_dbg == 3) BSC_PASS_Q(true, 3, 0);
+            else if (steal.heads && ctx->blr_q_prio == 1)
+                hipLaunchKernelGGL((blr_pass_q_kernel<true, 0, 1, true>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0, ctx->stream, X, ldx, y,
+                                   B, W, sg, slab, q_all, q_a, rev, keep, stamps, fold, steal);
+            else if (steal.heads)
+                hipLaunchKernelGGL((blr_pass_q_kernel<true, 0, 0, true>), dim3(g.n_blocks), dim3(PASS_BLOCK), 0, ctx->stream, X, ldx, y,
+                                   B, W, sg, slab, q_all, q_a, rev, keep, stamps, fold, steal);
             else if (nt && ctx->blr_q_prio == 1) BSC_PASS_Q(true, 0, 1);
             else if (nt && ctx->blr_q_prio == 2) BSC_PASS_Q(true, 0, 2);
             else if (nt) BSC_PASS_Q(true, 0, 0);

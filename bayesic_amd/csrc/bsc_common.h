@@ -55,6 +55,8 @@ struct bsc_ctx {
     int blr_q_prio = 1;          // blr_pass_q_kernel: s_setprio 1 from a tile's landing to the next tile's DMAs (1), or during the backward (2)
     int blr_fold = 0;            // 1: blr_pass_q_kernel carries its finish (or the float64 statistics of the N > 1 structure) in its tail -- one launch per update (FoldArgs).  Built and measured in round 4: break-even (162.9-163.1 vs 162.5-162.9 us per 1M-row update, 36.4 vs 35.3-36.4 at 125k rows, profiles/r04_fold_*.txt), so off by default
     unsigned* fold_counters = nullptr;   // [arrivals, roles done] of the folded finish: zero between launches
+    int blr_steal = 0;           // blr_pass_q_kernel, streaming sweep: per mille of the tiles left to the queues (StealArgs) the waves draw on after their static share.  Built and measured in round 4 (profiles/r04_ab_pass_q_steal.txt): every workgroup then ends within ~4 us of every other, but the launch gains 0.5-1.5 us of 157 at 1M rows, 2-2.7 of 85 at 500k, loses 0.5 of 28.7 at 125k -- the static schedule's early finishers leave their bandwidth to the late ones, so little was lost -- and the last bits of the sums are no longer reproducible: off by default
+    unsigned* steal_heads = nullptr;     // 64 queue heads 256 bytes apart + the workgroups-done counter (inside fold_counters' allocation): zero between launches
     int blr_stamps = 0;          // blr_pass_q_kernel: every workgroup leaves start / end s_memrealtime stamps and its XCD (bsc_blr_read_stamps)
     void* stamps = nullptr;      // 32 bytes per workgroup, allocated when blr_stamps is first used
     int stamp_rows = 0;          // workgroups of the last stamped launch

@@ -588,8 +588,9 @@ def test_earlier_pass_kernels_stay_selectable_and_correct(options):
             assert (Q == 0).all() and (G == 0).all()
 
 
-@pytest.mark.parametrize("options", [dict(blr_q_bias=0), dict(blr_q_bias=130), dict(blr_q_bias=400)],
-                         ids=["bias0", "bias130", "bias400"])
+@pytest.mark.parametrize("options", [dict(blr_q_bias=0), dict(blr_q_bias=130), dict(blr_q_bias=400),
+                                     dict(blr_steal=0), dict(blr_steal=60), dict(blr_steal=125), dict(blr_steal=500)],
+                         ids=["bias0", "bias130", "bias400", "static", "steal60", "steal125", "steal500"])
 def test_pass_schedules_cover_every_tile_once(options):
     """blr_pass_q_kernel's schedule gives the workgroups with an even blockIdx further windows (option blr_q_bias, per
     mille; default 70): static and reproducible whatever the value.  Exact-integer data (W = 0, y in {0, 1},
@@ -615,6 +616,31 @@ def test_pass_schedules_cover_every_tile_once(options):
             _check_pass(ctx, X, y, W)
         else:
             assert (Q == 0).all() and (G == 0).all()
+
+
+def test_stealing_tail_many_launches_of_changing_size():
+    """Option blr_steal: the queue heads must be back at zero after every launch (the last workgroup resets them) --
+    many launches of changing size on one context, exact-integer data, some with the chip busy on another stream."""
+    import torch
+    from bayesic_amd.device import Context
+    ctx = Context(0, options=dict(blr_steal=125))
+    D, S = 256, 8
+    W = np.zeros((S, D), np.float32)
+    busy = torch.randn((4096, 4096), device="cuda")
+    side = torch.cuda.Stream()
+    for i, B in enumerate([70_001, 33_000, 262_144, 9_000, 500_017, 33_000, 131_072, 40_000] * 2):
+        n = np.arange(B)[:, None]
+        d = np.arange(D)[None, :]
+        X = ((n * 7 + d * 5 + i) % 3 - 1).astype(np.float32)
+        y = ((np.arange(B) * 11 + i) % 17 < 9).astype(np.float32)
+        if i % 3 == 0:
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    busy = torch.tanh(busy @ busy * 1e-3)
+        Q, G = _pass(ctx, X, y, W)
+        np.testing.assert_array_equal(Q, np.full(S, float(y.sum())))
+        np.testing.assert_array_equal(G, np.tile(X.astype(np.float64).T @ y.astype(np.float64), (S, 1)))
+    torch.cuda.synchronize()
 
 
 # ---- round 4: the finish folded into the pass's tail (FoldArgs; bsc_blr_pass_update, bsc_blr_data_pass) -------------

@@ -20,7 +20,7 @@ LIMITS = {
     "bsc_blr.hip": {
         "blr_pass_mfma_kernelILb1E": (232, 0),          # 2 waves/SIMD needs <= 256
         "blr_pass_dma_kernelILb1E": (232, 0),           # round 3's pass (option blr_q = 0): the tile by LDS-DMA
-        "blr_pass_q_kernelILb1ELi0ELi0E": (200, 0),         # the default pass since round 4: both contractions on v_mfma_f32_4x4x1 (2 waves/SIMD)
+        "blr_pass_q_kernelILb1ELi0ELi0E": (224, 0),         # the default pass since round 4: both contractions on v_mfma_f32_4x4x1 (2 waves/SIMD)
         "blr_pass_mx_kernelILb1ELi2E": (232, 0),
         "blr_pass_mx_kernelILb1ELi4E": (256, 0),        # sixteen draws per pass: 64 accumulator registers
         "blr_pass_kernelILb1ELi8ELb1E": (256, 0),

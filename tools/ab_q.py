@@ -28,6 +28,13 @@ VARIANTS = {
     "q-bias0": dict(blr_q=1, blr_q_bias=0),
     "q-bias100": dict(blr_q=1, blr_q_bias=100),
     "q-bias130": dict(blr_q=1, blr_q_bias=130),
+    "q-steal1": dict(blr_q=1, blr_steal=1),
+    "q-steal60": dict(blr_q=1, blr_steal=60),
+    "q-steal100": dict(blr_q=1, blr_steal=100),
+    "q-steal150": dict(blr_q=1, blr_steal=150),
+    "q-steal200": dict(blr_q=1, blr_steal=200),
+    "q-steal350": dict(blr_q=1, blr_steal=350),
+    "q-steal250": dict(blr_q=1, blr_steal=250),
     "q-nocompute": dict(profiling_builds=1, blr_q=1, blr_q_dbg=1),
     "q-fwdonly": dict(profiling_builds=1, blr_q=1, blr_q_dbg=2),
     "q-bwdonly": dict(profiling_builds=1, blr_q=1, blr_q_dbg=3),
@@ -62,6 +69,14 @@ def stamp_report(c, name):
     print("    %-12s per CU (end of its last workgroup): even XCDs mean %.1f max %.1f | odd XCDs mean %.1f max %.1f; all: p10 %.1f p50 %.1f p90 %.1f"
           % (name, cu_end[cu_par == 0].mean(), cu_end[cu_par == 0].max(), cu_end[cu_par == 1].mean(), cu_end[cu_par == 1].max(),
              np.percentile(cu_end, 10), np.percentile(cu_end, 50), np.percentile(cu_end, 90)))
+    if VARIANTS[name].get("blr_steal"):
+        a = (st[:, 4] - t0).astype(np.float64) / 100.0
+        b = (st[:, 5] - t0).astype(np.float64) / 100.0
+        print("    %-12s wave 0 of a workgroup: static share read at p10 %.1f p50 %.1f p90 %.1f us; left the queue at p10 %.1f p50 %.1f p90 %.1f max %.1f;"
+              " queued tiles taken mean %.2f min %d max %d; end - left p50 %.1f max %.1f"
+              % (name, *np.percentile(a, [10, 50, 90]), *np.percentile(b, [10, 50, 90, 100]), st[:, 6].mean(), st[:, 6].min(), st[:, 6].max(),
+                 np.median(end - b), (end - b).max()))
+        print("    %-12s queued tiles taken by wave 0, mean per XCD:" % name, " ".join("[%d] %.2f" % (x, st[xcd == x, 6].mean()) for x in range(8) if (xcd == x).any()))
     pairs = [v for v in per_cu.values() if len(v) == 2]
     if pairs:
         d = np.array([abs(a - b) for a, b in pairs])
