@@ -425,37 +425,27 @@ __global__ __launch_bounds__(MOG_BLOCK, 2) void mog_estep_bx_kernel(
 #pragma unroll
             for (int q = 0; q < 16; q += 2) m = __builtin_fmaxf(__builtin_fmaxf(logit[cb][q], logit[cb][q + 1]), m);
         m = swap32_max(m);
-        // pairs of values through v_pk_add / v_pk_mul (a packed instruction takes the matrix pipe what a scalar one does:
-        // profiles/r01_ubench_mfma_valu_mix.txt)
-        const f32x2 m2 = {m, m};
-        f32x2 ssum2 = {0.f, 0.f};
+        float ssum = 0.f;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int q = 0; q < 16; q += 2) {
-                const f32x2 d = f32x2{logit[cb][q], logit[cb][q + 1]} - m2;
-                const f32x2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
-                logit[cb][q] = e[0];
-                logit[cb][q + 1] = e[1];
-                ssum2 += e;
+            for (int q = 0; q < 16; ++q) {
+                logit[cb][q] = __builtin_amdgcn_exp2f(logit[cb][q] - m);
+                ssum += logit[cb][q];
             }
-        const float ssum = swap32_sum(ssum2[0] + ssum2[1]);
+        ssum = swap32_sum(ssum);
         const float inv = valid ? 1.0f / ssum : 0.f;
         if (valid && half == 0) lse_acc += LN2 * (m + __builtin_amdgcn_logf(ssum));
         // ---- the responsibilities r = e / sum (two terms) and the features (the first two of the forward's three terms:
         // nothing to compute) to LDS.  Round 4: the 1 / sum went from the 16 features of a lane -- where it cost a second
-        // split of x and x^2, 64 vector instructions -- to its 32 responsibilities (16 packed multiplies).
-        const f32x2 inv2 = {inv, inv};
+        // split of x and x^2, 64 vector instructions -- to its 32 responsibilities (32 multiplies; packed ones were tried:
+        // no faster, and MI355X_MICROARCH.md counts packed f32 arithmetic beside MFMAs as an anti-lever).
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
-            for (int q = 0; q < 16; q += 2) {
-                const f32x2 r = f32x2{logit[cb][q], logit[cb][q + 1]} * inv2;
-                const f32x2 acc2 = f32x2{rsum[cb][q], rsum[cb][q + 1]} + r;
-                logit[cb][q] = r[0];
-                logit[cb][q + 1] = r[1];
-                rsum[cb][q] = acc2[0];
-                rsum[cb][q + 1] = acc2[1];
+            for (int q = 0; q < 16; ++q) {
+                logit[cb][q] *= inv;
+                rsum[cb][q] += logit[cb][q];
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {

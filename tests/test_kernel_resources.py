@@ -72,7 +72,7 @@ LIMITS = {
     },
     "bsc_mog.hip": {
         "mog_estep_kernel": (256, 0),
-        "mog_estep_bx_kernel": (256, 0),
+        "mog_estep_bx_kernel": (256, 8),                # (one register parked before the tile loop and fetched after it)
     },
     "bsc_bbvi.hip": {
         "logreg_loglik_kernel": (256, 0),
