@@ -263,7 +263,8 @@ int bsc_blr_data_pass_partial_sweep(bsc_ctx* ctx, const float* X, int64_t ldx, c
 
 /* Measurement aid (option "blr_stamps" = 1): the D = 256, S <= 8 pass leaves per workgroup
  * {start, end} in s_memrealtime ticks (100 MHz), the XCD it ran on and its HW_ID; this copies the
- * stamps of the LAST such launch to host_stamps[8 * rows] (synchronises; entries 4..7: the folded finish's hand-off).  Shows how evenly a static
+ * stamps of the LAST such launch to host_stamps[8 * rows] (synchronises; entries 4..7: the folded finish's hand-off, or with
+ * option "blr_steal" when wave 0 left its static share / its queue and how many queued tiles it took).  Shows how evenly a static
  * partition of the mini-batch finishes (tools/ab_q.py). */
 int bsc_blr_read_stamps(bsc_ctx* ctx, uint64_t* host_stamps, int32_t capacity_rows, int32_t* host_rows);
 
