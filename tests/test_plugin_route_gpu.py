@@ -330,6 +330,70 @@ def test_config5_plugin_route_runs_at_the_fused_drivers_speed(ctx):
 
 
 @pytest.mark.parametrize("two_latents", [False, True])
+def test_pass_route_with_its_state_on_the_device(two_latents):
+    """A Gaussian-linear model one term away from config 2 (known noise: no xi latent; optionally a second latent the
+    data term does not touch) takes the pass route; with resident=True draws, the ONE pass over X, the executor's walk of
+    the parameter-sized surrogate, the d Q / d w = -2 G correction and Adam stay on the device, and from the third
+    step on the whole step is a re-issued call list.  Same seed -> the host-side pass route's numbers."""
+    from bayesic_amd import algebra as A
+    from bayesic_amd.algebra.device_backend import DeviceBackend
+    from bayesic_amd.device import Context
+    from bayesic_amd.inference import ReparamVI
+    rs = np.random.RandomState(14)
+    N, D, S = 30000, 24, 8
+    Xs = rs.standard_normal((N, D)).astype(np.float32)
+    ys = (Xs @ (rs.standard_normal(D) / 4) + 0.5 * rs.standard_normal(N)).astype(np.float32)
+    X, y, W, c = A.var("X", 2), A.var("y", 1), A.var("W", 2), A.var("c", 2)
+    r = A.dimshuffle(y, "x", 0) - A.dot(W, X.T)
+    lj = A.sum(r * r, axis=1) * (-0.5 / 0.25) + A.sum(W * W, axis=1) * (-0.5)
+    latents = [(W, D)]
+    if two_latents:
+        lj = lj + A.sum(c * c, axis=1) * (-0.005)       # a latent that only the parameter-sized part mentions
+        latents.append((c, 1))
+    ctx = Context(0)
+    engines = [ReparamVI(lj, latents, dict(X=Xs, y=ys), n_samples=S, seed=9, backend=DeviceBackend(ctx), lr=0.02,
+                         resident=resident) for resident in (False, True)]
+    assert engines[0].route.startswith("pass") and engines[1].route.startswith("pass"), [e.route for e in engines]
+    assert "resident" in engines[1].route and "resident" not in engines[0].route
+    # ... and that is what route="auto" gives such a model unless told otherwise
+    assert "resident" in ReparamVI(lj, latents, dict(X=Xs, y=ys), n_samples=S, backend=DeviceBackend(ctx)).route
+    crossings = []
+    b1 = engines[1].backend
+    real_to_host, real_sync = b1.to_host, ctx.sync
+    b1.to_host = lambda value: (crossings.append("to_host"), real_to_host(value))[1]
+    for step in range(8):
+        host = engines[0].step()
+        ctx.sync = lambda: (crossings.append("sync"), real_sync())[1]
+        assert engines[1].step() is None
+        ctx.sync = real_sync
+        assert crossings == [], crossings
+        assert abs(engines[1].elbo - host) <= 2e-6 * abs(host), (step, host, engines[1].elbo)
+        scale = np.abs(engines[0].grad).max()
+        npt.assert_allclose(engines[1].grad, engines[0].grad, rtol=0, atol=2e-5 * scale)
+    npt.assert_allclose(engines[1].lam, engines[0].lam, rtol=0, atol=2e-4)
+    (entry,) = [e for k, e in b1._replays.items() if k[0] == "reparam-step"]
+    assert entry["calls"] is not None
+    assert [call[2] for call in entry["calls"]].count("bsc_blr_data_pass_sweep") == 1     # one pass over the data
+    walked = []
+    real_call = ctx.call
+    ctx.call = lambda name, *a: (walked.append(name), real_call(name, *a))[1]
+    engines[1].step()
+    ctx.call = real_call
+    assert sorted(walked) == ["bsc_adam_ascent", "bsc_adam_ascent", "bsc_philox_normal"], walked
+    engines[0].step()
+    # another mini-batch of the same shape: re-recorded, same numbers; another row count: refused (the surrogate holds N)
+    Xs2 = rs.standard_normal((N, D)).astype(np.float32)
+    for e in engines:
+        e.set_data(X=Xs2)
+    for step in range(4):
+        host = engines[0].step()
+        engines[1].step()
+        assert abs(engines[1].elbo - host) <= 2e-6 * abs(host), (step, host, engines[1].elbo)
+    with pytest.raises(ValueError):
+        engines[1].set_data(X=Xs2[:1000], y=ys[:1000])
+
+
+@pytest.mark.parametrize("two_latents", [False, True])
 def test_general_reparam_engine_with_its_state_on_the_device(two_latents):
     """ReparamVI(route="general", resident=True): draws, z, the ELBO estimate, the pathwise gradient and the Adam
     step stay on the device (no host synchronisation inside step()); same seed -> the host-side engine's

@@ -29,7 +29,8 @@ def main():
     data = dict(X=Xd, y=yd)
     for graph, route, resident, replay in ((False, "general", False, False), (True, "general", False, False),
                                            (False, "general", True, False), (False, "general", True, True),
-                                           (True, "general", True, False), (False, "auto", False, False)):
+                                           (True, "general", True, False), (False, "auto", False, False),
+                                           (False, "auto", True, False), (False, "auto", True, True)):
         eng = ReparamVI(lj, [(W, D)], data, n_samples=S, seed=1, backend=DeviceBackend(ctx), lr=1e-3, graph=graph,
                         route=route, resident=resident, replay=replay)
         for _ in range(5):
