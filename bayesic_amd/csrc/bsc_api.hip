@@ -82,6 +82,7 @@ const bsc_option OPTIONS[] = {
     {"gemm_dbg", &bsc_ctx::gemm_dbg, 0, 15, nullptr, true},
     {"gemm_nt_c", &bsc_ctx::gemm_nt_c, 0, 1, nullptr, false},
     {"gemm_sym", &bsc_ctx::gemm_sym, 0, 1, nullptr, false},
+    {"gram_pp", &bsc_ctx::gram_pp, 0, 1, nullptr, false},
     {"gram_dbg", &bsc_ctx::gram_dbg, 0, 7, nullptr, true},
     {"rows_dbg", &bsc_ctx::rows_dbg, 0, 15, nullptr, true},
     {"rows_wg", &bsc_ctx::rows_wg_per_cu, 0, 64, nullptr, false},

@@ -23,6 +23,7 @@ struct bsc_ctx {
     int blr_tile_rows = 16;      // 16: forward on the MFMA pipe when D == 256 (else 8-row VALU tiles); 8 | 4: VALU variants
     int blr_waves_per_simd = 0;  // tuning: cap resident waves per SIMD (0 = kernel's own limit)
     int fused_map_blocks_per_cu = 8;  // bsc_map_reduce, pure map: grid cap (256-thread blocks)
+    int gram_pp = 0;                  // 1: gram256_pp_kernel (the two waves of a SIMD take turns on the matrix pipe: two half-steps, two barriers a step) instead of gram256_bx_kernel -- measured no faster (267 vs 261 us), off
     int gram_dbg = 0;                 // deletion builds of gram256_bx_kernel (BSC_GRAM_DBG + BSC_PROFILING_BUILDS): WRONG results
     int rows_dbg = 0;                 // deletion builds of map_reduce_rows_f32_kernel (BSC_ROWS_DBG + BSC_PROFILING_BUILDS): WRONG results
     int rows_wg_per_cu = 64;          // map_reduce_rows_f32_kernel: workgroups per CU in the grid, eight of them resident (BSC_ROWS_WG; 0 = one step per wave)

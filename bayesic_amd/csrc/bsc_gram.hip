@@ -380,6 +380,223 @@ __global__ __launch_bounds__(512, 1) void gram256_bx_kernel(const float* __restr
     }
 }
 
+// ---- round 4: the same product with the two waves of a SIMD taking TURNS on the matrix pipe (option gram_pp = 1; OFF) ----
+//
+// (MI355X_MICROARCH.md, "Two waves per SIMD": one wave in a matrix segment beside its partner in an LDS / DMA segment, a
+// barrier between segments.)  gram256_bx_kernel's one barrier a step puts all eight waves into the same phase --
+// fragment reads and conversion, then MFMAs: the matrix pipe idles while everybody reads, the LDS pipe while everybody
+// multiplies.  Here a step is two half-steps with a barrier after each:
+//     half-step 2 i    : waves 0-3 multiply step i                | waves 4-7 read the fragments of step i, convert step i + 1
+//     half-step 2 i + 1: waves 0-3 read step i + 1, convert i + 2 | waves 4-7 multiply step i
+// Images of step j are written in half-steps 2 j - 3 (waves 0-3) and 2 j - 2 (waves 4-7) and first read in 2 j - 1: two
+// image sets as before.  The raw tile of step j + 1 is last read in half-step 2 j, so a wave sends its four DMAs of the
+// step that reuses the stage at the START OF ITS NEXT MATRIX SEGMENT (a DMA costs ~60 cycles beside bare MFMAs, 100-185
+// in a segment full of LDS reads).  The images and the raw ring are SEPARATE __shared__ arrays: the fragment reads are
+// compiler-visible ds_read_b64_tr_b16 builtins (two reads land in adjacent registers: no copies into the MFMA operand;
+// the waits are the compiler's), and they do not draw a vmcnt(0) for the DMAs in flight into the other array.
+//
+// MEASURED (tools/ab_gram_pp.py, profiles/r04_ab_gram_pp.txt): same bits as gram256_bx_kernel, 267 us of kernel against its
+// 261 (a first form inside gram256_bx_kernel, asm reads and register copies kept: 284-288).  The deletion builds say why
+// taking turns buys nothing here: fragment reads + barriers alone 75 us, + conversion 135, MFMAs + reads 175, all
+// but the DMAs 220, everything 290 -- the parts ADD UP in either loop.  The transposed reads alone run the LDS pipe at
+// ~100 of its 128 bytes a clock for those 75 us; with the conversion's reads and writes and the DMAs' writes a step
+// moves ~210 KiB through LDS, and what the matrix pipe waits for is that pipe, whoever's turn it is.  The lever is
+// fewer LDS bytes per MFMA (larger register blocks per wave), not the order of the segments.  Kept as an option, not used.
+template <int DBG = 0>
+__global__ __launch_bounds__(512, 1) void gram256_pp_kernel(const float* __restrict__ X, int64_t ldx, int64_t N,
+                                                            float* __restrict__ slab, int n_steps_total) {
+    constexpr int NB = 36;
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    typedef short v8s __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) v4s* tr_ptr;
+    __shared__ __attribute__((aligned(1024))) char img[GR_IMG_BYTES];
+    __shared__ __attribute__((aligned(1024))) char raw[GR_STAGES * GR_RAW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    // (not __syncthreads(): its fence waits for every DMA in flight -- vmcnt(0) -- now that the kernel has compiler-visible
+    // LDS accesses.  What a barrier here has to order is this wave's image writes, and the DMAs it waited for by hand.)
+    auto wg_barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    bsc_f32x16 acc[5];
+#pragma unroll
+    for (int b = 0; b < 5; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    // image writes (this lane's 16 columns of row l31 of column block `wave`) and transposed reads: byte offsets in `img`
+    const int sw = 2 * ((l31 >> 1) & 3);
+    const int wr0 = wave * 2 * GB_IMG + l31 * 64 + 8 * ((4 * half) ^ sw);
+    const int wr1 = wave * 2 * GB_IMG + l31 * 64 + 8 * ((4 * half + 2) ^ sw);
+    const int gg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    int rd[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int row = 8 * (gg >> 1) + 4 * e + tq, ch = 4 * (gg & 1) + tp;
+        rd[e] = row * 64 + 8 * (ch ^ (2 * ((row >> 1) & 3)));
+    }
+    // raw-tile reads of the converting lane (inline asm: DMA-written memory, waited for by hand): row l31, chunks 8 wave + 4 half + q
+    const unsigned raw_base = (unsigned)(uintptr_t)(bsc_lds_ptr)raw;
+    unsigned rr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rr[q] = raw_base + (unsigned)(l31 * 1024 + 16 * ((8 * wave + 4 * half + q) ^ (l31 & 15)));
+
+    const int64_t stride = gridDim.x;
+    const int my_steps = (int)((n_steps_total - (int64_t)blockIdx.x + stride - 1) / stride);     // >= 1 (host: grid <= steps)
+    auto issue = [&](int i) __attribute__((always_inline)) {
+        const int64_t row0 = ((int64_t)blockIdx.x + (int64_t)i * stride) * 32;
+        const int64_t rem = N - row0;                 // > 0
+        const uint64_t bytes = ((uint64_t)(rem - 1) * (uint64_t)ldx + 256u) * 4u;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + row0 * ldx), 0, bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes, 0x00020000);
+        char* const dst = raw + (i % GR_STAGES) * GR_RAW + (4 * wave) * 1024;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int row = 4 * wave + jj;
+            const unsigned voff = (unsigned)(row * (int)(ldx * 4) + 16 * (lane ^ (row & 15)));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (bsc_lds_ptr)(dst + jj * 1024), 16, voff, 0, 0, 2);
+        }
+    };
+    auto tr8 = [&](int off) __attribute__((always_inline)) {           // rows r0 .. r0 + 7 of this lane's column: one operand term
+        const v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(img + rd[0] + off));
+        const v4s b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(img + rd[1] + off));
+        return __builtin_bit_cast(bsc_u32x4, (v8s)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto frag_read = [&](auto wc, int set, int s, bsc_u32x4 (&fr)[4][2]) __attribute__((always_inline)) {
+        constexpr GramPlan P = GRAM_PLAN8[decltype(wc)::value];
+#pragma unroll
+        for (int f = 0; f < P.n_frag; ++f) {
+            const int off = set + P.frag[f] * 2 * GB_IMG + s * 1024;
+            fr[f][0] = tr8(off);
+            fr[f][1] = tr8(off + GB_IMG);
+        }
+    };
+    auto frag_mfma = [&](auto wc, bsc_u32x4 (&fr)[4][2]) __attribute__((always_inline)) {
+        constexpr GramPlan P = GRAM_PLAN8[decltype(wc)::value];
+        if (DBG & 2) {
+#pragma unroll
+            for (int f = 0; f < P.n_frag; ++f) acc[0][f] += __uint_as_float(fr[f][0][0] ^ fr[f][1][3]);
+            return;
+        }
+#pragma unroll
+        for (int b = 0; b < P.n_blk; ++b) acc[b] = bsc_mfma_split<2>(fr[P.blk[b][0]], fr[P.blk[b][1]], acc[b]);
+    };
+    auto convert = [&](int i) __attribute__((always_inline)) {
+        if (DBG & 1) return;
+        f32x4_t nx[4];
+        const unsigned soff = (unsigned)((i % GR_STAGES) * GR_RAW);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("ds_read_b128 %0, %1" : "=v"(nx[q]) : "v"(rr[q] + soff) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nx[0]), "+v"(nx[1]), "+v"(nx[2]), "+v"(nx[3]));
+        bsc_u32x4 t0[2], t1[2];
+        unsigned pk[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            bsc_split_pk<2>(nx[q][0], nx[q][1], pk); t0[0][2 * q] = pk[0]; t0[1][2 * q] = pk[1];
+            bsc_split_pk<2>(nx[q][2], nx[q][3], pk); t0[0][2 * q + 1] = pk[0]; t0[1][2 * q + 1] = pk[1];
+            bsc_split_pk<2>(nx[2 + q][0], nx[2 + q][1], pk); t1[0][2 * q] = pk[0]; t1[1][2 * q] = pk[1];
+            bsc_split_pk<2>(nx[2 + q][2], nx[2 + q][3], pk); t1[0][2 * q + 1] = pk[0]; t1[1][2 * q + 1] = pk[1];
+        }
+        const int set = (i & 1) * GR_IMG_SET;
+#pragma unroll
+        for (int term = 0; term < 2; ++term) {
+            *reinterpret_cast<bsc_u32x4*>(img + wr0 + set + term * GB_IMG) = t0[term];
+            *reinterpret_cast<bsc_u32x4*>(img + wr1 + set + term * GB_IMG) = t1[term];
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < GR_STAGES; ++i)
+        if (i < my_steps) issue(i);
+    // step 0 has landed when at most the DMAs of steps 1, 2 are outstanding
+    if (my_steps >= 3) __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(8));
+    else if (my_steps == 2) __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(4));
+    else __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+    wg_barrier();
+    convert(0);
+    // before half-step -1: everybody's image of step 0 is written and its rows of step 1 have landed (step 2's may be out)
+    if (my_steps >= 3) __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(4));
+    else __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+    wg_barrier();
+    // one copy of the half-step loop per wave (its plan and its group are compile-time constants in it); all copies pass
+    // the same 2 my_steps + 1 barriers
+    auto run = [&](auto wc) __attribute__((always_inline)) {
+        constexpr int GRP = decltype(wc)::value >> 2;
+        bsc_u32x4 f0[4][2], f1[4][2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { f0[a][c] = bsc_u32x4{0u, 0u, 0u, 0u}; f1[a][c] = bsc_u32x4{0u, 0u, 0u, 0u}; }
+        auto load_phase = [&](int j) __attribute__((always_inline)) {
+            const int set = (j & 1) * GR_IMG_SET;
+            frag_read(wc, set, 0, f0);
+            if (j + 1 < my_steps) convert(j + 1);
+            frag_read(wc, set, 1, f1);
+        };
+        for (int h = -1; h < 2 * my_steps; ++h) {
+            if (GRP == 0) {
+                if (h & 1) {
+                    const int j = (h + 1) >> 1;
+                    if (j < my_steps) load_phase(j);
+                } else {
+                    const int j4 = (h >> 1) + 3;                // the stage of step h / 2: last read two half-steps ago
+                    if (!(DBG & 4) && j4 < my_steps) issue(j4);
+                    frag_mfma(wc, f0);
+                    frag_mfma(wc, f1);
+                }
+            } else {
+                if (h & 1) {
+                    const int j4 = (h - 1) / 2 + 4;             // the stage of step (h + 1) / 2: last read a half-step ago
+                    if (!(DBG & 4) && j4 < my_steps) issue(j4);
+                    if (h > 0) {
+                        frag_mfma(wc, f0);
+                        frag_mfma(wc, f1);
+                    }
+                } else {
+                    load_phase(h >> 1);
+                }
+            }
+            if (!(h & 1)) {
+                // the rows of step h / 2 + 2 are converted from the next half-step on: own DMAs landed, step h / 2 + 3's may be out
+                if ((h >> 1) + 3 < my_steps) __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(4));
+                else __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+            }
+            wg_barrier();
+        }
+    };
+    switch (wave) {
+        case 0: run(std::integral_constant<int, 0>{}); break;
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 3: run(std::integral_constant<int, 3>{}); break;
+        case 4: run(std::integral_constant<int, 4>{}); break;
+        case 5: run(std::integral_constant<int, 5>{}); break;
+        case 6: run(std::integral_constant<int, 6>{}); break;
+        default: run(std::integral_constant<int, 7>{}); break;
+    }
+    __builtin_amdgcn_s_waitcnt(bsc_vmcnt_only(0));
+    float* out = slab + (int64_t)blockIdx.x * NB * 1024;
+    auto store = [&](auto wc) __attribute__((always_inline)) {
+        constexpr GramPlan P = GRAM_PLAN8[decltype(wc)::value];
+#pragma unroll
+        for (int b = 0; b < P.n_blk; ++b) {
+            const int bi = gram_tri_index(8, P.frag[P.blk[b][0]], P.frag[P.blk[b][1]]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[bi * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[b][r];
+        }
+    };
+    switch (wave) {
+        case 0: store(std::integral_constant<int, 0>{}); break;
+        case 1: store(std::integral_constant<int, 1>{}); break;
+        case 2: store(std::integral_constant<int, 2>{}); break;
+        case 3: store(std::integral_constant<int, 3>{}); break;
+        case 4: store(std::integral_constant<int, 4>{}); break;
+        case 5: store(std::integral_constant<int, 5>{}); break;
+        case 6: store(std::integral_constant<int, 6>{}); break;
+        default: store(std::integral_constant<int, 7>{}); break;
+    }
+}
+
 // C[d][e] = scale * sum over workgroups of their partials, float64, in workgroup order -- in two levels (one thread per
 // element walking all 256 partials took ~100 us of a 360-us call): chunk sums of GR_CHUNK workgroups' partials (every CU
 // busy), then the chunks in order; both triangles written.
@@ -450,7 +667,8 @@ int bsc_gram_split(bsc_ctx* ctx, const float* X, int64_t ldx, int64_t N, int64_t
 #define BSC_GRAMD(DBG) case DBG: hipLaunchKernelGGL(gram256_bx_kernel<DBG>, dim3((unsigned)n_wg), dim3(512), 0, ctx->stream, X, ldx, N, (float*)ws, (int)steps); break;
             switch (ctx->gram_dbg) { BSC_GRAMD(1) BSC_GRAMD(2) BSC_GRAMD(3) BSC_GRAMD(4) BSC_GRAMD(5) BSC_GRAMD(6) BSC_GRAMD(7) default: break; }
 #undef BSC_GRAMD
-        } else if (DB == 8) hipLaunchKernelGGL(gram256_bx_kernel<0>, dim3((unsigned)n_wg), dim3(512), 0, ctx->stream, X, ldx, N, (float*)ws, (int)steps);
+        } else if (DB == 8 && ctx->gram_pp) hipLaunchKernelGGL((gram256_pp_kernel<0>), dim3((unsigned)n_wg), dim3(512), 0, ctx->stream, X, ldx, N, (float*)ws, (int)steps);
+        else if (DB == 8) hipLaunchKernelGGL(gram256_bx_kernel<0>, dim3((unsigned)n_wg), dim3(512), 0, ctx->stream, X, ldx, N, (float*)ws, (int)steps);
         else switch (DB) {
             BSC_GRAM(1) BSC_GRAM(2) BSC_GRAM(3) BSC_GRAM(4) BSC_GRAM(5) BSC_GRAM(6) BSC_GRAM(7)
         }

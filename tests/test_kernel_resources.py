@@ -56,6 +56,7 @@ LIMITS = {
     },
     "bsc_gram.hip": {
         "gram256_bx_kernel": (256, 0),                  # eight waves a CU = two per SIMD
+        "gram256_pp_kernel": (256, 0),                  # (option gram_pp: the same budget)
     },
     "bsc_gemm.hip": {
         "gemm_f32_mfma_kernelILb1ELb1ELb1E": (256, 0),

@@ -211,6 +211,30 @@ def test_mog_driver_on_split_operands_tracks_the_oracle(ctx, split_ctx):
         model.eta.copy_(torch.as_tensor(eta, dtype=torch.float64))
 
 
+@pytest.mark.parametrize("N", [4096 + 17, 33_000, 262_144 + 5])
+def test_gram_ping_pong_loop_gives_the_same_bits(N):
+    """Option gram_pp = 1 (gram256_pp_kernel: the two waves of a SIMD take turns on the matrix pipe; measured no faster,
+    off by default): the same products added in the same order -- bit for bit gram256_bx_kernel's result, ragged
+    row counts and a padded leading dimension included."""
+    from bayesic_amd.device import Context
+    D, ld = 256, 260
+    rs = np.random.RandomState(N)
+    Xp = (rs.standard_normal((N, ld)) + 0.3).astype(np.float32)
+    outs = []
+    for pp in (0, 1):
+        c = Context(0, options=dict(gram_pp=pp))
+        c.call("bsc_ctx_set_mfma_split", 2)
+        Xd = c.to_device(Xp)
+        out = torch.full((D, D), float("nan"), dtype=torch.float32, device=c.device)
+        c.call("bsc_gemm_strided_batched", 0, 1, D, D, N, Xd, 0, 1, ld, Xd, 0, ld, 1, out, 0, D, 1)
+        c.sync()
+        outs.append(out.cpu().numpy())
+    X_ = Xp[:, :D].astype(np.float64)
+    n2 = np.sqrt((X_ ** 2).sum(0))
+    assert (np.abs(outs[1] - X_.T @ X_) <= 2e-5 * n2[:, None] * n2[None, :]).all()
+    npt.assert_array_equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("N,D,ld", [(5000, 256, 256), (4096, 32, 32), (100000, 96, 100), (7001, 160, 160), (300000, 256, 256)])
 def test_gram_statistic_on_split_operands(ctx, split_ctx, N, D, ld):
     """dot(X.T, X) -- the summed second-moment statistic -- with X as two bf16 terms (csrc/bsc_gram.hip): through the

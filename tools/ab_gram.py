@@ -25,9 +25,7 @@ def main():
     names = {0: "as shipped", 1: "no conversion", 2: "no MFMAs", 3: "no conversion, no MFMAs", 4: "no DMAs",
              5: "no DMAs, no conversion", 6: "no DMAs, no MFMAs", 7: "fragment reads and barriers only"}
     for dbg in range(8):
-        os.environ["BSC_GRAM_DBG"] = str(dbg)
-        ctx = Context(0)
-        del os.environ["BSC_GRAM_DBG"]
+        ctx = Context(0, options=dict(profiling_builds=1, gram_dbg=dbg))
         ctx.call("bsc_ctx_set_mfma_split", 2)
         k = [0]
 
