@@ -199,6 +199,7 @@ class Workload:
 
 class Cfg2(Workload):
     """Bayesian linear regression, reparameterisation-trick ELBO (the metric's config)."""
+    spin_is_one_kernel = True       # spin() = bsc_blr_data_pass_partial_sweep = ONE launch of the pass kernel
     name = "cfg2"
     default_rows, default_samples = 1_000_000, 8
     kernel_ms = 0.17
@@ -820,17 +821,28 @@ def run_rank(args):
         ctx.profile(0)
         # dedicated burst AFTER the timed region: every launch of the dominant kernel timed on the
         # launch stream, so roofline.avg_launch_us rests on >= 50 samples whatever --steps was
-        burst_ms, burst_n = 0.0, 0
+        burst_ms, burst_n, pairs = 0.0, 0, (0.0, 0)
         if timing and burst and args.burst > 0:
+            # (a) the launches back to back between TWO events: launch-to-launch period, nothing else in the stream --
+            # the figure rocprofv3's per-dispatch durations add up to.  (b) one event pair per launch, as rounds 1-3
+            # reported it: the records themselves cost 1.6-2.2 us per launch (tools/launch_train.py), kept for comparison.
             ctx.profile(1)
             for _ in range(args.burst):
                 wl.spin()
-            burst_ms, burst_n = ctx.profile_read(0)
+            pairs = ctx.profile_read(0)
             ctx.profile(0)
+            burst_ms, burst_n = pairs
+            if getattr(wl, "spin_is_one_kernel", False):        # (a spin() that also launches a reduce is timed per kernel)
+                e0, e1 = ctx.event(), ctx.event()
+                e0.record()
+                for _ in range(args.burst):
+                    wl.spin()
+                e1.record()
+                burst_ms, burst_n = e0.elapsed_ms(e1), args.burst
         blocks = sorted(reduce_max(blocks))
         median = blocks[len(blocks) // 2] if len(blocks) % 2 else 0.5 * (blocks[len(blocks) // 2 - 1] + blocks[len(blocks) // 2])
         return {"blocks": blocks, "median_s": median, "in_region": in_region, "burst": (burst_ms, burst_n),
-                "spin_launches": spin_launches}
+                "burst_pairs": pairs, "spin_launches": spin_launches}
 
     def block_stats(m):
         k = args.steps
@@ -885,12 +897,18 @@ def run_rank(args):
         if burst_n:
             avg_s = burst_ms / burst_n * 1e-3
             roofline = rwl.roofline(avg_s)
+            train = getattr(rwl, "spin_is_one_kernel", False)
             roofline.update({"avg_launch_us": avg_s * 1e6, "launches": burst_n,
-                             "timed": "burst of %d consecutive launches after the timed region, one "
-                                      "hipEvent pair each on the launch stream" % burst_n})
+                             "timed": ("burst of %d consecutive launches after the timed region between two hipEvents on "
+                                       "the launch stream (launch-to-launch period)" if train else
+                                       "burst of %d consecutive launches after the timed region, one hipEvent pair "
+                                       "each on the launch stream") % burst_n})
+            pm, pn = head.get("burst_pairs", (0.0, 0))
+            if pn and train:
+                roofline["avg_launch_us_event_pair_each"] = pm / pn * 1e3     # (rounds 1-3 reported this one)
             ms0, n0 = head["in_region"].get(0, (0.0, 0))
             if n0:
-                roofline["avg_launch_us_in_timed_region"] = ms0 / n0 * 1e3
+                roofline["avg_launch_us_in_timed_region"] = ms0 / n0 * 1e3     # (one event pair per sampled launch)
                 roofline["launches_in_timed_region"] = n0
             if head.get("read_ceiling"):
                 roofline["read_ceiling_this_box"] = head["read_ceiling"]
